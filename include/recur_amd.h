@@ -1,0 +1,439 @@
+/* recur_amd.h -- C ABI of librecur_amd.so, the MI355X (gfx950) implementation of
+ * Recur's RNN core.
+ *
+ * Part 1 of this header is the drop-in contract: the public structs, enums and
+ * extern functions that the reference exposes in recur-nn.h (the reference has
+ * no FFI layer; callers link recur-nn.o / recur-nn-init.o / recur-nn-io.o
+ * statically and poke struct fields).  Every
+ * declaration cites the reference line it replaces.  Field order, field types
+ * and enum values are ABI and therefore identical; everything else in this
+ * repository is written from scratch.
+ *
+ * Part 2 is additive: batched ("training set at once") entry points and the
+ * host/device coherence calls a GPU-resident core needs.  A batched call is
+ * defined to be equal to looping the per-net call of Part 1 over the set.
+ *
+ * Plain pointers and sizes only; no C++ or torch types.
+ */
+#ifndef RECUR_AMD_H
+#define RECUR_AMD_H 1
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* Short integer names used throughout the reference (recur-common.h:83-91). */
+#ifndef RECUR_AMD_NO_SHORT_TYPES
+typedef uint64_t u64;
+typedef int64_t s64;
+typedef uint32_t u32;
+typedef int32_t s32;
+typedef uint16_t u16;
+typedef int16_t s16;
+typedef uint8_t u8;
+typedef int8_t s8;
+typedef unsigned int uint;
+#endif
+
+/* Jenkins small-fast 64 bit PRNG state (recur-rng.h:15-20).  It is saved in
+ * net files as 32 raw bytes, so the layout is part of the file format. */
+typedef struct _rand_ctx {
+  uint64_t a;
+  uint64_t b;
+  uint64_t c;
+  uint64_t d;
+} rand_ctx;
+
+#define RECUR_RNG_RANDOM_SEED (-1ULL) /* recur-rng.h:13: seed from the clock   */
+#define RECUR_RNG_SUBSEED (-2ULL)     /* recur-nn.h:15: seed from parent's rng */
+
+/* Numeric constants of the algorithm (recur-nn.h:19-57, 107). */
+#define RANDOM_DAMAGE_FACTOR 0.5f
+#define MAX_TOP_ERROR_FACTOR 2.0f
+#define MAX_ERROR_GAIN 2.0f
+#define ERROR_GAIN_CEILING 1.0f
+#define BASE_MIN_ERROR_FACTOR 1e-12f
+#define MAX_MIN_ERROR_FACTOR 1e-2f
+#define ABS_MIN_ERROR_FACTOR 1e-20f
+#define MIN_ERROR_GAIN 1e-8f
+#define RNN_HIDDEN_PENALTY 0.0f
+#define HIDDEN_MEAN_SOFT_TOP 16.0f
+#define INPUT_MEAN_SOFT_TOP 16.0f
+#define RNN_INITIAL_WEIGHT_VARIANCE_FACTOR 2.0f
+#define WEIGHT_SCALE (1.0f - 1e-6f)
+#define RNN_CONDITIONING_INTERVAL 8
+#define RNN_TALL_POPPY_THRESHOLD 1.0f
+#define RNN_TALL_POPPY_SCALE 0.99f
+#define RNN_LAWN_MOWER_THRESHOLD 10.0f
+#define RNN_MOMENTUM_WEIGHT 0.5f
+#define RNN_COND_USE_OFFSET 16
+
+/* Position of each conditioning task in the 8-generation cycle
+ * (recur-nn.h:70-76). */
+enum {
+  RNN_COND_BIT_SCALE = 0U,
+  RNN_COND_BIT_ZERO = 2U,
+  RNN_COND_BIT_LAWN_MOWER = 3U,
+  RNN_COND_BIT_TALL_POPPY = 4U,
+  RNN_COND_BIT_RAND = 6U
+};
+
+/* net->flags bits (recur-nn.h:78-103). */
+enum {
+  RNN_NET_FLAG_OWN_BPTT = 1,
+  RNN_NET_FLAG_OWN_WEIGHTS = 2,
+  RNN_NET_FLAG_LOG_APPEND = 8,
+  RNN_NET_FLAG_LOG_HIDDEN_SUM = 16,
+  RNN_NET_FLAG_LOG_WEIGHT_SUM = 32,
+  RNN_NET_FLAG_BPTT_ADAPTIVE_MIN_ERROR = 64,
+  RNN_NET_FLAG_NO_MOMENTUMS = 128,
+  RNN_NET_FLAG_NO_DELTAS = 256,
+  RNN_NET_FLAG_BOTTOM_LAYER = 1024,
+  RNN_NET_FLAG_AUX_ARRAYS = 2048,
+
+  RNN_COND_USE_SCALE = (1 << (RNN_COND_BIT_SCALE + RNN_COND_USE_OFFSET)),
+  RNN_COND_USE_ZERO = (1 << (RNN_COND_BIT_ZERO + RNN_COND_USE_OFFSET)),
+  RNN_COND_USE_LAWN_MOWER = (1 << (RNN_COND_BIT_LAWN_MOWER + RNN_COND_USE_OFFSET)),
+  RNN_COND_USE_TALL_POPPY = (1 << (RNN_COND_BIT_TALL_POPPY + RNN_COND_USE_OFFSET)),
+  RNN_COND_USE_RAND = (1 << (RNN_COND_BIT_RAND + RNN_COND_USE_OFFSET)),
+
+  RNN_NET_FLAG_STANDARD = (RNN_NET_FLAG_OWN_BPTT | RNN_NET_FLAG_OWN_WEIGHTS |
+                           RNN_COND_USE_ZERO | RNN_NET_FLAG_LOG_HIDDEN_SUM)
+};
+
+/* recur-nn.h:109-119 */
+typedef enum {
+  RNN_MOMENTUM_WEIGHTED = 0,
+  RNN_MOMENTUM_NESTEROV,
+  RNN_MOMENTUM_SIMPLIFIED_NESTEROV,
+  RNN_MOMENTUM_CLASSICAL,
+  RNN_ADAGRAD,
+  RNN_ADADELTA,
+  RNN_RPROP,
+  RNN_LAST_LEARNING_METHOD
+} rnn_learning_method;
+
+/* recur-nn.h:121-128 */
+typedef enum {
+  RNN_INIT_ZERO = 0,
+  RNN_INIT_FLAT,
+  RNN_INIT_FAN_IN,
+  RNN_INIT_RUNS,
+  RNN_INIT_LAST
+} rnn_init_method;
+
+/* recur-nn.h:130-140 (values are stored in net files) */
+typedef enum {
+  RNN_RELU = 1,
+  RNN_RESQRT,
+  RNN_RESERVED_ACTIVATION_1,
+  RNN_RESERVED_ACTIVATION_2,
+  RNN_RECLIP20 = 5,
+  RNN_ACTIVATION_LAST
+} rnn_activation;
+
+/* recur-nn.h:142-151 */
+typedef enum {
+  RNN_INIT_DIST_UNIFORM = 1,
+  RNN_INIT_DIST_GAUSSIAN,
+  RNN_INIT_DIST_LOG_NORMAL,
+  RNN_INIT_DIST_SEMICIRCLE,
+  RNN_INIT_DIST_DEFAULT
+} rnn_init_distribution;
+
+typedef struct _RecurNN RecurNN;
+typedef struct _RecurNNBPTT RecurNNBPTT;
+typedef struct _RecurExtraLayer RecurExtraLayer;
+typedef struct _RecurErrorRange RecurErrorRange;
+
+/* One net == one stream of the synchronic mini-batch (recur-nn.h:158-186).
+ * All pointers are host pointers; see rnn_amd_sync_host() below for when the
+ * large arrays they point at are current. */
+struct _RecurNN {
+  int i_size; /* padded: 1 bias + hidden feedback + real inputs, rounded up to 4 */
+  int h_size; /* padded: 1 bias + hidden_size */
+  int o_size; /* padded output_size */
+  int input_size;
+  int hidden_size;
+  int output_size;
+  int ih_size; /* i_size * h_size */
+  int ho_size; /* h_size * o_size */
+  uint32_t flags;
+  FILE *log;
+  float *mem; /* private */
+  float *input_layer;
+  float *hidden_layer;
+  float *output_layer;
+  float *ih_weights; /* row major [i_size][h_size] */
+  float *ho_weights; /* row major [h_size][o_size] */
+  float *real_inputs;
+  rand_ctx rng;
+  RecurNNBPTT *bptt;
+  RecurExtraLayer *bottom_layer;
+  char *metadata;
+  uint32_t generation;
+  float presynaptic_noise;
+  rnn_activation activation;
+};
+
+/* Training state of one stream (recur-nn.h:188-209). */
+struct _RecurNNBPTT {
+  int depth;
+  int index;
+  float *i_error;
+  float *h_error;
+  float *o_error;
+  float *ih_momentum;
+  float *ho_momentum;
+  float *history; /* ring of depth slots, i_size floats each */
+  float *ih_delta;
+  float *ho_delta;
+  float *ih_delta_tmp;
+  float *ih_aux;
+  float *ho_aux;
+  float *mem; /* private */
+  float learn_rate;
+  float ih_scale;
+  float ho_scale;
+  float momentum;
+  float momentum_weight;
+  float min_error_factor;
+};
+
+/* Optional dense layer below the recurrent one (recur-nn.h:211-227). */
+struct _RecurExtraLayer {
+  float *mem;
+  float *weights;
+  float *momentums;
+  float *aux;
+  float *delta;
+  float *inputs;
+  float *outputs;
+  float *i_error;
+  float *o_error;
+  float learn_rate_scale;
+  int input_size;
+  int output_size;
+  int i_size;
+  int o_size;
+  int overlap;
+};
+
+/* recur-nn.h:230-258 */
+struct RecurInitialisationParameters {
+  rnn_init_method method;
+  rnn_init_method submethod;
+  int bias_uses_submethod;
+  int inputs_use_submethod;
+
+  float fan_in_sum;
+  float fan_in_step;
+  float fan_in_min;
+  float fan_in_ratio;
+
+  float flat_variance;
+  rnn_init_distribution flat_shape;
+  double flat_perforation;
+
+  float run_input_probability;
+  float run_input_magnitude;
+  float run_gain;
+  float run_len_mean;
+  float run_len_stddev;
+  int run_n;
+  int run_loop;
+  int run_crossing_paths;
+  int run_inputs_miss;
+  int run_input_at_start;
+};
+
+/* Column range of the output layer that carries error (recur-nn.h:260-265);
+ * arrays of these end with an entry whose start is negative. */
+struct _RecurErrorRange {
+  int start;
+  int len;
+};
+
+/* ----- construction / destruction (recur-nn.h:269-300) ------------------- */
+RecurNN *rnn_new(uint input_size, uint hidden_size, uint output_size, u32 flags,
+                 u64 rng_seed, const char *log_file, int depth, float learn_rate,
+                 float momentum, float presynaptic_noise, rnn_activation activation);
+RecurNN *rnn_clone(RecurNN *parent, u32 flags, u64 rng_seed, const char *log_file);
+RecurExtraLayer *rnn_new_extra_layer(int input_size, int output_size, int overlap,
+                                     u32 flags);
+RecurNN *rnn_new_with_bottom_layer(int n_inputs, int r_input_size, int hidden_size,
+                                   int output_size, u32 flags, u64 rng_seed,
+                                   const char *log_file, int bptt_depth,
+                                   float learn_rate, float momentum,
+                                   float presynaptic_noise, rnn_activation activation,
+                                   int convolutional_overlap);
+void rnn_set_log_file(RecurNN *net, const char *log_file, int append_dont_truncate);
+void rnn_delete_net(RecurNN *net);
+RecurNN **rnn_new_training_set(RecurNN *prototype, int n_nets);
+void rnn_delete_training_set(RecurNN **nets, int n_nets, int leave_prototype);
+
+/* ----- weight initialisation (recur-nn.h:287-296, 324, 333-334) ---------- */
+void rnn_randomise_weights_clever(RecurNN *net, struct RecurInitialisationParameters *p);
+void rnn_randomise_weights_simple(RecurNN *net, const rnn_init_method method);
+void rnn_randomise_weights_auto(RecurNN *net);
+void rnn_init_default_weight_parameters(RecurNN *net,
+                                        struct RecurInitialisationParameters *q);
+void rnn_scale_initial_weights(RecurNN *net, float target_gain);
+void rnn_print_net_stats(RecurNN *net);
+void rnn_perforate_weights(RecurNN *net, float p);
+void rnn_zap_non_diagonals(RecurNN *net, int start, int stop, int n_friends);
+void rnn_clear_diagonal_only_section(RecurNN *net, uint len, uint friends);
+
+/* ----- the hot path (recur-nn.h:302, 309-322) ---------------------------- */
+float *rnn_opinion(RecurNN *net, const float *inputs, float presynaptic_noise);
+void rnn_bptt_clear_deltas(RecurNN *net);
+void rnn_bptt_advance(RecurNN *net);
+void rnn_bptt_calculate(RecurNN *net, uint batch_size);
+void rnn_apply_learning(RecurNN *net, int learning_style, float momentum);
+float rnn_calculate_momentum_soft_start(float generation, float momentum,
+                                        float momentum_soft_start);
+void rnn_bptt_calc_deltas(RecurNN *net, int accumulate_delta,
+                          RecurErrorRange *top_error_ranges);
+void rnn_condition_net(RecurNN *net);
+void rnn_log_net(RecurNN *net);
+void rnn_forget_history(RecurNN *net, int bptt_too);
+
+/* ----- cold helpers (recur-nn.h:304, 328-331) ---------------------------- */
+void rnn_multi_pgm_dump(RecurNN *net, const char *dumpees, const char *basename);
+void rnn_weight_noise(RecurNN *net, float deviation);
+void rnn_set_momentum_values(RecurNN *net, float x);
+void rnn_set_aux_values(RecurNN *net, float x);
+
+/* ----- CDB net files, format version 10 (recur-nn.h:306-307) ------------- */
+RecurNN *rnn_load_net(const char *filename);
+int rnn_save_net(RecurNN *net, const char *filename, int backup);
+
+/* recur-nn.h:337-349: one "name value" line per call on net->log. */
+static inline void rnn_log_float(RecurNN *net, char *name, float value) {
+  if (net->log) {
+    fprintf(net->log, "%s %.5g\n", name, value);
+  }
+}
+static inline void rnn_log_int(RecurNN *net, char *name, int value) {
+  if (net->log) {
+    fprintf(net->log, "%s %d\n", name, value);
+  }
+}
+
+/* ======================================================================== */
+/* Part 2: additive entry points.                                            */
+
+/* Number of usable HIP devices.  With 0 devices the host-only functions
+ * (construction, initialisation, file I/O, PRNG) still work; every function
+ * that has to compute on the device prints a message and abort()s.  There is
+ * no CPU fallback. */
+int rnn_amd_device_count(void);
+/* Select the HIP device (default: LOCAL_RANK from the environment, else 0)
+ * and optionally an externally created hipStream_t for all launches. */
+void rnn_amd_use_device(int device, void *hip_stream);
+void *rnn_amd_current_stream(void);
+const char *rnn_amd_version(void);
+
+/* Which copies to bring up to date (bit set). */
+enum {
+  RNN_AMD_WEIGHTS = 1,   /* ih_weights, ho_weights, bottom layer weights     */
+  RNN_AMD_MOMENTUMS = 2, /* ih/ho_momentum, ih/ho_aux                       */
+  RNN_AMD_DELTAS = 4,    /* ih_delta, ho_delta                              */
+  RNN_AMD_STREAM = 8,    /* this net's history, layers, error vectors, scalars */
+  RNN_AMD_ALL_STREAMS = 16, /* the same for every net sharing its weights   */
+  RNN_AMD_EVERYTHING = 31
+};
+/* The device copy of the large arrays is authoritative once a net has been
+ * used on the device.  rnn_amd_sync_host makes the host arrays behind the
+ * struct pointers current; rnn_amd_host_written tells the library that the
+ * caller modified them through the pointers (e.g. net->ih_weights[k] += x).
+ * Library functions do both themselves; the per-net calls of Part 1 also keep
+ * the small per-stream vectors (input/hidden/output layer, o_error, h_error,
+ * i_error, bptt scalars) current on return. */
+void rnn_amd_sync_host(RecurNN *net, int what);
+void rnn_amd_host_written(RecurNN *net, int what);
+
+/* A training set opened for batched work: nets[0] is the prototype and the
+ * others are its rnn_new_training_set() clones. */
+typedef struct RnnAmdSet RnnAmdSet;
+RnnAmdSet *rnn_amd_set_open(RecurNN **nets, int n_nets);
+void rnn_amd_set_close(RnnAmdSet *set);
+int rnn_amd_set_size(const RnnAmdSet *set);
+
+/* == rnn_bptt_advance() on every net of the set. */
+void rnn_amd_set_advance(RnnAmdSet *set);
+
+/* == rnn_opinion(nets[j], inputs + j * ld_inputs, nets[j]->presynaptic_noise)
+ * for every j.  inputs (host, n_nets rows) may be NULL when the inputs were
+ * set by one of the calls below.  If outputs is not NULL the n_nets x o_size
+ * answers are copied there (host), which synchronises. */
+void rnn_amd_set_opinion(RnnAmdSet *set, const float *inputs, int ld_inputs,
+                         float *outputs);
+/* One-hot inputs (charmodel-helpers.h:16-33): hot[j] is the input index of
+ * stream j (host array). */
+void rnn_amd_set_one_hot_opinion(RnnAmdSet *set, const int *hot, float *outputs);
+
+/* Upload n_nets x o_size error rows (host) into bptt->o_error of the streams. */
+void rnn_amd_set_put_o_error(RnnAmdSet *set, const float *o_error, int ld);
+/* Device version of net_error_bptt's loss (charmodel-predict.c:18-27):
+ * o_error = onehot(target) - softmax(output) with the reference's fast_expf
+ * (badmaths.h:14-29, 71-141).  Per stream it adds the error of the target
+ * class, log2(1 - that error) (capped, charmodel-helpers.h:11-13) and the
+ * "winner == target" count into device accumulators read by
+ * rnn_amd_set_read_stats. */
+void rnn_amd_set_softmax_error(RnnAmdSet *set, const int *target);
+
+/* == for every j with (active == NULL || active[j]):
+ *      rnn_bptt_calc_deltas(nets[j], accumulate || not the first, ranges)
+ * i.e. with accumulate == 0 the deltas are zeroed first, exactly as the
+ * reference callers do with "j ? 1 : 0" (charmodel-predict.c:309). */
+void rnn_amd_set_calc_deltas(RnnAmdSet *set, int accumulate,
+                             RecurErrorRange *top_error_ranges, const u8 *active);
+
+/* Text on the device, for a host-free epoch loop (charmodel-predict.c:288-311). */
+void rnn_amd_set_load_text(RnnAmdSet *set, const u8 *text, int len);
+/* One generation of rnn_char_epoch's multi-tap branch for text position i:
+ * stream j reads text[off] and is scored against text[off + 1], with
+ * off = i + j * ((len - 1) / n_nets), wrapped at len - 1;
+ * advance, one-hot opinion, softmax error, calc_deltas(j ? 1 : 0), and then
+ * rnn_apply_learning(nets[0], learning_style, momentum).  Nothing is copied to
+ * the host. */
+void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float momentum);
+
+typedef struct RnnAmdStats {
+  double error;   /* sum of target-class errors                */
+  double entropy; /* sum of capped log2(1 - error)            */
+  long correct;   /* count of winner == target                */
+  long count;     /* stream-timesteps accumulated              */
+  double bptt_depth_sum; /* sum of executed BPTT steps          */
+  double hidden_zeros;   /* sum over stream-steps of the zero fraction of hiddens */
+} RnnAmdStats;
+/* Reads (and optionally clears) the device accumulators; synchronises. */
+void rnn_amd_set_read_stats(RnnAmdSet *set, RnnAmdStats *stats, int clear);
+
+/* Multi-GPU: when set, ih_delta||ho_delta of the set live in the caller's
+ * device buffer (ih_size + ho_size floats, ih first), so that the caller can
+ * all-reduce it (RCCL) between calc_deltas and apply_learning.  Pass NULL to
+ * go back to library-owned storage. */
+void rnn_amd_set_external_delta(RnnAmdSet *set, void *device_buffer);
+/* Split rnn_amd_set_char_step for that use: everything up to and including
+ * calc_deltas, then the update. */
+void rnn_amd_set_char_step_deltas(RnnAmdSet *set, int i);
+/* Block until all queued device work of the library has finished. */
+void rnn_amd_synchronize(void);
+
+/* Timing hook for bench.py: HIP-event time (ms) accumulated over the dominant
+ * kernel class since the last reset, and the number of launches.
+ * which: 0 = BPTT chain GEMM, 1 = delta GEMM, 2 = forward GEMM, 3 = optimiser. */
+void rnn_amd_kernel_time_enable(int enable);
+double rnn_amd_kernel_time_ms(int which, long *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

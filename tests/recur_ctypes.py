@@ -1,0 +1,401 @@
+"""ctypes views of the three C libraries the tests talk to.
+
+* ``load_amd()``  -> recur_amd/lib/librecur_amd.so, the product (HIP, gfx950)
+* ``load_ref()``  -> oracle/_ref/librecur_ref.so, the real reference compiled from
+  /root/reference by oracle/Makefile (absent on machines without the reference
+  unless the prebuilt file travelled there)
+* ``load_oracle()`` -> oracle/liboracle.so, this repo's CPU restatement
+
+The product and the reference share one ABI (include/recur_amd.h mirrors
+recur-nn.h:158-334), so one set of struct definitions and prototypes serves
+both, and a test body can be run against either library.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+AMD_LIB = os.path.join(ROOT, "recur_amd", "lib", "librecur_amd.so")
+REF_LIB = os.path.join(ROOT, "oracle", "_ref", "librecur_ref.so")
+REF_FAST_LIB = os.path.join(ROOT, "oracle", "_ref", "librecur_ref_fast.so")
+ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle.so")
+ORACLE_FAST_LIB = os.path.join(ROOT, "oracle", "liboracle_fast.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+c_u8_p = C.POINTER(C.c_uint8)
+
+
+class RandCtx(C.Structure):
+    _fields_ = [("a", C.c_uint64), ("b", C.c_uint64), ("c", C.c_uint64), ("d", C.c_uint64)]
+
+
+class RecurNNBPTT(C.Structure):
+    _fields_ = [
+        ("depth", C.c_int),
+        ("index", C.c_int),
+        ("i_error", c_float_p),
+        ("h_error", c_float_p),
+        ("o_error", c_float_p),
+        ("ih_momentum", c_float_p),
+        ("ho_momentum", c_float_p),
+        ("history", c_float_p),
+        ("ih_delta", c_float_p),
+        ("ho_delta", c_float_p),
+        ("ih_delta_tmp", c_float_p),
+        ("ih_aux", c_float_p),
+        ("ho_aux", c_float_p),
+        ("mem", c_float_p),
+        ("learn_rate", C.c_float),
+        ("ih_scale", C.c_float),
+        ("ho_scale", C.c_float),
+        ("momentum", C.c_float),
+        ("momentum_weight", C.c_float),
+        ("min_error_factor", C.c_float),
+    ]
+
+
+class RecurExtraLayer(C.Structure):
+    _fields_ = [
+        ("mem", c_float_p),
+        ("weights", c_float_p),
+        ("momentums", c_float_p),
+        ("aux", c_float_p),
+        ("delta", c_float_p),
+        ("inputs", c_float_p),
+        ("outputs", c_float_p),
+        ("i_error", c_float_p),
+        ("o_error", c_float_p),
+        ("learn_rate_scale", C.c_float),
+        ("input_size", C.c_int),
+        ("output_size", C.c_int),
+        ("i_size", C.c_int),
+        ("o_size", C.c_int),
+        ("overlap", C.c_int),
+    ]
+
+
+class RecurNN(C.Structure):
+    _fields_ = [
+        ("i_size", C.c_int),
+        ("h_size", C.c_int),
+        ("o_size", C.c_int),
+        ("input_size", C.c_int),
+        ("hidden_size", C.c_int),
+        ("output_size", C.c_int),
+        ("ih_size", C.c_int),
+        ("ho_size", C.c_int),
+        ("flags", C.c_uint32),
+        ("log", C.c_void_p),
+        ("mem", c_float_p),
+        ("input_layer", c_float_p),
+        ("hidden_layer", c_float_p),
+        ("output_layer", c_float_p),
+        ("ih_weights", c_float_p),
+        ("ho_weights", c_float_p),
+        ("real_inputs", c_float_p),
+        ("rng", RandCtx),
+        ("bptt", C.POINTER(RecurNNBPTT)),
+        ("bottom_layer", C.POINTER(RecurExtraLayer)),
+        ("metadata", C.c_char_p),
+        ("generation", C.c_uint32),
+        ("presynaptic_noise", C.c_float),
+        ("activation", C.c_int),
+    ]
+
+
+class InitParams(C.Structure):
+    _fields_ = [
+        ("method", C.c_int),
+        ("submethod", C.c_int),
+        ("bias_uses_submethod", C.c_int),
+        ("inputs_use_submethod", C.c_int),
+        ("fan_in_sum", C.c_float),
+        ("fan_in_step", C.c_float),
+        ("fan_in_min", C.c_float),
+        ("fan_in_ratio", C.c_float),
+        ("flat_variance", C.c_float),
+        ("flat_shape", C.c_int),
+        ("flat_perforation", C.c_double),
+        ("run_input_probability", C.c_float),
+        ("run_input_magnitude", C.c_float),
+        ("run_gain", C.c_float),
+        ("run_len_mean", C.c_float),
+        ("run_len_stddev", C.c_float),
+        ("run_n", C.c_int),
+        ("run_loop", C.c_int),
+        ("run_crossing_paths", C.c_int),
+        ("run_inputs_miss", C.c_int),
+        ("run_input_at_start", C.c_int),
+    ]
+
+
+class ErrorRange(C.Structure):
+    _fields_ = [("start", C.c_int), ("len", C.c_int)]
+
+
+class AmdStats(C.Structure):
+    _fields_ = [
+        ("error", C.c_double),
+        ("entropy", C.c_double),
+        ("correct", C.c_long),
+        ("count", C.c_long),
+        ("bptt_depth_sum", C.c_double),
+        ("hidden_zeros", C.c_double),
+    ]
+
+
+NetP = C.POINTER(RecurNN)
+
+# flags / enums (include/recur_amd.h)
+FLAG_OWN_BPTT = 1
+FLAG_OWN_WEIGHTS = 2
+FLAG_LOG_HIDDEN_SUM = 16
+FLAG_ADAPTIVE_MIN_ERROR = 64
+FLAG_NO_MOMENTUMS = 128
+FLAG_NO_DELTAS = 256
+FLAG_AUX_ARRAYS = 2048
+COND_USE_SCALE = 1 << 16
+COND_USE_ZERO = 1 << 18
+COND_USE_LAWN_MOWER = 1 << 19
+COND_USE_TALL_POPPY = 1 << 20
+COND_USE_RAND = 1 << 22
+FLAG_STANDARD = FLAG_OWN_BPTT | FLAG_OWN_WEIGHTS | COND_USE_ZERO | FLAG_LOG_HIDDEN_SUM
+RELU, RESQRT, RECLIP20 = 1, 2, 5
+WEIGHTED, NESTEROV, SIMPLIFIED_NESTEROV, CLASSICAL, ADAGRAD, ADADELTA, RPROP = range(7)
+INIT_ZERO, INIT_FLAT, INIT_FAN_IN, INIT_RUNS = range(4)
+DIST_UNIFORM, DIST_GAUSSIAN, DIST_LOG_NORMAL, DIST_SEMICIRCLE = 1, 2, 3, 4
+SUBSEED = C.c_uint64(-2).value
+
+# The drop-in surface: name -> (restype, argtypes).  This is recur-nn.h:269-334.
+RNN_API = {
+    "rnn_new": (NetP, [C.c_uint, C.c_uint, C.c_uint, C.c_uint32, C.c_uint64, C.c_char_p,
+                       C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]),
+    "rnn_clone": (NetP, [NetP, C.c_uint32, C.c_uint64, C.c_char_p]),
+    "rnn_new_extra_layer": (C.POINTER(RecurExtraLayer), [C.c_int, C.c_int, C.c_int, C.c_uint32]),
+    "rnn_new_with_bottom_layer": (NetP, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
+                                         C.c_uint64, C.c_char_p, C.c_int, C.c_float,
+                                         C.c_float, C.c_float, C.c_int, C.c_int]),
+    "rnn_set_log_file": (None, [NetP, C.c_char_p, C.c_int]),
+    "rnn_randomise_weights_clever": (None, [NetP, C.POINTER(InitParams)]),
+    "rnn_randomise_weights_simple": (None, [NetP, C.c_int]),
+    "rnn_randomise_weights_auto": (None, [NetP]),
+    "rnn_init_default_weight_parameters": (None, [NetP, C.POINTER(InitParams)]),
+    "rnn_scale_initial_weights": (None, [NetP, C.c_float]),
+    "rnn_print_net_stats": (None, [NetP]),
+    "rnn_delete_net": (None, [NetP]),
+    "rnn_new_training_set": (C.POINTER(NetP), [NetP, C.c_int]),
+    "rnn_delete_training_set": (None, [C.POINTER(NetP), C.c_int, C.c_int]),
+    "rnn_opinion": (c_float_p, [NetP, c_float_p, C.c_float]),
+    "rnn_multi_pgm_dump": (None, [NetP, C.c_char_p, C.c_char_p]),
+    "rnn_load_net": (NetP, [C.c_char_p]),
+    "rnn_save_net": (C.c_int, [NetP, C.c_char_p, C.c_int]),
+    "rnn_bptt_clear_deltas": (None, [NetP]),
+    "rnn_bptt_advance": (None, [NetP]),
+    "rnn_bptt_calculate": (None, [NetP, C.c_uint]),
+    "rnn_apply_learning": (None, [NetP, C.c_int, C.c_float]),
+    "rnn_calculate_momentum_soft_start": (C.c_float, [C.c_float, C.c_float, C.c_float]),
+    "rnn_bptt_calc_deltas": (None, [NetP, C.c_int, C.POINTER(ErrorRange)]),
+    "rnn_condition_net": (None, [NetP]),
+    "rnn_log_net": (None, [NetP]),
+    "rnn_forget_history": (None, [NetP, C.c_int]),
+    "rnn_perforate_weights": (None, [NetP, C.c_float]),
+    "rnn_weight_noise": (None, [NetP, C.c_float]),
+    "rnn_set_momentum_values": (None, [NetP, C.c_float]),
+    "rnn_set_aux_values": (None, [NetP, C.c_float]),
+    "rnn_zap_non_diagonals": (None, [NetP, C.c_int, C.c_int, C.c_int]),
+    "rnn_clear_diagonal_only_section": (None, [NetP, C.c_uint, C.c_uint]),
+}
+# recur-nn-io.c needs tinycdb, so the compiled reference lacks these two.
+REF_MISSING = {"rnn_load_net", "rnn_save_net"}
+
+# Additive entry points of include/recur_amd.h part 2.
+AMD_API = {
+    "rnn_amd_device_count": (C.c_int, []),
+    "rnn_amd_use_device": (None, [C.c_int, C.c_void_p]),
+    "rnn_amd_current_stream": (C.c_void_p, []),
+    "rnn_amd_version": (C.c_char_p, []),
+    "rnn_amd_sync_host": (None, [NetP, C.c_int]),
+    "rnn_amd_host_written": (None, [NetP, C.c_int]),
+    "rnn_amd_set_open": (C.c_void_p, [C.POINTER(NetP), C.c_int]),
+    "rnn_amd_set_close": (None, [C.c_void_p]),
+    "rnn_amd_set_size": (C.c_int, [C.c_void_p]),
+    "rnn_amd_set_advance": (None, [C.c_void_p]),
+    "rnn_amd_set_opinion": (None, [C.c_void_p, c_float_p, C.c_int, c_float_p]),
+    "rnn_amd_set_one_hot_opinion": (None, [C.c_void_p, c_int_p, c_float_p]),
+    "rnn_amd_set_put_o_error": (None, [C.c_void_p, c_float_p, C.c_int]),
+    "rnn_amd_set_softmax_error": (None, [C.c_void_p, c_int_p]),
+    "rnn_amd_set_calc_deltas": (None, [C.c_void_p, C.c_int, C.POINTER(ErrorRange), c_u8_p]),
+    "rnn_amd_set_load_text": (None, [C.c_void_p, c_u8_p, C.c_int]),
+    "rnn_amd_set_char_step": (None, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
+    "rnn_amd_set_read_stats": (None, [C.c_void_p, C.POINTER(AmdStats), C.c_int]),
+    "rnn_amd_set_external_delta": (None, [C.c_void_p, C.c_void_p]),
+    "rnn_amd_set_char_step_deltas": (None, [C.c_void_p, C.c_int]),
+    "rnn_amd_synchronize": (None, []),
+    "rnn_amd_kernel_time_enable": (None, [C.c_int]),
+    "rnn_amd_kernel_time_ms": (C.c_double, [C.c_int, C.POINTER(C.c_long), C.c_int]),
+}
+RNN_AMD_WEIGHTS, RNN_AMD_MOMENTUMS, RNN_AMD_DELTAS, RNN_AMD_STREAM, RNN_AMD_ALL_STREAMS = 1, 2, 4, 8, 16
+RNN_AMD_EVERYTHING = 31
+
+REF_SHIM_API = {
+    "ref_rand64": (C.c_uint64, [C.POINTER(RandCtx)]),
+    "ref_init_rand64": (None, [C.POINTER(RandCtx), C.c_uint64]),
+    "ref_rand_double": (C.c_double, [C.POINTER(RandCtx)]),
+    "ref_rand_small_int": (C.c_int, [C.POINTER(RandCtx), C.c_int]),
+    "ref_cheap_gaussian_noise": (C.c_float, [C.POINTER(RandCtx)]),
+    "ref_fast_expf": (C.c_float, [C.c_float]),
+    "ref_softmax": (None, [c_float_p, c_float_p, C.c_int]),
+    "ref_softmax_best_guess": (C.c_int, [c_float_p, c_float_p, C.c_int]),
+    "ref_soft_clip": (C.c_float, [C.c_float, C.c_float]),
+    "ref_sizeof_net": (C.c_int, []),
+    "ref_sizeof_bptt": (C.c_int, []),
+}
+
+
+def _bind(lib, table, skip=()):
+    for name, (res, args) in table.items():
+        if name in skip:
+            continue
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def have_ref():
+    return os.path.exists(REF_LIB)
+
+
+def load_ref(fast=False):
+    lib = C.CDLL(REF_FAST_LIB if fast else REF_LIB)
+    _bind(lib, RNN_API, skip=REF_MISSING)
+    _bind(lib, REF_SHIM_API)
+    return lib
+
+
+def load_amd():
+    if not os.path.exists(AMD_LIB):
+        raise RuntimeError("librecur_amd.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(AMD_LIB)
+    _bind(lib, RNN_API)
+    _bind(lib, AMD_API)
+    return lib
+
+
+# ------------------------------------------------------------------ oracle --
+
+class OrcRng(C.Structure):
+    _fields_ = [("a", C.c_uint64), ("b", C.c_uint64), ("c", C.c_uint64), ("d", C.c_uint64)]
+
+
+class OrcSet(C.Structure):
+    _fields_ = [
+        ("input_size", C.c_int), ("hidden_size", C.c_int), ("output_size", C.c_int),
+        ("I", C.c_int), ("H", C.c_int), ("O", C.c_int),
+        ("S", C.c_int), ("D", C.c_int),
+        ("activation", C.c_int),
+        ("flags", C.c_uint32),
+        ("ih_w", c_float_p), ("ho_w", c_float_p),
+        ("ih_m", c_float_p), ("ho_m", c_float_p),
+        ("ih_aux", c_float_p), ("ho_aux", c_float_p),
+        ("ih_delta", c_float_p), ("ho_delta", c_float_p), ("ih_delta_tmp", c_float_p),
+        ("hist", c_float_p), ("hidden", c_float_p), ("output", c_float_p),
+        ("o_error", c_float_p), ("err_a", c_float_p), ("err_b", c_float_p),
+        ("index", c_int_p),
+        ("learn_rate", c_float_p),
+        ("min_error_factor", c_float_p),
+        ("ih_scale", c_float_p),
+        ("top_error_raw", c_float_p), ("top_error_scaled", c_float_p), ("bptt_error", c_float_p),
+        ("bptt_depth", c_int_p),
+        ("generation", C.POINTER(C.c_uint32)),
+        ("rng", C.POINTER(OrcRng)),
+        ("ho_scale", C.c_float), ("momentum_weight", C.c_float),
+        ("presynaptic_noise", C.c_float),
+        ("stat_error", C.c_double), ("stat_entropy", C.c_double),
+        ("stat_correct", C.c_long), ("stat_count", C.c_long),
+        ("stat_depth", C.c_double), ("stat_zeros", C.c_double),
+    ]
+
+
+OrcP = C.POINTER(OrcSet)
+ORACLE_API = {
+    "orc_rand64": (C.c_uint64, [C.POINTER(OrcRng)]),
+    "orc_init_rand64": (None, [C.POINTER(OrcRng), C.c_uint64]),
+    "orc_rand_double": (C.c_double, [C.POINTER(OrcRng)]),
+    "orc_rand_small_int": (C.c_int, [C.POINTER(OrcRng), C.c_int]),
+    "orc_cheap_gaussian_noise": (C.c_float, [C.POINTER(OrcRng)]),
+    "orc_fast_expf": (C.c_float, [C.c_float]),
+    "orc_softmax": (None, [c_float_p, c_float_p, C.c_int]),
+    "orc_softmax_best_guess": (C.c_int, [c_float_p, c_float_p, C.c_int]),
+    "orc_soft_clip": (C.c_float, [C.c_float, C.c_float]),
+    "orc_capped_log2f": (C.c_float, [C.c_float]),
+    "orc_momentum_soft_start": (C.c_float, [C.c_float, C.c_float, C.c_float]),
+    "orc_padded_sizes": (None, [C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p]),
+    "orc_set_new": (OrcP, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
+                           C.c_float, C.c_uint64]),
+    "orc_set_free": (None, [OrcP]),
+    "orc_set_seed_clones": (None, [OrcP]),
+    "orc_set_init_flat": (None, [OrcP, C.c_float, C.c_int, C.c_double]),
+    "orc_advance": (None, [OrcP, C.c_int]),
+    "orc_opinion": (c_float_p, [OrcP, C.c_int, c_float_p, C.c_float]),
+    "orc_one_hot_opinion": (c_float_p, [OrcP, C.c_int, C.c_int, C.c_float]),
+    "orc_net_error_bptt": (C.c_float, [OrcP, C.c_int, C.c_int, C.c_int, c_int_p]),
+    "orc_calc_deltas": (None, [OrcP, C.c_int, C.c_int, c_int_p]),
+    "orc_clear_deltas": (None, [OrcP]),
+    "orc_apply_learning": (None, [OrcP, C.c_int, C.c_float]),
+    "orc_condition": (None, [OrcP, C.c_uint32]),
+    "orc_bptt_calculate": (None, [OrcP, C.c_int, C.c_uint, C.c_float]),
+    "orc_cross_entropy": (C.c_double, [OrcP, C.c_int, c_u8_p, C.c_int, C.c_int]),
+    "orc_set_char_step": (None, [OrcP, c_u8_p, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "orc_set_char_step_deltas": (None, [OrcP, c_u8_p, C.c_int, C.c_int]),
+}
+
+
+def build_oracle():
+    """Compile oracle/ (gcc only); also refreshes oracle/_ref when the reference
+    sources are present.  Building the checker is not using it."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+
+
+def load_oracle(fast=False):
+    path = ORACLE_FAST_LIB if fast else ORACLE_LIB
+    if not os.path.exists(path):
+        build_oracle()
+    return _bind(C.CDLL(path), ORACLE_API)
+
+
+# ------------------------------------------------------------ numpy helpers --
+
+def view(ptr, *shape):
+    """numpy view (no copy) of the C float/int array behind a ctypes pointer."""
+    n = int(np.prod(shape))
+    if n == 0:
+        return np.zeros(shape, dtype=np.float32)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape)
+
+
+def fptr(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_float_p)
+
+
+def iptr(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_int_p)
+
+
+def u8ptr(a):
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_u8_p)
+
+
+def rel_err(a, b):
+    """|a-b| / |b| in the 2-norm: the parity metric for fp32 arrays."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    d = np.linalg.norm(a - b)
+    n = np.linalg.norm(b)
+    return d / n if n > 0 else d

@@ -1,0 +1,215 @@
+"""Scenario drivers shared by the parity tests.
+
+``ApiSet`` drives a library that speaks the recur-nn.h ABI (the compiled
+reference, or librecur_amd.so through its per-net drop-in calls) exactly the way
+the reference's own caller does (rnn_char_epoch, charmodel-predict.c:288-311).
+``OracleSet`` drives oracle/liboracle.so through the same steps.  Both expose
+``snapshot()`` in the oracle/device layout so arrays can be compared directly.
+"""
+import ctypes as C
+
+import numpy as np
+
+import recur_ctypes as rc
+
+
+def synthetic_text(n, alphabet=42, seed=7):
+    """Seeded symbol stream: SURVEY.md section 8(d)'s data-free variant
+    (symbols from rand_small_int(seed 7, 42))."""
+    orc = rc.load_oracle()
+    rng = rc.OrcRng()
+    orc.orc_init_rand64(C.byref(rng), seed)
+    out = np.empty(n, dtype=np.uint8)
+    for i in range(n):
+        out[i] = orc.orc_rand_small_int(C.byref(rng), alphabet)
+    return out
+
+
+class ApiSet:
+    """A training set held by an rnn_* library (reference or product)."""
+
+    def __init__(self, lib, input_size, hidden_size, output_size, S, D, activation=rc.RELU,
+                 flags=rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR, learn_rate=1e-3, seed=1,
+                 momentum=0.95, variance=None, shape=rc.DIST_SEMICIRCLE, perforation=0.0,
+                 softmax_best_guess=None):
+        self.lib = lib
+        self.S, self.D = S, D
+        net = lib.rnn_new(input_size, hidden_size, output_size, flags, seed, None, D,
+                          learn_rate, momentum, 0.0, activation)
+        self.net = net
+        n = net.contents
+        self.I, self.H, self.O = n.i_size, n.h_size, n.o_size
+        self.input_size, self.hidden_size, self.output_size = input_size, hidden_size, output_size
+        p = rc.InitParams()
+        lib.rnn_init_default_weight_parameters(net, C.byref(p))
+        p.method = rc.INIT_FLAT
+        if variance is not None:
+            p.flat_variance = variance
+        p.flat_shape = shape
+        p.flat_perforation = perforation
+        lib.rnn_randomise_weights_clever(net, C.byref(p))
+        self.nets = lib.rnn_new_training_set(net, S)
+        # the caller-side loss (softmax_best_guess is a static inline of the
+        # reference's badmaths.h, i.e. caller code, not library code)
+        self._sbg = softmax_best_guess
+
+    def close(self):
+        self.lib.rnn_delete_training_set(self.nets, self.S, 0)
+
+    # -- per-stream steps (the reference call sequence) --
+    def one_hot_opinion(self, j, hot, noise=0.0):
+        n = self.nets[j].contents
+        real = rc.view(n.real_inputs, self.input_size)
+        real[:] = 0
+        real[hot] = 1.0
+        return self.lib.rnn_opinion(self.nets[j], None, noise)
+
+    def net_error_bptt(self, j, c, nxt):
+        n = self.nets[j].contents
+        answer = self.one_hot_opinion(j, c, n.presynaptic_noise)
+        err = n.bptt.contents.o_error
+        winner = self._sbg(err, answer, self.output_size)
+        e = rc.view(err, self.O)
+        e[nxt] += 1.0
+        return float(e[nxt]), int(winner == nxt)
+
+    def char_step_deltas(self, text, i):
+        L = len(text)
+        spacing = (L - 1) // self.S
+        stats = []
+        for j in range(self.S):
+            off = i + j * spacing
+            if off >= L - 1:
+                off -= L - 1
+            self.lib.rnn_bptt_advance(self.nets[j])
+            stats.append(self.net_error_bptt(j, int(text[off]), int(text[off + 1])))
+            self.lib.rnn_bptt_calc_deltas(self.nets[j], 1 if j else 0, None)
+        return stats
+
+    def char_step(self, text, i, method=rc.WEIGHTED, momentum=0.95):
+        stats = self.char_step_deltas(text, i)
+        self.lib.rnn_apply_learning(self.net, method, momentum)
+        return stats
+
+    def sync(self):
+        if hasattr(self.lib, "rnn_amd_sync_host"):
+            self.lib.rnn_amd_sync_host(self.net, rc.RNN_AMD_EVERYTHING)
+
+    def snapshot(self):
+        self.sync()
+        n0 = self.net.contents
+        b0 = n0.bptt.contents
+        S, D, I, H, O = self.S, self.D, self.I, self.H, self.O
+        snap = {
+            "ih_w": rc.view(n0.ih_weights, I, H).copy(),
+            "ho_w": rc.view(n0.ho_weights, H, O).copy(),
+            "ih_m": rc.view(b0.ih_momentum, I, H).copy(),
+            "ho_m": rc.view(b0.ho_momentum, H, O).copy(),
+            "ih_delta": rc.view(b0.ih_delta, I, H).copy(),
+            "ho_delta": rc.view(b0.ho_delta, H, O).copy(),
+        }
+        hist = np.zeros((D, S, I), np.float32)
+        hidden = np.zeros((S, H), np.float32)
+        output = np.zeros((S, O), np.float32)
+        o_error = np.zeros((S, O), np.float32)
+        index = np.zeros(S, np.int32)
+        mef = np.zeros(S, np.float32)
+        ih_scale = np.zeros(S, np.float32)
+        gen = np.zeros(S, np.uint32)
+        rng = np.zeros((S, 4), np.uint64)
+        for j in range(S):
+            n = self.nets[j].contents
+            b = n.bptt.contents
+            hist[:, j, :] = rc.view(b.history, D, I)
+            hidden[j] = rc.view(n.hidden_layer, H)
+            output[j] = rc.view(n.output_layer, O)
+            o_error[j] = rc.view(b.o_error, O)
+            index[j] = b.index
+            mef[j] = b.min_error_factor
+            ih_scale[j] = b.ih_scale
+            gen[j] = n.generation
+            rng[j] = (n.rng.a, n.rng.b, n.rng.c, n.rng.d)
+        snap.update(hist=hist, hidden=hidden, output=output, o_error=o_error, index=index,
+                    min_error_factor=mef, ih_scale=ih_scale, generation=gen, rng=rng)
+        return snap
+
+
+class OracleSet:
+    """The same scenario on oracle/liboracle.so."""
+
+    def __init__(self, input_size, hidden_size, output_size, S, D, activation=rc.RELU,
+                 flags=rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR, learn_rate=1e-3, seed=1,
+                 momentum=0.95, variance=None, shape=rc.DIST_SEMICIRCLE, perforation=0.0,
+                 fast=False):
+        self.orc = orc = rc.load_oracle(fast=fast)
+        self.z = orc.orc_set_new(input_size, hidden_size, output_size, S, D, activation, flags,
+                                 learn_rate, seed)
+        z = self.z.contents
+        self.S, self.D, self.I, self.H, self.O = S, D, z.I, z.H, z.O
+        self.input_size, self.hidden_size, self.output_size = input_size, hidden_size, output_size
+        if variance is None:
+            variance = np.float32(2.0) / np.float32(z.H)
+        orc.orc_set_init_flat(self.z, variance, shape, perforation)
+        orc.orc_set_seed_clones(self.z)
+
+    def close(self):
+        self.orc.orc_set_free(self.z)
+
+    def char_step_deltas(self, text, i):
+        self.orc.orc_set_char_step_deltas(self.z, rc.u8ptr(text), len(text), i)
+
+    def char_step(self, text, i, method=rc.WEIGHTED, momentum=0.95):
+        self.orc.orc_set_char_step(self.z, rc.u8ptr(text), len(text), i, method, momentum)
+
+    def arrays(self):
+        """numpy VIEWS of the oracle's arrays (writable)."""
+        z = self.z.contents
+        S, D, I, H, O = self.S, self.D, self.I, self.H, self.O
+        return {
+            "ih_w": rc.view(z.ih_w, I, H), "ho_w": rc.view(z.ho_w, H, O),
+            "ih_m": rc.view(z.ih_m, I, H), "ho_m": rc.view(z.ho_m, H, O),
+            "ih_aux": rc.view(z.ih_aux, I, H), "ho_aux": rc.view(z.ho_aux, H, O),
+            "ih_delta": rc.view(z.ih_delta, I, H), "ho_delta": rc.view(z.ho_delta, H, O),
+            "hist": rc.view(z.hist, D, S, I), "hidden": rc.view(z.hidden, S, H),
+            "output": rc.view(z.output, S, O), "o_error": rc.view(z.o_error, S, O),
+            "err_a": rc.view(z.err_a, S, I), "err_b": rc.view(z.err_b, S, I),
+            "index": np.ctypeslib.as_array(z.index, shape=(S,)),
+            "min_error_factor": rc.view(z.min_error_factor, S),
+            "learn_rate": rc.view(z.learn_rate, S),
+            "ih_scale": rc.view(z.ih_scale, S),
+            "top_error_raw": rc.view(z.top_error_raw, S),
+            "top_error_scaled": rc.view(z.top_error_scaled, S),
+            "bptt_error": rc.view(z.bptt_error, S),
+            "bptt_depth": np.ctypeslib.as_array(z.bptt_depth, shape=(S,)),
+            "generation": np.ctypeslib.as_array(z.generation, shape=(S,)),
+        }
+
+    def snapshot(self):
+        a = self.arrays()
+        snap = {k: np.array(v, copy=True) for k, v in a.items()}
+        z = self.z.contents
+        rng = np.zeros((self.S, 4), np.uint64)
+        for j in range(self.S):
+            r = z.rng[j]
+            rng[j] = (r.a, r.b, r.c, r.d)
+        snap["rng"] = rng
+        return snap
+
+
+FLOAT_KEYS = ["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hist", "hidden", "output",
+              "o_error", "min_error_factor", "ih_scale"]
+EXACT_KEYS = ["index", "generation", "rng"]
+
+
+def compare(got, want, rtol, keys=FLOAT_KEYS, exact=EXACT_KEYS):
+    """Returns a list of human-readable mismatches (empty == parity)."""
+    bad = []
+    for k in keys:
+        if k in got and k in want:
+            e = rc.rel_err(got[k], want[k])
+            if not e <= rtol:
+                bad.append("%s: rel err %.3g > %.1g" % (k, e, rtol))
+    for k in exact:
+        if k in got and k in want and not np.array_equal(got[k], want[k]):
+            bad.append("%s: not bit-exact" % k)
+    return bad
