@@ -1,0 +1,1102 @@
+// kernels.hip -- CDNA4 (gfx950) kernels of the Recur RNN core and their thin
+// C-ABI launchers (ramd_internal.h).  Written for wave64 / MFMA / LDS directly;
+// there is no other backend.
+//
+// Heavy lifting is three fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32), all with
+// M = "streams of the synchronic mini-batch":
+//   forward   Hpre[S x H] = X[S x I] . W_ih[I x H]              (recur-nn.c:18-48, 117)
+//   chain     E_i[S x I]  = E_h[S x H] . W_ih^T   per BPTT step (recur-nn.c:338-376)
+//   delta     dW[I x H]   = sum_t X_t^T . diag(c_t) . E_h,t      (recur-nn.c:344-356, 738)
+// Each GEMM is split along K over blockIdx.z into fp32 slabs; a small finalize
+// kernel sums the slabs in a fixed order (deterministic) and applies the
+// reference's elementwise rule (activation / zero-row mask + sum of squares /
+// accumulate).  The top layer (O is 4..44 in the text and classify configs) and
+// the per-stream control logic are plain VALU kernels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include "ramd_internal.h"
+
+#define HIP_CHECK(x)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "librecur_amd: HIP error %s at %s:%d\n", hipGetErrorString(e_), \
+              __FILE__, __LINE__);                                                \
+      abort();                                                                    \
+    }                                                                             \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// constants of the algorithm (recur-nn.h:28-47)
+#define INPUT_MEAN_SOFT_TOP_F 16.0f
+#define MAX_TOP_ERROR_FACTOR_F 2.0f
+#define MAX_ERROR_GAIN_F 2.0f
+#define ERROR_GAIN_CEILING_F 1.0f
+#define MIN_ERROR_GAIN_F 1e-8f
+#define MAX_MIN_ERROR_FACTOR_F 1e-2f
+#define ABS_MIN_ERROR_FACTOR_F 1e-20f
+
+// ----------------------------------------------------------------- helpers --
+
+struct View {
+  RamdShape sh;
+  RamdBuffers b;
+};
+
+// input row (history slot or forward-only input row) of state row r, `back`
+// steps into the past (back = 0: the slot rnn_bptt_advance points at)
+__device__ __forceinline__ float *input_row(const View &v, int r, int back) {
+  const RamdShape &s = v.sh;
+  if (r < s.Scap) {
+    int slot = v.b.idx[r] - back;
+    if (slot < 0) slot += s.D;
+    return v.b.arena + ((size_t)slot * s.Scap + r) * s.I;
+  }
+  return v.b.arena + ((size_t)s.D * s.Scap + (r - s.Scap)) * s.I;
+}
+
+// recur-nn-helpers.h:104-113
+__device__ __forceinline__ float soft_clip_dev(float sum, float halfmax) {
+  if (halfmax == 0) return sum;
+  float x = sum / halfmax;
+  float fudge = (float)(0.99 + (double)(x * x) / 100);
+  return 2.0f * x / (1 + x * x * fudge);
+}
+
+// deterministic block-wide sum (fixed tree), blockDim.x == 256
+__device__ __forceinline__ float block_sum_256(float v, float *red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ------------------------------------------------------------ K0: advance --
+
+// rnn_bptt_advance (recur-nn.c:696-704) for a range of training streams
+__global__ void k_advance(View v, int row0, int nrows) {
+  int r = row0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < row0 + nrows && r < v.sh.Scap) {
+    int i = v.b.idx[r] + 1;
+    if (i == v.sh.D) i -= v.sh.D;
+    v.b.idx[r] = i;
+  }
+}
+
+// ----------------------------------------------------------- K4: assemble --
+
+// Builds the input row of each stream: previous hiddens, bias, real inputs
+// (recur-nn.c:104-112) and the emergency soft clip of the whole row
+// (maybe_scale_inputs, recur-nn.c:68-81).  One workgroup per stream.
+__global__ __launch_bounds__(256) void k_assemble(View v, int row0, int mode,
+                                                  const float *dense, int ld, int text_i,
+                                                  int n_set) {
+  __shared__ float red[4];
+  const RamdShape &s = v.sh;
+  int j = blockIdx.x;
+  int r = row0 + j;
+  float *slot = input_row(v, r, 0);
+  const float *hid = v.b.hidden + (size_t)r * s.H;
+  int off = s.hidden_size + 1;
+  int hot = -1;
+  if (mode == RAMD_IN_ONE_HOT) {
+    hot = v.b.hot[r];
+  } else if (mode == RAMD_IN_TEXT) {
+    // charmodel-predict.c:273, 295-298
+    int len = v.b.text_len;
+    int spacing = (len - 1) / n_set;
+    int o = text_i + j * spacing;
+    if (o >= len - 1) o -= len - 1;
+    hot = v.b.text[o];
+    if (threadIdx.x == 0) v.b.target[r] = v.b.text[o + 1];
+  }
+  float sum = 0.0f;
+  for (int i = threadIdx.x; i < s.I; i += 256) {
+    float x;
+    if (i == 0) {
+      x = 1.0f;
+    } else if (i < off) {
+      x = hid[i];
+    } else if (i < off + s.input_size) {
+      int k = i - off;
+      if (mode == RAMD_IN_KEEP) x = slot[i];
+      else if (mode == RAMD_IN_DENSE) x = dense[(size_t)j * ld + k];
+      else x = (k == hot) ? 1.0f : 0.0f;
+    } else {
+      x = slot[i]; /* padding: stays as it is (zero) */
+    }
+    slot[i] = x;
+    sum += x;
+  }
+  sum = block_sum_256(sum, red);
+  float softclip = s.I * INPUT_MEAN_SOFT_TOP_F;
+  if (sum > softclip) {
+    float scale = soft_clip_dev(sum, softclip);
+    for (int i = threadIdx.x; i < s.I; i += 256) slot[i] *= scale;
+  }
+}
+
+// ------------------------------------------------------------- MFMA GEMM --
+//
+// Workgroup = 256 threads = 4 waves in a 2 x 2 grid; wave tile 32 x 32 (one
+// v_mfma_f32_32x32x2_f32 accumulator of 16 VGPRs), workgroup tile 64 x 64,
+// K tile 32.  Operand tiles go global -> registers -> LDS (double buffered, one
+// barrier per K tile).  An operand whose global image is K-contiguous ("KC":
+// rows of A / rows of W) sits in LDS as [row][32 + 4] and a lane fetches the
+// four k it feeds to four consecutive MFMAs with one ds_read_b128 (row stride
+// 36 dwords keeps the 16-lane groups of ds_read_b128 conflict free).  An
+// operand whose global image is K-major ("KM": K rows of contiguous m) sits as
+// [k][64] and is fetched with four conflict-free ds_read_b32.
+//
+// MFMA operand maps (f32 32x32x2): lane l supplies A[m = l & 31][k = l >> 5]
+// and B[k = l >> 5][n = l & 31]; D register g holds row (g & 3) + 8 (g >> 2) +
+// 4 (l >> 5), column l & 31.  Within a group of 8 k, MFMA j uses
+// k = 8 g + 4 (l >> 5) + j on both operands.
+
+constexpr int BM = 64, BN = 64, BK = 32, LDK = BK + 4;
+
+template <bool KM> struct TileLds { float v[KM ? BK * BM : BM * LDK]; };
+
+struct GemmOut {
+  float *slab;   // [KS][M][ldc]
+  int M, N, ldc;
+  int nkt;       // K tiles in total
+};
+
+// Stage one 64-row operand tile: two float4 per thread.
+template <bool KM, class Prob, bool IS_A>
+__device__ __forceinline__ void tile_load(const Prob &p, int kt, int base, float4 (&reg)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    int idx = threadIdx.x + i * 256;
+    if (KM) {
+      int k = idx >> 4, q = idx & 15; /* 16 float4 per k row */
+      reg[i] = IS_A ? p.a_km(kt, k, base + 4 * q) : p.b_km(kt, k, base + 4 * q);
+    } else {
+      int row = idx >> 3, q = idx & 7; /* 8 float4 per row */
+      reg[i] = IS_A ? p.a_kc(kt, base + row, 4 * q) : p.b_kc(kt, base + row, 4 * q);
+    }
+  }
+}
+
+template <bool KM>
+__device__ __forceinline__ void tile_store(float *lds, const float4 (&reg)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    int idx = threadIdx.x + i * 256;
+    if (KM) {
+      int k = idx >> 4, q = idx & 15;
+      *reinterpret_cast<float4 *>(lds + k * BM + 4 * q) = reg[i];
+    } else {
+      int row = idx >> 3, q = idx & 7;
+      *reinterpret_cast<float4 *>(lds + row * LDK + 4 * q) = reg[i];
+    }
+  }
+}
+
+// the 4 values (k = 8 g + 4 kh + 0..3) of row/column `rc` for this lane
+template <bool KM>
+__device__ __forceinline__ float4 frag_read(const float *lds, int rc, int g, int kh) {
+  if (KM) {
+    const float *p = lds + (8 * g + 4 * kh) * BM + rc;
+    return make_float4(p[0], p[BM], p[2 * BM], p[3 * BM]);
+  }
+  return *reinterpret_cast<const float4 *>(lds + rc * LDK + 8 * g + 4 * kh);
+}
+
+template <bool A_KM, bool B_KM, class Prob>
+__global__ __launch_bounds__(256) void k_gemm(Prob p, GemmOut o) {
+  __shared__ __attribute__((aligned(16))) float lds[2][(A_KM ? BK * BM : BM * LDK) +
+                                                       (B_KM ? BK * BN : BN * LDK)];
+  constexpr int A_FLOATS = A_KM ? BK * BM : BM * LDK;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int ks = gridDim.z, z = blockIdx.z;
+  const int kt0 = (int)(((long)o.nkt * z) / ks), kt1 = (int)(((long)o.nkt * (z + 1)) / ks);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lm = lane & 31, kh = lane >> 5;
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+
+  float4 ra[2], rb[2];
+  if (kt0 < kt1) {
+    tile_load<A_KM, Prob, true>(p, kt0, m0, ra);
+    tile_load<B_KM, Prob, false>(p, kt0, n0, rb);
+    tile_store<A_KM>(lds[0], ra);
+    tile_store<B_KM>(lds[0] + A_FLOATS, rb);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; kt++) {
+    const int cur = (kt - kt0) & 1;
+    const bool more = kt + 1 < kt1;
+    if (more) {
+      tile_load<A_KM, Prob, true>(p, kt + 1, m0, ra);
+      tile_load<B_KM, Prob, false>(p, kt + 1, n0, rb);
+    }
+    const float *la = lds[cur], *lb = lds[cur] + A_FLOATS;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      float4 a = frag_read<A_KM>(la, wm * 32 + lm, g, kh);
+      float4 b = frag_read<B_KM>(lb, wn * 32 + lm, g, kh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    if (more) {
+      tile_store<A_KM>(lds[cur ^ 1], ra);
+      tile_store<B_KM>(lds[cur ^ 1] + A_FLOATS, rb);
+    }
+    __syncthreads();
+  }
+  float *c = o.slab + (size_t)z * o.M * o.ldc;
+  const int col = n0 + wn * 32 + lm;
+  if (col < o.N) {
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+      int row = m0 + wm * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
+      if (row < o.M) c[(size_t)row * o.ldc + col] = acc[g];
+    }
+  }
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) {
+  return *reinterpret_cast<const float4 *>(p);
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// zero column 0 and columns > hidden_size of an error row: what the reference
+// does to h_error at the top of every BPTT step (recur-nn.c:334-337)
+__device__ __forceinline__ float4 mask_herr(float4 v, int c, int hs) {
+  if (c == 0) v.x = 0.0f;
+  if (c + 0 > hs) v.x = 0.0f;
+  if (c + 1 > hs) v.y = 0.0f;
+  if (c + 2 > hs) v.z = 0.0f;
+  if (c + 3 > hs) v.w = 0.0f;
+  return v;
+}
+
+// forward: A = input rows (KC), B = W_ih [I][H] (KM)
+struct ProbFwd {
+  View v;
+  int row0, nrows;
+  __device__ float4 a_kc(int kt, int row, int k) const {
+    k += kt * BK;
+    if (row >= nrows || k >= v.sh.I) return zero4();
+    return ld4(input_row(v, row0 + row, 0) + k);
+  }
+  __device__ float4 b_km(int kt, int k, int n) const {
+    k += kt * BK;
+    if (k >= v.sh.I || n >= v.sh.H) return zero4();
+    return ld4(v.b.ih_w + (size_t)k * v.sh.H + n);
+  }
+  __device__ float4 a_km(int, int, int) const { return zero4(); }
+  __device__ float4 b_kc(int, int, int) const { return zero4(); }
+};
+
+// chain step t: A = masked error rows ehi[t] (KC), B = W_ih rows (KC); K = H
+struct ProbChain {
+  View v;
+  int row0, nrows, t;
+  __device__ float4 a_kc(int kt, int row, int k) const {
+    k += kt * BK;
+    if (row >= nrows || k >= v.sh.H) return zero4();
+    const float *e = v.b.ehi + ((size_t)t * v.sh.Scap + row0 + row) * v.sh.I;
+    return mask_herr(ld4(e + k), k, v.sh.hidden_size);
+  }
+  __device__ float4 b_kc(int kt, int n, int k) const {
+    k += kt * BK;
+    if (n >= v.sh.I || k >= v.sh.H) return zero4();
+    return ld4(v.b.ih_w + (size_t)n * v.sh.H + k);
+  }
+  __device__ float4 a_km(int, int, int) const { return zero4(); }
+  __device__ float4 b_km(int, int, int) const { return zero4(); }
+};
+
+// delta: K runs over (step t, stream r) in tiles of 32 streams.
+// A[k][m] = X_t[r][m] (KM), B[k][n] = coef[t][r] * masked ehi[t][r][n] (KM)
+struct ProbDelta {
+  View v;
+  int row0, nrows, rtiles;
+  __device__ float4 a_km(int kt, int k, int m) const {
+    int t = kt / rtiles, r = (kt % rtiles) * BK + k;
+    if (r >= nrows || m >= v.sh.I) return zero4();
+    return ld4(input_row(v, row0 + r, t) + m);
+  }
+  __device__ float4 b_km(int kt, int k, int n) const {
+    int t = kt / rtiles, r = (kt % rtiles) * BK + k;
+    if (r >= nrows || n >= v.sh.H) return zero4();
+    float c = v.b.coef[(size_t)t * v.sh.Scap + row0 + r];
+    if (c == 0.0f) return zero4(); /* select, never multiply: a dead step may hold inf */
+    const float *e = v.b.ehi + ((size_t)t * v.sh.Scap + row0 + r) * v.sh.I;
+    float4 x = mask_herr(ld4(e + n), n, v.sh.hidden_size);
+    x.x *= c; x.y *= c; x.z *= c; x.w *= c;
+    return x;
+  }
+  __device__ float4 a_kc(int, int, int) const { return zero4(); }
+  __device__ float4 b_kc(int, int, int) const { return zero4(); }
+};
+
+// ---------------------------------------------------------- finalize: fwd --
+
+// sums the K slabs, applies the activation (recur-nn.c:123-148) and writes
+// the hidden rows.  Element-wise, float4 per thread.
+__global__ __launch_bounds__(256) void k_fwd_finalize(View v, int row0, int nrows, int ks) {
+  const RamdShape &s = v.sh;
+  int q = blockIdx.x * 256 + threadIdx.x; /* float4 index */
+  int per_row = s.H >> 2;
+  if (q >= nrows * per_row) return;
+  int j = q / per_row, c = (q - j * per_row) * 4;
+  const float *p = v.b.slab + (size_t)j * s.H + c;
+  float4 a = ld4(p);
+  for (int z = 1; z < ks; z++) {
+    float4 t = ld4(p + (size_t)z * nrows * s.H);
+    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+  }
+  float h[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float x = h[i];
+    if (s.activation == 2) { /* RNN_RESQRT */
+      x = (x > 0.0f) ? sqrtf(x + 1.0f) - 1.0f : 0.0f;
+    } else if (s.activation == 5) { /* RNN_RECLIP20 */
+      x = x < 20.0f ? x : 20.0f;
+      x = (x > 0.0f) ? x : 0.0f;
+    } else {
+      x = (x > 0.0f) ? x : 0.0f;
+    }
+    h[i] = x;
+  }
+  if (c == 0) h[0] = 1.0f; /* the bias node, recur-nn.c:148 */
+  *reinterpret_cast<float4 *>(v.b.hidden + (size_t)(row0 + j) * s.H + c) =
+      make_float4(h[0], h[1], h[2], h[3]);
+}
+
+// ------------------------------------------------------- K3: output layer --
+
+// out = hidden . W_ho (recur-nn.c:150-151).  One workgroup per stream; the
+// hidden row sits in LDS; thread (kpart, o) sums a quarter of the rows for one
+// output column, then the four partial sums are added in a fixed order.
+__global__ __launch_bounds__(256) void k_out_layer(View v, int row0) {
+  extern __shared__ float sh[];
+  const RamdShape &s = v.sh;
+  float *hrow = sh;               /* [H] */
+  float *part = sh + s.H;         /* [4][64] */
+  int r = row0 + blockIdx.x;
+  const float *hid = v.b.hidden + (size_t)r * s.H;
+  for (int i = threadIdx.x; i < s.H; i += 256) hrow[i] = hid[i];
+  __syncthreads();
+  int oc = threadIdx.x & 63, kp = threadIdx.x >> 6;
+  int kq = (s.H + 3) / 4;
+  for (int o0 = 0; o0 < s.O; o0 += 64) {
+    int o = o0 + oc;
+    float acc = 0.0f;
+    if (o < s.O) {
+      int k1 = min(s.H, (kp + 1) * kq);
+      for (int k = kp * kq; k < k1; k++) acc += hrow[k] * v.b.ho_w[(size_t)k * s.O + o];
+    }
+    part[kp * 64 + oc] = acc;
+    __syncthreads();
+    if (kp == 0 && o < s.O) {
+      v.b.out[(size_t)r * s.O + o] =
+          (part[oc] + part[64 + oc]) + (part[128 + oc] + part[192 + oc]);
+    }
+    __syncthreads();
+  }
+}
+
+// -------------------------------------------------------- loss on device --
+
+#pragma clang fp contract(off)
+// badmaths.h:14-29, kept operation for operation
+__device__ float fast_expf_dev(float x) {
+  int count = 0;
+  while (fabsf(x) > 0.2) {
+    x *= 0.125;
+    count++;
+  }
+  float a = ((x + 3) * (x + 3) + 3) / ((x - 3) * (x - 3) + 3);
+  while (count) {
+    a *= a;
+    a *= a;
+    a *= a;
+    count--;
+  }
+  return a;
+}
+
+// net_error_bptt's loss (charmodel-predict.c:18-27): softmax (badmaths.h:71-111),
+// best guess and negation (badmaths.h:113-141), +1 on the target; plus the
+// running statistics of the epoch loop (charmodel-predict.c:302-304).  One
+// thread per stream walks its row in the reference's order, so the sums round
+// the same way.
+__global__ void k_softmax_error(View v, int row0, int nrows) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nrows) return;
+  const RamdShape &s = v.sh;
+  int r = row0 + j;
+  const float *src = v.b.out + (size_t)r * s.O;
+  float *err = v.b.o_error + (size_t)r * s.O;
+  int len = s.output_size;
+  float lo = src[0], hi = src[0];
+  for (int i = 1; i < len; i++) {
+    hi = fmaxf(hi, src[i]);
+    lo = fminf(lo, src[i]);
+  }
+  float adj = 0.0f;
+  if (hi > 50.0f) adj = 50.0f - hi;
+  else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+  float sum = 0.0f;
+  for (int i = 0; i < len; i++) {
+    float x = fast_expf_dev(src[i] + adj);
+    sum += x;
+    err[i] = x;
+  }
+  int best_i = 0;
+  float best_e = err[0] / sum;
+  err[0] = -best_e;
+  for (int i = 1; i < len; i++) {
+    float e = err[i] / sum;
+    if (e > best_e) {
+      best_e = e;
+      best_i = i;
+    }
+    err[i] = -e;
+  }
+  int target = v.b.target[r];
+  err[target] += 1.0f;
+  float e = err[target];
+  float l = 1.0f - e;
+  v.b.stat_err[r] += e;
+  v.b.stat_ent[r] += (l < 1e-30f) ? -100.0f : log2f(l); /* charmodel-helpers.h:11-13 */
+  v.b.stat_correct[r] += (best_i == target);
+  v.b.stat_count[r] += 1;
+  const float *hid = v.b.hidden + (size_t)r * s.H;
+  int zeros = 0;
+  for (int i = 0; i < s.H; i++) zeros += (hid[i] == 0.0f);
+  v.b.stat_zero[r] += zeros / (double)s.hidden_size; /* recur-nn.c:438-442 */
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------- K5/K6: top backprop --
+
+// backprop_single_layer / _sparse + softclip_scale (recur-nn.c:156-228,
+// 719-721).  One workgroup per stream.  Writes the (scaled) error both to
+// ehi[0] (what the BPTT chain reads) and leaves err_a for the lazy write-back.
+__global__ __launch_bounds__(256) void k_top_backprop(View v, int row0, const int *ranges,
+                                                      const unsigned char *active) {
+  extern __shared__ float sh[];
+  __shared__ float red[4];
+  const RamdShape &s = v.sh;
+  int j = blockIdx.x, r = row0 + j;
+  if (active && !active[j]) return;
+  float *oerr = sh;          /* [O] */
+  float *herr = sh + s.O;    /* [H] */
+  for (int i = threadIdx.x; i < s.O; i += 256) oerr[i] = v.b.o_error[(size_t)r * s.O + i];
+  __syncthreads();
+  const float *hid = v.b.hidden + (size_t)r * s.H;
+  const float *old = v.b.err_a + (size_t)r * s.I;
+  float sum = 0.0f;
+  for (int y = threadIdx.x; y < s.H; y += 256) {
+    float e;
+    if (y == 0) {
+      e = 0.0f; /* the reference's loop starts at 1; step 1 of the BPTT zeroes it */
+    } else if (hid[y] != 0.0f) {
+      const float *row = v.b.ho_w + (size_t)y * s.O;
+      e = 0.0f;
+      if (ranges) {
+        for (int i = 0; ranges[2 * i] >= 0; i++) {
+          int start = ranges[2 * i] & ~3, len = (ranges[2 * i + 1] + 3) & ~3;
+          for (int x = 0; x < len; x++) e += row[start + x] * oerr[start + x];
+          sum += fabsf(e); /* once per range, e keeps running: recur-nn.c:178-191 */
+        }
+      } else {
+        for (int x = 0; x < s.O; x++) e += row[x] * oerr[x];
+        sum += fabsf(e);
+      }
+    } else {
+      e = ranges ? old[y] : 0.0f; /* sparse path leaves the stale value */
+    }
+    herr[y] = e;
+  }
+  sum = block_sum_256(sum, red);
+  float halfmax = s.H * MAX_TOP_ERROR_FACTOR_F;
+  float scaled = sum, scale = 1.0f;
+  if (sum > halfmax) {
+    scale = soft_clip_dev(sum, halfmax);
+    scaled = scale * sum;
+  }
+  float *dst = v.b.ehi + (size_t)r * s.I; /* step 0 plane */
+  for (int y = threadIdx.x; y < s.H; y += 256) dst[y] = (sum > halfmax) ? herr[y] * scale : herr[y];
+  if (threadIdx.x == 0) {
+    v.b.top_raw[r] = sum;
+    v.b.top_scaled[r] = scaled;
+  }
+}
+
+// single_layer_sgd / _sparse for all streams at once (recur-nn.c:256-301):
+// one thread per element of ho_delta adds the streams in index order, which
+// is the order the reference's j loop accumulates them in.
+__global__ void k_ho_delta(View v, int row0, int nrows, int accumulate, const int *ranges,
+                           const unsigned char *active) {
+  const RamdShape &s = v.sh;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= s.H * s.O) return;
+  int y = e / s.O, x = e - y * s.O;
+  float acc = accumulate ? v.b.ho_delta[e] : 0.0f;
+  bool live = true;
+  if (ranges) {
+    live = false;
+    for (int i = 0; ranges[2 * i] >= 0; i++) {
+      int start = ranges[2 * i] & ~3, len = (ranges[2 * i + 1] + 3) & ~3;
+      if (x >= start && x < start + len) live = true;
+    }
+  }
+  if (live) {
+    for (int j = 0; j < nrows; j++) {
+      if (active && !active[j]) continue;
+      float h = v.b.hidden[(size_t)(row0 + j) * s.H + y];
+      if (h != 0.0f) acc += v.b.o_error[(size_t)(row0 + j) * s.O + x] * h;
+    }
+  }
+  v.b.ho_delta[e] = acc;
+}
+
+// ------------------------------------------------------- finalize: chain --
+
+// Sums the K slabs of one BPTT step and applies the reference's per-row rule
+// (recur-nn.c:338-376): a row of the input vector that is zero (or >= 20 for
+// RECLIP20) gets no error; RESQRT divides by 2 (x + 1); the squares are summed
+// per stream.  One workgroup per stream; the sum is a fixed tree.
+__global__ __launch_bounds__(256) void k_chain_finalize(View v, int row0, int nrows, int t,
+                                                        int ks) {
+  __shared__ float red[4];
+  const RamdShape &s = v.sh;
+  int j = blockIdx.x, r = row0 + j;
+  const float *x = input_row(v, r, t);
+  const float *p = v.b.slab + (size_t)j * s.I;
+  float *dst = v.b.ehi + ((size_t)(t + 1) * s.Scap + r) * s.I;
+  float sq = 0.0f;
+  for (int c = threadIdx.x * 4; c < s.I; c += 1024) {
+    float4 a = ld4(p + c);
+    for (int z = 1; z < ks; z++) {
+      float4 q = ld4(p + (size_t)z * nrows * s.I + c);
+      a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+    }
+    float4 in = ld4(x + c);
+    float e[4] = {a.x, a.y, a.z, a.w};
+    float xi[4] = {in.x, in.y, in.z, in.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      bool on = xi[i] != 0.0f && (s.activation != 5 || xi[i] < 20.0f);
+      float ev = on ? e[i] : 0.0f;
+      if (on && s.activation == 2) ev /= 2 * (xi[i] + 1.0f);
+      e[i] = ev;
+      sq += ev * ev;
+    }
+    *reinterpret_cast<float4 *>(dst + c) = make_float4(e[0], e[1], e[2], e[3]);
+  }
+  sq = block_sum_256(sq, red);
+  if (threadIdx.x == 0) v.b.esum[(size_t)t * s.Scap + r] = sq;
+}
+
+// ----------------------------------------------------- K9: BPTT control --
+
+// The data-dependent part of bptt_and_accumulate_error (recur-nn.c:317-330,
+// 383-413), one thread per stream: walks the per-step error sums, finds the
+// step at which the reference's loop would have stopped, derives ih_scale and
+// the adaptive min_error_factor, and publishes coef[t][r] = ih_scale while the
+// step counts, 0 afterwards.
+__global__ void k_bptt_control(View v, int row0, int nrows, const unsigned char *active,
+                               unsigned flags) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nrows) return;
+  const RamdShape &s = v.sh;
+  int r = row0 + j;
+  const int D = s.D;
+  if (active && !active[j]) {
+    for (int k = 0; k < D; k++) v.b.coef[(size_t)k * s.Scap + r] = 0.0f;
+    return;
+  }
+  float top = v.b.top_scaled[r];
+  float max_error_sum = MAX_ERROR_GAIN_F * top + 1;
+  float error_sum_ceiling = ERROR_GAIN_CEILING_F * top;
+  float min_error_gain = MIN_ERROR_GAIN_F * top;
+  float mef = v.b.mef[r];
+  /* MIN(a, b) of the reference is (a < b) ? a : b: keep NaN behaviour aligned */
+  float mef_rate = mef / v.b.lr[r];
+  float min_error_sum = (mef_rate < min_error_gain) ? mef_rate : min_error_gain;
+  float error_sum = 0.0f;
+  int t = D, n_exec = 0;
+  for (int k = 0; k < D; k++) {
+    error_sum = v.b.esum[(size_t)k * s.Scap + r];
+    n_exec = k + 1;
+    if (error_sum <= min_error_sum || error_sum > max_error_sum) {
+      t = D - k;
+      break;
+    }
+    t = D - k - 1;
+  }
+  float scale;
+  if (error_sum > error_sum_ceiling) {
+    scale = soft_clip_dev(error_sum, max_error_sum);
+  } else {
+    scale = 1.0f;
+    if (flags & 64u) { /* RNN_NET_FLAG_BPTT_ADAPTIVE_MIN_ERROR */
+      int depth_error = D / 4 - t;
+      if (mef < MAX_MIN_ERROR_FACTOR_F && (min_error_gain != min_error_sum || depth_error < 0)) {
+        mef *= (float)(1.0f + depth_error * 1e-3);
+      }
+      mef = (mef >= ABS_MIN_ERROR_FACTOR_F) ? mef : ABS_MIN_ERROR_FACTOR_F;
+    }
+  }
+  v.b.mef[r] = mef;
+  v.b.ih_scale[r] = scale;
+  v.b.bptt_err[r] = error_sum;
+  v.b.n_exec[r] = n_exec;
+  v.b.depth_log[r] = D - t;
+  v.b.stat_depth[r] += (double)(D - t);
+  for (int k = 0; k < D; k++) v.b.coef[(size_t)k * s.Scap + r] = (k < n_exec) ? scale : 0.0f;
+}
+
+// ------------------------------------------------------- finalize: delta --
+
+// ih_delta (+)= sum of the K slabs (recur-nn.c:735-748 folded: the per-stream
+// ih_scale already multiplies the error rows that went into the GEMM)
+__global__ __launch_bounds__(256) void k_delta_finalize(float *delta, const float *slab,
+                                                        size_t n4, size_t n, int ks,
+                                                        int accumulate) {
+  size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= n4) return;
+  float4 a = accumulate ? ld4(delta + 4 * q) : zero4();
+  for (int z = 0; z < ks; z++) {
+    float4 t = ld4(slab + (size_t)z * n + 4 * q);
+    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+  }
+  *reinterpret_cast<float4 *>(delta + 4 * q) = a;
+}
+
+// Rebuilds bptt->h_error (err_a) and bptt->i_error (err_b) as the reference
+// leaves them: the loop ping-pongs between the two buffers (recur-nn.c:384-386),
+// zeroing element 0 and the pad of whichever one it reads (334-337).
+__global__ __launch_bounds__(256) void k_err_writeback(View v, int row0) {
+  const RamdShape &s = v.sh;
+  int r = row0 + blockIdx.x;
+  int n = v.b.n_exec[r];
+  if (n <= 0) return;
+  float *A = v.b.err_a + (size_t)r * s.I, *B = v.b.err_b + (size_t)r * s.I;
+  float *last_written = (n & 1) ? B : A; /* step n wrote it in full        */
+  float *last_read = (n & 1) ? A : B;    /* step n read it (and zeroed bits) */
+  const float *en = v.b.ehi + ((size_t)n * s.Scap + r) * s.I;
+  const float *ep = v.b.ehi + ((size_t)(n - 1) * s.Scap + r) * s.I;
+  int lim = (n == 1) ? s.H : s.I; /* the top error only covers h_size entries */
+  for (int i = threadIdx.x; i < s.I; i += 256) {
+    last_written[i] = en[i];
+    if (i < lim) {
+      float x = ep[i];
+      if (i == 0 || (i > s.hidden_size && i < s.H)) x = 0.0f;
+      last_read[i] = x;
+    }
+  }
+}
+
+// --------------------------------------------------------- K11: optimiser --
+
+// The seven update rules of rnn_apply_learning (recur-nn.c:454-593) as one
+// float4-wide elementwise kernel.  `rs` optionally points at a device float
+// that multiplies the rate (ih_scale of the fused single-net path).
+template <int METHOD>
+__global__ __launch_bounds__(256) void k_apply(float *w, const float *delta, float *m, float *aux,
+                                               size_t n4, float rate, float momentum, float mw,
+                                               const float *rs) {
+  size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= n4) return;
+  if (rs) rate *= *rs;
+  float4 W = ld4(w + 4 * q), Dl = ld4(delta + 4 * q), M = ld4(m + 4 * q);
+  float4 A = (METHOD == 5 || METHOD == 6) ? ld4(aux + 4 * q) : zero4();
+  float wv[4] = {W.x, W.y, W.z, W.w}, dv[4] = {Dl.x, Dl.y, Dl.z, Dl.w};
+  float mv[4] = {M.x, M.y, M.z, M.w}, av[4] = {A.x, A.y, A.z, A.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (METHOD == 0) { /* weighted / simplified nesterov / classical: 482-487 */
+      float t = dv[i] * rate;
+      float mm = mv[i];
+      wv[i] += t + mm * mw;
+      mv[i] = (mm + t) * momentum;
+    } else if (METHOD == 1) { /* nesterov: 501-508 */
+      float t = dv[i] * rate;
+      wv[i] += t;
+      float mm = (mv[i] + t) * momentum;
+      mv[i] = mm;
+      wv[i] += mm;
+    } else if (METHOD == 4) { /* adagrad: 518-524 */
+      float d = dv[i];
+      float a = mv[i] + d * d;
+      wv[i] += d * rate / sqrtf(a);
+      mv[i] = a;
+    } else if (METHOD == 5) { /* adadelta, abs-value branch: 537-557 */
+      const float renewal = 1.0f - momentum;
+      float d = dv[i];
+      float g = mv[i] * momentum;
+      float s = av[i] * momentum;
+      g += fabsf(d) * renewal + rate;
+      float step = s / g * d;
+      s += fabsf(step) * renewal + rate;
+      mv[i] = g;
+      av[i] = s;
+      wv[i] += step;
+    } else if (METHOD == 6) { /* rprop: 568-592 */
+      const float max_step = 1 * rate;
+      const float min_step = (float)(1e-6 * (double)rate);
+      float d = dv[i], p = mv[i], step = av[i];
+      if (d * p > 0.0f) {
+        float g = step * 1.2f;
+        step = (g < max_step) ? g : max_step;
+      } else if (d * p < 0.0f) {
+        float g = step * 0.5f;
+        step = (g >= min_step) ? g : min_step;
+        d = 0;
+      }
+      if (d > 0.0f) wv[i] += step;
+      else wv[i] -= step;
+      av[i] = step;
+      mv[i] = d;
+    }
+  }
+  *reinterpret_cast<float4 *>(w + 4 * q) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+  *reinterpret_cast<float4 *>(m + 4 * q) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+  if (METHOD == 5 || METHOD == 6)
+    *reinterpret_cast<float4 *>(aux + 4 * q) = make_float4(av[0], av[1], av[2], av[3]);
+}
+
+// apply_sgd_top_layer's immediate update for one stream (recur-nn.c:941-964)
+__global__ void k_top_apply_now(View v, int row, float rate, float momentum, float mw) {
+  const RamdShape &s = v.sh;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= s.H * s.O) return;
+  int y = e / s.O, x = e - y * s.O;
+  float h = v.b.hidden[(size_t)row * s.H + y];
+  float mm = v.b.ho_m[e];
+  if (h != 0.0f) {
+    float d = v.b.o_error[(size_t)row * s.O + x] * (h * rate);
+    v.b.ho_w[e] += d + mm * mw;
+    mm += d;
+    v.b.ho_m[e] = mm * momentum;
+  } else {
+    v.b.ho_w[e] += mm * mw;
+    v.b.ho_m[e] = mm * momentum;
+  }
+}
+
+// -------------------------------------------------------- K12: conditioning --
+
+__global__ void k_scale(float *a, size_t n, float scale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] *= scale;
+}
+__global__ void k_zero_small(float *a, size_t n) { /* recur-nn-helpers.h:126-133 */
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = (fabsf(a[i]) > 1e-34f) ? a[i] : 0.0f;
+}
+__global__ void k_clamp(float *a, size_t n, float lo, float hi) { /* recur-nn.c:848-851 */
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    float x = a[i];
+    x = (x >= lo) ? x : lo;
+    x = (x < hi) ? x : hi;
+    a[i] = x;
+  }
+}
+__global__ void k_add_at(float *a, size_t index, float v) { a[index] += v; }
+
+// arg-max of |a| with the reference's tie rule (first index wins,
+// recur-nn.c:830-838): each block publishes its best (value, index), block 0
+// of a second launch reduces them.
+struct BestAbs {
+  float v;
+  unsigned long long i;
+};
+__global__ __launch_bounds__(256) void k_absmax_part(const float *a, size_t n, BestAbs *part) {
+  __shared__ BestAbs sh[256];
+  size_t chunk = (n + gridDim.x - 1) / gridDim.x;
+  size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  BestAbs b = {-1.0f, 0};
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+    float x = fabsf(a[i]);
+    if (x > b.v) { b.v = x; b.i = i; }
+  }
+  sh[threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      BestAbs o = sh[threadIdx.x + off], m = sh[threadIdx.x];
+      if (o.v > m.v || (o.v == m.v && o.i < m.i)) sh[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ void k_tall_poppy(float *a, const BestAbs *part, int nparts, float threshold,
+                             float scale) {
+  BestAbs b = part[0];
+  for (int i = 1; i < nparts; i++) {
+    BestAbs o = part[i];
+    if (o.v > b.v || (o.v == b.v && o.i < b.i)) b = o;
+  }
+  if (b.v > threshold) a[b.i] *= scale;
+}
+
+__global__ void k_zero_f4(float *a, size_t n4) {
+  size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n4) *reinterpret_cast<float4 *>(a + 4 * q) = zero4();
+}
+
+// ================================================================ launchers ==
+
+static inline View make_view(const RamdShape *sh, const RamdBuffers *b) {
+  View v;
+  v.sh = *sh;
+  v.b = *b;
+  return v;
+}
+
+// ---- HIP-event timing of the GEMM classes (bench.py's roofline leg) ----
+enum { T_CHAIN = 0, T_DELTA = 1, T_FWD = 2, T_APPLY = 3, T_CLASSES = 4 };
+static int g_timing = 0;
+struct TimedLaunch {
+  hipEvent_t a, b;
+  int cls;
+};
+static TimedLaunch g_ev[8192];
+static int g_nev = 0;
+static double g_ms[T_CLASSES];
+static long g_launches[T_CLASSES];
+
+static inline int timing_begin(hipStream_t st, int cls) {
+  if (!g_timing || g_nev >= 8192) return -1;
+  int i = g_nev++;
+  HIP_CHECK(hipEventCreate(&g_ev[i].a));
+  HIP_CHECK(hipEventCreate(&g_ev[i].b));
+  g_ev[i].cls = cls;
+  HIP_CHECK(hipEventRecord(g_ev[i].a, st));
+  return i;
+}
+static inline void timing_end(hipStream_t st, int i) {
+  if (i >= 0) HIP_CHECK(hipEventRecord(g_ev[i].b, st));
+}
+static void timing_collect() {
+  for (int i = 0; i < g_nev; i++) {
+    float ms = 0;
+    HIP_CHECK(hipEventSynchronize(g_ev[i].b));
+    HIP_CHECK(hipEventElapsedTime(&ms, g_ev[i].a, g_ev[i].b));
+    g_ms[g_ev[i].cls] += ms;
+    g_launches[g_ev[i].cls]++;
+    hipEventDestroy(g_ev[i].a);
+    hipEventDestroy(g_ev[i].b);
+  }
+  g_nev = 0;
+}
+extern "C" void ramd_timing_enable(int enable) { g_timing = enable; }
+extern "C" double ramd_timing_ms(int which, long *launches, int reset) {
+  timing_collect();
+  double ms = g_ms[which];
+  if (launches) *launches = g_launches[which];
+  if (reset) {
+    for (int c = 0; c < T_CLASSES; c++) {
+      g_ms[c] = 0;
+      g_launches[c] = 0;
+    }
+  }
+  return ms;
+}
+
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
+// Split-K factor: enough workgroups to give every CU several, without
+// shredding K into single tiles.
+static int pick_ks(int tiles, int nkt, const char *env, size_t slab_floats, size_t out_floats) {
+  int forced = env_int(env, 0);
+  int ks;
+  if (forced > 0) {
+    ks = forced;
+  } else {
+    const int cus = 256;
+    double best = 1e30;
+    ks = 1;
+    for (int k = 1; k <= 16 && k <= nkt; k++) {
+      long wgs = (long)tiles * k;
+      double rounds = (double)((wgs + cus - 1) / cus);       /* CU-rounds of workgroups */
+      double cost = rounds * ((double)nkt / k + 1.5);        /* +1.5 tiles of fill/drain */
+      if (cost < best * 0.97) {
+        best = cost;
+        ks = k;
+      }
+    }
+  }
+  if (ks > nkt) ks = nkt;
+  if (ks < 1) ks = 1;
+  while (ks > 1 && (size_t)ks * out_floats > slab_floats) ks--;
+  return ks;
+}
+
+extern "C" void ramd_launch_advance(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
+                                    int row0, int nrows) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  hipLaunchKernelGGL(k_advance, dim3((nrows + 255) / 256), dim3(256), 0, st, v, row0, nrows);
+}
+
+extern "C" void ramd_launch_assemble(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
+                                     int row0, int nrows, int mode, const float *dense, int ld,
+                                     int text_i, int n_set) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  hipLaunchKernelGGL(k_assemble, dim3(nrows), dim3(256), 0, st, v, row0, mode, dense, ld, text_i,
+                     n_set);
+}
+
+extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
+                                    int row0, int nrows) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  int tm = (nrows + BM - 1) / BM, tn = (sh->H + BN - 1) / BN;
+  int nkt = (sh->I + BK - 1) / BK;
+  int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_FWD", b->slab_floats, (size_t)nrows * sh->H);
+  ProbFwd p = {v, row0, nrows};
+  GemmOut o = {b->slab, nrows, sh->H, sh->H, nkt};
+  int ev = timing_begin(st, T_FWD);
+  hipLaunchKernelGGL((k_gemm<false, true, ProbFwd>), dim3(tn, tm, ks), dim3(256), 0, st, p, o);
+  timing_end(st, ev);
+  int n4 = nrows * (sh->H / 4);
+  hipLaunchKernelGGL(k_fwd_finalize, dim3((n4 + 255) / 256), dim3(256), 0, st, v, row0, nrows, ks);
+  size_t shm = (size_t)(sh->H + 256) * sizeof(float);
+  hipLaunchKernelGGL(k_out_layer, dim3(nrows), dim3(256), shm, st, v, row0);
+}
+
+extern "C" void ramd_launch_softmax_error(ramd_stream_t st_, const RamdShape *sh,
+                                          const RamdBuffers *b, int row0, int nrows) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  hipLaunchKernelGGL(k_softmax_error, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows);
+}
+
+extern "C" void ramd_launch_clear_deltas(ramd_stream_t st_, const RamdShape *sh,
+                                         const RamdBuffers *b) {
+  hipStream_t st = (hipStream_t)st_;
+  size_t ih4 = (size_t)sh->I * sh->H / 4, ho4 = (size_t)sh->H * sh->O / 4;
+  hipLaunchKernelGGL(k_zero_f4, dim3((unsigned)((ih4 + 255) / 256)), dim3(256), 0, st, b->ih_delta, ih4);
+  hipLaunchKernelGGL(k_zero_f4, dim3((unsigned)((ho4 + 255) / 256)), dim3(256), 0, st, b->ho_delta, ho4);
+}
+
+extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
+                                        const RamdBuffers *b, int row0, int nrows, int accumulate,
+                                        const int *ranges, const unsigned char *active,
+                                        unsigned flags) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  // top layer
+  size_t shm = (size_t)(sh->O + sh->H) * sizeof(float);
+  hipLaunchKernelGGL(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges, active);
+  if (!(flags & 0x80000000u)) { /* the fused single-net path updates W_ho directly */
+    int ho = sh->H * sh->O;
+    hipLaunchKernelGGL(k_ho_delta, dim3((ho + 255) / 256), dim3(256), 0, st, v, row0, nrows,
+                       accumulate, ranges, active);
+  }
+  // BPTT chain: D dependent steps
+  {
+    int tm = (nrows + BM - 1) / BM, tn = (sh->I + BN - 1) / BN;
+    int nkt = (sh->H + BK - 1) / BK;
+    int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_CHAIN", b->slab_floats, (size_t)nrows * sh->I);
+    GemmOut o = {b->slab, nrows, sh->I, sh->I, nkt};
+    for (int t = 0; t < sh->D; t++) {
+      ProbChain p = {v, row0, nrows, t};
+      int ev = timing_begin(st, T_CHAIN);
+      hipLaunchKernelGGL((k_gemm<false, false, ProbChain>), dim3(tn, tm, ks), dim3(256), 0, st, p, o);
+      timing_end(st, ev);
+      hipLaunchKernelGGL(k_chain_finalize, dim3(nrows), dim3(256), 0, st, v, row0, nrows, t, ks);
+    }
+  }
+  hipLaunchKernelGGL(k_bptt_control, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows,
+                     active, flags);
+  // weight deltas: one GEMM over (step, stream)
+  {
+    int tm = (sh->I + BM - 1) / BM, tn = (sh->H + BN - 1) / BN;
+    int rtiles = (nrows + BK - 1) / BK;
+    int nkt = sh->D * rtiles;
+    size_t n = (size_t)sh->I * sh->H;
+    int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_DELTA", b->slab_floats, n);
+    ProbDelta p = {v, row0, nrows, rtiles};
+    GemmOut o = {b->slab, sh->I, sh->H, sh->H, nkt};
+    int ev = timing_begin(st, T_DELTA);
+    hipLaunchKernelGGL((k_gemm<true, true, ProbDelta>), dim3(tn, tm, ks), dim3(256), 0, st, p, o);
+    timing_end(st, ev);
+    size_t n4 = n / 4;
+    hipLaunchKernelGGL(k_delta_finalize, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                       b->ih_delta, b->slab, n4, n, ks, accumulate);
+  }
+}
+
+extern "C" void ramd_launch_err_writeback(ramd_stream_t st_, const RamdShape *sh,
+                                          const RamdBuffers *b, int row0, int nrows) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  hipLaunchKernelGGL(k_err_writeback, dim3(nrows), dim3(256), 0, st, v, row0);
+}
+
+extern "C" void ramd_launch_apply(ramd_stream_t st_, int method, float *w, const float *delta,
+                                  float *m, float *aux, size_t n, float rate, float momentum,
+                                  float mw, const float *rs) {
+  hipStream_t st = (hipStream_t)st_;
+  size_t n4 = n / 4;
+  dim3 g((unsigned)((n4 + 255) / 256)), bl(256);
+  int ev = timing_begin(st, T_APPLY);
+  switch (method) {
+  case 1: hipLaunchKernelGGL(k_apply<1>, g, bl, 0, st, w, delta, m, aux, n4, rate, momentum, mw, rs); break;
+  case 4: hipLaunchKernelGGL(k_apply<4>, g, bl, 0, st, w, delta, m, aux, n4, rate, momentum, mw, rs); break;
+  case 5: hipLaunchKernelGGL(k_apply<5>, g, bl, 0, st, w, delta, m, aux, n4, rate, momentum, mw, rs); break;
+  case 6: hipLaunchKernelGGL(k_apply<6>, g, bl, 0, st, w, delta, m, aux, n4, rate, momentum, mw, rs); break;
+  default: hipLaunchKernelGGL(k_apply<0>, g, bl, 0, st, w, delta, m, aux, n4, rate, momentum, mw, rs); break;
+  }
+  timing_end(st, ev);
+}
+
+extern "C" void ramd_launch_top_apply_now(ramd_stream_t st_, const RamdShape *sh,
+                                          const RamdBuffers *b, int row, float rate,
+                                          float momentum, float mw) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  int ho = sh->H * sh->O;
+  hipLaunchKernelGGL(k_top_apply_now, dim3((ho + 255) / 256), dim3(256), 0, st, v, row, rate,
+                     momentum, mw);
+}
+
+extern "C" void ramd_launch_scale(ramd_stream_t st, float *a, size_t n, float scale) {
+  hipLaunchKernelGGL(k_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)st, a, n, scale);
+}
+extern "C" void ramd_launch_zero_small(ramd_stream_t st, float *a, size_t n) {
+  hipLaunchKernelGGL(k_zero_small, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)st, a, n);
+}
+extern "C" void ramd_launch_clamp(ramd_stream_t st, float *a, size_t n, float lo, float hi) {
+  hipLaunchKernelGGL(k_clamp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)st, a, n, lo, hi);
+}
+extern "C" void ramd_launch_add_at(ramd_stream_t st, float *a, size_t index, float v) {
+  hipLaunchKernelGGL(k_add_at, dim3(1), dim3(1), 0, (hipStream_t)st, a, index, v);
+}
+extern "C" void ramd_launch_tall_poppy(ramd_stream_t st, float *a, size_t n, float threshold,
+                                       float scale, void *scratch) {
+  const int parts = 256; /* scratch holds 256 BestAbs */
+  hipLaunchKernelGGL(k_absmax_part, dim3(parts), dim3(256), 0, (hipStream_t)st, a, n, (BestAbs *)scratch);
+  hipLaunchKernelGGL(k_tall_poppy, dim3(1), dim3(1), 0, (hipStream_t)st, a, (const BestAbs *)scratch, parts,
+                     threshold, scale);
+}

@@ -1,0 +1,115 @@
+/* ramd_internal.h -- private interface between the gnu11 C host code
+ * (rnn_core.c, rnn_init.c, rnn_io.c) and the HIP kernels (kernels.hip).
+ *
+ * The HIP side is a thin shim: every ramd_launch_* function enqueues one
+ * kernel (or a fixed short sequence) on the given stream and returns.  All
+ * policy -- what lives where, when to copy, the order of launches -- is in the
+ * C code.
+ */
+#ifndef RAMD_INTERNAL_H
+#define RAMD_INTERNAL_H 1
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Shape of one engine: a set of weights and the streams that share it. */
+typedef struct RamdShape {
+  int input_size, hidden_size, output_size;
+  int I, H, O;    /* padded sizes (multiples of 4), recur-nn-init.c:87-91 */
+  int D;          /* BPTT ring depth                                      */
+  int Scap;       /* capacity in training streams: row stride of a slot    */
+  int Fcap;       /* capacity in forward-only streams                      */
+  int activation; /* rnn_activation                                        */
+} RamdShape;
+
+/* Device arrays.  "state row" r addresses hidden/out: r < Scap is training
+ * stream r, r >= Scap is forward-only stream r - Scap.
+ *
+ * HBM layout (all fp32, row major):
+ *   arena   [D][Scap][I] history ring, slot major, then [Fcap][I] input rows
+ *           of the forward-only streams
+ *   ehi     [D+1][Scap][I] back-propagated error per BPTT step: row 0 is the
+ *           (soft-clipped) top-layer error, row t+1 the input error of step t
+ *   esum    [D][Scap]  sum of squares of each step's input error
+ *   coef    [D][Scap]  ih_scale of the stream while the step was executed, else 0
+ */
+typedef struct RamdBuffers {
+  float *ih_w, *ho_w, *ih_m, *ho_m, *ih_aux, *ho_aux, *ih_delta, *ho_delta;
+  float *arena, *hidden, *out, *o_error, *err_a, *err_b, *ehi, *esum, *coef;
+  float *slab;
+  size_t slab_floats;
+  int *idx;       /* [Scap] ring position                           */
+  float *lr;      /* [Scap] each stream's own learn_rate copy        */
+  float *mef;     /* [Scap] min_error_factor                         */
+  float *ih_scale, *top_raw, *top_scaled, *bptt_err; /* [Scap]       */
+  int *n_exec;    /* [Scap] executed BPTT steps                      */
+  int *depth_log; /* [Scap] "depth - t" as the reference logs it     */
+  int *target;    /* [Scap] class the loss kernel scores against     */
+  int *hot;       /* [Scap+Fcap] one-hot input index scratch         */
+  unsigned char *active; /* [Scap] scratch for the active mask       */
+  /* per-stream loss statistics (single writer per entry: deterministic) */
+  double *stat_err, *stat_ent, *stat_zero, *stat_depth; /* [Scap]    */
+  long long *stat_correct, *stat_count;                 /* [Scap]    */
+  unsigned char *text;   /* encoded text for the host-free epoch loop */
+  int text_len;
+} RamdBuffers;
+
+enum { RAMD_IN_KEEP = 0, RAMD_IN_ONE_HOT = 1, RAMD_IN_DENSE = 2, RAMD_IN_TEXT = 3 };
+
+typedef void *ramd_stream_t;
+
+/* ---- forward ---- */
+void ramd_launch_advance(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
+                         int row0, int nrows);
+/* builds the input rows (recur-nn.c:104-115 + 68-81).  mode selects where the
+ * real inputs come from; dense is a device pointer with leading dimension ld;
+ * text_i is the text position for RAMD_IN_TEXT (also fills b->target). */
+void ramd_launch_assemble(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
+                          int row0, int nrows, int mode, const float *dense, int ld,
+                          int text_i, int n_set);
+/* hidden = act(X . W_ih), out = hidden . W_ho (recur-nn.c:117-151) */
+void ramd_launch_forward(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
+                         int row0, int nrows);
+/* o_error = onehot(target) - softmax(out) and statistics
+ * (charmodel-predict.c:18-27, 299-304) */
+void ramd_launch_softmax_error(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
+                               int row0, int nrows);
+
+/* ---- backward ---- */
+/* ranges: device array of (start,len) pairs ending with start < 0, or NULL;
+ * active: device mask per row or NULL.  accumulate == 0 zeroes the deltas
+ * first.  This is rnn_bptt_calc_deltas (recur-nn.c:707-772) for the rows. */
+void ramd_launch_calc_deltas(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
+                             int row0, int nrows, int accumulate, const int *ranges,
+                             const unsigned char *active, unsigned flags);
+/* rebuilds err_a / err_b (bptt->h_error, i_error) from ehi after a calc_deltas */
+void ramd_launch_err_writeback(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
+                               int row0, int nrows);
+void ramd_launch_clear_deltas(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b);
+
+/* ---- optimiser (recur-nn.c:454-678): one array at a time ---- */
+void ramd_launch_apply(ramd_stream_t st, int method, float *w, const float *delta, float *m,
+                       float *aux, size_t n, float rate, float momentum,
+                       float momentum_weight, const float *rate_scale_dev);
+/* conditioning pieces (recur-nn.c:782-855) */
+void ramd_launch_scale(ramd_stream_t st, float *a, size_t n, float scale);
+void ramd_launch_zero_small(ramd_stream_t st, float *a, size_t n);
+void ramd_launch_clamp(ramd_stream_t st, float *a, size_t n, float lo, float hi);
+void ramd_launch_tall_poppy(ramd_stream_t st, float *a, size_t n, float threshold,
+                            float scale, void *scratch);
+void ramd_launch_add_at(ramd_stream_t st, float *a, size_t index, float v);
+/* the immediate top-layer update of rnn_bptt_calculate (recur-nn.c:941-964) */
+void ramd_launch_top_apply_now(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
+                               int row, float rate, float momentum, float momentum_weight);
+
+/* ---- timing hooks ---- */
+void ramd_timing_enable(int enable);
+double ramd_timing_ms(int which, long *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

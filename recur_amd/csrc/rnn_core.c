@@ -1,0 +1,1450 @@
+/* rnn_core.c -- host side of the RNN core (gnu11 C).
+ *
+ * Implements the reference's RecurNN API (recur-nn.h:269-334; behaviour of
+ * recur-nn.c and recur-nn-init.c) on top of the HIP kernels in kernels.hip.
+ * The structs the caller sees are host memory, as the ABI demands; the device
+ * holds the authoritative copy of anything that has been computed on, and this
+ * file is the coherence protocol between the two plus the order of launches.
+ *
+ * There is no CPU implementation of the arithmetic here: without a HIP device
+ * every compute entry point aborts (ramd_require_device).
+ */
+#include "rnn_host.h"
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#define HIP_OK(x)                                                                  \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      fprintf(stderr, "librecur_amd: HIP error \"%s\" at %s:%d\n", hipGetErrorString(e_), \
+              __FILE__, __LINE__);                                                 \
+      abort();                                                                     \
+    }                                                                              \
+  } while (0)
+
+static int g_device = -1;      /* -1: not initialised */
+static int g_device_count = -1;
+static hipStream_t g_stream = NULL;
+static RamdEngine *g_engines = NULL;
+
+/* ------------------------------------------------------------------ device -- */
+
+int rnn_amd_device_count(void) {
+  if (g_device_count < 0) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+      n = 0;
+    }
+    g_device_count = n;
+  }
+  return g_device_count;
+}
+
+void ramd_require_device(const char *what) {
+  if (rnn_amd_device_count() <= 0) {
+    fprintf(stderr,
+            "librecur_amd: %s needs a HIP device (gfx950) and none is visible; "
+            "this library has no CPU fallback\n",
+            what);
+    abort();
+  }
+  if (g_device < 0) {
+    int dev = 0;
+    const char *lr = getenv("LOCAL_RANK");
+    if (lr && *lr) {
+      dev = atoi(lr) % rnn_amd_device_count();
+    }
+    HIP_OK(hipSetDevice(dev));
+    g_device = dev;
+  }
+}
+
+void rnn_amd_use_device(int device, void *hip_stream) {
+  if (rnn_amd_device_count() <= 0) {
+    ramd_require_device("rnn_amd_use_device");
+  }
+  HIP_OK(hipSetDevice(device));
+  g_device = device;
+  g_stream = (hipStream_t)hip_stream;
+}
+
+void *rnn_amd_current_stream(void) { return (void *)g_stream; }
+const char *rnn_amd_version(void) { return "recur_amd 0.1 (gfx950, fp32 MFMA)"; }
+void rnn_amd_synchronize(void) {
+  if (g_device >= 0) {
+    HIP_OK(hipStreamSynchronize(g_stream));
+  }
+}
+void rnn_amd_kernel_time_enable(int enable) { ramd_timing_enable(enable); }
+double rnn_amd_kernel_time_ms(int which, long *launches, int reset) {
+  return ramd_timing_ms(which, launches, reset);
+}
+
+static void *dev_alloc(size_t bytes) {
+  void *p = NULL;
+  if (bytes == 0) {
+    bytes = 16;
+  }
+  HIP_OK(hipMalloc(&p, bytes));
+  HIP_OK(hipMemsetAsync(p, 0, bytes, g_stream));
+  return p;
+}
+static void dev_free(void *p) {
+  if (p) {
+    HIP_OK(hipFree(p));
+  }
+}
+static void h2d(void *d, const void *h, size_t bytes) {
+  if (bytes) {
+    HIP_OK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, g_stream));
+  }
+}
+static void d2h(void *h, const void *d, size_t bytes) {
+  if (bytes) {
+    HIP_OK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, g_stream));
+  }
+}
+static void dsync(void) { HIP_OK(hipStreamSynchronize(g_stream)); }
+
+void *ramd_zalloc(size_t bytes) {
+  void *p = NULL;
+  if (posix_memalign(&p, 64, bytes ? bytes : 64)) {
+    fprintf(stderr, "librecur_amd: cannot allocate %zu bytes\n", bytes);
+    abort(); /* recur-common.h:95-132: allocation failure aborts */
+  }
+  memset(p, 0, bytes ? bytes : 64);
+  return p;
+}
+
+/* ----------------------------------------------------------------- engines -- */
+
+static RamdEngine *engine_new(RecurNN *owner) {
+  RamdEngine *e = ramd_zalloc(sizeof(RamdEngine));
+  e->owner = owner;
+  e->sh.input_size = owner->input_size;
+  e->sh.hidden_size = owner->hidden_size;
+  e->sh.output_size = owner->output_size;
+  e->sh.I = owner->i_size;
+  e->sh.H = owner->h_size;
+  e->sh.O = owner->o_size;
+  e->sh.activation = owner->activation;
+  e->ih_size = (size_t)owner->ih_size;
+  e->ho_size = (size_t)owner->ho_size;
+  e->host_valid = RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS;
+  e->next = g_engines;
+  g_engines = e;
+  return e;
+}
+
+static void engine_free_device(RamdEngine *e) {
+  if (!e->dev_ready) {
+    return;
+  }
+  RamdBuffers *b = &e->b;
+  dev_free(b->ih_w); dev_free(b->ho_w); dev_free(b->ih_m); dev_free(b->ho_m);
+  dev_free(b->ih_aux); dev_free(b->ho_aux); dev_free(e->delta_own);
+  dev_free(b->arena); dev_free(b->hidden); dev_free(b->out); dev_free(b->o_error);
+  dev_free(b->err_a); dev_free(b->err_b); dev_free(b->ehi); dev_free(b->esum);
+  dev_free(b->coef); dev_free(b->slab); dev_free(b->idx); dev_free(b->lr); dev_free(b->mef);
+  dev_free(b->ih_scale); dev_free(b->top_raw); dev_free(b->top_scaled); dev_free(b->bptt_err);
+  dev_free(b->n_exec); dev_free(b->depth_log); dev_free(b->target); dev_free(b->hot);
+  dev_free(b->active); dev_free(b->stat_err); dev_free(b->stat_ent); dev_free(b->stat_zero);
+  dev_free(b->stat_depth); dev_free(b->stat_correct); dev_free(b->stat_count);
+  dev_free(b->text);
+  dev_free(e->d_scratch); dev_free(e->d_ranges); dev_free(e->d_dense);
+  free(e->lr_pushed);
+  e->lr_pushed = NULL;
+  memset(b, 0, sizeof(*b));
+  e->delta_own = NULL;
+  e->delta_external = 0;
+  e->dev_ready = 0;
+}
+
+static void engine_delete(RamdEngine *e) {
+  if (g_device >= 0) {
+    dsync();
+  }
+  engine_free_device(e);
+  RamdEngine **pp = &g_engines;
+  while (*pp && *pp != e) {
+    pp = &(*pp)->next;
+  }
+  if (*pp) {
+    *pp = e->next;
+  }
+  free(e->streams);
+  free(e->fwd);
+  free(e);
+}
+
+static void engine_attach(RamdEngine *e, RecurNN *net) {
+  RamdPriv *p = ramd_priv(net);
+  p->eng = e;
+  p->host_valid = 1;
+  p->dev_valid = 0;
+  if (net->bptt) {
+    if (e->n_streams == 0) {
+      e->sh.D = net->bptt->depth;
+    } else if (net->bptt->depth != e->sh.D) {
+      fprintf(stderr, "librecur_amd: nets sharing weights must share the BPTT depth (%d vs %d)\n",
+              net->bptt->depth, e->sh.D);
+      abort();
+    }
+    if (e->n_streams == e->cap_streams) {
+      e->cap_streams = e->cap_streams ? e->cap_streams * 2 : 4;
+      e->streams = realloc(e->streams, e->cap_streams * sizeof(RecurNN *));
+    }
+    p->stream = e->n_streams;
+    p->fwd = -1;
+    e->streams[e->n_streams++] = net;
+  } else {
+    if (e->n_fwd == e->cap_fwd) {
+      e->cap_fwd = e->cap_fwd ? e->cap_fwd * 2 : 4;
+      e->fwd = realloc(e->fwd, e->cap_fwd * sizeof(RecurNN *));
+    }
+    p->fwd = e->n_fwd;
+    p->stream = -1;
+    e->fwd[e->n_fwd++] = net;
+  }
+}
+
+RamdEngine *ramd_engine_of(RecurNN *net) {
+  RamdPriv *p = ramd_priv(net);
+  if (!p->eng) {
+    /* a net made by rnn_new without OWN_WEIGHTS whose caller pointed it at
+     * somebody's weights by hand: find that somebody */
+    for (RamdEngine *e = g_engines; e; e = e->next) {
+      if (e->owner->ih_weights == net->ih_weights) {
+        engine_attach(e, net);
+        break;
+      }
+    }
+    if (!p->eng) {
+      fprintf(stderr, "librecur_amd: net %p has no weights known to the library\n", (void *)net);
+      abort();
+    }
+  }
+  return p->eng;
+}
+
+static int state_row(const RamdEngine *e, const RamdPriv *p) {
+  return p->stream >= 0 ? p->stream : e->sh.Scap + p->fwd;
+}
+
+/* -------------------------------------------- host <-> device: one stream -- */
+
+static void stream_copy(RamdEngine *e, RecurNN *net, int to_device) {
+  RamdPriv *p = ramd_priv(net);
+  const RamdShape *s = &e->sh;
+  RamdBuffers *b = &e->b;
+  int r = state_row(e, p);
+  size_t I = s->I, H = s->H, O = s->O;
+#define COPY(dptr, hptr, n)                                                        \
+  do {                                                                             \
+    if (to_device) h2d((dptr), (hptr), (n) * sizeof(float));                       \
+    else d2h((hptr), (dptr), (n) * sizeof(float));                                 \
+  } while (0)
+  COPY(b->hidden + (size_t)r * H, net->hidden_layer, H);
+  COPY(b->out + (size_t)r * O, net->output_layer, O);
+  if (p->stream >= 0) {
+    RecurNNBPTT *bp = net->bptt;
+    int j = p->stream;
+    /* history: host [D][I] per net <-> device [D][Scap][I] */
+    if (to_device) {
+      HIP_OK(hipMemcpy2DAsync(b->arena + (size_t)j * I, (size_t)s->Scap * I * sizeof(float),
+                              bp->history, I * sizeof(float), I * sizeof(float), s->D,
+                              hipMemcpyHostToDevice, g_stream));
+    } else {
+      HIP_OK(hipMemcpy2DAsync(bp->history, I * sizeof(float), b->arena + (size_t)j * I,
+                              (size_t)s->Scap * I * sizeof(float), I * sizeof(float), s->D,
+                              hipMemcpyDeviceToHost, g_stream));
+    }
+    COPY(b->o_error + (size_t)j * O, bp->o_error, O);
+    COPY(b->err_a + (size_t)j * I, bp->h_error, I);
+    COPY(b->err_b + (size_t)j * I, bp->i_error, I);
+    COPY(b->mef + j, &bp->min_error_factor, 1);
+    COPY(b->ih_scale + j, &bp->ih_scale, 1);
+    if (to_device) {
+      h2d(b->idx + j, &bp->index, sizeof(int));
+      h2d(b->lr + j, &bp->learn_rate, sizeof(float));
+      e->lr_pushed[j] = bp->learn_rate;
+    }
+  } else {
+    COPY(b->arena + ((size_t)s->D * s->Scap + p->fwd) * I, net->input_layer, I);
+  }
+#undef COPY
+}
+
+static void err_flush(RamdEngine *e) {
+  if (e->err_pending) {
+    ramd_launch_err_writeback(g_stream, &e->sh, &e->b, e->err_row0, e->err_nrows);
+    e->err_pending = 0;
+  }
+}
+
+static void stream_need_host(RamdEngine *e, RecurNN *net) {
+  RamdPriv *p = ramd_priv(net);
+  if (!p->host_valid && e->dev_ready) {
+    err_flush(e);
+    stream_copy(e, net, 0);
+    dsync();
+  }
+  p->host_valid = 1;
+}
+
+static void stream_need_dev(RamdEngine *e, RecurNN *net) {
+  RamdPriv *p = ramd_priv(net);
+  if (!p->dev_valid) {
+    stream_copy(e, net, 1);
+    dsync(); /* the host arrays may change as soon as we return */
+  }
+  p->dev_valid = 1;
+}
+
+/* ------------------------------------------- host <-> device: the big arrays -- */
+
+static void engine_need_host(RamdEngine *e, int what) {
+  RecurNN *o = e->owner;
+  int fetch = what & ~e->host_valid & (RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+  if (fetch && e->dev_ready) {
+    if (fetch & RNN_AMD_WEIGHTS) {
+      d2h(o->ih_weights, e->b.ih_w, e->ih_size * sizeof(float));
+      d2h(o->ho_weights, e->b.ho_w, e->ho_size * sizeof(float));
+    }
+    if ((fetch & RNN_AMD_MOMENTUMS) && o->bptt) {
+      if (e->has_momentum) {
+        d2h(o->bptt->ih_momentum, e->b.ih_m, e->ih_size * sizeof(float));
+        d2h(o->bptt->ho_momentum, e->b.ho_m, e->ho_size * sizeof(float));
+      }
+      if (e->has_aux) {
+        d2h(o->bptt->ih_aux, e->b.ih_aux, e->ih_size * sizeof(float));
+        d2h(o->bptt->ho_aux, e->b.ho_aux, e->ho_size * sizeof(float));
+      }
+    }
+    if ((fetch & RNN_AMD_DELTAS) && o->bptt && e->has_delta) {
+      d2h(o->bptt->ih_delta, e->b.ih_delta, e->ih_size * sizeof(float));
+      d2h(o->bptt->ho_delta, e->b.ho_delta, e->ho_size * sizeof(float));
+    }
+    dsync();
+  }
+  e->host_valid |= fetch;
+}
+
+static void engine_need_dev(RamdEngine *e, int what) {
+  RecurNN *o = e->owner;
+  int push = what & ~e->dev_valid & (RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+  if (!push) {
+    return;
+  }
+  if (push & RNN_AMD_WEIGHTS) {
+    h2d(e->b.ih_w, o->ih_weights, e->ih_size * sizeof(float));
+    h2d(e->b.ho_w, o->ho_weights, e->ho_size * sizeof(float));
+  }
+  if ((push & RNN_AMD_MOMENTUMS) && o->bptt) {
+    if (e->has_momentum) {
+      h2d(e->b.ih_m, o->bptt->ih_momentum, e->ih_size * sizeof(float));
+      h2d(e->b.ho_m, o->bptt->ho_momentum, e->ho_size * sizeof(float));
+    }
+    if (e->has_aux) {
+      h2d(e->b.ih_aux, o->bptt->ih_aux, e->ih_size * sizeof(float));
+      h2d(e->b.ho_aux, o->bptt->ho_aux, e->ho_size * sizeof(float));
+    }
+  }
+  if ((push & RNN_AMD_DELTAS) && o->bptt && e->has_delta) {
+    h2d(e->b.ih_delta, o->bptt->ih_delta, e->ih_size * sizeof(float));
+    h2d(e->b.ho_delta, o->bptt->ho_delta, e->ho_size * sizeof(float));
+  }
+  dsync();
+  e->dev_valid |= push;
+}
+
+static void engine_dev_wrote(RamdEngine *e, int what) {
+  e->dev_valid |= what;
+  e->host_valid &= ~what;
+}
+
+/* public: bring host copies up to date */
+void ramd_need_host(RecurNN *net, int what) {
+  RamdEngine *e = ramd_engine_of(net);
+  engine_need_host(e, what);
+  if (what & RNN_AMD_ALL_STREAMS) {
+    for (int i = 0; i < e->n_streams; i++) {
+      stream_need_host(e, e->streams[i]);
+    }
+    for (int i = 0; i < e->n_fwd; i++) {
+      stream_need_host(e, e->fwd[i]);
+    }
+  } else if (what & RNN_AMD_STREAM) {
+    stream_need_host(e, net);
+  }
+}
+
+void ramd_host_wrote(RecurNN *net, int what) {
+  RamdEngine *e = ramd_engine_of(net);
+  int big = what & (RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+  /* a partial host write on top of a stale host copy would lose the rest */
+  engine_need_host(e, big);
+  e->host_valid |= big;
+  e->dev_valid &= ~big;
+  if (what & RNN_AMD_ALL_STREAMS) {
+    for (int i = 0; i < e->n_streams; i++) {
+      stream_need_host(e, e->streams[i]);
+      ramd_priv(e->streams[i])->dev_valid = 0;
+    }
+    for (int i = 0; i < e->n_fwd; i++) {
+      stream_need_host(e, e->fwd[i]);
+      ramd_priv(e->fwd[i])->dev_valid = 0;
+    }
+  } else if (what & RNN_AMD_STREAM) {
+    stream_need_host(e, net);
+    ramd_priv(net)->dev_valid = 0;
+  }
+}
+
+void rnn_amd_sync_host(RecurNN *net, int what) { ramd_need_host(net, what); }
+void rnn_amd_host_written(RecurNN *net, int what) { ramd_host_wrote(net, what); }
+
+/* Allocate (or grow) the device image.  Growing evicts everything to the host
+ * first and starts over; it only happens when nets are cloned after the first
+ * device call. */
+static void engine_ensure_device(RamdEngine *e) {
+  ramd_require_device("this call");
+  if (e->dev_ready && e->sh.Scap >= e->n_streams && e->sh.Fcap >= e->n_fwd) {
+    return;
+  }
+  if (e->dev_ready) {
+    engine_need_host(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+    for (int i = 0; i < e->n_streams; i++) {
+      RamdPriv *p = ramd_priv(e->streams[i]);
+      if (p->dev_valid && !p->host_valid) {
+        stream_need_host(e, e->streams[i]);
+      }
+    }
+    for (int i = 0; i < e->n_fwd; i++) {
+      RamdPriv *p = ramd_priv(e->fwd[i]);
+      if (p->dev_valid && !p->host_valid) {
+        stream_need_host(e, e->fwd[i]);
+      }
+    }
+    dsync();
+    engine_free_device(e);
+  }
+  RamdShape *s = &e->sh;
+  RamdBuffers *b = &e->b;
+  RecurNN *o = e->owner;
+  s->Scap = RAMD_MAX(e->n_streams, 1);
+  s->Fcap = RAMD_MAX(e->n_fwd, 1);
+  if (s->D < 1) {
+    s->D = 1;
+  }
+  size_t I = s->I, H = s->H, O = s->O, S = s->Scap, F = s->Fcap, D = s->D;
+  size_t fl = sizeof(float);
+  e->has_momentum = o->bptt && o->bptt->ih_momentum;
+  e->has_aux = o->bptt && o->bptt->ih_aux;
+  e->has_delta = o->bptt && o->bptt->ih_delta;
+  b->ih_w = dev_alloc(e->ih_size * fl);
+  b->ho_w = dev_alloc(e->ho_size * fl);
+  b->ih_m = dev_alloc(e->ih_size * fl);
+  b->ho_m = dev_alloc(e->ho_size * fl);
+  if (e->has_aux) {
+    b->ih_aux = dev_alloc(e->ih_size * fl);
+    b->ho_aux = dev_alloc(e->ho_size * fl);
+  }
+  e->delta_own = dev_alloc((e->ih_size + e->ho_size) * fl);
+  b->ih_delta = e->delta_own;
+  b->ho_delta = e->delta_own + e->ih_size;
+  b->arena = dev_alloc((D * S + F) * I * fl);
+  b->hidden = dev_alloc((S + F) * H * fl);
+  b->out = dev_alloc((S + F) * O * fl);
+  b->o_error = dev_alloc(S * O * fl);
+  b->err_a = dev_alloc(S * I * fl);
+  b->err_b = dev_alloc(S * I * fl);
+  b->ehi = dev_alloc((D + 1) * S * I * fl);
+  b->esum = dev_alloc(D * S * fl);
+  b->coef = dev_alloc(D * S * fl);
+  /* split-K workspace: up to 16 slabs of the largest GEMM output */
+  {
+    size_t per = RAMD_MAX(e->ih_size, RAMD_MAX((S + F) * I, (S + F) * H));
+    size_t slabs = 16;
+    const char *env = getenv("RECUR_AMD_MAX_SLABS");
+    if (env && atoi(env) > 0) {
+      slabs = (size_t)atoi(env);
+    }
+    b->slab_floats = per * slabs;
+    b->slab = dev_alloc(b->slab_floats * fl);
+  }
+  b->idx = dev_alloc(S * sizeof(int));
+  b->lr = dev_alloc(S * fl);
+  b->mef = dev_alloc(S * fl);
+  b->ih_scale = dev_alloc(S * fl);
+  b->top_raw = dev_alloc(S * fl);
+  b->top_scaled = dev_alloc(S * fl);
+  b->bptt_err = dev_alloc(S * fl);
+  b->n_exec = dev_alloc(S * sizeof(int));
+  b->depth_log = dev_alloc(S * sizeof(int));
+  b->target = dev_alloc(S * sizeof(int));
+  b->hot = dev_alloc((S + F) * sizeof(int));
+  b->active = dev_alloc(S);
+  b->stat_err = dev_alloc(S * sizeof(double));
+  b->stat_ent = dev_alloc(S * sizeof(double));
+  b->stat_zero = dev_alloc(S * sizeof(double));
+  b->stat_depth = dev_alloc(S * sizeof(double));
+  b->stat_correct = dev_alloc(S * sizeof(long long));
+  b->stat_count = dev_alloc(S * sizeof(long long));
+  e->d_scratch = dev_alloc(256 * 16);
+  e->d_ranges = dev_alloc(130 * sizeof(int));
+  e->d_dense = dev_alloc((S + F) * (size_t)s->input_size * fl);
+  e->lr_pushed = ramd_zalloc(S * sizeof(float));
+  e->dev_ready = 1;
+  e->dev_valid = 0;
+  e->err_pending = 0;
+  for (int i = 0; i < e->n_streams; i++) {
+    ramd_priv(e->streams[i])->dev_valid = 0;
+  }
+  for (int i = 0; i < e->n_fwd; i++) {
+    ramd_priv(e->fwd[i])->dev_valid = 0;
+  }
+  dsync();
+}
+
+/* ------------------------------------------------- construction (host only) -- */
+
+static size_t round4(size_t x) { return (x + 3) & ~(size_t)3; }
+
+/* rnn_bptt_advance (recur-nn.c:696-704), host side */
+static void host_advance(RecurNN *net) {
+  RecurNNBPTT *bptt = net->bptt;
+  bptt->index++;
+  if (bptt->index == bptt->depth) {
+    bptt->index -= bptt->depth;
+  }
+  net->input_layer = bptt->history + (size_t)bptt->index * net->i_size;
+  net->real_inputs = net->input_layer + net->hidden_size + 1;
+}
+
+/* new_bptt (recur-nn-init.c:6-78): which arrays exist depends on the flags;
+ * the order inside the block is ours. */
+static RecurNNBPTT *bptt_new(RecurNN *net, int depth, float learn_rate, float momentum,
+                             u32 flags) {
+  RecurNNBPTT *bptt = ramd_zalloc(sizeof(RecurNNBPTT));
+  int own_momentums = !(flags & RNN_NET_FLAG_NO_MOMENTUMS);
+  int own_deltas = !(flags & RNN_NET_FLAG_NO_DELTAS);
+  int aux_arrays = !!(flags & RNN_NET_FLAG_AUX_ARRAYS);
+  size_t ih = (size_t)net->ih_size, ho = (size_t)net->ho_size;
+  size_t I = net->i_size, O = net->o_size;
+  size_t n = O + 2 * I + (size_t)depth * I;
+  if (own_momentums) n += ih + ho;
+  if (own_deltas) n += 2 * ih + ho;
+  if (aux_arrays) n += ih + ho;
+  float *fm = ramd_zalloc(n * sizeof(float));
+  bptt->mem = fm;
+  bptt->depth = depth;
+  bptt->learn_rate = learn_rate;
+  bptt->momentum = momentum;
+  bptt->momentum_weight = RNN_MOMENTUM_WEIGHT;
+#define TAKE(field, count) do { bptt->field = fm; fm += (count); } while (0)
+  TAKE(o_error, O);
+  TAKE(i_error, I);
+  TAKE(h_error, I); /* i_size long so the two can be swapped, recur-nn-init.c:39-41 */
+  TAKE(history, (size_t)depth * I);
+  if (own_momentums) {
+    TAKE(ih_momentum, ih);
+    TAKE(ho_momentum, ho);
+  }
+  if (own_deltas) {
+    TAKE(ih_delta, ih);
+    TAKE(ho_delta, ho);
+    TAKE(ih_delta_tmp, ih);
+  }
+  if (aux_arrays) {
+    TAKE(ih_aux, ih);
+    TAKE(ho_aux, ho);
+  }
+#undef TAKE
+  bptt->index = 0;
+  bptt->ho_scale = 1.0f;
+  bptt->ih_scale = 1.0f;
+  bptt->min_error_factor = BASE_MIN_ERROR_FACTOR * net->h_size;
+  return bptt;
+}
+
+static RecurNN *net_new(uint input_size, uint hidden_size, uint output_size, u32 flags,
+                        u64 rng_seed, const char *log_file, int bptt_depth, float learn_rate,
+                        float momentum, float presynaptic_noise, rnn_activation activation,
+                        RamdEngine *borrow) {
+  RecurNN *net = ramd_zalloc(sizeof(RecurNN));
+  /* padded sizes, recur-nn-init.c:87-91 */
+  size_t i_size = round4((size_t)hidden_size + input_size + 1);
+  size_t h_size = round4((size_t)hidden_size + 1);
+  size_t o_size = round4(output_size);
+  size_t ih_size = i_size * h_size, ho_size = h_size * o_size;
+  net->i_size = (int)i_size;
+  net->h_size = (int)h_size;
+  net->o_size = (int)o_size;
+  net->input_size = (int)input_size;
+  net->hidden_size = (int)hidden_size;
+  net->output_size = (int)output_size;
+  net->ih_size = (int)ih_size;
+  net->ho_size = (int)ho_size;
+  net->generation = 0;
+  net->flags = flags;
+  net->presynaptic_noise = presynaptic_noise;
+  if (activation >= RNN_ACTIVATION_LAST) {
+    activation = RNN_RELU;
+  }
+  net->activation = activation;
+  ramd_init_rand64_maybe_randomly(&net->rng, rng_seed);
+
+  size_t n = RAMD_HDR_FLOATS + i_size + h_size + o_size;
+  if (flags & RNN_NET_FLAG_OWN_WEIGHTS) {
+    n += ih_size + ho_size;
+  }
+  float *fm = ramd_zalloc(n * sizeof(float));
+  net->mem = fm;
+  RamdPriv *priv = (RamdPriv *)fm;
+  priv->magic = RAMD_MAGIC;
+  priv->stream = priv->fwd = -1;
+  priv->host_valid = 1;
+  fm += RAMD_HDR_FLOATS;
+  net->input_layer = fm; fm += i_size;
+  net->hidden_layer = fm; fm += h_size;
+  net->output_layer = fm; fm += o_size;
+  if (flags & RNN_NET_FLAG_OWN_WEIGHTS) {
+    net->ih_weights = fm; fm += ih_size;
+    net->ho_weights = fm; fm += ho_size;
+  }
+  if (flags & RNN_NET_FLAG_OWN_BPTT) {
+    net->bptt = bptt_new(net, bptt_depth, learn_rate, momentum, flags);
+    host_advance(net); /* recur-nn-init.c:133: the first slot in use is 1 */
+  } else {
+    net->real_inputs = net->input_layer + net->hidden_size + 1;
+  }
+  if (flags & RNN_NET_FLAG_OWN_WEIGHTS) {
+    engine_attach(engine_new(net), net);
+  } else if (borrow) {
+    engine_attach(borrow, net);
+  }
+  if (log_file) {
+    rnn_set_log_file(net, log_file, flags & RNN_NET_FLAG_LOG_APPEND);
+  }
+  return net;
+}
+
+/* recur-nn.h:269-271 / recur-nn-init.c:80-143 */
+RecurNN *rnn_new(uint input_size, uint hidden_size, uint output_size, u32 flags, u64 rng_seed,
+                 const char *log_file, int bptt_depth, float learn_rate, float momentum,
+                 float presynaptic_noise, rnn_activation activation) {
+  return net_new(input_size, hidden_size, output_size, flags, rng_seed, log_file, bptt_depth,
+                 learn_rate, momentum, presynaptic_noise, activation, NULL);
+}
+
+/* recur-nn-init.c:158-192.  The layer is allocated so that struct users find
+ * what they expect; computing through it on the device is not done yet, so
+ * rnn_new_with_bottom_layer refuses a non-zero size. */
+RecurExtraLayer *rnn_new_extra_layer(int input_size, int output_size, int overlap, u32 flags) {
+  RecurExtraLayer *layer = ramd_zalloc(sizeof(RecurExtraLayer));
+  layer->input_size = input_size;
+  layer->output_size = output_size;
+  layer->overlap = overlap;
+  layer->learn_rate_scale = 1.0;
+  layer->i_size = (int)round4(input_size + 1);
+  layer->o_size = (int)round4(output_size);
+  size_t m = (size_t)layer->i_size * layer->o_size;
+  int aux = !!(flags & RNN_NET_FLAG_AUX_ARRAYS);
+  size_t n = m * (3 + aux) + 2 * (size_t)(layer->i_size + layer->o_size);
+  float *fm = ramd_zalloc(n * sizeof(float));
+  layer->mem = fm;
+  layer->momentums = fm; fm += m;
+  layer->inputs = fm; fm += layer->i_size;
+  layer->weights = fm; fm += m;
+  layer->outputs = fm; fm += layer->o_size;
+  layer->delta = fm; fm += m;
+  layer->i_error = fm; fm += layer->i_size;
+  layer->o_error = fm; fm += layer->o_size;
+  if (aux) {
+    layer->aux = fm;
+  }
+  return layer;
+}
+
+/* recur-nn-init.c:194-219 */
+RecurNN *rnn_new_with_bottom_layer(int n_inputs, int r_input_size, int hidden_size,
+                                   int output_size, u32 flags, u64 rng_seed,
+                                   const char *log_file, int bptt_depth, float learn_rate,
+                                   float momentum, float presynaptic_noise,
+                                   rnn_activation activation, int convolutional_overlap) {
+  (void)convolutional_overlap;
+  if (r_input_size == 0) {
+    flags &= ~RNN_NET_FLAG_BOTTOM_LAYER;
+    return rnn_new(n_inputs, hidden_size, output_size, flags, rng_seed, log_file, bptt_depth,
+                   learn_rate, momentum, presynaptic_noise, activation);
+  }
+  fprintf(stderr, "librecur_amd: a bottom layer (r_input_size %d) is not supported by the "
+                  "device core yet\n", r_input_size);
+  abort();
+}
+
+/* recur-nn-init.c:145-155 */
+void rnn_delete_net(RecurNN *net) {
+  RamdPriv *p = ramd_priv(net);
+  RamdEngine *e = p->eng;
+  if (e) {
+    if (e->owner == net) {
+      engine_delete(e);
+    } else {
+      /* the row stays reserved; forget the pointer */
+      if (p->stream >= 0 && p->stream < e->n_streams) e->streams[p->stream] = e->owner;
+      if (p->fwd >= 0 && p->fwd < e->n_fwd) e->fwd[p->fwd] = e->owner;
+      /* trailing rows can be given back */
+      while (e->n_streams > 0 && e->streams[e->n_streams - 1] == e->owner &&
+             ramd_priv(e->owner)->stream != e->n_streams - 1) {
+        e->n_streams--;
+      }
+      while (e->n_fwd > 0 && e->fwd[e->n_fwd - 1] == e->owner &&
+             ramd_priv(e->owner)->fwd != e->n_fwd - 1) {
+        e->n_fwd--;
+      }
+    }
+  }
+  if (net->bptt && (net->flags & RNN_NET_FLAG_OWN_BPTT)) {
+    free(net->bptt->mem);
+    free(net->bptt);
+  }
+  if (net->log) {
+    fclose(net->log);
+  }
+  free(net->mem);
+  free(net);
+}
+
+/* recur-nn-init.c:268-283 */
+void rnn_set_log_file(RecurNN *net, const char *log_file, int append_dont_truncate) {
+  if (net->log) {
+    fclose(net->log);
+  }
+  if (log_file) {
+    net->log = fopen(log_file, append_dont_truncate ? "a" : "w");
+    if (!append_dont_truncate) {
+      rnn_log_int(net, "generation", net->generation);
+    }
+  } else {
+    net->log = NULL;
+  }
+}
+
+/* recur-nn-init.c:296-350 */
+RecurNN *rnn_clone(RecurNN *parent, u32 flags, u64 rng_seed, const char *log_file) {
+  if (rng_seed == RECUR_RNG_SUBSEED) {
+    do {
+      rng_seed = ramd_rand64(&parent->rng);
+    } while (rng_seed == RECUR_RNG_RANDOM_SEED);
+  }
+  float learn_rate = 0, momentum = 0;
+  int bptt_depth = 0;
+  if (parent->bptt && (flags & RNN_NET_FLAG_OWN_BPTT)) {
+    learn_rate = parent->bptt->learn_rate;
+    bptt_depth = parent->bptt->depth;
+    momentum = parent->bptt->momentum;
+  }
+  if (!(parent->bptt && (flags & RNN_NET_FLAG_OWN_BPTT))) {
+    flags &= ~RNN_NET_FLAG_OWN_BPTT; /* no parent bptt to model it on */
+  }
+  RamdEngine *pe = ramd_engine_of(parent);
+  RecurNN *net = net_new(parent->input_size, parent->hidden_size, parent->output_size, flags,
+                         rng_seed, log_file, bptt_depth, learn_rate, momentum,
+                         parent->presynaptic_noise, parent->activation,
+                         (flags & RNN_NET_FLAG_OWN_WEIGHTS) ? NULL : pe);
+  if (net->bptt) {
+    net->bptt->momentum_weight = parent->bptt->momentum_weight;
+    if (flags & RNN_NET_FLAG_NO_MOMENTUMS) {
+      net->bptt->ih_momentum = parent->bptt->ih_momentum;
+      net->bptt->ho_momentum = parent->bptt->ho_momentum;
+    }
+    if (flags & RNN_NET_FLAG_NO_DELTAS) {
+      net->bptt->ih_delta = parent->bptt->ih_delta;
+      net->bptt->ho_delta = parent->bptt->ho_delta;
+    }
+  }
+  if (flags & RNN_NET_FLAG_OWN_WEIGHTS) {
+    ramd_need_host(parent, RNN_AMD_WEIGHTS);
+    memcpy(net->ih_weights, parent->ih_weights, (size_t)net->ih_size * sizeof(float));
+    memcpy(net->ho_weights, parent->ho_weights, (size_t)net->ho_size * sizeof(float));
+  } else {
+    net->ih_weights = parent->ih_weights;
+    net->ho_weights = parent->ho_weights;
+  }
+  net->bottom_layer = parent->bottom_layer;
+  net->generation = parent->generation;
+  net->presynaptic_noise = parent->presynaptic_noise;
+  return net;
+}
+
+/* recur-nn-init.c:221-243 */
+RecurNN **rnn_new_training_set(RecurNN *prototype, int n_nets) {
+  if (n_nets < 1) {
+    fprintf(stderr, "A training set of size %d is not possible\n", n_nets);
+    return NULL;
+  }
+  RecurNN **nets = ramd_zalloc(n_nets * sizeof(RecurNN *));
+  nets[0] = prototype;
+  u32 flags = prototype->flags;
+  flags &= ~RNN_NET_FLAG_OWN_WEIGHTS;
+  flags |= RNN_NET_FLAG_NO_MOMENTUMS;
+  flags |= RNN_NET_FLAG_NO_DELTAS;
+  for (int i = 1; i < n_nets; i++) {
+    nets[i] = rnn_clone(prototype, flags, RECUR_RNG_SUBSEED, NULL);
+    nets[i]->bptt->ih_delta = prototype->bptt->ih_delta;
+    nets[i]->bptt->ih_delta_tmp = prototype->bptt->ih_delta_tmp;
+    nets[i]->bptt->ho_delta = prototype->bptt->ho_delta;
+  }
+  return nets;
+}
+
+/* recur-nn-init.c:245-257 */
+void rnn_delete_training_set(RecurNN **nets, int n_nets, int leave_prototype) {
+  /* clones first: the prototype owns the weights and the device image */
+  for (int i = n_nets - 1; i >= 1; i--) {
+    if (nets[i]) {
+      rnn_delete_net(nets[i]);
+    }
+  }
+  if (!leave_prototype && nets[0]) {
+    rnn_delete_net(nets[0]);
+  }
+  free(nets);
+}
+
+/* ------------------------------------------------------------ scalars push -- */
+
+/* learn_rate is host-authoritative (callers write bptt->learn_rate, e.g.
+ * charmodel-predict.c:107, and clones keep their stale copy: SURVEY quirk 4). */
+static void push_learn_rates(RamdEngine *e, int row0, int nrows) {
+  int dirty = 0;
+  for (int j = row0; j < row0 + nrows; j++) {
+    float lr = e->streams[j]->bptt->learn_rate;
+    if (lr != e->lr_pushed[j]) {
+      e->lr_pushed[j] = lr;
+      dirty = 1;
+    }
+  }
+  if (dirty) {
+    h2d(e->b.lr + row0, e->lr_pushed + row0, nrows * sizeof(float));
+    dsync();
+  }
+}
+
+/* device mef / ih_scale -> host structs, for a range of streams */
+static void pull_scalars(RamdEngine *e, int row0, int nrows) {
+  float *tmp = malloc(2 * nrows * sizeof(float));
+  d2h(tmp, e->b.mef + row0, nrows * sizeof(float));
+  d2h(tmp + nrows, e->b.ih_scale + row0, nrows * sizeof(float));
+  dsync();
+  for (int j = 0; j < nrows; j++) {
+    RecurNNBPTT *bp = e->streams[row0 + j]->bptt;
+    bp->min_error_factor = tmp[j];
+    bp->ih_scale = tmp[nrows + j];
+  }
+  free(tmp);
+}
+
+/* ----------------------------------------------------------------- logging -- */
+
+/* What bptt_and_accumulate_error and rnn_bptt_calc_deltas write to net->log
+ * (recur-nn.c:415-448, 766-771), rebuilt from the device's per-stream results. */
+static void log_bptt(RamdEngine *e, RecurNN *net, float mef_before) {
+  if (!net->log) {
+    return;
+  }
+  RamdPriv *p = ramd_priv(net);
+  int j = p->stream, D = e->sh.D, S = e->sh.Scap;
+  float top_raw, top_scaled, bptt_err, scale, mef;
+  int depth, n_exec;
+  float *es = malloc(D * sizeof(float));
+  d2h(&top_raw, e->b.top_raw + j, 4);
+  d2h(&top_scaled, e->b.top_scaled + j, 4);
+  d2h(&bptt_err, e->b.bptt_err + j, 4);
+  d2h(&scale, e->b.ih_scale + j, 4);
+  d2h(&mef, e->b.mef + j, 4);
+  d2h(&depth, e->b.depth_log + j, 4);
+  d2h(&n_exec, e->b.n_exec + j, 4);
+  HIP_OK(hipMemcpy2DAsync(es, sizeof(float), e->b.esum + j, S * sizeof(float), sizeof(float), D,
+                          hipMemcpyDeviceToHost, g_stream));
+  d2h(net->hidden_layer, e->b.hidden + (size_t)j * e->sh.H, e->sh.H * sizeof(float));
+  dsync();
+  float cum_error = 0.0f;
+  for (int k = 0; k < n_exec; k++) {
+    cum_error += sqrtf(es[k]);
+  }
+  free(es);
+  float min_gain = MIN_ERROR_GAIN * top_scaled;
+  float thr = RAMD_MIN(mef_before / net->bptt->learn_rate, min_gain);
+  rnn_log_int(net, "depth", depth);
+  rnn_log_float(net, "scaled_error", scale * bptt_err);
+  rnn_log_float(net, "ih_scale", scale);
+  rnn_log_float(net, "min_error_threshold", thr);
+  rnn_log_float(net, "min_error_factor", mef);
+  rnn_log_float(net, "cum_error", cum_error);
+  if (net->flags & RNN_NET_FLAG_LOG_HIDDEN_SUM) {
+    float hidden_sum = 0, hidden_magnitude = 0;
+    int hidden_zeros = 0;
+    for (int i = 0; i < net->h_size; i++) {
+      float h = net->hidden_layer[i];
+      hidden_sum += h;
+      hidden_magnitude += h * h;
+      hidden_zeros += (h == 0.0f);
+    }
+    rnn_log_float(net, "hidden_sum", hidden_sum);
+    rnn_log_float(net, "hidden_magnitude", sqrtf(hidden_magnitude));
+    rnn_log_float(net, "hidden_zeros", hidden_zeros / (float)net->hidden_size);
+  }
+  if (net->flags & RNN_NET_FLAG_LOG_WEIGHT_SUM) {
+    engine_need_host(e, RNN_AMD_WEIGHTS);
+    float weight_sum = 0.0f;
+    for (int i = 0; i < net->ih_size; i++) {
+      weight_sum += fabsf(net->ih_weights[i]);
+    }
+    rnn_log_float(net, "weight_sum", weight_sum);
+  }
+  rnn_log_float(net, "error_gain", bptt_err / (top_scaled + 1e-6));
+  rnn_log_float(net, "top_error_scaled", top_scaled);
+  rnn_log_float(net, "top_error_raw", top_raw);
+}
+
+/* ---------------------------------------------------------- per-net hot path -- */
+
+static void check_supported(RecurNN *net, float noise) {
+  if (net->bottom_layer) {
+    fprintf(stderr, "librecur_amd: bottom layer not supported on the device yet\n");
+    abort();
+  }
+  if (noise != 0.0f) {
+    fprintf(stderr, "librecur_amd: presynaptic noise not supported on the device yet\n");
+    abort();
+  }
+}
+
+/* recur-nn.h:310 */
+void rnn_bptt_advance(RecurNN *net) {
+  host_advance(net);
+  RamdPriv *p = ramd_priv(net);
+  if (p->eng && p->eng->dev_ready && p->stream >= 0 && p->stream < p->eng->sh.Scap) {
+    h2d(p->eng->b.idx + p->stream, &net->bptt->index, sizeof(int));
+    dsync();
+  }
+}
+
+/* recur-nn.h:302 / recur-nn.c:83-154 for one stream */
+float *rnn_opinion(RecurNN *net, const float *inputs, float presynaptic_noise) {
+  check_supported(net, presynaptic_noise);
+  RamdEngine *e = ramd_engine_of(net);
+  RamdPriv *p = ramd_priv(net);
+  engine_ensure_device(e);
+  engine_need_dev(e, RNN_AMD_WEIGHTS);
+  const RamdShape *s = &e->sh;
+  /* the caller's real inputs are authoritative: keep them across a refresh */
+  float *keep = malloc(sizeof(float) * s->input_size);
+  memcpy(keep, inputs ? inputs : net->real_inputs, sizeof(float) * s->input_size);
+  stream_need_host(e, net);
+  stream_need_dev(e, net);
+  memcpy(net->real_inputs, keep, sizeof(float) * s->input_size);
+  free(keep);
+  int r = state_row(e, p);
+  float *d_slot;
+  if (p->stream >= 0) {
+    d_slot = e->b.arena + ((size_t)net->bptt->index * s->Scap + p->stream) * s->I;
+    h2d(e->b.idx + p->stream, &net->bptt->index, sizeof(int));
+  } else {
+    d_slot = e->b.arena + ((size_t)s->D * s->Scap + p->fwd) * s->I;
+  }
+  h2d(d_slot + s->hidden_size + 1, net->real_inputs, sizeof(float) * s->input_size);
+  ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 1);
+  ramd_launch_forward(g_stream, s, &e->b, r, 1);
+  d2h(net->input_layer, d_slot, sizeof(float) * s->I);
+  d2h(net->hidden_layer, e->b.hidden + (size_t)r * s->H, sizeof(float) * s->H);
+  d2h(net->output_layer, e->b.out + (size_t)r * s->O, sizeof(float) * s->O);
+  dsync();
+  return net->output_layer;
+}
+
+static const int *push_ranges(RamdEngine *e, RecurErrorRange *ranges) {
+  if (!ranges) {
+    return NULL;
+  }
+  int n = 0;
+  while (ranges[n].start >= 0) {
+    n++;
+  }
+  if (n > 64) {
+    fprintf(stderr, "librecur_amd: more than 64 error ranges\n");
+    abort();
+  }
+  h2d(e->d_ranges, ranges, (n + 1) * sizeof(RecurErrorRange));
+  dsync();
+  return e->d_ranges;
+}
+
+static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *ranges, unsigned fused) {
+  if (net->bottom_layer) {
+    check_supported(net, 0);
+  }
+  RamdEngine *e = ramd_engine_of(net);
+  RamdPriv *p = ramd_priv(net);
+  if (p->stream < 0) {
+    fprintf(stderr, "librecur_amd: rnn_bptt_calc_deltas on a net without bptt\n");
+    abort();
+  }
+  engine_ensure_device(e);
+  const RamdShape *s = &e->sh;
+  int j = p->stream;
+  engine_need_dev(e, RNN_AMD_WEIGHTS | (accumulate ? RNN_AMD_DELTAS : 0));
+  if (fused) {
+    engine_need_dev(e, RNN_AMD_MOMENTUMS);
+  }
+  float *keep = malloc(sizeof(float) * s->O);
+  memcpy(keep, net->bptt->o_error, sizeof(float) * s->O);
+  stream_need_host(e, net);
+  stream_need_dev(e, net);
+  memcpy(net->bptt->o_error, keep, sizeof(float) * s->O);
+  free(keep);
+  RecurNNBPTT *bp = net->bptt;
+  float mef_before = bp->min_error_factor;
+  h2d(e->b.o_error + (size_t)j * s->O, bp->o_error, sizeof(float) * s->O);
+  h2d(e->b.idx + j, &bp->index, sizeof(int));
+  h2d(e->b.mef + j, &bp->min_error_factor, sizeof(float));
+  if (ranges) {
+    /* the sparse top path reads last time's h_error */
+    err_flush(e);
+    h2d(e->b.err_a + (size_t)j * s->I, bp->h_error, sizeof(float) * s->I);
+  }
+  push_learn_rates(e, j, 1);
+  const int *d_ranges = push_ranges(e, ranges);
+  if (e->err_pending) {
+    err_flush(e);
+  }
+  ramd_launch_calc_deltas(g_stream, s, &e->b, j, 1, accumulate, d_ranges, NULL,
+                          net->flags | (fused ? 0x80000000u : 0));
+  engine_dev_wrote(e, RNN_AMD_DELTAS);
+  e->err_pending = 1;
+  e->err_row0 = j;
+  e->err_nrows = 1;
+  err_flush(e);
+  d2h(bp->h_error, e->b.err_a + (size_t)j * s->I, sizeof(float) * s->I);
+  d2h(bp->i_error, e->b.err_b + (size_t)j * s->I, sizeof(float) * s->I);
+  pull_scalars(e, j, 1);
+  net->generation++;
+  log_bptt(e, net, mef_before);
+}
+
+/* recur-nn.h:316 / recur-nn.c:707-772 */
+void rnn_bptt_calc_deltas(RecurNN *net, int accumulate_delta, RecurErrorRange *top_error_ranges) {
+  calc_deltas_one(net, accumulate_delta, top_error_ranges, 0);
+  rnn_log_int(net, "generation", net->generation);
+}
+
+/* recur-nn.h:309 / recur-nn.c:681-693 */
+void rnn_bptt_clear_deltas(RecurNN *net) {
+  RamdEngine *e = ramd_engine_of(net);
+  engine_ensure_device(e);
+  ramd_launch_clear_deltas(g_stream, &e->sh, &e->b);
+  engine_dev_wrote(e, RNN_AMD_DELTAS);
+}
+
+/* recur-nn.h:313 / recur-nn.c:595-599 */
+float rnn_calculate_momentum_soft_start(float generation, float max_momentum, float x) {
+  return RAMD_MIN(max_momentum, 1.0f - x / (1.0f + generation + 2.0f * x));
+}
+
+static void apply_arrays(RamdEngine *e, int method, float lr, float lr_top, float momentum,
+                         float mw, const float *rate_scale_dev) {
+  RamdBuffers *b = &e->b;
+  if ((method == RNN_ADADELTA || method == RNN_RPROP) && !e->has_aux) {
+    fprintf(stderr, "librecur_amd: learning method %d needs RNN_NET_FLAG_AUX_ARRAYS\n", method);
+    abort();
+  }
+  /* top layer first, then the recurrent layer, as recur-nn.c:606-676 */
+  ramd_launch_apply(g_stream, method, b->ho_w, b->ho_delta, b->ho_m, b->ho_aux, e->ho_size,
+                    lr_top, momentum, mw, rate_scale_dev);
+  ramd_launch_apply(g_stream, method, b->ih_w, b->ih_delta, b->ih_m, b->ih_aux, e->ih_size, lr,
+                    momentum, mw, rate_scale_dev);
+}
+
+/* recur-nn.h:312 / recur-nn.c:601-678 */
+void rnn_apply_learning(RecurNN *net, int learning_method, float momentum) {
+  RamdEngine *e = ramd_engine_of(net);
+  engine_ensure_device(e);
+  engine_need_dev(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+  RecurNNBPTT *bptt = net->bptt;
+  float mw;
+  if (learning_method == RNN_MOMENTUM_SIMPLIFIED_NESTEROV) {
+    mw = momentum / (1.0 + momentum);
+  } else if (learning_method == RNN_MOMENTUM_CLASSICAL) {
+    mw = 1.0f;
+  } else {
+    mw = bptt->momentum_weight;
+  }
+  int kernel_method = learning_method;
+  if (learning_method == RNN_MOMENTUM_SIMPLIFIED_NESTEROV ||
+      learning_method == RNN_MOMENTUM_CLASSICAL || learning_method >= RNN_LAST_LEARNING_METHOD ||
+      learning_method < 0) {
+    kernel_method = RNN_MOMENTUM_WEIGHTED;
+  }
+  apply_arrays(e, kernel_method, bptt->learn_rate, bptt->learn_rate * bptt->ho_scale, momentum, mw,
+               NULL);
+  engine_dev_wrote(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS);
+}
+
+/* recur-nn.h:319 / recur-nn.c:782-855 */
+void rnn_condition_net(RecurNN *net) {
+  u32 mask = net->flags >> RNN_COND_USE_OFFSET;
+  u32 m = net->generation % RNN_CONDITIONING_INTERVAL;
+  if (((1u << m) & mask) == 0) {
+    return;
+  }
+  RamdEngine *e = ramd_engine_of(net);
+  engine_ensure_device(e);
+  RamdBuffers *b = &e->b;
+  switch (m) {
+  case RNN_COND_BIT_SCALE:
+    engine_need_dev(e, RNN_AMD_WEIGHTS);
+    ramd_launch_scale(g_stream, b->ih_w, e->ih_size, WEIGHT_SCALE);
+    ramd_launch_scale(g_stream, b->ho_w, e->ho_size, WEIGHT_SCALE);
+    engine_dev_wrote(e, RNN_AMD_WEIGHTS);
+    break;
+  case RNN_COND_BIT_ZERO:
+    engine_need_dev(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS);
+    ramd_launch_zero_small(g_stream, b->ih_w, e->ih_size);
+    ramd_launch_zero_small(g_stream, b->ho_w, e->ho_size);
+    if (net->bptt) {
+      ramd_launch_zero_small(g_stream, b->ih_m, e->ih_size);
+      ramd_launch_zero_small(g_stream, b->ho_m, e->ho_size);
+    }
+    engine_dev_wrote(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS);
+    break;
+  case RNN_COND_BIT_RAND: {
+    int t = ramd_rand_small_int(&net->rng, net->ih_size + net->ho_size);
+    float damage = (ramd_cheap_gaussian_noise(&net->rng) * RANDOM_DAMAGE_FACTOR * net->h_size *
+                    net->bptt->learn_rate);
+    engine_need_dev(e, RNN_AMD_WEIGHTS);
+    if (t >= net->ih_size) {
+      t -= net->ih_size;
+      if (t % net->o_size < net->output_size) {
+        ramd_launch_add_at(g_stream, b->ho_w, t, damage);
+      }
+    } else {
+      int col = t % net->h_size;
+      if (col >= 1 && col < net->hidden_size + 1) {
+        ramd_launch_add_at(g_stream, b->ih_w, t, damage);
+      }
+    }
+    engine_dev_wrote(e, RNN_AMD_WEIGHTS);
+  } break;
+  case RNN_COND_BIT_TALL_POPPY:
+    engine_need_dev(e, RNN_AMD_WEIGHTS);
+    ramd_launch_tall_poppy(g_stream, b->ih_w, e->ih_size, RNN_TALL_POPPY_THRESHOLD,
+                           RNN_TALL_POPPY_SCALE, e->d_scratch);
+    engine_dev_wrote(e, RNN_AMD_WEIGHTS);
+    break;
+  case RNN_COND_BIT_LAWN_MOWER:
+    engine_need_dev(e, RNN_AMD_WEIGHTS);
+    ramd_launch_clamp(g_stream, b->ih_w, e->ih_size, -RNN_LAWN_MOWER_THRESHOLD,
+                      RNN_LAWN_MOWER_THRESHOLD);
+    engine_dev_wrote(e, RNN_AMD_WEIGHTS);
+    break;
+  }
+}
+
+/* recur-nn.h:311 / recur-nn.c:919-1019: the single-net path that updates the
+ * weights at once.  Top layer: backprop with the old weights, then the
+ * rank-1 update with momentum (no ho_scale, recur-nn.c:927); recurrent layer:
+ * BPTT deltas (the per-stream ih_scale is already folded into them) applied
+ * with the weighted-momentum rule, every step or every batch_size steps. */
+void rnn_bptt_calculate(RecurNN *net, uint batch_size) {
+  RamdEngine *e = ramd_engine_of(net);
+  RamdPriv *p = ramd_priv(net);
+  RecurNNBPTT *bptt = net->bptt;
+  int batched = batch_size > 1;
+  calc_deltas_one(net, batched, NULL, 1); /* also does generation++ */
+  ramd_launch_top_apply_now(g_stream, &e->sh, &e->b, p->stream, bptt->learn_rate, bptt->momentum,
+                            bptt->momentum_weight);
+  /* generation was already incremented; the reference tests the value before
+   * its increment (recur-nn.c:991, 1010) */
+  if (!batched || ((net->generation - 1) % batch_size) == 0) {
+    ramd_launch_apply(g_stream, RNN_MOMENTUM_WEIGHTED, e->b.ih_w, e->b.ih_delta, e->b.ih_m, NULL,
+                      e->ih_size, bptt->learn_rate, bptt->momentum, bptt->momentum_weight, NULL);
+    if (batched) {
+      ramd_launch_clear_deltas(g_stream, &e->sh, &e->b);
+    }
+  }
+  engine_dev_wrote(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+  if (net->log) {
+    rnn_log_int(net, "generation", net->generation);
+  }
+  rnn_condition_net(net);
+}
+
+/* recur-nn.h:322 / recur-nn.c:8-16 */
+void rnn_forget_history(RecurNN *net, int bptt_too) {
+  RamdEngine *e = ramd_engine_of(net);
+  stream_need_host(e, net);
+  memset(net->hidden_layer, 0, net->h_size * sizeof(float));
+  memset(net->input_layer, 0, (net->hidden_size + 1) * sizeof(float));
+  if (bptt_too && net->bptt) {
+    memset(net->bptt->history, 0, (size_t)net->bptt->depth * net->i_size * sizeof(float));
+  }
+  ramd_priv(net)->dev_valid = 0;
+}
+
+/* recur-nn.h:320 / recur-nn.c:887-904 */
+void rnn_log_net(RecurNN *net) {
+  if (net->log == NULL) {
+    return;
+  }
+  if (net->bptt) {
+    ramd_need_host(net, RNN_AMD_STREAM);
+    float top_error = 0, hidden_error = 0;
+    for (int i = 0; i < net->o_size; i++) {
+      top_error += fabsf(net->bptt->o_error[i]);
+    }
+    for (int i = 0; i < net->h_size; i++) {
+      hidden_error += fabsf(net->bptt->h_error[i]);
+    }
+    rnn_log_float(net, "output_error", top_error);
+    rnn_log_float(net, "hidden_error", hidden_error);
+  }
+}
+
+/* ================================================================ batched == */
+
+RnnAmdSet *rnn_amd_set_open(RecurNN **nets, int n_nets) {
+  if (!nets || n_nets < 1) {
+    return NULL;
+  }
+  RamdEngine *e = ramd_engine_of(nets[0]);
+  int row0 = ramd_priv(nets[0])->stream;
+  for (int j = 0; j < n_nets; j++) {
+    RamdPriv *p = ramd_priv(nets[j]);
+    if (ramd_engine_of(nets[j]) != e || p->stream != row0 + j) {
+      fprintf(stderr, "librecur_amd: rnn_amd_set_open: nets must be one training set in "
+                      "rnn_new_training_set order\n");
+      return NULL;
+    }
+  }
+  engine_ensure_device(e);
+  RnnAmdSet *set = ramd_zalloc(sizeof(RnnAmdSet));
+  set->eng = e;
+  set->nets = nets;
+  set->n = n_nets;
+  set->row0 = row0;
+  return set;
+}
+
+void rnn_amd_set_close(RnnAmdSet *set) {
+  if (!set) {
+    return;
+  }
+  ramd_need_host(set->nets[0], RNN_AMD_EVERYTHING);
+  free(set);
+}
+
+int rnn_amd_set_size(const RnnAmdSet *set) { return set->n; }
+
+static void set_streams_to_dev(RnnAmdSet *set) {
+  RamdEngine *e = set->eng;
+  int any = 0;
+  for (int j = 0; j < set->n; j++) {
+    RamdPriv *p = ramd_priv(set->nets[j]);
+    if (!p->dev_valid) {
+      stream_copy(e, set->nets[j], 1);
+      p->dev_valid = 1;
+      any = 1;
+    }
+  }
+  if (any) {
+    dsync();
+  }
+}
+
+static void set_streams_dev_wrote(RnnAmdSet *set) {
+  for (int j = 0; j < set->n; j++) {
+    RamdPriv *p = ramd_priv(set->nets[j]);
+    p->dev_valid = 1;
+    p->host_valid = 0;
+  }
+}
+
+void rnn_amd_set_advance(RnnAmdSet *set) {
+  RamdEngine *e = set->eng;
+  set_streams_to_dev(set);
+  for (int j = 0; j < set->n; j++) {
+    host_advance(set->nets[j]); /* the index is deterministic: both sides step */
+  }
+  ramd_launch_advance(g_stream, &e->sh, &e->b, set->row0, set->n);
+}
+
+static void set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, int text_i,
+                        float *outputs) {
+  RamdEngine *e = set->eng;
+  for (int j = 0; j < set->n; j++) {
+    check_supported(set->nets[j], set->nets[j]->presynaptic_noise);
+  }
+  engine_need_dev(e, RNN_AMD_WEIGHTS);
+  set_streams_to_dev(set);
+  ramd_launch_assemble(g_stream, &e->sh, &e->b, set->row0, set->n, mode, d_dense, ld, text_i,
+                       set->n);
+  ramd_launch_forward(g_stream, &e->sh, &e->b, set->row0, set->n);
+  set_streams_dev_wrote(set);
+  if (outputs) {
+    d2h(outputs, e->b.out + (size_t)set->row0 * e->sh.O, (size_t)set->n * e->sh.O * sizeof(float));
+    dsync();
+  }
+}
+
+void rnn_amd_set_opinion(RnnAmdSet *set, const float *inputs, int ld_inputs, float *outputs) {
+  RamdEngine *e = set->eng;
+  if (inputs) {
+    int w = e->sh.input_size;
+    HIP_OK(hipMemcpy2DAsync(e->d_dense, w * sizeof(float), inputs, ld_inputs * sizeof(float),
+                            w * sizeof(float), set->n, hipMemcpyHostToDevice, g_stream));
+    dsync();
+    set_forward(set, RAMD_IN_DENSE, e->d_dense, w, 0, outputs);
+  } else {
+    set_forward(set, RAMD_IN_KEEP, NULL, 0, 0, outputs);
+  }
+}
+
+void rnn_amd_set_one_hot_opinion(RnnAmdSet *set, const int *hot, float *outputs) {
+  RamdEngine *e = set->eng;
+  h2d(e->b.hot + set->row0, hot, set->n * sizeof(int));
+  dsync();
+  set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, outputs);
+}
+
+void rnn_amd_set_put_o_error(RnnAmdSet *set, const float *o_error, int ld) {
+  RamdEngine *e = set->eng;
+  set_streams_to_dev(set);
+  HIP_OK(hipMemcpy2DAsync(e->b.o_error + (size_t)set->row0 * e->sh.O, e->sh.O * sizeof(float),
+                          o_error, ld * sizeof(float), e->sh.O * sizeof(float), set->n,
+                          hipMemcpyHostToDevice, g_stream));
+  dsync();
+  set_streams_dev_wrote(set);
+}
+
+void rnn_amd_set_softmax_error(RnnAmdSet *set, const int *target) {
+  RamdEngine *e = set->eng;
+  set_streams_to_dev(set);
+  if (target) {
+    h2d(e->b.target + set->row0, target, set->n * sizeof(int));
+    dsync();
+  }
+  ramd_launch_softmax_error(g_stream, &e->sh, &e->b, set->row0, set->n);
+  set_streams_dev_wrote(set);
+}
+
+void rnn_amd_set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ranges,
+                             const u8 *active) {
+  RamdEngine *e = set->eng;
+  engine_need_dev(e, RNN_AMD_WEIGHTS | (accumulate ? RNN_AMD_DELTAS : 0));
+  set_streams_to_dev(set);
+  push_learn_rates(e, set->row0, set->n);
+  const int *d_ranges = push_ranges(e, ranges);
+  const unsigned char *d_active = NULL;
+  if (active) {
+    h2d(e->b.active, active, set->n);
+    dsync();
+    d_active = e->b.active;
+  }
+  if (e->err_pending && (ranges || e->err_row0 != set->row0 || e->err_nrows != set->n)) {
+    err_flush(e);
+  }
+  ramd_launch_calc_deltas(g_stream, &e->sh, &e->b, set->row0, set->n, accumulate, d_ranges,
+                          d_active, set->nets[0]->flags);
+  e->err_pending = 1;
+  e->err_row0 = set->row0;
+  e->err_nrows = set->n;
+  engine_dev_wrote(e, RNN_AMD_DELTAS);
+  set_streams_dev_wrote(set);
+  for (int j = 0; j < set->n; j++) {
+    if (!active || active[j]) {
+      set->nets[j]->generation++; /* recur-nn.c:765 */
+    }
+  }
+  if (set->nets[0]->log) {
+    log_bptt(e, set->nets[0], set->nets[0]->bptt->min_error_factor);
+    pull_scalars(e, set->row0, 1);
+    rnn_log_int(set->nets[0], "generation", set->nets[0]->generation);
+  }
+}
+
+void rnn_amd_set_load_text(RnnAmdSet *set, const u8 *text, int len) {
+  RamdEngine *e = set->eng;
+  dsync();
+  dev_free(e->b.text);
+  e->b.text = dev_alloc(len);
+  h2d(e->b.text, text, len);
+  e->b.text_len = len;
+  dsync();
+}
+
+void rnn_amd_set_char_step_deltas(RnnAmdSet *set, int i) {
+  RamdEngine *e = set->eng;
+  if (!e->b.text) {
+    fprintf(stderr, "librecur_amd: rnn_amd_set_char_step without rnn_amd_set_load_text\n");
+    abort();
+  }
+  rnn_amd_set_advance(set);
+  set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL);
+  ramd_launch_softmax_error(g_stream, &e->sh, &e->b, set->row0, set->n);
+  rnn_amd_set_calc_deltas(set, 0, NULL, NULL);
+}
+
+void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float momentum) {
+  rnn_amd_set_char_step_deltas(set, i);
+  rnn_apply_learning(set->nets[0], learning_style, momentum);
+}
+
+void rnn_amd_set_read_stats(RnnAmdSet *set, RnnAmdStats *stats, int clear) {
+  RamdEngine *e = set->eng;
+  int n = set->n, r0 = set->row0;
+  double *d = malloc(4 * n * sizeof(double));
+  long long *l = malloc(2 * n * sizeof(long long));
+  d2h(d, e->b.stat_err + r0, n * sizeof(double));
+  d2h(d + n, e->b.stat_ent + r0, n * sizeof(double));
+  d2h(d + 2 * n, e->b.stat_zero + r0, n * sizeof(double));
+  d2h(d + 3 * n, e->b.stat_depth + r0, n * sizeof(double));
+  d2h(l, e->b.stat_correct + r0, n * sizeof(long long));
+  d2h(l + n, e->b.stat_count + r0, n * sizeof(long long));
+  dsync();
+  memset(stats, 0, sizeof(*stats));
+  for (int j = 0; j < n; j++) {
+    stats->error += d[j];
+    stats->entropy += d[n + j];
+    stats->hidden_zeros += d[2 * n + j];
+    stats->bptt_depth_sum += d[3 * n + j];
+    stats->correct += l[j];
+    stats->count += l[n + j];
+  }
+  free(d);
+  free(l);
+  if (clear) {
+    HIP_OK(hipMemsetAsync(e->b.stat_err + r0, 0, n * sizeof(double), g_stream));
+    HIP_OK(hipMemsetAsync(e->b.stat_ent + r0, 0, n * sizeof(double), g_stream));
+    HIP_OK(hipMemsetAsync(e->b.stat_zero + r0, 0, n * sizeof(double), g_stream));
+    HIP_OK(hipMemsetAsync(e->b.stat_depth + r0, 0, n * sizeof(double), g_stream));
+    HIP_OK(hipMemsetAsync(e->b.stat_correct + r0, 0, n * sizeof(long long), g_stream));
+    HIP_OK(hipMemsetAsync(e->b.stat_count + r0, 0, n * sizeof(long long), g_stream));
+  }
+}
+
+void rnn_amd_set_external_delta(RnnAmdSet *set, void *device_buffer) {
+  RamdEngine *e = set->eng;
+  float *dst = device_buffer ? (float *)device_buffer : e->delta_own;
+  if (dst != e->b.ih_delta) {
+    HIP_OK(hipMemcpyAsync(dst, e->b.ih_delta, (e->ih_size + e->ho_size) * sizeof(float),
+                          hipMemcpyDeviceToDevice, g_stream));
+    dsync();
+    e->b.ih_delta = dst;
+    e->b.ho_delta = dst + e->ih_size;
+  }
+  e->delta_external = device_buffer != NULL;
+}

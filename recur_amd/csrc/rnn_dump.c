@@ -1,0 +1,81 @@
+/* rnn_dump.c -- rnn_multi_pgm_dump: debug images of the weight-shaped arrays
+ * (recur-nn.h:304; recur-nn-init.c:744-823 choose the array, pgm_dump.h:126-170,
+ * 215-220 define the picture: a binary PPM named
+ * images/<basename>-<token>-<generation as %08d>-<w>x<h>.ppm whose pixels are
+ * red for negative, green for positive, blue for exactly zero, scaled so the
+ * largest magnitude is 255).  Cold path, host only. */
+#include "rnn_host.h"
+
+static void write_signed_ppm(const float *a, int width, int height, const char *name) {
+  size_t n = (size_t)width * height;
+  float biggest = 1e-35f;
+  for (size_t i = 0; i < n; i++) {
+    float f = fabsf(a[i]);
+    if (f > biggest) {
+      biggest = f;
+    }
+  }
+  float scale = 255.99f / biggest;
+  FILE *fh = fopen(name, "w");
+  if (fh == NULL) {
+    fprintf(stderr, "could not open '%s' for writing\n", name);
+    return;
+  }
+  fprintf(fh, "P6\n%u %u\n255\n", width, height);
+  for (size_t i = 0; i < n; i++) {
+    float f = a[i] * scale;
+    unsigned char px[3] = {0, 0, 0};
+    if (f < 0.0) {
+      px[0] = (unsigned char)fabsf(f);
+    } else if (f > 0.0) {
+      px[1] = (unsigned char)fabsf(f);
+    } else {
+      px[2] = 180;
+    }
+    fwrite(px, 1, 3, fh);
+  }
+  fclose(fh);
+}
+
+void rnn_multi_pgm_dump(RecurNN *net, const char *dumpees, const char *basename) {
+  RecurNNBPTT *bptt = net->bptt;
+  char *copy = strdup(dumpees), *cursor = copy, *token;
+  ramd_need_host(net, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+  int aux = (net->flags & RNN_NET_FLAG_AUX_ARRAYS) != 0;
+  while ((token = strsep(&cursor, " "))) {
+    if (strlen(token) != 3) {
+      continue;
+    }
+    char in = token[0], out = token[1], v = token[2];
+    const float *array = NULL;
+    int x = 0, y = 0;
+    if (out == 'h' && (in == 'i' || in == 'h')) {
+      x = net->h_size;
+      y = (in == 'i') ? net->i_size : net->hidden_size;
+      array = v == 'w' ? net->ih_weights
+              : !bptt  ? NULL
+              : v == 'm' ? bptt->ih_momentum
+              : v == 'd' ? bptt->ih_delta
+              : v == 't' ? bptt->ih_delta_tmp
+              : (v == 'a' && aux) ? bptt->ih_aux
+                                  : NULL;
+    } else if (in == 'h' && out == 'o') {
+      x = net->o_size;
+      y = net->h_size;
+      array = v == 'w' ? net->ho_weights
+              : !bptt  ? NULL
+              : v == 'm' ? bptt->ho_momentum
+              : v == 'd' ? bptt->ho_delta
+              : (v == 'a' && aux) ? bptt->ho_aux
+                                  : NULL;
+    }
+    if (array) {
+      char name[200];
+      snprintf(name, sizeof(name), "images/%s-%s-%08d-%dx%d.ppm",
+               (basename && basename[0]) ? basename : "untitled", token, (int)net->generation, x,
+               y);
+      write_signed_ppm(array, x, y, name);
+    }
+  }
+  free(copy);
+}

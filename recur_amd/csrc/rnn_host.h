@@ -1,0 +1,93 @@
+/* rnn_host.h -- private declarations shared by the gnu11 C host files. */
+#ifndef RNN_HOST_H
+#define RNN_HOST_H 1
+#define _GNU_SOURCE 1
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "recur_amd.h"
+#include "ramd_internal.h"
+
+#define RAMD_MAGIC 0x444d4152u /* "RAMD" */
+#define RAMD_HDR_FLOATS 16     /* 64-byte private header in front of net->mem */
+
+#define RAMD_MIN(a, b) (((a) < (b)) ? (a) : (b))
+#define RAMD_MAX(a, b) (((a) >= (b)) ? (a) : (b))
+
+struct RamdEngine;
+
+/* Lives in the first 64 bytes of the block net->mem points at.  The public
+ * struct has no spare field (its layout is ABI), and no caller of the
+ * reference touches net->mem (it only exists for free()). */
+typedef struct RamdPriv {
+  uint32_t magic;
+  int stream; /* training-stream row in the engine, or -1 */
+  int fwd;    /* forward-only row, or -1                   */
+  int host_valid, dev_valid; /* this stream's state (RNN_AMD_STREAM) */
+  struct RamdEngine *eng;
+} RamdPriv;
+
+/* One engine per set of weights: the device image of everything that the
+ * nets sharing those weights own between them. */
+typedef struct RamdEngine {
+  struct RamdEngine *next;
+  RecurNN *owner; /* the net whose ih_weights/ho_weights these are */
+  RamdShape sh;
+  RamdBuffers b;
+  size_t ih_size, ho_size;
+  int n_streams, cap_streams;
+  RecurNN **streams;
+  int n_fwd, cap_fwd;
+  RecurNN **fwd;
+  int dev_ready;
+  /* coherence of the engine-level array classes (RNN_AMD_WEIGHTS, _MOMENTUMS,
+   * _DELTAS): bit set = that copy is current */
+  int host_valid, dev_valid;
+  int has_momentum, has_aux, has_delta;
+  /* device scratch */
+  void *d_scratch;      /* 256 (value,index) pairs for tall poppy + ranges */
+  int *d_ranges;        /* up to 64 (start,len) pairs                       */
+  float *d_dense;       /* staging for dense inputs, [Scap+Fcap][input_size] */
+  float *delta_own;     /* library-owned ih_delta||ho_delta                */
+  int delta_external;
+  /* h_error/i_error images are rebuilt lazily from ehi */
+  int err_pending, err_row0, err_nrows;
+  /* last per-stream scalars pushed to the device */
+  float *lr_pushed;
+  int scalars_dev_valid; /* device mef/ih_scale newer than the host structs */
+} RamdEngine;
+
+struct RnnAmdSet {
+  RamdEngine *eng;
+  RecurNN **nets;
+  int n;
+  int row0;
+};
+
+static inline RamdPriv *ramd_priv(const RecurNN *net) {
+  RamdPriv *p = (RamdPriv *)net->mem;
+  if (!p || p->magic != RAMD_MAGIC) {
+    fprintf(stderr, "librecur_amd: RecurNN %p was not created by this library\n", (void *)net);
+    abort();
+  }
+  return p;
+}
+
+/* rnn_core.c */
+void *ramd_zalloc(size_t bytes);
+RamdEngine *ramd_engine_of(RecurNN *net);
+void ramd_need_host(RecurNN *net, int what);
+void ramd_host_wrote(RecurNN *net, int what);
+void ramd_require_device(const char *what);
+
+/* rnn_init.c: Jenkins PRNG (recur-rng.h) */
+uint64_t ramd_rand64(rand_ctx *x);
+void ramd_init_rand64(rand_ctx *x, uint64_t seed);
+void ramd_init_rand64_maybe_randomly(rand_ctx *x, uint64_t seed);
+double ramd_rand_double(rand_ctx *x);
+int ramd_rand_small_int(rand_ctx *x, int cap);
+float ramd_cheap_gaussian_noise(rand_ctx *x);
+float ramd_fast_expf(float x);
+
+#endif

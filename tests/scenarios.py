@@ -213,3 +213,37 @@ def compare(got, want, rtol, keys=FLOAT_KEYS, exact=EXACT_KEYS):
         if k in got and k in want and not np.array_equal(got[k], want[k]):
             bad.append("%s: not bit-exact" % k)
     return bad
+
+
+class AmdBatchedSet(ApiSet):
+    """librecur_amd.so driven through its additive batched entry points
+    (include/recur_amd.h part 2): the whole set per call, text on the device."""
+
+    def __init__(self, lib, *args, **kw):
+        super().__init__(lib, *args, **kw)
+        self.handle = lib.rnn_amd_set_open(self.nets, self.S)
+        assert self.handle, "rnn_amd_set_open failed"
+        self._text = None
+
+    def load_text(self, text):
+        self._text = np.ascontiguousarray(text, dtype=np.uint8)
+        self.lib.rnn_amd_set_load_text(self.handle, rc.u8ptr(self._text), len(self._text))
+
+    def char_step_deltas(self, text, i):
+        if self._text is None or self._text is not text:
+            self.load_text(text)
+        self.lib.rnn_amd_set_char_step_deltas(self.handle, i)
+
+    def char_step(self, text, i, method=rc.WEIGHTED, momentum=0.95):
+        if self._text is None or (self._text is not text and not np.array_equal(self._text, text)):
+            self.load_text(text)
+        self.lib.rnn_amd_set_char_step(self.handle, i, method, momentum)
+
+    def stats(self, clear=False):
+        st = rc.AmdStats()
+        self.lib.rnn_amd_set_read_stats(self.handle, C.byref(st), int(clear))
+        return st
+
+    def close(self):
+        self.lib.rnn_amd_set_close(self.handle)
+        super().close()
