@@ -421,6 +421,12 @@ void rnn_amd_set_read_stats(RnnAmdSet *set, RnnAmdStats *stats, int clear);
  * all-reduce it (RCCL) between calc_deltas and apply_learning.  Pass NULL to
  * go back to library-owned storage. */
 void rnn_amd_set_external_delta(RnnAmdSet *set, void *device_buffer);
+/* When the streams of one logical training set are sharded over several
+ * processes (one per GPU), this set holds global streams
+ * [global_first, global_first + n_nets) of global_count: rnn_amd_set_char_step
+ * then spaces the text offsets over global_count streams
+ * (charmodel-predict.c:273, 295).  Default: global_first 0, global_count n_nets. */
+void rnn_amd_set_shard(RnnAmdSet *set, int global_first, int global_count);
 /* Split rnn_amd_set_char_step for that use: everything up to and including
  * calc_deltas, then the update. */
 void rnn_amd_set_char_step_deltas(RnnAmdSet *set, int i);

@@ -96,7 +96,7 @@ __global__ void k_advance(View v, int row0, int nrows) {
 // (maybe_scale_inputs, recur-nn.c:68-81).  One workgroup per stream.
 __global__ __launch_bounds__(256) void k_assemble(View v, int row0, int mode,
                                                   const float *dense, int ld, int text_i,
-                                                  int n_set) {
+                                                  int global_first, int n_set) {
   __shared__ float red[4];
   const RamdShape &s = v.sh;
   int j = blockIdx.x;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_assemble(View v, int row0, int mode,
     // charmodel-predict.c:273, 295-298
     int len = v.b.text_len;
     int spacing = (len - 1) / n_set;
-    int o = text_i + j * spacing;
+    int o = text_i + (global_first + j) * spacing;
     if (o >= len - 1) o -= len - 1;
     hot = v.b.text[o];
     if (threadIdx.x == 0) v.b.target[r] = v.b.text[o + 1];
@@ -158,45 +158,55 @@ __global__ __launch_bounds__(256) void k_assemble(View v, int row0, int mode,
 // and B[k = l >> 5][n = l & 31]; D register g holds row (g & 3) + 8 (g >> 2) +
 // 4 (l >> 5), column l & 31.  Within a group of 8 k, MFMA j uses
 // k = 8 g + 4 (l >> 5) + j on both operands.
+//
+// Global loads are unconditional (out-of-range lanes read a clamped, valid
+// address) and everything that depends on the loaded value -- zero fill, the
+// h_error mask, the per-stream coefficient -- is applied when the registers
+// are written to LDS, i.e. after the MFMAs of the current tile, so the loads
+// of tile k+1 stay in flight across the compute of tile k.
+//
+// Grid: 1-D.  Blocks are dealt round-robin over the 8 XCDs, so block id L runs
+// on the XCD labelled L % 8.  The tiles that share a B panel (same n tile and K
+// range, different m tile) are given ids with equal L % 8 and therefore meet in
+// one XCD's L2 (MI355X_MICROARCH.md "Workgroup dispatch"; speed only).
 
 constexpr int BM = 64, BN = 64, BK = 32, LDK = BK + 4;
-
-template <bool KM> struct TileLds { float v[KM ? BK * BM : BM * LDK]; };
 
 struct GemmOut {
   float *slab;   // [KS][M][ldc]
   int M, N, ldc;
   int nkt;       // K tiles in total
+  int tm, tn, ks;
 };
 
-// Stage one 64-row operand tile: two float4 per thread.
+struct Raw {
+  float4 v;
+  float aux;
+};
+
 template <bool KM, class Prob, bool IS_A>
-__device__ __forceinline__ void tile_load(const Prob &p, int kt, int base, float4 (&reg)[2]) {
+__device__ __forceinline__ void tile_load(const Prob &p, int kt, int base, Raw (&reg)[2]) {
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     int idx = threadIdx.x + i * 256;
-    if (KM) {
-      int k = idx >> 4, q = idx & 15; /* 16 float4 per k row */
-      reg[i] = IS_A ? p.a_km(kt, k, base + 4 * q) : p.b_km(kt, k, base + 4 * q);
-    } else {
-      int row = idx >> 3, q = idx & 7; /* 8 float4 per row */
-      reg[i] = IS_A ? p.a_kc(kt, base + row, 4 * q) : p.b_kc(kt, base + row, 4 * q);
-    }
+    int x0 = KM ? (idx >> 4) : base + (idx >> 3);       /* KM: k row     KC: row      */
+    int x1 = KM ? base + 4 * (idx & 15) : 4 * (idx & 7); /* KM: column    KC: k in tile */
+    if (IS_A) p.a_load(kt, x0, x1, reg[i]);
+    else p.b_load(kt, x0, x1, reg[i]);
   }
 }
 
-template <bool KM>
-__device__ __forceinline__ void tile_store(float *lds, const float4 (&reg)[2]) {
+template <bool KM, class Prob, bool IS_A>
+__device__ __forceinline__ void tile_store(const Prob &p, int kt, int base, float *lds,
+                                           const Raw (&reg)[2]) {
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     int idx = threadIdx.x + i * 256;
-    if (KM) {
-      int k = idx >> 4, q = idx & 15;
-      *reinterpret_cast<float4 *>(lds + k * BM + 4 * q) = reg[i];
-    } else {
-      int row = idx >> 3, q = idx & 7;
-      *reinterpret_cast<float4 *>(lds + row * LDK + 4 * q) = reg[i];
-    }
+    int x0 = KM ? (idx >> 4) : base + (idx >> 3);
+    int x1 = KM ? base + 4 * (idx & 15) : 4 * (idx & 7);
+    float4 v = IS_A ? p.a_fix(kt, x0, x1, reg[i]) : p.b_fix(kt, x0, x1, reg[i]);
+    float *dst = KM ? lds + (idx >> 4) * BM + 4 * (idx & 15) : lds + (idx >> 3) * LDK + 4 * (idx & 7);
+    *reinterpret_cast<float4 *>(dst) = v;
   }
 }
 
@@ -212,12 +222,17 @@ __device__ __forceinline__ float4 frag_read(const float *lds, int rc, int g, int
 
 template <bool A_KM, bool B_KM, class Prob>
 __global__ __launch_bounds__(256) void k_gemm(Prob p, GemmOut o) {
-  __shared__ __attribute__((aligned(16))) float lds[2][(A_KM ? BK * BM : BM * LDK) +
-                                                       (B_KM ? BK * BN : BN * LDK)];
   constexpr int A_FLOATS = A_KM ? BK * BM : BM * LDK;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int ks = gridDim.z, z = blockIdx.z;
-  const int kt0 = (int)(((long)o.nkt * z) / ks), kt1 = (int)(((long)o.nkt * (z + 1)) / ks);
+  constexpr int B_FLOATS = B_KM ? BK * BN : BN * LDK;
+  __shared__ __attribute__((aligned(16))) float lds[2][A_FLOATS + B_FLOATS];
+  // block id -> (m tile, panel = (n tile, K slice)), XCD aware
+  const int L = blockIdx.x;
+  const int xcd = L & 7, q = L >> 3;
+  const int mt = q % o.tm, panel = (q / o.tm) * 8 + xcd;
+  if (panel >= o.tn * o.ks) return;
+  const int nt = panel % o.tn, z = panel / o.tn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int kt0 = (int)(((long)o.nkt * z) / o.ks), kt1 = (int)(((long)o.nkt * (z + 1)) / o.ks);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int lm = lane & 31, kh = lane >> 5;
@@ -226,21 +241,23 @@ __global__ __launch_bounds__(256) void k_gemm(Prob p, GemmOut o) {
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.0f;
 
-  float4 ra[2], rb[2];
+  Raw ra[2], rb[2];
   if (kt0 < kt1) {
     tile_load<A_KM, Prob, true>(p, kt0, m0, ra);
     tile_load<B_KM, Prob, false>(p, kt0, n0, rb);
-    tile_store<A_KM>(lds[0], ra);
-    tile_store<B_KM>(lds[0] + A_FLOATS, rb);
+    tile_store<A_KM, Prob, true>(p, kt0, m0, lds[0], ra);
+    tile_store<B_KM, Prob, false>(p, kt0, n0, lds[0] + A_FLOATS, rb);
   }
   __syncthreads();
   for (int kt = kt0; kt < kt1; kt++) {
     const int cur = (kt - kt0) & 1;
     const bool more = kt + 1 < kt1;
-    if (more) {
-      tile_load<A_KM, Prob, true>(p, kt + 1, m0, ra);
-      tile_load<B_KM, Prob, false>(p, kt + 1, n0, rb);
-    }
+    const int ktn = more ? kt + 1 : kt; /* the last iteration re-loads its own tile: no branch */
+    tile_load<A_KM, Prob, true>(p, ktn, m0, ra);
+    tile_load<B_KM, Prob, false>(p, ktn, n0, rb);
+    /* pin the issue order: hipcc otherwise sinks the loads below the MFMAs and
+     * then waits for them at once (seen in the .s) */
+    __builtin_amdgcn_sched_barrier(0);
     const float *la = lds[cur], *lb = lds[cur] + A_FLOATS;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
@@ -251,9 +268,10 @@ __global__ __launch_bounds__(256) void k_gemm(Prob p, GemmOut o) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (more) {
-      tile_store<A_KM>(lds[cur ^ 1], ra);
-      tile_store<B_KM>(lds[cur ^ 1] + A_FLOATS, rb);
+      tile_store<A_KM, Prob, true>(p, ktn, m0, lds[cur ^ 1], ra);
+      tile_store<B_KM, Prob, false>(p, ktn, n0, lds[cur ^ 1] + A_FLOATS, rb);
     }
     __syncthreads();
   }
@@ -284,41 +302,102 @@ __device__ __forceinline__ float4 mask_herr(float4 v, int c, int hs) {
   return v;
 }
 
-// forward: A = input rows (KC), B = W_ih [I][H] (KM)
+// Every Prob supplies, for A and for B: x_load (issue the global load of one
+// float4, always from a valid address) and x_fix (what to do with the value
+// once it has arrived).  (x0, x1) = (row, k in tile) for a KC operand and
+// (k in tile, column) for a KM operand.
+
+// forward: A = input rows (KC), B = W_ih [I][H] (KM); K = I
 struct ProbFwd {
   View v;
   int row0, nrows;
-  __device__ float4 a_kc(int kt, int row, int k) const {
+  __device__ void a_load(int kt, int row, int k, Raw &r) const {
     k += kt * BK;
-    if (row >= nrows || k >= v.sh.I) return zero4();
-    return ld4(input_row(v, row0 + row, 0) + k);
+    bool ok = row < nrows && k < v.sh.I;
+    r.v = ld4(input_row(v, row0 + (row < nrows ? row : 0), 0) + (ok ? k : 0));
   }
-  __device__ float4 b_km(int kt, int k, int n) const {
+  __device__ float4 a_fix(int kt, int row, int k, const Raw &r) const {
+    return (row < nrows && k + kt * BK < v.sh.I) ? r.v : zero4();
+  }
+  __device__ void b_load(int kt, int k, int n, Raw &r) const {
     k += kt * BK;
-    if (k >= v.sh.I || n >= v.sh.H) return zero4();
-    return ld4(v.b.ih_w + (size_t)k * v.sh.H + n);
+    bool ok = k < v.sh.I && n < v.sh.H;
+    r.v = ld4(v.b.ih_w + (ok ? (size_t)k * v.sh.H + n : 0));
   }
-  __device__ float4 a_km(int, int, int) const { return zero4(); }
-  __device__ float4 b_kc(int, int, int) const { return zero4(); }
+  __device__ float4 b_fix(int kt, int k, int n, const Raw &r) const {
+    return (k + kt * BK < v.sh.I && n < v.sh.H) ? r.v : zero4();
+  }
 };
 
-// chain step t: A = masked error rows ehi[t] (KC), B = W_ih rows (KC); K = H
+// output layer: A = hidden rows (KC), B = W_ho [H][O] (KM); K = H
+struct ProbOut {
+  View v;
+  int row0, nrows;
+  __device__ void a_load(int kt, int row, int k, Raw &r) const {
+    k += kt * BK;
+    bool ok = row < nrows && k < v.sh.H;
+    r.v = ld4(v.b.hidden + (ok ? (size_t)(row0 + row) * v.sh.H + k : 0));
+  }
+  __device__ float4 a_fix(int kt, int row, int k, const Raw &r) const {
+    return (row < nrows && k + kt * BK < v.sh.H) ? r.v : zero4();
+  }
+  __device__ void b_load(int kt, int k, int n, Raw &r) const {
+    k += kt * BK;
+    bool ok = k < v.sh.H && n < v.sh.O;
+    r.v = ld4(v.b.ho_w + (ok ? (size_t)k * v.sh.O + n : 0));
+  }
+  __device__ float4 b_fix(int kt, int k, int n, const Raw &r) const {
+    return (k + kt * BK < v.sh.H && n < v.sh.O) ? r.v : zero4();
+  }
+};
+
+// top-layer delta: ho_delta[H][O] += hidden^T . o_error over the streams.
+// A[k = stream][m] = hidden (KM), B[k = stream][n] = o_error (KM); K = streams
+struct ProbHoDelta {
+  View v;
+  int row0, nrows;
+  const unsigned char *active;
+  __device__ void a_load(int kt, int k, int m, Raw &r) const {
+    k += kt * BK;
+    bool ok = k < nrows && m < v.sh.H;
+    r.v = ld4(v.b.hidden + (ok ? (size_t)(row0 + k) * v.sh.H + m : 0));
+  }
+  __device__ float4 a_fix(int kt, int k, int m, const Raw &r) const {
+    return (k + kt * BK < nrows && m < v.sh.H) ? r.v : zero4();
+  }
+  __device__ void b_load(int kt, int k, int n, Raw &r) const {
+    k += kt * BK;
+    bool ok = k < nrows && n < v.sh.O;
+    r.v = ld4(v.b.o_error + (ok ? (size_t)(row0 + k) * v.sh.O + n : 0));
+    r.aux = (active && k < nrows && !active[k]) ? 0.0f : 1.0f;
+  }
+  __device__ float4 b_fix(int kt, int k, int n, const Raw &r) const {
+    return (k + kt * BK < nrows && n < v.sh.O && r.aux != 0.0f) ? r.v : zero4();
+  }
+};
+
+// chain step t: A = error rows ehi[t] (KC, masked), B = W_ih rows (KC); K = H
 struct ProbChain {
   View v;
   int row0, nrows, t;
-  __device__ float4 a_kc(int kt, int row, int k) const {
+  __device__ void a_load(int kt, int row, int k, Raw &r) const {
     k += kt * BK;
-    if (row >= nrows || k >= v.sh.H) return zero4();
-    const float *e = v.b.ehi + ((size_t)t * v.sh.Scap + row0 + row) * v.sh.I;
-    return mask_herr(ld4(e + k), k, v.sh.hidden_size);
+    bool ok = row < nrows && k < v.sh.H;
+    const float *e = v.b.ehi + ((size_t)t * v.sh.Scap + row0 + (row < nrows ? row : 0)) * v.sh.I;
+    r.v = ld4(e + (ok ? k : 0));
   }
-  __device__ float4 b_kc(int kt, int n, int k) const {
+  __device__ float4 a_fix(int kt, int row, int k, const Raw &r) const {
     k += kt * BK;
-    if (n >= v.sh.I || k >= v.sh.H) return zero4();
-    return ld4(v.b.ih_w + (size_t)n * v.sh.H + k);
+    return (row < nrows && k < v.sh.H) ? mask_herr(r.v, k, v.sh.hidden_size) : zero4();
   }
-  __device__ float4 a_km(int, int, int) const { return zero4(); }
-  __device__ float4 b_km(int, int, int) const { return zero4(); }
+  __device__ void b_load(int kt, int n, int k, Raw &r) const {
+    k += kt * BK;
+    bool ok = n < v.sh.I && k < v.sh.H;
+    r.v = ld4(v.b.ih_w + (ok ? (size_t)n * v.sh.H + k : 0));
+  }
+  __device__ float4 b_fix(int kt, int n, int k, const Raw &r) const {
+    return (n < v.sh.I && k + kt * BK < v.sh.H) ? r.v : zero4();
+  }
 };
 
 // delta: K runs over (step t, stream r) in tiles of 32 streams.
@@ -326,24 +405,48 @@ struct ProbChain {
 struct ProbDelta {
   View v;
   int row0, nrows, rtiles;
-  __device__ float4 a_km(int kt, int k, int m) const {
-    int t = kt / rtiles, r = (kt % rtiles) * BK + k;
-    if (r >= nrows || m >= v.sh.I) return zero4();
-    return ld4(input_row(v, row0 + r, t) + m);
+  __device__ void a_load(int kt, int k, int m, Raw &r) const {
+    int t = kt / rtiles, s = (kt - t * rtiles) * BK + k;
+    bool ok = s < nrows && m < v.sh.I;
+    r.v = ld4(input_row(v, row0 + (s < nrows ? s : 0), t) + (ok ? m : 0));
   }
-  __device__ float4 b_km(int kt, int k, int n) const {
-    int t = kt / rtiles, r = (kt % rtiles) * BK + k;
-    if (r >= nrows || n >= v.sh.H) return zero4();
-    float c = v.b.coef[(size_t)t * v.sh.Scap + row0 + r];
-    if (c == 0.0f) return zero4(); /* select, never multiply: a dead step may hold inf */
-    const float *e = v.b.ehi + ((size_t)t * v.sh.Scap + row0 + r) * v.sh.I;
-    float4 x = mask_herr(ld4(e + n), n, v.sh.hidden_size);
+  __device__ float4 a_fix(int kt, int k, int m, const Raw &r) const {
+    int t = kt / rtiles, s = (kt - t * rtiles) * BK + k;
+    return (s < nrows && m < v.sh.I) ? r.v : zero4();
+  }
+  __device__ void b_load(int kt, int k, int n, Raw &r) const {
+    int t = kt / rtiles, s = (kt - t * rtiles) * BK + k;
+    bool ok = s < nrows && n < v.sh.H;
+    size_t row = (size_t)t * v.sh.Scap + row0 + (s < nrows ? s : 0);
+    r.aux = v.b.coef[row];
+    r.v = ld4(v.b.ehi + row * v.sh.I + (ok ? n : 0));
+  }
+  __device__ float4 b_fix(int kt, int k, int n, const Raw &r) const {
+    int t = kt / rtiles, s = (kt - t * rtiles) * BK + k;
+    float c = r.aux;
+    /* select, never multiply by zero: a step past the break may hold inf */
+    if (!(s < nrows && n < v.sh.H) || c == 0.0f) return zero4();
+    float4 x = mask_herr(r.v, n, v.sh.hidden_size);
     x.x *= c; x.y *= c; x.z *= c; x.w *= c;
     return x;
   }
-  __device__ float4 a_kc(int, int, int) const { return zero4(); }
-  __device__ float4 b_kc(int, int, int) const { return zero4(); }
 };
+
+// plain "sum the K slabs" finalize: dst[r][c] (+)= sum_z slab[z][r][c]
+__global__ __launch_bounds__(256) void k_sum_slabs(float *dst, int ld_dst, const float *slab,
+                                                   int M, int N, int ks, int accumulate) {
+  int q = blockIdx.x * 256 + threadIdx.x;
+  int per_row = N >> 2;
+  if (q >= M * per_row) return;
+  int r = q / per_row, c = (q - r * per_row) * 4;
+  const float *p = slab + (size_t)r * N + c;
+  float4 a = accumulate ? ld4(dst + (size_t)r * ld_dst + c) : zero4();
+  for (int z = 0; z < ks; z++) {
+    float4 t = ld4(p + (size_t)z * M * N);
+    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+  }
+  *reinterpret_cast<float4 *>(dst + (size_t)r * ld_dst + c) = a;
+}
 
 // ---------------------------------------------------------- finalize: fwd --
 
@@ -380,39 +483,6 @@ __global__ __launch_bounds__(256) void k_fwd_finalize(View v, int row0, int nrow
       make_float4(h[0], h[1], h[2], h[3]);
 }
 
-// ------------------------------------------------------- K3: output layer --
-
-// out = hidden . W_ho (recur-nn.c:150-151).  One workgroup per stream; the
-// hidden row sits in LDS; thread (kpart, o) sums a quarter of the rows for one
-// output column, then the four partial sums are added in a fixed order.
-__global__ __launch_bounds__(256) void k_out_layer(View v, int row0) {
-  extern __shared__ float sh[];
-  const RamdShape &s = v.sh;
-  float *hrow = sh;               /* [H] */
-  float *part = sh + s.H;         /* [4][64] */
-  int r = row0 + blockIdx.x;
-  const float *hid = v.b.hidden + (size_t)r * s.H;
-  for (int i = threadIdx.x; i < s.H; i += 256) hrow[i] = hid[i];
-  __syncthreads();
-  int oc = threadIdx.x & 63, kp = threadIdx.x >> 6;
-  int kq = (s.H + 3) / 4;
-  for (int o0 = 0; o0 < s.O; o0 += 64) {
-    int o = o0 + oc;
-    float acc = 0.0f;
-    if (o < s.O) {
-      int k1 = min(s.H, (kp + 1) * kq);
-      for (int k = kp * kq; k < k1; k++) acc += hrow[k] * v.b.ho_w[(size_t)k * s.O + o];
-    }
-    part[kp * 64 + oc] = acc;
-    __syncthreads();
-    if (kp == 0 && o < s.O) {
-      v.b.out[(size_t)r * s.O + o] =
-          (part[oc] + part[64 + oc]) + (part[128 + oc] + part[192 + oc]);
-    }
-    __syncthreads();
-  }
-}
-
 // -------------------------------------------------------- loss on device --
 
 #pragma clang fp contract(off)
@@ -438,11 +508,17 @@ __device__ float fast_expf_dev(float x) {
 // running statistics of the epoch loop (charmodel-predict.c:302-304).  One
 // thread per stream walks its row in the reference's order, so the sums round
 // the same way.
-__global__ void k_softmax_error(View v, int row0, int nrows) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void k_softmax_error(View v, int row0, int nrows) {
+  int j = blockIdx.x;
   if (j >= nrows) return;
   const RamdShape &s = v.sh;
   int r = row0 + j;
+  // zero fraction of the hidden row (recur-nn.c:438-442), counted by the wave
+  const float *hid = v.b.hidden + (size_t)r * s.H;
+  int zeros = 0;
+  for (int i = threadIdx.x; i < s.H; i += 64) zeros += (hid[i] == 0.0f);
+  for (int off = 32; off > 0; off >>= 1) zeros += __shfl_down(zeros, off, 64);
+  if (threadIdx.x != 0) return;
   const float *src = v.b.out + (size_t)r * s.O;
   float *err = v.b.o_error + (size_t)r * s.O;
   int len = s.output_size;
@@ -479,10 +555,7 @@ __global__ void k_softmax_error(View v, int row0, int nrows) {
   v.b.stat_ent[r] += (l < 1e-30f) ? -100.0f : log2f(l); /* charmodel-helpers.h:11-13 */
   v.b.stat_correct[r] += (best_i == target);
   v.b.stat_count[r] += 1;
-  const float *hid = v.b.hidden + (size_t)r * s.H;
-  int zeros = 0;
-  for (int i = 0; i < s.H; i++) zeros += (hid[i] == 0.0f);
-  v.b.stat_zero[r] += zeros / (double)s.hidden_size; /* recur-nn.c:438-442 */
+  v.b.stat_zero[r] += zeros / (double)s.hidden_size;
 }
 #pragma clang fp contract(fast)
 
@@ -543,14 +616,16 @@ __global__ __launch_bounds__(256) void k_top_backprop(View v, int row0, const in
 }
 
 // single_layer_sgd / _sparse for all streams at once (recur-nn.c:256-301):
-// one thread per element of ho_delta adds the streams in index order, which
-// is the order the reference's j loop accumulates them in.
-__global__ void k_ho_delta(View v, int row0, int nrows, int accumulate, const int *ranges,
-                           const unsigned char *active) {
+// hidden^T . o_error comes from the MFMA GEMM (ProbHoDelta); this sums its K
+// slabs into ho_delta.  With error ranges only the columns inside a range
+// receive anything.
+__global__ void k_ho_delta_finalize(View v, const float *slab, int ks, int accumulate,
+                                    const int *ranges) {
   const RamdShape &s = v.sh;
   int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= s.H * s.O) return;
-  int y = e / s.O, x = e - y * s.O;
+  int n = s.H * s.O;
+  if (e >= n) return;
+  int x = e % s.O;
   float acc = accumulate ? v.b.ho_delta[e] : 0.0f;
   bool live = true;
   if (ranges) {
@@ -561,11 +636,7 @@ __global__ void k_ho_delta(View v, int row0, int nrows, int accumulate, const in
     }
   }
   if (live) {
-    for (int j = 0; j < nrows; j++) {
-      if (active && !active[j]) continue;
-      float h = v.b.hidden[(size_t)(row0 + j) * s.H + y];
-      if (h != 0.0f) acc += v.b.o_error[(size_t)(row0 + j) * s.O + x] * h;
-    }
+    for (int z = 0; z < ks; z++) acc += slab[(size_t)z * n + e];
   }
   v.b.ho_delta[e] = acc;
 }
@@ -869,7 +940,7 @@ static inline View make_view(const RamdShape *sh, const RamdBuffers *b) {
 }
 
 // ---- HIP-event timing of the GEMM classes (bench.py's roofline leg) ----
-enum { T_CHAIN = 0, T_DELTA = 1, T_FWD = 2, T_APPLY = 3, T_CLASSES = 4 };
+enum { T_CHAIN = 0, T_DELTA = 1, T_FWD = 2, T_APPLY = 3, T_OTHER = 4, T_CLASSES = 5 };
 static int g_timing = 0;
 struct TimedLaunch {
   hipEvent_t a, b;
@@ -923,7 +994,7 @@ static int env_int(const char *name, int dflt) {
   return (e && *e) ? atoi(e) : dflt;
 }
 
-// Split-K factor: enough workgroups to give every CU several, without
+// Split-K factor: enough workgroups to give every CU two or three, without
 // shredding K into single tiles.
 static int pick_ks(int tiles, int nkt, const char *env, size_t slab_floats, size_t out_floats) {
   int forced = env_int(env, 0);
@@ -936,9 +1007,11 @@ static int pick_ks(int tiles, int nkt, const char *env, size_t slab_floats, size
     ks = 1;
     for (int k = 1; k <= 16 && k <= nkt; k++) {
       long wgs = (long)tiles * k;
-      double rounds = (double)((wgs + cus - 1) / cus);       /* CU-rounds of workgroups */
-      double cost = rounds * ((double)nkt / k + 1.5);        /* +1.5 tiles of fill/drain */
-      if (cost < best * 0.97) {
+      /* CUs run up to ~3 of these workgroups side by side; count time in
+       * "K tiles on the busiest CU" plus a fill/drain charge per workgroup */
+      double per_cu = (double)((wgs + cus - 1) / cus);
+      double cost = per_cu * ((double)nkt / k) + 2.0 * (per_cu > 3 ? per_cu / 3 : 1) + 0.15 * k;
+      if (cost < best) {
         best = cost;
         ks = k;
       }
@@ -950,6 +1023,25 @@ static int pick_ks(int tiles, int nkt, const char *env, size_t slab_floats, size
   return ks;
 }
 
+template <bool A_KM, bool B_KM, class Prob>
+static void launch_gemm(hipStream_t st, const Prob &p, float *slab, int M, int N, int nkt, int ks,
+                        int cls) {
+  GemmOut o;
+  o.slab = slab;
+  o.M = M;
+  o.N = N;
+  o.ldc = N;
+  o.nkt = nkt;
+  o.tm = (M + BM - 1) / BM;
+  o.tn = (N + BN - 1) / BN;
+  o.ks = ks;
+  int panels = o.tn * ks;
+  int blocks = ((panels + 7) / 8) * 8 * o.tm;
+  int ev = timing_begin(st, cls);
+  hipLaunchKernelGGL((k_gemm<A_KM, B_KM, Prob>), dim3(blocks), dim3(256), 0, st, p, o);
+  timing_end(st, ev);
+}
+
 extern "C" void ramd_launch_advance(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
                                     int row0, int nrows) {
   hipStream_t st = (hipStream_t)st_;
@@ -959,36 +1051,42 @@ extern "C" void ramd_launch_advance(ramd_stream_t st_, const RamdShape *sh, cons
 
 extern "C" void ramd_launch_assemble(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
                                      int row0, int nrows, int mode, const float *dense, int ld,
-                                     int text_i, int n_set) {
+                                     int text_i, int global_first, int n_set) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   hipLaunchKernelGGL(k_assemble, dim3(nrows), dim3(256), 0, st, v, row0, mode, dense, ld, text_i,
-                     n_set);
+                     global_first, n_set);
 }
 
 extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
                                     int row0, int nrows) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  int tm = (nrows + BM - 1) / BM, tn = (sh->H + BN - 1) / BN;
-  int nkt = (sh->I + BK - 1) / BK;
-  int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_FWD", b->slab_floats, (size_t)nrows * sh->H);
-  ProbFwd p = {v, row0, nrows};
-  GemmOut o = {b->slab, nrows, sh->H, sh->H, nkt};
-  int ev = timing_begin(st, T_FWD);
-  hipLaunchKernelGGL((k_gemm<false, true, ProbFwd>), dim3(tn, tm, ks), dim3(256), 0, st, p, o);
-  timing_end(st, ev);
-  int n4 = nrows * (sh->H / 4);
-  hipLaunchKernelGGL(k_fwd_finalize, dim3((n4 + 255) / 256), dim3(256), 0, st, v, row0, nrows, ks);
-  size_t shm = (size_t)(sh->H + 256) * sizeof(float);
-  hipLaunchKernelGGL(k_out_layer, dim3(nrows), dim3(256), shm, st, v, row0);
+  int tm = (nrows + BM - 1) / BM;
+  {
+    int tn = (sh->H + BN - 1) / BN, nkt = (sh->I + BK - 1) / BK;
+    int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_FWD", b->slab_floats, (size_t)nrows * sh->H);
+    ProbFwd p = {v, row0, nrows};
+    launch_gemm<false, true, ProbFwd>(st, p, b->slab, nrows, sh->H, nkt, ks, T_FWD);
+    int n4 = nrows * (sh->H / 4);
+    hipLaunchKernelGGL(k_fwd_finalize, dim3((n4 + 255) / 256), dim3(256), 0, st, v, row0, nrows, ks);
+  }
+  {
+    int tn = (sh->O + BN - 1) / BN, nkt = (sh->H + BK - 1) / BK;
+    int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_OUT", b->slab_floats, (size_t)nrows * sh->O);
+    ProbOut p = {v, row0, nrows};
+    launch_gemm<false, true, ProbOut>(st, p, b->slab, nrows, sh->O, nkt, ks, T_OTHER);
+    int n4 = nrows * (sh->O / 4);
+    hipLaunchKernelGGL(k_sum_slabs, dim3((n4 + 255) / 256), dim3(256), 0, st,
+                       b->out + (size_t)row0 * sh->O, sh->O, b->slab, nrows, sh->O, ks, 0);
+  }
 }
 
 extern "C" void ramd_launch_softmax_error(ramd_stream_t st_, const RamdShape *sh,
                                           const RamdBuffers *b, int row0, int nrows) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  hipLaunchKernelGGL(k_softmax_error, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows);
+  hipLaunchKernelGGL(k_softmax_error, dim3(nrows), dim3(64), 0, st, v, row0, nrows);
 }
 
 extern "C" void ramd_launch_clear_deltas(ramd_stream_t st_, const RamdShape *sh,
@@ -1009,21 +1107,23 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   size_t shm = (size_t)(sh->O + sh->H) * sizeof(float);
   hipLaunchKernelGGL(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges, active);
   if (!(flags & 0x80000000u)) { /* the fused single-net path updates W_ho directly */
+    int tm = (sh->H + BM - 1) / BM, tn = (sh->O + BN - 1) / BN;
+    int nkt = (nrows + BK - 1) / BK;
     int ho = sh->H * sh->O;
-    hipLaunchKernelGGL(k_ho_delta, dim3((ho + 255) / 256), dim3(256), 0, st, v, row0, nrows,
-                       accumulate, ranges, active);
+    int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_HO", b->slab_floats, (size_t)ho);
+    ProbHoDelta p = {v, row0, nrows, active};
+    launch_gemm<true, true, ProbHoDelta>(st, p, b->slab, sh->H, sh->O, nkt, ks, T_OTHER);
+    hipLaunchKernelGGL(k_ho_delta_finalize, dim3((ho + 255) / 256), dim3(256), 0, st, v, b->slab,
+                       ks, accumulate, ranges);
   }
   // BPTT chain: D dependent steps
   {
     int tm = (nrows + BM - 1) / BM, tn = (sh->I + BN - 1) / BN;
     int nkt = (sh->H + BK - 1) / BK;
     int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_CHAIN", b->slab_floats, (size_t)nrows * sh->I);
-    GemmOut o = {b->slab, nrows, sh->I, sh->I, nkt};
     for (int t = 0; t < sh->D; t++) {
       ProbChain p = {v, row0, nrows, t};
-      int ev = timing_begin(st, T_CHAIN);
-      hipLaunchKernelGGL((k_gemm<false, false, ProbChain>), dim3(tn, tm, ks), dim3(256), 0, st, p, o);
-      timing_end(st, ev);
+      launch_gemm<false, false, ProbChain>(st, p, b->slab, nrows, sh->I, nkt, ks, T_CHAIN);
       hipLaunchKernelGGL(k_chain_finalize, dim3(nrows), dim3(256), 0, st, v, row0, nrows, t, ks);
     }
   }
@@ -1037,10 +1137,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     size_t n = (size_t)sh->I * sh->H;
     int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_DELTA", b->slab_floats, n);
     ProbDelta p = {v, row0, nrows, rtiles};
-    GemmOut o = {b->slab, sh->I, sh->H, sh->H, nkt};
-    int ev = timing_begin(st, T_DELTA);
-    hipLaunchKernelGGL((k_gemm<true, true, ProbDelta>), dim3(tn, tm, ks), dim3(256), 0, st, p, o);
-    timing_end(st, ev);
+    launch_gemm<true, true, ProbDelta>(st, p, b->slab, sh->I, sh->H, nkt, ks, T_DELTA);
     size_t n4 = n / 4;
     hipLaunchKernelGGL(k_delta_finalize, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
                        b->ih_delta, b->slab, n4, n, ks, accumulate);

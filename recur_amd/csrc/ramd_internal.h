@@ -66,10 +66,11 @@ void ramd_launch_advance(ramd_stream_t st, const RamdShape *sh, const RamdBuffer
                          int row0, int nrows);
 /* builds the input rows (recur-nn.c:104-115 + 68-81).  mode selects where the
  * real inputs come from; dense is a device pointer with leading dimension ld;
- * text_i is the text position for RAMD_IN_TEXT (also fills b->target). */
+ * text_i is the text position for RAMD_IN_TEXT (also fills b->target); the
+ * row's global stream number is global_first + (row - row0) of global_count. */
 void ramd_launch_assemble(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                           int row0, int nrows, int mode, const float *dense, int ld,
-                          int text_i, int n_set);
+                          int text_i, int global_first, int global_count);
 /* hidden = act(X . W_ih), out = hidden . W_ho (recur-nn.c:117-151) */
 void ramd_launch_forward(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                          int row0, int nrows);

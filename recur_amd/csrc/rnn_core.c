@@ -958,7 +958,7 @@ float *rnn_opinion(RecurNN *net, const float *inputs, float presynaptic_noise) {
     d_slot = e->b.arena + ((size_t)s->D * s->Scap + p->fwd) * s->I;
   }
   h2d(d_slot + s->hidden_size + 1, net->real_inputs, sizeof(float) * s->input_size);
-  ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 1);
+  ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1);
   ramd_launch_forward(g_stream, s, &e->b, r, 1);
   d2h(net->input_layer, d_slot, sizeof(float) * s->I);
   d2h(net->hidden_layer, e->b.hidden + (size_t)r * s->H, sizeof(float) * s->H);
@@ -1236,6 +1236,8 @@ RnnAmdSet *rnn_amd_set_open(RecurNN **nets, int n_nets) {
   set->nets = nets;
   set->n = n_nets;
   set->row0 = row0;
+  set->global_first = 0;
+  set->global_count = n_nets;
   return set;
 }
 
@@ -1248,6 +1250,11 @@ void rnn_amd_set_close(RnnAmdSet *set) {
 }
 
 int rnn_amd_set_size(const RnnAmdSet *set) { return set->n; }
+
+void rnn_amd_set_shard(RnnAmdSet *set, int global_first, int global_count) {
+  set->global_first = global_first;
+  set->global_count = global_count;
+}
 
 static void set_streams_to_dev(RnnAmdSet *set) {
   RamdEngine *e = set->eng;
@@ -1291,7 +1298,7 @@ static void set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, 
   engine_need_dev(e, RNN_AMD_WEIGHTS);
   set_streams_to_dev(set);
   ramd_launch_assemble(g_stream, &e->sh, &e->b, set->row0, set->n, mode, d_dense, ld, text_i,
-                       set->n);
+                       set->global_first, set->global_count);
   ramd_launch_forward(g_stream, &e->sh, &e->b, set->row0, set->n);
   set_streams_dev_wrote(set);
   if (outputs) {

@@ -63,6 +63,7 @@ struct RnnAmdSet {
   RecurNN **nets;
   int n;
   int row0;
+  int global_first, global_count;
 };
 
 static inline RamdPriv *ramd_priv(const RecurNN *net) {

@@ -233,6 +233,7 @@ AMD_API = {
     "rnn_amd_set_read_stats": (None, [C.c_void_p, C.POINTER(AmdStats), C.c_int]),
     "rnn_amd_set_external_delta": (None, [C.c_void_p, C.c_void_p]),
     "rnn_amd_set_char_step_deltas": (None, [C.c_void_p, C.c_int]),
+    "rnn_amd_set_shard": (None, [C.c_void_p, C.c_int, C.c_int]),
     "rnn_amd_synchronize": (None, []),
     "rnn_amd_kernel_time_enable": (None, [C.c_int]),
     "rnn_amd_kernel_time_ms": (C.c_double, [C.c_int, C.POINTER(C.c_long), C.c_int]),
