@@ -27,6 +27,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HIDDEN, STREAMS, DEPTH, ALPHABET = 1024, 256, 20, 42
@@ -133,19 +134,18 @@ def main():
     gpu = sc.AmdBatchedSet(amd, input_size=ALPHABET, hidden_size=Hd, output_size=ALPHABET, S=S,
                            D=D, learn_rate=LEARN_RATE, seed=1, momentum=MOMENTUM)
     gpu.load_text(text)
-    amd.rnn_amd_set_shard(gpu.handle, rank * S, S * world)
+    from recur_amd.dist import shard_range
+    first, _, total = shard_range(rank, world, S)
+    amd.rnn_amd_set_shard(gpu.handle, first, total)
     delta = None
     if world > 1:
         delta = torch.zeros(gpu.I * gpu.H + gpu.H * gpu.O, dtype=torch.float32, device="cuda")
         amd.rnn_amd_set_external_delta(gpu.handle, C.c_void_p(delta.data_ptr()))
 
-    def step(i):
-        if world == 1:
-            amd.rnn_amd_set_char_step(gpu.handle, i, rc.WEIGHTED, MOMENTUM)
-        else:
-            amd.rnn_amd_set_char_step_deltas(gpu.handle, i)
-            dist.all_reduce(delta)
-            amd.rnn_apply_learning(gpu.net, rc.WEIGHTED, MOMENTUM)
+    from recur_amd.dist import ShardedStep
+    step = ShardedStep(lambda i: amd.rnn_amd_set_char_step_deltas(gpu.handle, i),
+                       (lambda: dist.all_reduce(delta)) if world > 1 else None,
+                       lambda: amd.rnn_apply_learning(gpu.net, rc.WEIGHTED, MOMENTUM))
 
     def fence():
         amd.rnn_amd_synchronize()

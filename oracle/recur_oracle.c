@@ -875,9 +875,10 @@ void orc_bptt_calculate(OrcSet *z, int s, unsigned batch_size, float momentum) {
 
 /* the j loop of rnn_char_epoch (charmodel-predict.c:293-310) */
 void orc_set_char_step_deltas(OrcSet *z, const uint8_t *text, int len, int i) {
-  int spacing = (len - 1) / z->S;
+  int count = z->global_count ? z->global_count : z->S;
+  int spacing = (len - 1) / count;
   for (int j = 0; j < z->S; j++) {
-    int offset = i + j * spacing;
+    int offset = i + (z->global_first + j) * spacing;
     if (offset >= len - 1) {
       offset -= len - 1;
     }

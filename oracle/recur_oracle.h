@@ -70,6 +70,9 @@ typedef struct OrcSet {
   double stat_error, stat_entropy;
   long stat_correct, stat_count;
   double stat_depth, stat_zeros;
+  /* when this set is one shard of a larger one: its streams are global streams
+   * [global_first, global_first + S) of global_count (0 = not sharded) */
+  int global_first, global_count;
 } OrcSet;
 
 /* ---- PRNG (recur-rng.h) ---- */

@@ -49,10 +49,16 @@ struct View {
 
 // input row (history slot or forward-only input row) of state row r, `back`
 // steps into the past (back = 0: the slot rnn_bptt_advance points at)
+//
+// When every stream of the call sits at the same ring position (the normal case:
+// the set advances in lock step) the host passes it in b.uniform_idx and no
+// index has to be fetched; a load here would sit on the address path of the
+// GEMM operand loads and drain their pipeline.
+template <bool UNI = false>
 __device__ __forceinline__ float *input_row(const View &v, int r, int back) {
   const RamdShape &s = v.sh;
   if (r < s.Scap) {
-    int slot = v.b.idx[r] - back;
+    int slot = (UNI ? v.b.uniform_idx : v.b.idx[r]) - back;
     if (slot < 0) slot += s.D;
     return v.b.arena + ((size_t)slot * s.Scap + r) * s.I;
   }
@@ -179,20 +185,35 @@ struct GemmOut {
   int tm, tn, ks;
 };
 
+__device__ __forceinline__ float4 ld4(const float *p) {
+  return *reinterpret_cast<const float4 *>(p);
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
 struct Raw {
   float4 v;
   float aux;
 };
 
+// `live` is wave-uniform.  A dead load still issues (from one fixed valid
+// address, so it costs a single cached request): every path then issues the same
+// number of loads and hipcc can keep counted s_waitcnt vmcnt(N) across the
+// pipeline instead of draining it.
 template <bool KM, class Prob, bool IS_A>
-__device__ __forceinline__ void tile_load(const Prob &p, int kt, int base, Raw (&reg)[2]) {
+__device__ __forceinline__ void tile_load(const Prob &p, int kt, bool live, int base,
+                                          Raw (&reg)[2]) {
+  const float *dummy = p.v.b.slab;
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     int idx = threadIdx.x + i * 256;
     int x0 = KM ? (idx >> 4) : base + (idx >> 3);       /* KM: k row     KC: row      */
     int x1 = KM ? base + 4 * (idx & 15) : 4 * (idx & 7); /* KM: column    KC: k in tile */
-    if (IS_A) p.a_load(kt, x0, x1, reg[i]);
-    else p.b_load(kt, x0, x1, reg[i]);
+    const float *src = IS_A ? p.a_ptr(kt, x0, x1) : p.b_ptr(kt, x0, x1);
+    reg[i].v = ld4(live ? src : dummy);
+    if (!IS_A && Prob::B_AUX) {
+      const float *ax = p.b_aux_ptr(kt, x0);
+      reg[i].aux = *(live ? ax : dummy);
+    }
   }
 }
 
@@ -220,6 +241,14 @@ __device__ __forceinline__ float4 frag_read(const float *lds, int rc, int g, int
   return *reinterpret_cast<const float4 *>(lds + rc * LDK + 8 * g + 4 * kh);
 }
 
+// Register prefetch depth: tiles k+1 .. k+PF are in flight (in registers or on
+// their way) while tile k is being multiplied.  One K tile is 1024 MFMA cycles
+// of work per wave but a load round trip under load is 2-3x that, so a single
+// tile of look-ahead leaves the kernel latency bound (measured: 13 us for a
+// 3.7 us chain step); four tiles per workgroup and two or three workgroups per
+// CU keep roughly 100-200 KB in flight per CU.
+constexpr int PF = 4;
+
 template <bool A_KM, bool B_KM, class Prob>
 __global__ __launch_bounds__(256) void k_gemm(Prob p, GemmOut o) {
   constexpr int A_FLOATS = A_KM ? BK * BM : BM * LDK;
@@ -241,39 +270,54 @@ __global__ __launch_bounds__(256) void k_gemm(Prob p, GemmOut o) {
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.0f;
 
-  Raw ra[2], rb[2];
+  Raw ra[PF][2], rb[PF][2];
+#pragma unroll
+  for (int j = 0; j < PF; j++) {
+    {
+      const bool live = kt0 + j < kt1;
+      tile_load<A_KM, Prob, true>(p, kt0 + j, live, m0, ra[j]);
+      tile_load<B_KM, Prob, false>(p, kt0 + j, live, n0, rb[j]);
+    }
+  }
   if (kt0 < kt1) {
-    tile_load<A_KM, Prob, true>(p, kt0, m0, ra);
-    tile_load<B_KM, Prob, false>(p, kt0, n0, rb);
-    tile_store<A_KM, Prob, true>(p, kt0, m0, lds[0], ra);
-    tile_store<B_KM, Prob, false>(p, kt0, n0, lds[0] + A_FLOATS, rb);
+    tile_store<A_KM, Prob, true>(p, kt0, m0, lds[0], ra[0]);
+    tile_store<B_KM, Prob, false>(p, kt0, n0, lds[0] + A_FLOATS, rb[0]);
   }
   __syncthreads();
-  for (int kt = kt0; kt < kt1; kt++) {
-    const int cur = (kt - kt0) & 1;
-    const bool more = kt + 1 < kt1;
-    const int ktn = more ? kt + 1 : kt; /* the last iteration re-loads its own tile: no branch */
-    tile_load<A_KM, Prob, true>(p, ktn, m0, ra);
-    tile_load<B_KM, Prob, false>(p, ktn, n0, rb);
-    /* pin the issue order: hipcc otherwise sinks the loads below the MFMAs and
-     * then waits for them at once (seen in the .s) */
-    __builtin_amdgcn_sched_barrier(0);
-    const float *la = lds[cur], *lb = lds[cur] + A_FLOATS;
+  for (int ktb = kt0; ktb < kt1; ktb += PF) {
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      float4 a = frag_read<A_KM>(la, wm * 32 + lm, g, kh);
-      float4 b = frag_read<B_KM>(lb, wn * 32 + lm, g, kh);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    for (int j = 0; j < PF; j++) {
+      const int kt = ktb + j;
+      if (kt >= kt1) break;
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int cur = j & 1; /* PF is even, so the LDS buffer parity follows j */
+      /* register set j held tile kt (already in LDS); refill it with tile kt + PF */
+      {
+        const bool live = kt + PF < kt1;
+        tile_load<A_KM, Prob, true>(p, kt + PF, live, m0, ra[j]);
+        tile_load<B_KM, Prob, false>(p, kt + PF, live, n0, rb[j]);
+      }
+      /* pin the issue order: hipcc otherwise sinks the loads below the MFMAs
+       * and then waits for them at once (seen in the .s) */
+      __builtin_amdgcn_sched_barrier(0);
+      const float *la = lds[cur], *lb = lds[cur] + A_FLOATS;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float4 a = frag_read<A_KM>(la, wm * 32 + lm, g, kh);
+        float4 b = frag_read<B_KM>(lb, wn * 32 + lm, g, kh);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < kt1) { /* tile kt + 1 sits in register set (j + 1) % PF */
+        tile_store<A_KM, Prob, true>(p, kt + 1, m0, lds[cur ^ 1], ra[(j + 1) % PF]);
+        tile_store<B_KM, Prob, false>(p, kt + 1, n0, lds[cur ^ 1] + A_FLOATS, rb[(j + 1) % PF]);
+      }
+      __syncthreads();
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) {
-      tile_store<A_KM, Prob, true>(p, ktn, m0, lds[cur ^ 1], ra);
-      tile_store<B_KM, Prob, false>(p, ktn, n0, lds[cur ^ 1] + A_FLOATS, rb);
-    }
-    __syncthreads();
   }
   float *c = o.slab + (size_t)z * o.M * o.ldc;
   const int col = n0 + wn * 32 + lm;
@@ -286,10 +330,6 @@ __global__ __launch_bounds__(256) void k_gemm(Prob p, GemmOut o) {
   }
 }
 
-__device__ __forceinline__ float4 ld4(const float *p) {
-  return *reinterpret_cast<const float4 *>(p);
-}
-__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // zero column 0 and columns > hidden_size of an error row: what the reference
 // does to h_error at the top of every BPTT step (recur-nn.c:334-337)
@@ -308,68 +348,77 @@ __device__ __forceinline__ float4 mask_herr(float4 v, int c, int hs) {
 // (k in tile, column) for a KM operand.
 
 // forward: A = input rows (KC), B = W_ih [I][H] (KM); K = I
-struct ProbFwd {
+template <bool UNI> struct ProbFwd {
+  static constexpr bool B_AUX = false;
   View v;
   int row0, nrows;
-  __device__ void a_load(int kt, int row, int k, Raw &r) const {
+  __device__ const float *a_ptr(int kt, int row, int k) const {
     k += kt * BK;
     bool ok = row < nrows && k < v.sh.I;
-    r.v = ld4(input_row(v, row0 + (row < nrows ? row : 0), 0) + (ok ? k : 0));
+    return input_row<UNI>(v, row0 + (row < nrows ? row : 0), 0) + (ok ? k : 0);
   }
   __device__ float4 a_fix(int kt, int row, int k, const Raw &r) const {
     return (row < nrows && k + kt * BK < v.sh.I) ? r.v : zero4();
   }
-  __device__ void b_load(int kt, int k, int n, Raw &r) const {
+  __device__ const float *b_ptr(int kt, int k, int n) const {
     k += kt * BK;
     bool ok = k < v.sh.I && n < v.sh.H;
-    r.v = ld4(v.b.ih_w + (ok ? (size_t)k * v.sh.H + n : 0));
+    return v.b.ih_w + (ok ? (size_t)k * v.sh.H + n : 0);
   }
   __device__ float4 b_fix(int kt, int k, int n, const Raw &r) const {
     return (k + kt * BK < v.sh.I && n < v.sh.H) ? r.v : zero4();
   }
+  __device__ const float *b_aux_ptr(int, int) const { return v.b.slab; }
 };
 
 // output layer: A = hidden rows (KC), B = W_ho [H][O] (KM); K = H
 struct ProbOut {
+  static constexpr bool B_AUX = false;
   View v;
   int row0, nrows;
-  __device__ void a_load(int kt, int row, int k, Raw &r) const {
+  __device__ const float *a_ptr(int kt, int row, int k) const {
     k += kt * BK;
     bool ok = row < nrows && k < v.sh.H;
-    r.v = ld4(v.b.hidden + (ok ? (size_t)(row0 + row) * v.sh.H + k : 0));
+    return v.b.hidden + (ok ? (size_t)(row0 + row) * v.sh.H + k : 0);
   }
   __device__ float4 a_fix(int kt, int row, int k, const Raw &r) const {
     return (row < nrows && k + kt * BK < v.sh.H) ? r.v : zero4();
   }
-  __device__ void b_load(int kt, int k, int n, Raw &r) const {
+  __device__ const float *b_ptr(int kt, int k, int n) const {
     k += kt * BK;
     bool ok = k < v.sh.H && n < v.sh.O;
-    r.v = ld4(v.b.ho_w + (ok ? (size_t)k * v.sh.O + n : 0));
+    return v.b.ho_w + (ok ? (size_t)k * v.sh.O + n : 0);
   }
   __device__ float4 b_fix(int kt, int k, int n, const Raw &r) const {
     return (k + kt * BK < v.sh.H && n < v.sh.O) ? r.v : zero4();
   }
+  __device__ const float *b_aux_ptr(int, int) const { return v.b.slab; }
 };
 
 // top-layer delta: ho_delta[H][O] += hidden^T . o_error over the streams.
-// A[k = stream][m] = hidden (KM), B[k = stream][n] = o_error (KM); K = streams
+// A[k = stream][m] = hidden (KM), B[k = stream][n] = o_error (KM); K = streams.
+// `live` holds 1.0 per stream that takes part (the active mask), as floats.
 struct ProbHoDelta {
+  static constexpr bool B_AUX = true;
   View v;
   int row0, nrows;
-  const unsigned char *active;
-  __device__ void a_load(int kt, int k, int m, Raw &r) const {
+  const float *live;
+  __device__ const float *a_ptr(int kt, int k, int m) const {
     k += kt * BK;
     bool ok = k < nrows && m < v.sh.H;
-    r.v = ld4(v.b.hidden + (ok ? (size_t)(row0 + k) * v.sh.H + m : 0));
+    return v.b.hidden + (ok ? (size_t)(row0 + k) * v.sh.H + m : 0);
   }
   __device__ float4 a_fix(int kt, int k, int m, const Raw &r) const {
     return (k + kt * BK < nrows && m < v.sh.H) ? r.v : zero4();
   }
-  __device__ void b_load(int kt, int k, int n, Raw &r) const {
+  __device__ const float *b_ptr(int kt, int k, int n) const {
     k += kt * BK;
     bool ok = k < nrows && n < v.sh.O;
-    r.v = ld4(v.b.o_error + (ok ? (size_t)(row0 + k) * v.sh.O + n : 0));
-    r.aux = (active && k < nrows && !active[k]) ? 0.0f : 1.0f;
+    return v.b.o_error + (ok ? (size_t)(row0 + k) * v.sh.O + n : 0);
+  }
+  __device__ const float *b_aux_ptr(int kt, int k) const {
+    k += kt * BK;
+    return live + (k < nrows ? k : 0);
   }
   __device__ float4 b_fix(int kt, int k, int n, const Raw &r) const {
     return (k + kt * BK < nrows && n < v.sh.O && r.aux != 0.0f) ? r.v : zero4();
@@ -378,48 +427,54 @@ struct ProbHoDelta {
 
 // chain step t: A = error rows ehi[t] (KC, masked), B = W_ih rows (KC); K = H
 struct ProbChain {
+  static constexpr bool B_AUX = false;
   View v;
   int row0, nrows, t;
-  __device__ void a_load(int kt, int row, int k, Raw &r) const {
+  __device__ const float *a_ptr(int kt, int row, int k) const {
     k += kt * BK;
     bool ok = row < nrows && k < v.sh.H;
     const float *e = v.b.ehi + ((size_t)t * v.sh.Scap + row0 + (row < nrows ? row : 0)) * v.sh.I;
-    r.v = ld4(e + (ok ? k : 0));
+    return e + (ok ? k : 0);
   }
   __device__ float4 a_fix(int kt, int row, int k, const Raw &r) const {
     k += kt * BK;
     return (row < nrows && k < v.sh.H) ? mask_herr(r.v, k, v.sh.hidden_size) : zero4();
   }
-  __device__ void b_load(int kt, int n, int k, Raw &r) const {
+  __device__ const float *b_ptr(int kt, int n, int k) const {
     k += kt * BK;
     bool ok = n < v.sh.I && k < v.sh.H;
-    r.v = ld4(v.b.ih_w + (ok ? (size_t)n * v.sh.H + k : 0));
+    return v.b.ih_w + (ok ? (size_t)n * v.sh.H + k : 0);
   }
   __device__ float4 b_fix(int kt, int n, int k, const Raw &r) const {
     return (n < v.sh.I && k + kt * BK < v.sh.H) ? r.v : zero4();
   }
+  __device__ const float *b_aux_ptr(int, int) const { return v.b.slab; }
 };
 
 // delta: K runs over (step t, stream r) in tiles of 32 streams.
 // A[k][m] = X_t[r][m] (KM), B[k][n] = coef[t][r] * masked ehi[t][r][n] (KM)
-struct ProbDelta {
+template <bool UNI> struct ProbDelta {
+  static constexpr bool B_AUX = true;
   View v;
   int row0, nrows, rtiles;
-  __device__ void a_load(int kt, int k, int m, Raw &r) const {
+  __device__ const float *a_ptr(int kt, int k, int m) const {
     int t = kt / rtiles, s = (kt - t * rtiles) * BK + k;
     bool ok = s < nrows && m < v.sh.I;
-    r.v = ld4(input_row(v, row0 + (s < nrows ? s : 0), t) + (ok ? m : 0));
+    return input_row<UNI>(v, row0 + (s < nrows ? s : 0), t) + (ok ? m : 0);
   }
   __device__ float4 a_fix(int kt, int k, int m, const Raw &r) const {
     int t = kt / rtiles, s = (kt - t * rtiles) * BK + k;
     return (s < nrows && m < v.sh.I) ? r.v : zero4();
   }
-  __device__ void b_load(int kt, int k, int n, Raw &r) const {
+  __device__ const float *b_ptr(int kt, int k, int n) const {
     int t = kt / rtiles, s = (kt - t * rtiles) * BK + k;
     bool ok = s < nrows && n < v.sh.H;
     size_t row = (size_t)t * v.sh.Scap + row0 + (s < nrows ? s : 0);
-    r.aux = v.b.coef[row];
-    r.v = ld4(v.b.ehi + row * v.sh.I + (ok ? n : 0));
+    return v.b.ehi + row * v.sh.I + (ok ? n : 0);
+  }
+  __device__ const float *b_aux_ptr(int kt, int k) const {
+    int t = kt / rtiles, s = (kt - t * rtiles) * BK + k;
+    return v.b.coef + (size_t)t * v.sh.Scap + row0 + (s < nrows ? s : 0);
   }
   __device__ float4 b_fix(int kt, int k, int n, const Raw &r) const {
     int t = kt / rtiles, s = (kt - t * rtiles) * BK + k;
@@ -613,6 +668,11 @@ __global__ __launch_bounds__(256) void k_top_backprop(View v, int row0, const in
     v.b.top_raw[r] = sum;
     v.b.top_scaled[r] = scaled;
   }
+}
+
+__global__ void k_live_mask(float *dst, const unsigned char *active, int n) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) dst[j] = (!active || active[j]) ? 1.0f : 0.0f;
 }
 
 // single_layer_sgd / _sparse for all streams at once (recur-nn.c:256-301):
@@ -1066,8 +1126,13 @@ extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, cons
   {
     int tn = (sh->H + BN - 1) / BN, nkt = (sh->I + BK - 1) / BK;
     int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_FWD", b->slab_floats, (size_t)nrows * sh->H);
-    ProbFwd p = {v, row0, nrows};
-    launch_gemm<false, true, ProbFwd>(st, p, b->slab, nrows, sh->H, nkt, ks, T_FWD);
+    if (b->uniform_idx >= 0) {
+      ProbFwd<true> p = {v, row0, nrows};
+      launch_gemm<false, true, ProbFwd<true>>(st, p, b->slab, nrows, sh->H, nkt, ks, T_FWD);
+    } else {
+      ProbFwd<false> p = {v, row0, nrows};
+      launch_gemm<false, true, ProbFwd<false>>(st, p, b->slab, nrows, sh->H, nkt, ks, T_FWD);
+    }
     int n4 = nrows * (sh->H / 4);
     hipLaunchKernelGGL(k_fwd_finalize, dim3((n4 + 255) / 256), dim3(256), 0, st, v, row0, nrows, ks);
   }
@@ -1111,7 +1176,11 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int nkt = (nrows + BK - 1) / BK;
     int ho = sh->H * sh->O;
     int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_HO", b->slab_floats, (size_t)ho);
-    ProbHoDelta p = {v, row0, nrows, active};
+    /* per-stream 1.0 / 0.0 participation flags as floats (b->coef plane 0 is free here:
+     * k_bptt_control rewrites it later in this call) */
+    hipLaunchKernelGGL(k_live_mask, dim3((nrows + 255) / 256), dim3(256), 0, st, b->coef + row0,
+                       active, nrows);
+    ProbHoDelta p = {v, row0, nrows, b->coef + row0};
     launch_gemm<true, true, ProbHoDelta>(st, p, b->slab, sh->H, sh->O, nkt, ks, T_OTHER);
     hipLaunchKernelGGL(k_ho_delta_finalize, dim3((ho + 255) / 256), dim3(256), 0, st, v, b->slab,
                        ks, accumulate, ranges);
@@ -1136,8 +1205,13 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int nkt = sh->D * rtiles;
     size_t n = (size_t)sh->I * sh->H;
     int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_DELTA", b->slab_floats, n);
-    ProbDelta p = {v, row0, nrows, rtiles};
-    launch_gemm<true, true, ProbDelta>(st, p, b->slab, sh->I, sh->H, nkt, ks, T_DELTA);
+    if (b->uniform_idx >= 0) {
+      ProbDelta<true> p = {v, row0, nrows, rtiles};
+      launch_gemm<true, true, ProbDelta<true>>(st, p, b->slab, sh->I, sh->H, nkt, ks, T_DELTA);
+    } else {
+      ProbDelta<false> p = {v, row0, nrows, rtiles};
+      launch_gemm<true, true, ProbDelta<false>>(st, p, b->slab, sh->I, sh->H, nkt, ks, T_DELTA);
+    }
     size_t n4 = n / 4;
     hipLaunchKernelGGL(k_delta_finalize, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
                        b->ih_delta, b->slab, n4, n, ks, accumulate);

@@ -55,6 +55,9 @@ typedef struct RamdBuffers {
   long long *stat_correct, *stat_count;                 /* [Scap]    */
   unsigned char *text;   /* encoded text for the host-free epoch loop */
   int text_len;
+  /* ring position shared by every training stream of the current call, or -1
+   * when they differ (set by the host before each launch) */
+  int uniform_idx;
 } RamdBuffers;
 
 enum { RAMD_IN_KEEP = 0, RAMD_IN_ONE_HOT = 1, RAMD_IN_DENSE = 2, RAMD_IN_TEXT = 3 };

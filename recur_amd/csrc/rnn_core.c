@@ -815,6 +815,22 @@ void rnn_delete_training_set(RecurNN **nets, int n_nets, int leave_prototype) {
   free(nets);
 }
 
+/* The ring position every stream of [row0, row0 + nrows) shares, or -1.  The
+ * host mirrors the indices exactly (they only ever change by rnn_bptt_advance). */
+static void set_uniform_idx(RamdEngine *e, int row0, int nrows) {
+  int u = -1;
+  if (row0 < e->n_streams && nrows > 0) {
+    u = e->streams[row0]->bptt->index;
+    for (int j = row0 + 1; j < row0 + nrows && j < e->n_streams; j++) {
+      if (e->streams[j]->bptt->index != u) {
+        u = -1;
+        break;
+      }
+    }
+  }
+  e->b.uniform_idx = u;
+}
+
 /* ------------------------------------------------------------ scalars push -- */
 
 /* learn_rate is host-authoritative (callers write bptt->learn_rate, e.g.
@@ -958,6 +974,7 @@ float *rnn_opinion(RecurNN *net, const float *inputs, float presynaptic_noise) {
     d_slot = e->b.arena + ((size_t)s->D * s->Scap + p->fwd) * s->I;
   }
   h2d(d_slot + s->hidden_size + 1, net->real_inputs, sizeof(float) * s->input_size);
+  set_uniform_idx(e, p->stream >= 0 ? p->stream : e->n_streams, p->stream >= 0 ? 1 : 0);
   ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1);
   ramd_launch_forward(g_stream, s, &e->b, r, 1);
   d2h(net->input_layer, d_slot, sizeof(float) * s->I);
@@ -1022,6 +1039,7 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
   if (e->err_pending) {
     err_flush(e);
   }
+  set_uniform_idx(e, j, 1);
   ramd_launch_calc_deltas(g_stream, s, &e->b, j, 1, accumulate, d_ranges, NULL,
                           net->flags | (fused ? 0x80000000u : 0));
   engine_dev_wrote(e, RNN_AMD_DELTAS);
@@ -1297,6 +1315,7 @@ static void set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, 
   }
   engine_need_dev(e, RNN_AMD_WEIGHTS);
   set_streams_to_dev(set);
+  set_uniform_idx(e, set->row0, set->n);
   ramd_launch_assemble(g_stream, &e->sh, &e->b, set->row0, set->n, mode, d_dense, ld, text_i,
                        set->global_first, set->global_count);
   ramd_launch_forward(g_stream, &e->sh, &e->b, set->row0, set->n);
@@ -1364,6 +1383,7 @@ void rnn_amd_set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ra
   if (e->err_pending && (ranges || e->err_row0 != set->row0 || e->err_nrows != set->n)) {
     err_flush(e);
   }
+  set_uniform_idx(e, set->row0, set->n);
   ramd_launch_calc_deltas(g_stream, &e->sh, &e->b, set->row0, set->n, accumulate, d_ranges,
                           d_active, set->nets[0]->flags);
   e->err_pending = 1;

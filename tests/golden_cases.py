@@ -1,0 +1,91 @@
+"""Scenario definitions shared by tests/golden/make_golden.py (which runs them on
+the REAL reference, oracle/_ref/librecur_ref.so, in the build container) and by
+the tests (which replay them on the oracle restatement and on librecur_amd.so
+and compare with the stored reference results).
+
+Each scenario is a dict of plain parameters; ``run_scenario`` drives any driver
+object with the ApiSet / OracleSet interface of scenarios.py.
+"""
+import numpy as np
+
+import recur_ctypes as rc
+
+TEXT_LEN = 6000
+
+# name -> parameters.  "steps" generations of the multi-tap text loop
+# (charmodel-predict.c:288-311) from a freshly initialised net.
+TRAIN_CASES = {
+    "relu_weighted": dict(hidden=39, S=4, D=8, act=rc.RELU, method=rc.WEIGHTED, lr=1e-2, steps=30, seed=3),
+    "relu_nesterov": dict(hidden=39, S=4, D=8, act=rc.RELU, method=rc.NESTEROV, lr=1e-2, steps=30, seed=3),
+    "relu_adagrad": dict(hidden=39, S=4, D=8, act=rc.RELU, method=rc.ADAGRAD, lr=1e-2, steps=30, seed=3,
+                         ballast=0.1),
+    "resqrt_weighted": dict(hidden=39, S=4, D=8, act=rc.RESQRT, method=rc.WEIGHTED, lr=1e-2, steps=30, seed=4),
+    "reclip_simplified": dict(hidden=39, S=4, D=8, act=rc.RECLIP20, method=rc.SIMPLIFIED_NESTEROV, lr=1e-2,
+                              steps=30, seed=5),
+    "relu_classical": dict(hidden=39, S=3, D=5, act=rc.RELU, method=rc.CLASSICAL, lr=3e-3, steps=20, seed=6),
+    "relu_adadelta": dict(hidden=39, S=3, D=5, act=rc.RELU, method=rc.ADADELTA, lr=1e-3, steps=20, seed=7,
+                          aux=True, momentum=0.95, ballast=0.0),
+    "relu_rprop": dict(hidden=39, S=3, D=5, act=rc.RELU, method=rc.RPROP, lr=1e-3, steps=20, seed=8, aux=True,
+                       aux_value=1e-4),
+    # one generation only: a single forward/backward/update from a known state (G3)
+    "single_step_h99": dict(hidden=99, S=3, D=10, act=rc.RESQRT, method=rc.WEIGHTED, lr=1e-3, steps=1, seed=9),
+    "ragged_s7_h130": dict(hidden=130, S=7, D=6, act=rc.RELU, method=rc.WEIGHTED, lr=1e-3, steps=8, seed=10),
+    # a learn rate high enough that the error-gain clamp (ih_scale < 1) and the
+    # adaptive early exit both fire (recur-nn.c:387-413)
+    "hot_clamps": dict(hidden=39, S=4, D=12, act=rc.RELU, method=rc.WEIGHTED, lr=0.08, steps=40, seed=11),
+    "depth1": dict(hidden=23, S=2, D=1, act=rc.RELU, method=rc.WEIGHTED, lr=1e-2, steps=6, seed=12),
+}
+
+
+def case_kwargs(c):
+    flags = rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR
+    if c.get("aux"):
+        flags |= rc.FLAG_AUX_ARRAYS
+    return dict(input_size=42, hidden_size=c["hidden"], output_size=42, S=c["S"], D=c["D"],
+                activation=c["act"], learn_rate=c["lr"], seed=c["seed"], flags=flags)
+
+
+def synthetic_text_np(n=TEXT_LEN, alphabet=42, seed=7):
+    """The seeded symbol stream of scenarios.synthetic_text, restated in numpy so
+    that fixtures do not depend on any C library (Jenkins PRNG, recur-rng.h)."""
+    M = (1 << 64) - 1
+
+    def rot(x, k):
+        return ((x << k) | (x >> (64 - k))) & M
+
+    a, b, c, d = 0xF1EA5EED, seed, seed, seed
+
+    def step():
+        nonlocal a, b, c, d
+        e = (a - rot(b, 7)) & M
+        a = b ^ rot(c, 13)
+        b = (c + rot(d, 37)) & M
+        c = (d + e) & M
+        d = (e + a) & M
+        return d
+
+    for _ in range(20):
+        step()
+    out = np.empty(n, np.uint8)
+    for i in range(n):
+        bits = (step() & 0x000FFFFFFFFFFFFF) | 0x3FF0000000000000
+        x = np.frombuffer(np.uint64(bits).tobytes(), dtype=np.float64)[0] - 1.0
+        out[i] = int(x * alphabet)
+    return out
+
+
+def prepare(driver, c, set_momentum_values, set_aux_values):
+    """Optimiser ballast that some methods need before the first step."""
+    if "ballast" in c and c["ballast"]:
+        set_momentum_values(c["ballast"])
+    if "aux_value" in c:
+        set_aux_values(c["aux_value"])
+        set_momentum_values(0.0)
+
+
+def run_scenario(driver, c, text, trace=None):
+    m = c.get("momentum", 0.9)
+    for i in range(c["steps"]):
+        driver.char_step(text, i, c["method"], m)
+        if trace is not None:
+            trace(i)

@@ -318,6 +318,7 @@ class OrcSet(C.Structure):
         ("stat_error", C.c_double), ("stat_entropy", C.c_double),
         ("stat_correct", C.c_long), ("stat_count", C.c_long),
         ("stat_depth", C.c_double), ("stat_zeros", C.c_double),
+        ("global_first", C.c_int), ("global_count", C.c_int),
     ]
 
 

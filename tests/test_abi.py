@@ -1,0 +1,173 @@
+"""The drop-in boundary without a GPU: librecur_amd.so loads, exports every
+function include/recur_amd.h declares, lays its structs out like the reference,
+and its host-only half (construction, weight initialisation, CDB files) behaves
+like the reference.  No compute entry point is called here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import recur_ctypes as rc
+import replay
+
+ROOT = rc.ROOT
+AMD = rc.load_amd()
+Z = replay.golden()
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "recur_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(rnn_[a-z0-9_]+)\s*\(", src))
+    return sorted(n for n in names if n not in ("rnn_log_float", "rnn_log_int"))  # static inline
+
+
+def test_every_declared_symbol_is_exported():
+    missing = [n for n in declared_functions() if not hasattr(AMD, n)]
+    assert missing == []
+    assert len(declared_functions()) >= 50
+    # and the binding tables of the tests cover the whole header
+    bound = set(rc.RNN_API) | set(rc.AMD_API)
+    assert set(declared_functions()) <= bound
+
+
+def test_struct_layout_is_the_reference_abi():
+    # offsets the reference's own Python extension relies on (py-recur-text.c:594-599)
+    assert C.sizeof(rc.RecurNN) == 176 and C.sizeof(rc.RecurNNBPTT) == 128
+    assert rc.RecurNN.presynaptic_noise.offset == 164
+    assert rc.RecurNNBPTT.learn_rate.offset == 104
+    assert rc.RecurNNBPTT.ih_scale.offset == 108
+    assert rc.RecurNNBPTT.ho_scale.offset == 112
+    assert rc.RecurNNBPTT.momentum_weight.offset == 120
+
+
+def test_header_compiles_as_c_and_cxx(tmp_path):
+    prog = '#include "recur-nn.h"\nint main(void){RecurNN n; (void)n; return sizeof(RecurNNBPTT) == 128 ? 0 : 1;}\n'
+    for cc, ext, std in (("gcc", "c", "-std=gnu11"), ("g++", "cpp", "-std=c++17")):
+        f = tmp_path / ("t." + ext)
+        f.write_text(prog)
+        exe = tmp_path / ("t_" + ext)
+        subprocess.run([cc, std, "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(f), "-o",
+                        str(exe)], check=True)
+        assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_padded_sizes_and_first_ring_slot():
+    net = AMD.rnn_new(42, 1024, 42, rc.FLAG_STANDARD, 1, None, 20, 1e-5, 0.95, 0.0, rc.RELU)
+    n = net.contents
+    assert (n.i_size, n.h_size, n.o_size, n.ih_size, n.ho_size) == (1068, 1028, 44, 1097904, 45232)
+    b = n.bptt.contents
+    assert b.index == 1 and b.depth == 20                    # recur-nn-init.c:133
+    assert C.addressof(n.input_layer.contents) == C.addressof(b.history.contents) + 4 * n.i_size
+    assert C.addressof(n.real_inputs.contents) == C.addressof(n.input_layer.contents) + 4 * 1025
+    assert b.min_error_factor == np.float32(1e-12) * np.float32(1028)
+    assert b.ho_scale == 1.0 and b.momentum_weight == 0.5
+    AMD.rnn_delete_net(net)
+
+
+@pytest.mark.parametrize("name,hidden,shape,perf,seed", [
+    ("init_semicircle_h99", 99, rc.DIST_SEMICIRCLE, 0.0, 1),
+    ("init_uniform_perf_h99", 99, rc.DIST_UNIFORM, 0.7, 1),
+    ("init_gaussian_h1024", 1024, rc.DIST_GAUSSIAN, 0.0, 2),
+    ("init_lognormal_h64", 64, rc.DIST_LOG_NORMAL, 0.2, 3),
+])
+def test_weight_init_bit_exact_with_reference(name, hidden, shape, perf, seed):
+    net = AMD.rnn_new(42, hidden, 42, rc.FLAG_STANDARD, seed, None, 10, 1e-3, 0.9, 0.0, rc.RELU)
+    p = rc.InitParams()
+    AMD.rnn_init_default_weight_parameters(net, C.byref(p))
+    p.method, p.flat_shape, p.flat_perforation = rc.INIT_FLAT, shape, perf
+    AMD.rnn_randomise_weights_clever(net, C.byref(p))
+    n = net.contents
+    ih = rc.view(n.ih_weights, n.ih_size)
+    ho = rc.view(n.ho_weights, n.ho_size)
+    sums = np.array([ih.astype(np.float64).sum(), np.abs(ih).astype(np.float64).sum(),
+                     ho.astype(np.float64).sum(), np.abs(ho).astype(np.float64).sum()])
+    assert np.array_equal(sums, Z[name])
+    assert np.array_equal(ih[n.h_size:n.h_size + 256], Z[name + "_ih_head"])
+    assert np.array_equal(ho[:256], Z[name + "_ho_head"])
+    assert np.array_equal(np.array([n.rng.a, n.rng.b, n.rng.c, n.rng.d], dtype=np.uint64),
+                          Z[name + "_rng"])
+    AMD.rnn_delete_net(net)
+
+
+def test_training_set_clones_share_and_seed_like_reference():
+    c = replay.golden_case("relu_weighted")  # its rng snapshot is after 30 steps without noise == after cloning
+    import golden_cases as gc
+    import scenarios as sc
+    a = sc.ApiSet(AMD, **gc.case_kwargs(gc.TRAIN_CASES["relu_weighted"]))
+    for j in range(a.S):
+        n = a.nets[j].contents
+        assert (n.rng.a, n.rng.b, n.rng.c, n.rng.d) == tuple(int(x) for x in c["rng"][j])
+    n0, n1 = a.nets[0].contents, a.nets[1].contents
+    addr = lambda p: C.addressof(p.contents)
+    assert addr(n0.ih_weights) == addr(n1.ih_weights) and addr(n0.ho_weights) == addr(n1.ho_weights)
+    b0, b1 = n0.bptt.contents, n1.bptt.contents
+    for f in ("ih_momentum", "ho_momentum", "ih_delta", "ho_delta", "ih_delta_tmp"):
+        assert addr(getattr(b0, f)) == addr(getattr(b1, f)), f
+    assert addr(b0.history) != addr(b1.history) and addr(n0.hidden_layer) != addr(n1.hidden_layer)
+    assert AMD.rnn_new_training_set(a.net, 0) is None or not AMD.rnn_new_training_set(a.net, 0)
+    a.close()
+
+
+def test_cdb_reads_reference_fixture_and_round_trips(tmp_path):
+    fx = os.path.join(ROOT, "tests", "golden", "multi-text-6c34c563i73-h99-o3650.net")
+    net = AMD.rnn_load_net(fx.encode())
+    assert net
+    n = net.contents
+    # scalars of the committed reference net ("Checkpoint / resume")
+    assert (n.input_size, n.hidden_size, n.output_size) == (73, 99, 3650)
+    assert (n.i_size, n.h_size, n.o_size) == (176, 100, 3652)
+    assert n.generation == 10659 and n.flags == 0x40053 and n.activation == rc.RESQRT
+    b = n.bptt.contents
+    assert b.depth == 50 and abs(b.learn_rate - 0.1) < 1e-7
+    assert len(n.metadata) == 1050 and n.metadata.startswith(b"{")
+    w = rc.view(n.ih_weights, n.ih_size).copy()
+    assert np.isfinite(w).all() and np.abs(w).sum() > 100
+    cwd = os.getcwd()
+    os.chdir(tmp_path)  # rnn_save_net makes its temp file in the cwd (recur-nn-io.c:17-21)
+    try:
+        assert AMD.rnn_save_net(net, b"copy.net", 1) == 0
+        assert not os.path.exists("copy.net~")  # the reference's backup never happens (recur-nn-io.c:130)
+        again = AMD.rnn_load_net(b"copy.net")
+        m = again.contents
+        assert np.array_equal(rc.view(m.ih_weights, m.ih_size), w)
+        assert np.array_equal(rc.view(m.ho_weights, m.ho_size), rc.view(n.ho_weights, n.ho_size))
+        assert m.metadata == n.metadata and m.generation == n.generation
+        assert (m.rng.a, m.rng.d) == (n.rng.a, n.rng.d)
+        mb = m.bptt.contents
+        assert (mb.index, mb.ho_scale, mb.min_error_factor) == (b.index, b.ho_scale, b.min_error_factor)
+        # same record names in the same order as the reference writer
+        keys = cdb_keys("copy.net")
+        assert keys == cdb_keys(fx)
+        assert AMD.rnn_load_net(b"no-such-file.net") is None or not AMD.rnn_load_net(b"no-such-file.net")
+        assert AMD.rnn_save_net(None, b"x.net", 0) == -1
+    finally:
+        os.chdir(cwd)
+
+
+def cdb_keys(path):
+    """Independent reader of the container (the layout scripts/pycdb.py of the
+    reference documents): record keys in file order."""
+    data = open(path, "rb").read()
+    u32 = lambda o: int.from_bytes(data[o:o + 4], "little")
+    end = min(u32(8 * t) for t in range(256))
+    pos, keys = 2048, []
+    while pos < end:
+        kl, dl = u32(pos), u32(pos + 4)
+        keys.append((data[pos + 8:pos + 8 + kl].decode(), dl))
+        pos += 8 + kl + dl
+    return keys
+
+
+def test_compute_entry_points_fail_loudly_without_a_gpu():
+    if AMD.rnn_amd_device_count() > 0:
+        pytest.skip("a GPU is present")
+    code = ("import sys; sys.path.insert(0, %r); import recur_ctypes as rc; a = rc.load_amd();"
+            "n = a.rnn_new(4, 7, 3, rc.FLAG_STANDARD, 1, None, 4, 0.01, 0.9, 0.0, rc.RELU);"
+            "a.rnn_opinion(n, None, 0.0)") % os.path.join(ROOT, "tests")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
