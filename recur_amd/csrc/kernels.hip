@@ -425,28 +425,34 @@ struct ProbHoDelta {
   }
 };
 
-// chain step t: A = error rows ehi[t] (KC, masked), B = W_ih rows (KC); K = H
-struct ProbChain {
+// Chain "extras": the few columns of the input error that the next BPTT step
+// never reads -- the bias row (column 0) and the real-input rows (columns above
+// hidden_size) -- for ALL steps at once after the chain has run:
+// M = (step, stream), N = 1 + i_size - 1 - hidden_size, K = H.
+// A[m][k] = ehi[t][r][k] (KC), B[c][k] = W_ih[c ? hidden_size + c : 0][k] (KC).
+struct ProbExtras {
   static constexpr bool B_AUX = false;
   View v;
-  int row0, nrows, t;
-  __device__ const float *a_ptr(int kt, int row, int k) const {
+  int row0, nrows, nx;
+  __device__ const float *a_ptr(int kt, int m, int k) const {
     k += kt * BK;
-    bool ok = row < nrows && k < v.sh.H;
-    const float *e = v.b.ehi + ((size_t)t * v.sh.Scap + row0 + (row < nrows ? row : 0)) * v.sh.I;
-    return e + (ok ? k : 0);
+    int M = v.sh.D * nrows;
+    bool ok = m < M && k < v.sh.H;
+    int mm = m < M ? m : 0;
+    int t = mm / nrows, r = mm - t * nrows;
+    return v.b.ehi + ((size_t)t * v.sh.Scap + row0 + r) * v.sh.I + (ok ? k : 0);
   }
-  __device__ float4 a_fix(int kt, int row, int k, const Raw &r) const {
+  __device__ float4 a_fix(int kt, int m, int k, const Raw &r) const {
+    return (m < v.sh.D * nrows && k + kt * BK < v.sh.H) ? r.v : zero4();
+  }
+  __device__ const float *b_ptr(int kt, int c, int k) const {
     k += kt * BK;
-    return (row < nrows && k < v.sh.H) ? mask_herr(r.v, k, v.sh.hidden_size) : zero4();
+    bool ok = c < nx && k < v.sh.H;
+    int n = (c == 0 || c >= nx) ? 0 : v.sh.hidden_size + c;
+    return v.b.ih_w + (size_t)n * v.sh.H + (ok ? k : 0);
   }
-  __device__ const float *b_ptr(int kt, int n, int k) const {
-    k += kt * BK;
-    bool ok = n < v.sh.I && k < v.sh.H;
-    return v.b.ih_w + (ok ? (size_t)n * v.sh.H + k : 0);
-  }
-  __device__ float4 b_fix(int kt, int n, int k, const Raw &r) const {
-    return (n < v.sh.I && k + kt * BK < v.sh.H) ? r.v : zero4();
+  __device__ float4 b_fix(int kt, int c, int k, const Raw &r) const {
+    return (c < nx && k + kt * BK < v.sh.H) ? r.v : zero4();
   }
   __device__ const float *b_aux_ptr(int, int) const { return v.b.slab; }
 };
@@ -564,6 +570,7 @@ __device__ float fast_expf_dev(float x) {
 // thread per stream walks its row in the reference's order, so the sums round
 // the same way.
 __global__ __launch_bounds__(64) void k_softmax_error(View v, int row0, int nrows) {
+  extern __shared__ float ex[]; /* [output_size] exponentials */
   int j = blockIdx.x;
   if (j >= nrows) return;
   const RamdShape &s = v.sh;
@@ -573,29 +580,33 @@ __global__ __launch_bounds__(64) void k_softmax_error(View v, int row0, int nrow
   int zeros = 0;
   for (int i = threadIdx.x; i < s.H; i += 64) zeros += (hid[i] == 0.0f);
   for (int off = 32; off > 0; off >>= 1) zeros += __shfl_down(zeros, off, 64);
-  if (threadIdx.x != 0) return;
   const float *src = v.b.out + (size_t)r * s.O;
   float *err = v.b.o_error + (size_t)r * s.O;
   int len = s.output_size;
+  // max and min are order independent: one pass over the lanes
   float lo = src[0], hi = src[0];
-  for (int i = 1; i < len; i++) {
+  for (int i = threadIdx.x; i < len; i += 64) {
     hi = fmaxf(hi, src[i]);
     lo = fminf(lo, src[i]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    lo = fminf(lo, __shfl_xor(lo, off, 64));
   }
   float adj = 0.0f;
   if (hi > 50.0f) adj = 50.0f - hi;
   else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+  // the exponentials in parallel, their sum in the reference's order (lane 0)
+  for (int i = threadIdx.x; i < len; i += 64) ex[i] = fast_expf_dev(src[i] + adj);
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   float sum = 0.0f;
-  for (int i = 0; i < len; i++) {
-    float x = fast_expf_dev(src[i] + adj);
-    sum += x;
-    err[i] = x;
-  }
+  for (int i = 0; i < len; i++) sum += ex[i];
   int best_i = 0;
-  float best_e = err[0] / sum;
+  float best_e = ex[0] / sum;
   err[0] = -best_e;
   for (int i = 1; i < len; i++) {
-    float e = err[i] / sum;
+    float e = ex[i] / sum;
     if (e > best_e) {
       best_e = e;
       best_i = i;
@@ -663,7 +674,8 @@ __global__ __launch_bounds__(256) void k_top_backprop(View v, int row0, const in
     scaled = scale * sum;
   }
   float *dst = v.b.ehi + (size_t)r * s.I; /* step 0 plane */
-  for (int y = threadIdx.x; y < s.H; y += 256) dst[y] = (sum > halfmax) ? herr[y] * scale : herr[y];
+  for (int y = threadIdx.x; y < s.H; y += 256) /* ehi keeps column 0 and the pad at zero */
+    dst[y] = (y == 0 || y > s.hidden_size) ? 0.0f : (sum > halfmax) ? herr[y] * scale : herr[y];
   if (threadIdx.x == 0) {
     v.b.top_raw[r] = sum;
     v.b.top_scaled[r] = scaled;
@@ -701,42 +713,221 @@ __global__ void k_ho_delta_finalize(View v, const float *slab, int ks, int accum
   v.b.ho_delta[e] = acc;
 }
 
-// ------------------------------------------------------- finalize: chain --
+// ------------------------------------------------------ BPTT chain step --
+//
+// One launch per BPTT step t (recur-nn.c:338-376 for every stream at once):
+//     E[t+1][s][y] = on(X_t[s][y]) * sum_k E[t][s][k] W_ih[y][k],   y = 1..hidden_size
+// plus the per-stream sum of squares.  The hidden->hidden block is all the next
+// step needs, and for a power-of-two hidden size it tiles exactly: 32 x 32
+// output tiles, (S/32) x (hidden/32) workgroups = 256 at the 1024 / 256 size,
+// one per CU, no split-K slabs and no separate finalize pass.  Column 0 (bias
+// row) and the real-input rows only feed the sum of squares and are done for
+// all steps together afterwards (ProbExtras).
+//
+// Workgroup = 4 waves; each wave multiplies a quarter of every 128-deep K stage
+// (in-workgroup split-K, summed through LDS at the end).  Operand stages go
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), three
+// stages deep, with counted s_waitcnt vmcnt and raw s_barrier so that two stages
+// stay in flight across barriers.  LDS rows are 128 floats; the 16-byte chunk c
+// of row r is stored at chunk position c ^ (r & 15), applied on the DMA's global
+// address (the LDS side of a DMA is lane-linear) and again on the ds_read_b128
+// address, which makes the 16-lane groups of ds_read_b128 conflict free.
+// Fragments are fetched with inline-asm ds_read_b128: hipcc would otherwise
+// drain vmcnt to 0 before any LDS read that may alias an LDS-DMA destination.
 
-// Sums the K slabs of one BPTT step and applies the reference's per-row rule
-// (recur-nn.c:338-376): a row of the input vector that is zero (or >= 20 for
-// RECLIP20) gets no error; RESQRT divides by 2 (x + 1); the squares are summed
-// per stream.  One workgroup per stream; the sum is a fixed tree.
-__global__ __launch_bounds__(256) void k_chain_finalize(View v, int row0, int nrows, int t,
-                                                        int ks) {
-  __shared__ float red[4];
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+constexpr int CM = 32, CN = 32, CK = 128;
+constexpr int C_STAGES = 4;                    /* LDS ring: 3 stages in flight + 1 being read */
+constexpr int C_STAGE_FLOATS = (CM + CN) * CK; /* 32 KB */
+
+__device__ __forceinline__ uint32_t lds_byte_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(lds_void_t *)p;
+}
+__device__ __forceinline__ f32x4 lds_read_b128(uint32_t addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+template <bool UNI>
+__global__ __launch_bounds__(256) void k_chain_main(View v, int row0, int nrows, int t, int tm,
+                                                    int tn, int nstages, int ktail0, int ablate) {
+  __shared__ __attribute__((aligned(16))) float smem[C_STAGES * C_STAGE_FLOATS];
   const RamdShape &s = v.sh;
-  int j = blockIdx.x, r = row0 + j;
-  const float *x = input_row(v, r, t);
-  const float *p = v.b.slab + (size_t)j * s.I;
-  float *dst = v.b.ehi + ((size_t)(t + 1) * s.Scap + r) * s.I;
-  float sq = 0.0f;
-  for (int c = threadIdx.x * 4; c < s.I; c += 1024) {
-    float4 a = ld4(p + c);
-    for (int z = 1; z < ks; z++) {
-      float4 q = ld4(p + (size_t)z * nrows * s.I + c);
-      a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+  const int L = blockIdx.x;
+  const int xcd = L & 7, q = L >> 3;
+  const int mt = q % tm, nt = (q / tm) * 8 + xcd; /* the m tiles of one W panel share an XCD */
+  if (nt >= tn) return;
+  const int m0 = mt * CM, n0 = 1 + nt * CN;       /* output columns start at 1 */
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lm = lane & 31, kh = lane >> 5;
+  const float *ehi_t = v.b.ehi + ((size_t)t * s.Scap + row0) * s.I;
+
+  // --- LDS-DMA source addresses of this lane: 8 instructions per stage and wave.
+  // Instruction i (0..31 over the workgroup) fills rows 2 (i & 15), +1 of A (i < 16) or B.
+  const float *src[8];
+  int kcol[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    int i = wave * 8 + j;
+    int row = 2 * (i & 15) + (lane >> 5);
+    int c = (lane & 31) ^ (row & 15); /* global chunk stored at this LDS position */
+    const float *base;
+    if (i < 16) {
+      int r = m0 + row;
+      base = ehi_t + (size_t)(r < nrows ? r : nrows - 1) * s.I;
+    } else {
+      int n = n0 + row;
+      base = v.b.ih_w + (size_t)(n < s.I ? n : s.I - 1) * s.H;
     }
-    float4 in = ld4(x + c);
-    float e[4] = {a.x, a.y, a.z, a.w};
-    float xi[4] = {in.x, in.y, in.z, in.w};
+    src[j] = base + 4 * c;
+    kcol[j] = 4 * c;
+  }
+  // a stage whose 128 columns all lie inside K needs no per-chunk test
+  auto issue_one = [&](int stage, int j) {
+    float *dst = smem + (stage % C_STAGES) * C_STAGE_FLOATS + (wave * 8 + j) * 256;
+    const int k0 = stage * CK;
+    const float *g = src[j] + k0;
+    if (k0 + CK > s.H) g = (k0 + kcol[j] < s.H) ? g : v.b.zeros; /* last, partial stage only */
+    if (ablate & 1) g = v.b.zeros + (lane & 15) * 4; /* ABLATION: every DMA reads one hot line */
+    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)dst, 16, 0, 0);
+  };
+  auto issue = [&](int stage) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) issue_one(stage, j);
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+
+#pragma unroll
+  for (int p = 0; p < C_STAGES - 1; p++)
+    if (p < nstages) issue(p);
+  const uint32_t lds0 = lds_byte_addr(smem);
+  const uint32_t rowoff = (uint32_t)lm * (CK * 4u);
+  for (int st = 0; st < nstages; st++) {
+    // stages st+1 .. st+C_STAGES-2 may stay in flight (8 DMAs per stage and wave)
+    const int ahead = min(C_STAGES - 2, nstages - 1 - st);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const uint32_t abase = lds0 + (uint32_t)((st % C_STAGES) * C_STAGE_FLOATS) * 4u;
+    const uint32_t bbase = abase + (uint32_t)(CM * CK) * 4u;
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int gi = 0; gi < 4; gi++) {
+      int c = 2 * (4 * wave + gi) + kh;               /* chunk = 4 consecutive k */
+      uint32_t off = rowoff + (uint32_t)((c ^ (lm & 15)) * 16);
+      a[gi] = lds_read_b128(abase + off);
+      b[gi] = lds_read_b128(bbase + off);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // refill the buffer everybody finished reading before this stage's barrier,
+    // two DMA issues after every four MFMAs so that their address arithmetic sits
+    // in the shadow of the dependent MFMA chain
+    const bool refill = st + C_STAGES - 1 < nstages;
+    const bool domma = !(ablate & 2); /* ABLATION: skip the MFMAs */
+#pragma unroll
+    for (int gi = 0; gi < 4; gi++) {
+      if (domma) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].x, b[gi].x, acc, 0, 0, 0);
+      if (domma) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].y, b[gi].y, acc, 0, 0, 0);
+      if (refill) issue_one(st + C_STAGES - 1, 2 * gi);
+      if (domma) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].z, b[gi].z, acc, 0, 0, 0);
+      if (domma) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].w, b[gi].w, acc, 0, 0, 0);
+      if (refill) issue_one(st + C_STAGES - 1, 2 * gi + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // --- sum the four waves' partial tiles through LDS
+  __builtin_amdgcn_s_barrier();
+  float *red = smem; /* [4][32][32] */
+#pragma unroll
+  for (int g = 0; g < 16; g++) {
+    int row = (g & 3) + 8 * (g >> 2) + 4 * kh;
+    red[(wave * CM + row) * CN + lm] = acc[g];
+  }
+  __syncthreads();
+  const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+  float e[4];
+  {
+    float4 p0 = ld4(red + (0 * CM + row) * CN + c4), p1 = ld4(red + (1 * CM + row) * CN + c4);
+    float4 p2 = ld4(red + (2 * CM + row) * CN + c4), p3 = ld4(red + (3 * CM + row) * CN + c4);
+    e[0] = (p0.x + p1.x) + (p2.x + p3.x);
+    e[1] = (p0.y + p1.y) + (p2.y + p3.y);
+    e[2] = (p0.z + p1.z) + (p2.z + p3.z);
+    e[3] = (p0.w + p1.w) + (p2.w + p3.w);
+  }
+  const int r = m0 + row;
+  float sq = 0.0f;
+  if (r < nrows) {
+    const float *erow = ehi_t + (size_t)r * s.I;
+    const float *x = input_row<UNI>(v, row0 + r, t);
+    float *dst = v.b.ehi + ((size_t)(t + 1) * s.Scap + row0 + r) * s.I;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      bool on = xi[i] != 0.0f && (s.activation != 5 || xi[i] < 20.0f);
-      float ev = on ? e[i] : 0.0f;
-      if (on && s.activation == 2) ev /= 2 * (xi[i] + 1.0f);
-      e[i] = ev;
-      sq += ev * ev;
+      int n = n0 + c4 + i;
+      if (n <= s.hidden_size) {
+        float ev = e[i];
+        for (int k = ktail0; k < s.H; k++) ev += erow[k] * v.b.ih_w[(size_t)n * s.H + k];
+        float xi = x[n];
+        bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
+        ev = on ? ev : 0.0f;
+        if (on && s.activation == 2) ev /= 2 * (xi + 1.0f);
+        dst[n] = ev;
+        sq += ev * ev;
+      }
     }
-    *reinterpret_cast<float4 *>(dst + c) = make_float4(e[0], e[1], e[2], e[3]);
   }
-  sq = block_sum_256(sq, red);
-  if (threadIdx.x == 0) v.b.esum[(size_t)t * s.Scap + r] = sq;
+  sq += __shfl_xor(sq, 1, 64);
+  sq += __shfl_xor(sq, 2, 64);
+  sq += __shfl_xor(sq, 4, 64);
+  if ((threadIdx.x & 7) == 0 && r < nrows)
+    v.b.esum_part[((size_t)t * (tn + 1) + nt) * s.Scap + row0 + r] = sq;
+}
+
+// esum[t][s] = the step's sum of squares: its per-column-tile partials added in
+// a fixed order (one thread per (step, stream))
+__global__ void k_esum_reduce(View v, int row0, int nrows, int tn) {
+  const RamdShape &s = v.sh;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.D * nrows) return;
+  int t = i / nrows, r = row0 + (i - t * nrows);
+  float sum = 0.0f;
+  for (int p = 0; p <= tn; p++) sum += v.b.esum_part[((size_t)t * (tn + 1) + p) * s.Scap + r];
+  v.b.esum[(size_t)t * s.Scap + r] = sum;
+}
+
+// Finalize of the extras GEMM: applies the row rule to column 0 and the input
+// columns, keeps the raw values in ex[t+1][s][c] (for the h_error / i_error
+// images) and adds their squares as the last partial sum.  One wave per (t, s).
+__global__ __launch_bounds__(64) void k_extras_finalize(View v, int row0, int nrows, int nx, int nxp,
+                                                        int ks, int tn) {
+  const RamdShape &s = v.sh;
+  int m = blockIdx.x;
+  int t = m / nrows, j = m - t * nrows, r = row0 + j;
+  int M = s.D * nrows;
+  const float *x = input_row<false>(v, r, t);
+  float *dst = v.b.ex + ((size_t)(t + 1) * s.Scap + r) * nxp;
+  float sq = 0.0f;
+  for (int c = threadIdx.x; c < nx; c += 64) {
+    float e = 0.0f;
+    for (int z = 0; z < ks; z++) e += v.b.slab[((size_t)z * M + m) * nxp + c];
+    int n = c == 0 ? 0 : s.hidden_size + c;
+    float xi = x[n];
+    bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
+    e = on ? e : 0.0f;
+    if (on && s.activation == 2) e /= 2 * (xi + 1.0f);
+    dst[c] = e;
+    sq += e * e;
+  }
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+  if (threadIdx.x == 0) v.b.esum_part[((size_t)t * (tn + 1) + tn) * s.Scap + r] = sq;
 }
 
 // ----------------------------------------------------- K9: BPTT control --
@@ -747,7 +938,7 @@ __global__ __launch_bounds__(256) void k_chain_finalize(View v, int row0, int nr
 // the adaptive min_error_factor, and publishes coef[t][r] = ih_scale while the
 // step counts, 0 afterwards.
 __global__ void k_bptt_control(View v, int row0, int nrows, const unsigned char *active,
-                               unsigned flags) {
+                               unsigned flags, int tn) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nrows) return;
   const RamdShape &s = v.sh;
@@ -817,8 +1008,10 @@ __global__ __launch_bounds__(256) void k_delta_finalize(float *delta, const floa
 
 // Rebuilds bptt->h_error (err_a) and bptt->i_error (err_b) as the reference
 // leaves them: the loop ping-pongs between the two buffers (recur-nn.c:384-386),
-// zeroing element 0 and the pad of whichever one it reads (334-337).
-__global__ __launch_bounds__(256) void k_err_writeback(View v, int row0) {
+// zeroing element 0 and the pad of whichever one it reads (334-337).  Columns
+// 1..hidden_size of a step's error live in ehi, column 0 and the input columns
+// in ex.
+__global__ __launch_bounds__(256) void k_err_writeback(View v, int row0, int nxp) {
   const RamdShape &s = v.sh;
   int r = row0 + blockIdx.x;
   int n = v.b.n_exec[r];
@@ -828,13 +1021,15 @@ __global__ __launch_bounds__(256) void k_err_writeback(View v, int row0) {
   float *last_read = (n & 1) ? A : B;    /* step n read it (and zeroed bits) */
   const float *en = v.b.ehi + ((size_t)n * s.Scap + r) * s.I;
   const float *ep = v.b.ehi + ((size_t)(n - 1) * s.Scap + r) * s.I;
-  int lim = (n == 1) ? s.H : s.I; /* the top error only covers h_size entries */
+  const float *xn = v.b.ex + ((size_t)n * s.Scap + r) * nxp;
+  const float *xp = v.b.ex + ((size_t)(n - 1) * s.Scap + r) * nxp;
+  int hs = s.hidden_size;
   for (int i = threadIdx.x; i < s.I; i += 256) {
-    last_written[i] = en[i];
-    if (i < lim) {
-      float x = ep[i];
-      if (i == 0 || (i > s.hidden_size && i < s.H)) x = 0.0f;
-      last_read[i] = x;
+    last_written[i] = (i == 0) ? xn[0] : (i <= hs) ? en[i] : xn[i - hs];
+    if (i < s.H) {
+      last_read[i] = (i == 0 || i > hs) ? 0.0f : ep[i];
+    } else if (n > 1) { /* the top error (n == 1) only covers h_size entries */
+      last_read[i] = xp[i - hs];
     }
   }
 }
@@ -1151,7 +1346,8 @@ extern "C" void ramd_launch_softmax_error(ramd_stream_t st_, const RamdShape *sh
                                           const RamdBuffers *b, int row0, int nrows) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  hipLaunchKernelGGL(k_softmax_error, dim3(nrows), dim3(64), 0, st, v, row0, nrows);
+  hipLaunchKernelGGL(k_softmax_error, dim3(nrows), dim3(64), (size_t)sh->output_size * sizeof(float), st, v,
+                     row0, nrows);
 }
 
 extern "C" void ramd_launch_clear_deltas(ramd_stream_t st_, const RamdShape *sh,
@@ -1185,19 +1381,37 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     hipLaunchKernelGGL(k_ho_delta_finalize, dim3((ho + 255) / 256), dim3(256), 0, st, v, b->slab,
                        ks, accumulate, ranges);
   }
-  // BPTT chain: D dependent steps
+  // BPTT chain: D dependent steps, one launch each, then the extras of all steps
+  const int tn = (sh->hidden_size + CN - 1) / CN;
+  const int nx = sh->I - sh->hidden_size; /* column 0 + the input columns */
+  const int nxp = (nx + 3) & ~3;
   {
-    int tm = (nrows + BM - 1) / BM, tn = (sh->I + BN - 1) / BN;
-    int nkt = (sh->H + BK - 1) / BK;
-    int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_CHAIN", b->slab_floats, (size_t)nrows * sh->I);
+    int tm = (nrows + CM - 1) / CM;
+    int kfull = sh->H / CK, ktail = sh->H - kfull * CK;
+    int nstages = kfull + (ktail > 8 ? 1 : 0);
+    int ktail0 = ktail > 8 ? sh->H : kfull * CK; /* a short tail is added in the epilogue */
+    int blocks = ((tn + 7) / 8) * 8 * tm;
     for (int t = 0; t < sh->D; t++) {
-      ProbChain p = {v, row0, nrows, t};
-      launch_gemm<false, false, ProbChain>(st, p, b->slab, nrows, sh->I, nkt, ks, T_CHAIN);
-      hipLaunchKernelGGL(k_chain_finalize, dim3(nrows), dim3(256), 0, st, v, row0, nrows, t, ks);
+      int ev = timing_begin(st, T_CHAIN);
+      if (b->uniform_idx >= 0)
+        hipLaunchKernelGGL(k_chain_main<true>, dim3(blocks), dim3(256), 0, st, v, row0, nrows, t, tm,
+                           tn, nstages, ktail0, env_int("RECUR_AMD_ABLATE", 0));
+      else
+        hipLaunchKernelGGL(k_chain_main<false>, dim3(blocks), dim3(256), 0, st, v, row0, nrows, t,
+                           tm, tn, nstages, ktail0, 0);
+      timing_end(st, ev);
     }
+    int M = sh->D * nrows;
+    int etm = (M + BM - 1) / BM, etn = (nx + BN - 1) / BN, nkt = (sh->H + BK - 1) / BK;
+    int ks = pick_ks(etm * etn, nkt, "RECUR_AMD_KS_EXTRAS", b->slab_floats, (size_t)M * nxp);
+    ProbExtras p = {v, row0, nrows, nx};
+    launch_gemm<false, false, ProbExtras>(st, p, b->slab, M, nxp, nkt, ks, T_OTHER);
+    hipLaunchKernelGGL(k_extras_finalize, dim3(M), dim3(64), 0, st, v, row0, nrows, nx, nxp, ks, tn);
   }
+  hipLaunchKernelGGL(k_esum_reduce, dim3((sh->D * nrows + 255) / 256), dim3(256), 0, st, v, row0,
+                     nrows, tn);
   hipLaunchKernelGGL(k_bptt_control, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows,
-                     active, flags);
+                     active, flags, tn);
   // weight deltas: one GEMM over (step, stream)
   {
     int tm = (sh->I + BM - 1) / BM, tn = (sh->H + BN - 1) / BN;
@@ -1222,7 +1436,8 @@ extern "C" void ramd_launch_err_writeback(ramd_stream_t st_, const RamdShape *sh
                                           const RamdBuffers *b, int row0, int nrows) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  hipLaunchKernelGGL(k_err_writeback, dim3(nrows), dim3(256), 0, st, v, row0);
+  int nxp = (sh->I - sh->hidden_size + 3) & ~3;
+  hipLaunchKernelGGL(k_err_writeback, dim3(nrows), dim3(256), 0, st, v, row0, nxp);
 }
 
 extern "C" void ramd_launch_apply(ramd_stream_t st_, int method, float *w, const float *delta,

@@ -31,7 +31,8 @@ typedef struct RamdShape {
  * HBM layout (all fp32, row major):
  *   arena   [D][Scap][I] history ring, slot major, then [Fcap][I] input rows
  *           of the forward-only streams
- *   ehi     [D+1][Scap][I] back-propagated error per BPTT step: row 0 is the
+ *   ehi     [D+1][Scap][I] back-propagated error per BPTT step (columns
+ *           1..hidden_size; column 0 and the columns above stay zero): row 0 is the
  *           (soft-clipped) top-layer error, row t+1 the input error of step t
  *   esum    [D][Scap]  sum of squares of each step's input error
  *   coef    [D][Scap]  ih_scale of the stream while the step was executed, else 0
@@ -39,6 +40,9 @@ typedef struct RamdShape {
 typedef struct RamdBuffers {
   float *ih_w, *ho_w, *ih_m, *ho_m, *ih_aux, *ho_aux, *ih_delta, *ho_delta;
   float *arena, *hidden, *out, *o_error, *err_a, *err_b, *ehi, *esum, *coef;
+  float *ex;        /* [D+1][Scap][nxp] column 0 and the input columns of each step's error */
+  float *esum_part; /* [D][tn+1][Scap] per-column-tile partial sums of squares         */
+  float *zeros;     /* 256 bytes of zeros: source of out-of-range LDS-DMA chunks       */
   float *slab;
   size_t slab_floats;
   int *idx;       /* [Scap] ring position                           */

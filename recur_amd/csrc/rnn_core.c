@@ -146,7 +146,7 @@ static void engine_free_device(RamdEngine *e) {
   dev_free(b->ih_aux); dev_free(b->ho_aux); dev_free(e->delta_own);
   dev_free(b->arena); dev_free(b->hidden); dev_free(b->out); dev_free(b->o_error);
   dev_free(b->err_a); dev_free(b->err_b); dev_free(b->ehi); dev_free(b->esum);
-  dev_free(b->coef); dev_free(b->slab); dev_free(b->idx); dev_free(b->lr); dev_free(b->mef);
+  dev_free(b->coef); dev_free(b->ex); dev_free(b->esum_part); dev_free(b->zeros); dev_free(b->slab); dev_free(b->idx); dev_free(b->lr); dev_free(b->mef);
   dev_free(b->ih_scale); dev_free(b->top_raw); dev_free(b->top_scaled); dev_free(b->bptt_err);
   dev_free(b->n_exec); dev_free(b->depth_log); dev_free(b->target); dev_free(b->hot);
   dev_free(b->active); dev_free(b->stat_err); dev_free(b->stat_ent); dev_free(b->stat_zero);
@@ -463,9 +463,17 @@ static void engine_ensure_device(RamdEngine *e) {
   b->ehi = dev_alloc((D + 1) * S * I * fl);
   b->esum = dev_alloc(D * S * fl);
   b->coef = dev_alloc(D * S * fl);
+  {
+    size_t nxp = ((size_t)(s->I - s->hidden_size) + 3) & ~(size_t)3;
+    size_t tn = ((size_t)s->hidden_size + 31) / 32;
+    b->ex = dev_alloc((D + 1) * S * nxp * fl);
+    b->esum_part = dev_alloc(D * (tn + 1) * S * fl);
+    b->zeros = dev_alloc(256);
+  }
   /* split-K workspace: up to 16 slabs of the largest GEMM output */
   {
     size_t per = RAMD_MAX(e->ih_size, RAMD_MAX((S + F) * I, (S + F) * H));
+    per = RAMD_MAX(per, D * S * ((I - s->hidden_size + 3) & ~(size_t)3));
     size_t slabs = 16;
     const char *env = getenv("RECUR_AMD_MAX_SLABS");
     if (env && atoi(env) > 0) {
