@@ -754,7 +754,7 @@ __device__ __forceinline__ f32x4 lds_read_b128(uint32_t addr) {
 
 template <bool UNI>
 __global__ __launch_bounds__(256) void k_chain_main(View v, int row0, int nrows, int t, int tm,
-                                                    int tn, int nstages, int ktail0, int ablate) {
+                                                    int tn, int nstages, int ktail0) {
   __shared__ __attribute__((aligned(16))) float smem[C_STAGES * C_STAGE_FLOATS];
   const RamdShape &s = v.sh;
   const int L = blockIdx.x;
@@ -792,7 +792,6 @@ __global__ __launch_bounds__(256) void k_chain_main(View v, int row0, int nrows,
     const int k0 = stage * CK;
     const float *g = src[j] + k0;
     if (k0 + CK > s.H) g = (k0 + kcol[j] < s.H) ? g : v.b.zeros; /* last, partial stage only */
-    if (ablate & 1) g = v.b.zeros + (lane & 15) * 4; /* ABLATION: every DMA reads one hot line */
     __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)dst, 16, 0, 0);
   };
   auto issue = [&](int stage) {
@@ -832,14 +831,13 @@ __global__ __launch_bounds__(256) void k_chain_main(View v, int row0, int nrows,
     // two DMA issues after every four MFMAs so that their address arithmetic sits
     // in the shadow of the dependent MFMA chain
     const bool refill = st + C_STAGES - 1 < nstages;
-    const bool domma = !(ablate & 2); /* ABLATION: skip the MFMAs */
 #pragma unroll
     for (int gi = 0; gi < 4; gi++) {
-      if (domma) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].x, b[gi].x, acc, 0, 0, 0);
-      if (domma) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].y, b[gi].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].x, b[gi].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].y, b[gi].y, acc, 0, 0, 0);
       if (refill) issue_one(st + C_STAGES - 1, 2 * gi);
-      if (domma) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].z, b[gi].z, acc, 0, 0, 0);
-      if (domma) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].w, b[gi].w, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].z, b[gi].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].w, b[gi].w, acc, 0, 0, 0);
       if (refill) issue_one(st + C_STAGES - 1, 2 * gi + 1);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1199,19 +1197,20 @@ enum { T_CHAIN = 0, T_DELTA = 1, T_FWD = 2, T_APPLY = 3, T_OTHER = 4, T_CLASSES 
 static int g_timing = 0;
 struct TimedLaunch {
   hipEvent_t a, b;
-  int cls;
+  int cls, count;
 };
 static TimedLaunch g_ev[8192];
 static int g_nev = 0;
 static double g_ms[T_CLASSES];
 static long g_launches[T_CLASSES];
 
-static inline int timing_begin(hipStream_t st, int cls) {
+static inline int timing_begin(hipStream_t st, int cls, int count = 1) {
   if (!g_timing || g_nev >= 8192) return -1;
   int i = g_nev++;
   HIP_CHECK(hipEventCreate(&g_ev[i].a));
   HIP_CHECK(hipEventCreate(&g_ev[i].b));
   g_ev[i].cls = cls;
+  g_ev[i].count = count;
   HIP_CHECK(hipEventRecord(g_ev[i].a, st));
   return i;
 }
@@ -1224,7 +1223,7 @@ static void timing_collect() {
     HIP_CHECK(hipEventSynchronize(g_ev[i].b));
     HIP_CHECK(hipEventElapsedTime(&ms, g_ev[i].a, g_ev[i].b));
     g_ms[g_ev[i].cls] += ms;
-    g_launches[g_ev[i].cls]++;
+    g_launches[g_ev[i].cls] += g_ev[i].count;
     hipEventDestroy(g_ev[i].a);
     hipEventDestroy(g_ev[i].b);
   }
@@ -1391,16 +1390,18 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int nstages = kfull + (ktail > 8 ? 1 : 0);
     int ktail0 = ktail > 8 ? sh->H : kfull * CK; /* a short tail is added in the epilogue */
     int blocks = ((tn + 7) / 8) * 8 * tm;
+    /* one event pair around the D launches: the per-launch average then carries
+     * 1/D of the event overhead instead of all of it */
+    int ev = timing_begin(st, T_CHAIN, sh->D);
     for (int t = 0; t < sh->D; t++) {
-      int ev = timing_begin(st, T_CHAIN);
       if (b->uniform_idx >= 0)
         hipLaunchKernelGGL(k_chain_main<true>, dim3(blocks), dim3(256), 0, st, v, row0, nrows, t, tm,
-                           tn, nstages, ktail0, env_int("RECUR_AMD_ABLATE", 0));
+                           tn, nstages, ktail0);
       else
         hipLaunchKernelGGL(k_chain_main<false>, dim3(blocks), dim3(256), 0, st, v, row0, nrows, t,
-                           tm, tn, nstages, ktail0, 0);
-      timing_end(st, ev);
+                           tm, tn, nstages, ktail0);
     }
+    timing_end(st, ev);
     int M = sh->D * nrows;
     int etm = (M + BM - 1) / BM, etn = (nx + BN - 1) / BN, nkt = (sh->H + BK - 1) / BK;
     int ks = pick_ks(etm * etn, nkt, "RECUR_AMD_KS_EXTRAS", b->slab_floats, (size_t)M * nxp);

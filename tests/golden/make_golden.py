@@ -160,6 +160,13 @@ def main():
                                       for j in range(3)])
     a.close()
 
+    # text-predict on erewhon.txt (BASELINE.json configs[0] shape: 99 hidden), multi-tap 4:
+    # training entropy per window and the validation cross-entropy (G7) ------------------
+    import erewhon_case as ec
+    res = ec.run(ref, ref.ref_softmax_best_guess, ref.ref_softmax, batched=False)
+    for k, v in res.items():
+        out["erewhon." + k] = v
+
     path = os.path.join(HERE, "ref_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "%d arrays, %.1f KB" % (len(out), os.path.getsize(path) / 1e3))

@@ -401,3 +401,59 @@ def rel_err(a, b):
     d = np.linalg.norm(a - b)
     n = np.linalg.norm(b)
     return d / n if n > 0 else d
+
+
+# ---------------------------------------------------------- character model --
+
+class CharAlphabet(C.Structure):
+    _fields_ = [("points", c_int_p), ("collapsed_points", c_int_p), ("len", C.c_int),
+                ("collapsed_len", C.c_int), ("flags", C.c_uint32)]
+
+
+AlphaP = C.POINTER(CharAlphabet)
+CHAR_API = {
+    "rnn_char_new_alphabet": (AlphaP, []),
+    "rnn_char_free_alphabet": (None, [AlphaP]),
+    "rnn_char_alphabet_set_flags": (None, [AlphaP, C.c_bool, C.c_bool, C.c_bool]),
+    "rnn_char_find_alphabet_s": (C.c_int, [C.c_char_p, C.c_int, AlphaP, C.c_double, C.c_double, C.c_double]),
+    "rnn_char_find_alphabet_f": (C.c_int, [C.c_char_p, AlphaP, C.c_double, C.c_double, C.c_double]),
+    "rnn_char_new_char_lut": (c_int_p, [AlphaP]),
+    "rnn_char_alloc_encoded_text": (c_u8_p, [AlphaP, C.c_char_p, C.c_int, c_int_p, c_int_p, C.c_bool]),
+    "rnn_char_load_new_encoded_text": (c_u8_p, [C.c_char_p, AlphaP, c_int_p, C.c_int]),
+    "rnn_char_alloc_file_contents": (C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), c_int_p]),
+}
+CHAR_CASE_INSENSITIVE, CHAR_UTF8, CHAR_COLLAPSE_SPACE = 1, 2, 4
+# text-predict's default character set (text-predict.c:44-45)
+DEFAULT_CHARSET = b"8 etaonihsrdlucmwfygpb,v.k-;x\"qj'?:z)(_!*&"
+DEFAULT_COLLAPSE_CHARS = b"10872}{659/34][@"
+EREWHON = os.path.join(ROOT, "tests", "golden", "erewhon.txt")
+
+
+def bind_char(lib):
+    return _bind(lib, CHAR_API)
+
+
+def default_text_alphabet(lib):
+    """The alphabet text-predict builds from its defaults (text-predict.c:698-719):
+    case-insensitive, bytes, collapsed space; note that it fills collapsed_points
+    from the ALPHABET string, which leaves the collapse characters
+    to the table's default, space."""
+    a = lib.rnn_char_new_alphabet()
+    lib.rnn_char_alphabet_set_flags(a, True, False, True)
+    for i, c in enumerate(DEFAULT_CHARSET):
+        a.contents.points[i] = c
+        a.contents.collapsed_points[i] = c
+    a.contents.len = len(DEFAULT_CHARSET)
+    a.contents.collapsed_len = len(DEFAULT_CHARSET)
+    return a
+
+
+def encode_erewhon(lib):
+    """erewhon.txt as the u8 symbol stream text-predict trains on."""
+    bind_char(lib)
+    a = default_text_alphabet(lib)
+    n = C.c_int(0)
+    p = lib.rnn_char_load_new_encoded_text(EREWHON.encode(), a, C.byref(n), 2)
+    out = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+    lib.rnn_char_free_alphabet(a)
+    return out
