@@ -740,7 +740,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
 constexpr int CM = 32, CN = 32, CK = 128;
-constexpr int C_STAGES = 4;                    /* LDS ring: 3 stages in flight + 1 being read */
+constexpr int C_STAGES = 3;                    /* LDS ring: 2 stages in flight + 1 being read (a 4th buys nothing) */
 constexpr int C_STAGE_FLOATS = (CM + CN) * CK; /* 32 KB */
 
 __device__ __forceinline__ uint32_t lds_byte_addr(const void *p) {
