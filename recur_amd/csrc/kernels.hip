@@ -183,6 +183,7 @@ struct GemmOut {
   int M, N, ldc;
   int nkt;       // K tiles in total
   int tm, tn, ks;
+  int col0;      // first output column (tiles start here; columns below are not produced)
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) {
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void k_gemm(Prob p, GemmOut o) {
   const int mt = q % o.tm, panel = (q / o.tm) * 8 + xcd;
   if (panel >= o.tn * o.ks) return;
   const int nt = panel % o.tn, z = panel / o.tn;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = mt * BM, n0 = o.col0 + nt * BN;
   const int kt0 = (int)(((long)o.nkt * z) / o.ks), kt1 = (int)(((long)o.nkt * (z + 1)) / o.ks);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 1, wn = wave & 1;
@@ -330,6 +331,116 @@ __global__ __launch_bounds__(256) void k_gemm(Prob p, GemmOut o) {
   }
 }
 
+
+// ---- 128 x 128 variant for two K-major operands (the weight-delta GEMM) ----
+//
+// Same structure as k_gemm, but each wave owns a 64 x 64 sub-tile as 2 x 2
+// accumulators (64 VGPRs): every A fragment is reused for two B fragments and
+// vice versa, so LDS reads, global loads and barriers per MFMA are halved or
+// quartered, and the four independent accumulator chains keep the matrix pipe
+// fed from a single wave.  Register prefetch depth 2.
+constexpr int BM2 = 128, BN2 = 128, PF2 = 2;
+
+template <class Prob>
+__global__ __launch_bounds__(256) void k_gemm2(Prob p, GemmOut o) {
+  constexpr int A_FLOATS = BK * BM2, B_FLOATS = BK * BN2;
+  __shared__ __attribute__((aligned(16))) float lds[2][A_FLOATS + B_FLOATS];
+  const int L = blockIdx.x;
+  const int xcd = L & 7, q = L >> 3;
+  const int mt = q % o.tm, panel = (q / o.tm) * 8 + xcd;
+  if (panel >= o.tn * o.ks) return;
+  const int nt = panel % o.tn, z = panel / o.tn;
+  const int m0 = mt * BM2, n0 = o.col0 + nt * BN2;
+  const int kt0 = (int)(((long)o.nkt * z) / o.ks), kt1 = (int)(((long)o.nkt * (z + 1)) / o.ks);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lm = lane & 31, kh = lane >> 5;
+  const float *dummy = p.v.b.slab;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
+
+  Raw ra[PF2][4], rb[PF2][4];
+  auto load = [&](int kt, bool live, Raw (&a)[4], Raw (&b)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int idx = threadIdx.x + i * 256;
+      int k = idx >> 5, c = 4 * (idx & 31);
+      const float *sa = p.a_ptr(kt, k, m0 + c);
+      const float *sb = p.b_ptr(kt, k, n0 + c);
+      a[i].v = ld4(live ? sa : dummy);
+      b[i].v = ld4(live ? sb : dummy);
+      if (Prob::B_AUX) {
+        const float *ax = p.b_aux_ptr(kt, k);
+        b[i].aux = *(live ? ax : dummy);
+      }
+    }
+  };
+  auto store = [&](int kt, float *dst, const Raw (&a)[4], const Raw (&b)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int idx = threadIdx.x + i * 256;
+      int k = idx >> 5, c = 4 * (idx & 31);
+      *reinterpret_cast<float4 *>(dst + k * BM2 + c) = p.a_fix(kt, k, m0 + c, a[i]);
+      *reinterpret_cast<float4 *>(dst + A_FLOATS + k * BN2 + c) = p.b_fix(kt, k, n0 + c, b[i]);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < PF2; j++) load(kt0 + j, kt0 + j < kt1, ra[j], rb[j]);
+  if (kt0 < kt1) store(kt0, lds[0], ra[0], rb[0]);
+  __syncthreads();
+  for (int ktb = kt0; ktb < kt1; ktb += PF2) {
+#pragma unroll
+    for (int j = 0; j < PF2; j++) {
+      const int kt = ktb + j;
+      if (kt >= kt1) break;
+      const int cur = j & 1;
+      load(kt + PF2, kt + PF2 < kt1, ra[j], rb[j]);
+      __builtin_amdgcn_sched_barrier(0);
+      const float *la = lds[cur], *lb = lds[cur] + A_FLOATS;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float a[2][4], b[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int jj = 0; jj < 4; jj++) {
+            a[i][jj] = la[(8 * g + 4 * kh + jj) * BM2 + wm * 64 + i * 32 + lm];
+            b[i][jj] = lb[(8 * g + 4 * kh + jj) * BN2 + wn * 64 + i * 32 + lm];
+          }
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int jn = 0; jn < 2; jn++)
+              acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][jj], b[jn][jj], acc[i][jn], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < kt1) store(kt + 1, lds[cur ^ 1], ra[(j + 1) % PF2], rb[(j + 1) % PF2]);
+      __syncthreads();
+    }
+  }
+  float *c = o.slab + (size_t)z * o.M * o.ldc;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int jn = 0; jn < 2; jn++) {
+      const int col = n0 + wn * 64 + jn * 32 + lm;
+      if (col < o.N) {
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+          int row = m0 + wm * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
+          if (row < o.M) c[(size_t)row * o.ldc + col] = acc[i][jn][g];
+        }
+      }
+    }
+}
 
 // zero column 0 and columns > hidden_size of an error row: what the reference
 // does to h_error at the top of every BPTT step (recur-nn.c:334-337)
@@ -993,14 +1104,21 @@ __global__ void k_bptt_control(View v, int row0, int nrows, const unsigned char 
 // ih_scale already multiplies the error rows that went into the GEMM)
 __global__ __launch_bounds__(256) void k_delta_finalize(float *delta, const float *slab,
                                                         size_t n4, size_t n, int ks,
-                                                        int accumulate) {
+                                                        int accumulate, int H, int hidden_size) {
   size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (q >= n4) return;
   float4 a = accumulate ? ld4(delta + 4 * q) : zero4();
+  float4 sum = zero4();
   for (int z = 0; z < ks; z++) {
     float4 t = ld4(slab + (size_t)z * n + 4 * q);
-    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
   }
+  /* the GEMM only produced columns 1..hidden_size; the others are exactly zero */
+  int c = (int)((4 * q) % (size_t)H);
+  a.x += (c + 0 >= 1 && c + 0 <= hidden_size) ? sum.x : 0.0f;
+  a.y += (c + 1 >= 1 && c + 1 <= hidden_size) ? sum.y : 0.0f;
+  a.z += (c + 2 >= 1 && c + 2 <= hidden_size) ? sum.z : 0.0f;
+  a.w += (c + 3 >= 1 && c + 3 <= hidden_size) ? sum.w : 0.0f;
   *reinterpret_cast<float4 *>(delta + 4 * q) = a;
 }
 
@@ -1279,20 +1397,41 @@ static int pick_ks(int tiles, int nkt, const char *env, size_t slab_floats, size
 
 template <bool A_KM, bool B_KM, class Prob>
 static void launch_gemm(hipStream_t st, const Prob &p, float *slab, int M, int N, int nkt, int ks,
-                        int cls) {
+                        int cls, int col0 = 0, int ldc = 0) {
   GemmOut o;
   o.slab = slab;
   o.M = M;
   o.N = N;
-  o.ldc = N;
+  o.ldc = ldc > 0 ? ldc : N;
   o.nkt = nkt;
   o.tm = (M + BM - 1) / BM;
-  o.tn = (N + BN - 1) / BN;
+  o.tn = (N - col0 + BN - 1) / BN;
   o.ks = ks;
+  o.col0 = col0;
   int panels = o.tn * ks;
   int blocks = ((panels + 7) / 8) * 8 * o.tm;
   int ev = timing_begin(st, cls);
   hipLaunchKernelGGL((k_gemm<A_KM, B_KM, Prob>), dim3(blocks), dim3(256), 0, st, p, o);
+  timing_end(st, ev);
+}
+
+template <class Prob>
+static void launch_gemm2(hipStream_t st, const Prob &p, float *slab, int M, int N, int nkt, int ks,
+                         int cls, int col0, int ldc) {
+  GemmOut o;
+  o.slab = slab;
+  o.M = M;
+  o.N = N;
+  o.ldc = ldc;
+  o.nkt = nkt;
+  o.tm = (M + BM2 - 1) / BM2;
+  o.tn = (N - col0 + BN2 - 1) / BN2;
+  o.ks = ks;
+  o.col0 = col0;
+  int panels = o.tn * ks;
+  int blocks = ((panels + 7) / 8) * 8 * o.tm;
+  int ev = timing_begin(st, cls);
+  hipLaunchKernelGGL((k_gemm2<Prob>), dim3(blocks), dim3(256), 0, st, p, o);
   timing_end(st, ev);
 }
 
@@ -1415,21 +1554,36 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
                      active, flags, tn);
   // weight deltas: one GEMM over (step, stream)
   {
-    int tm = (sh->I + BM - 1) / BM, tn = (sh->H + BN - 1) / BN;
+    /* only columns 1..hidden_size of the delta can be non-zero (h_error[0] and the pad are
+     * zero, recur-nn.c:334-337), so the column tiles start at 1: at hidden 1024 that is 16
+     * exact tiles instead of 17 */
+    const int ncol = sh->hidden_size + 1;
+    int tm = (sh->I + BM - 1) / BM, tn = (ncol - 1 + BN - 1) / BN;
     int rtiles = (nrows + BK - 1) / BK;
     int nkt = sh->D * rtiles;
     size_t n = (size_t)sh->I * sh->H;
     int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_DELTA", b->slab_floats, n);
-    if (b->uniform_idx >= 0) {
+    const bool big = env_int("RECUR_AMD_DELTA_TILE", sh->I >= 256 && nkt >= 16 ? 128 : 64) == 128;
+    if (big) {
+      int tm2 = (sh->I + BM2 - 1) / BM2, tn2 = (ncol - 1 + BN2 - 1) / BN2;
+      ks = pick_ks(tm2 * tn2, nkt, "RECUR_AMD_KS_DELTA", b->slab_floats, n);
+    }
+    if (big && b->uniform_idx >= 0) {
       ProbDelta<true> p = {v, row0, nrows, rtiles};
-      launch_gemm<true, true, ProbDelta<true>>(st, p, b->slab, sh->I, sh->H, nkt, ks, T_DELTA);
+      launch_gemm2<ProbDelta<true>>(st, p, b->slab, sh->I, ncol, nkt, ks, T_DELTA, 1, sh->H);
+    } else if (big) {
+      ProbDelta<false> p = {v, row0, nrows, rtiles};
+      launch_gemm2<ProbDelta<false>>(st, p, b->slab, sh->I, ncol, nkt, ks, T_DELTA, 1, sh->H);
+    } else if (b->uniform_idx >= 0) {
+      ProbDelta<true> p = {v, row0, nrows, rtiles};
+      launch_gemm<true, true, ProbDelta<true>>(st, p, b->slab, sh->I, ncol, nkt, ks, T_DELTA, 1, sh->H);
     } else {
       ProbDelta<false> p = {v, row0, nrows, rtiles};
-      launch_gemm<true, true, ProbDelta<false>>(st, p, b->slab, sh->I, sh->H, nkt, ks, T_DELTA);
+      launch_gemm<true, true, ProbDelta<false>>(st, p, b->slab, sh->I, ncol, nkt, ks, T_DELTA, 1, sh->H);
     }
     size_t n4 = n / 4;
     hipLaunchKernelGGL(k_delta_finalize, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
-                       b->ih_delta, b->slab, n4, n, ks, accumulate);
+                       b->ih_delta, b->slab, n4, n, ks, accumulate, sh->H, sh->hidden_size);
   }
 }
 
