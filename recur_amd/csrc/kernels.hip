@@ -102,12 +102,23 @@ __global__ void k_advance(View v, int row0, int nrows) {
 // (maybe_scale_inputs, recur-nn.c:68-81).  One workgroup per stream.
 __global__ __launch_bounds__(256) void k_assemble(View v, int row0, int mode,
                                                   const float *dense, int ld, int text_i,
-                                                  int global_first, int n_set) {
+                                                  int global_first, int n_set, int advance) {
   __shared__ float red[4];
   const RamdShape &s = v.sh;
   int j = blockIdx.x;
   int r = row0 + j;
-  float *slot = input_row(v, r, 0);
+  float *slot;
+  if (r < s.Scap) {
+    int i = v.b.idx[r];
+    if (advance) { /* rnn_bptt_advance (recur-nn.c:696-704) for this stream, done here */
+      i = (i + 1 == s.D) ? 0 : i + 1;
+      __syncthreads(); /* every thread has read the old index */
+      if (threadIdx.x == 0) v.b.idx[r] = i;
+    }
+    slot = v.b.arena + ((size_t)i * s.Scap + r) * s.I;
+  } else {
+    slot = input_row(v, r, 0);
+  }
   const float *hid = v.b.hidden + (size_t)r * s.H;
   int off = s.hidden_size + 1;
   int hot = -1;
@@ -914,6 +925,30 @@ __global__ __launch_bounds__(256) void k_chain_main(View v, int row0, int nrows,
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.0f;
 
+  // --- what the epilogue needs from global memory (this thread's 4 output columns of one
+  // row: the input values that gate them, and the operands of a short K tail) is fetched
+  // now, so that its latency hides under the main loop
+  const int erow_i = threadIdx.x >> 3, ec4 = (threadIdx.x & 7) * 4;
+  const int er = m0 + erow_i < nrows ? m0 + erow_i : nrows - 1;
+  const float *xrow = input_row<UNI>(v, row0 + er, t);
+  float xin[4];
+  float4 et[2], wt[4][2];
+  const bool tail = ktail0 < s.H;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int n = n0 + ec4 + i;
+    n = n <= s.hidden_size ? n : s.hidden_size;
+    xin[i] = xrow[n];
+    if (tail) {
+      wt[i][0] = ld4(v.b.ih_w + (size_t)n * s.H + ktail0);
+      wt[i][1] = (s.H - ktail0 > 4) ? ld4(v.b.ih_w + (size_t)n * s.H + ktail0 + 4) : zero4();
+    }
+  }
+  if (tail) {
+    et[0] = ld4(ehi_t + (size_t)er * s.I + ktail0);
+    et[1] = (s.H - ktail0 > 4) ? ld4(ehi_t + (size_t)er * s.I + ktail0 + 4) : zero4();
+  }
+
 #pragma unroll
   for (int p = 0; p < C_STAGES - 1; p++)
     if (p < nstages) issue(p);
@@ -975,16 +1010,22 @@ __global__ __launch_bounds__(256) void k_chain_main(View v, int row0, int nrows,
   const int r = m0 + row;
   float sq = 0.0f;
   if (r < nrows) {
-    const float *erow = ehi_t + (size_t)r * s.I;
-    const float *x = input_row<UNI>(v, row0 + r, t);
     float *dst = v.b.ehi + ((size_t)(t + 1) * s.Scap + row0 + r) * s.I;
+    const int nt_tail = s.H - ktail0; /* 0..8 columns of K left over by the 128-wide stages */
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       int n = n0 + c4 + i;
       if (n <= s.hidden_size) {
         float ev = e[i];
-        for (int k = ktail0; k < s.H; k++) ev += erow[k] * v.b.ih_w[(size_t)n * s.H + k];
-        float xi = x[n];
+        if (tail) {
+          const float ek[8] = {et[0].x, et[0].y, et[0].z, et[0].w, et[1].x, et[1].y, et[1].z, et[1].w};
+          const float wk[8] = {wt[i][0].x, wt[i][0].y, wt[i][0].z, wt[i][0].w,
+                               wt[i][1].x, wt[i][1].y, wt[i][1].z, wt[i][1].w};
+#pragma unroll
+          for (int k = 0; k < 8; k++)
+            if (k < nt_tail) ev += ek[k] * wk[k];
+        }
+        float xi = xin[i];
         bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
         ev = on ? ev : 0.0f;
         if (on && s.activation == 2) ev /= 2 * (xi + 1.0f);
@@ -998,18 +1039,6 @@ __global__ __launch_bounds__(256) void k_chain_main(View v, int row0, int nrows,
   sq += __shfl_xor(sq, 4, 64);
   if ((threadIdx.x & 7) == 0 && r < nrows)
     v.b.esum_part[((size_t)t * (tn + 1) + nt) * s.Scap + row0 + r] = sq;
-}
-
-// esum[t][s] = the step's sum of squares: its per-column-tile partials added in
-// a fixed order (one thread per (step, stream))
-__global__ void k_esum_reduce(View v, int row0, int nrows, int tn) {
-  const RamdShape &s = v.sh;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= s.D * nrows) return;
-  int t = i / nrows, r = row0 + (i - t * nrows);
-  float sum = 0.0f;
-  for (int p = 0; p <= tn; p++) sum += v.b.esum_part[((size_t)t * (tn + 1) + p) * s.Scap + r];
-  v.b.esum[(size_t)t * s.Scap + r] = sum;
 }
 
 // Finalize of the extras GEMM: applies the row rule to column 0 and the input
@@ -1036,7 +1065,13 @@ __global__ __launch_bounds__(64) void k_extras_finalize(View v, int row0, int nr
     sq += e * e;
   }
   for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
-  if (threadIdx.x == 0) v.b.esum_part[((size_t)t * (tn + 1) + tn) * s.Scap + r] = sq;
+  /* the step's total: the column-tile partials of k_chain_main in index order, then
+   * the extras (a fixed order, so the break decisions are reproducible) */
+  if (threadIdx.x == 0) {
+    float sum = 0.0f;
+    for (int p = 0; p < tn; p++) sum += v.b.esum_part[((size_t)t * (tn + 1) + p) * s.Scap + r];
+    v.b.esum[(size_t)t * s.Scap + r] = sum + sq;
+  }
 }
 
 // ----------------------------------------------------- K9: BPTT control --
@@ -1444,11 +1479,11 @@ extern "C" void ramd_launch_advance(ramd_stream_t st_, const RamdShape *sh, cons
 
 extern "C" void ramd_launch_assemble(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
                                      int row0, int nrows, int mode, const float *dense, int ld,
-                                     int text_i, int global_first, int n_set) {
+                                     int text_i, int global_first, int n_set, int advance) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   hipLaunchKernelGGL(k_assemble, dim3(nrows), dim3(256), 0, st, v, row0, mode, dense, ld, text_i,
-                     global_first, n_set);
+                     global_first, n_set, advance);
 }
 
 extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
@@ -1512,9 +1547,13 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_HO", b->slab_floats, (size_t)ho);
     /* per-stream 1.0 / 0.0 participation flags as floats (b->coef plane 0 is free here:
      * k_bptt_control rewrites it later in this call) */
-    hipLaunchKernelGGL(k_live_mask, dim3((nrows + 255) / 256), dim3(256), 0, st, b->coef + row0,
-                       active, nrows);
-    ProbHoDelta p = {v, row0, nrows, b->coef + row0};
+    const float *live = b->ones + row0;
+    if (active) {
+      hipLaunchKernelGGL(k_live_mask, dim3((nrows + 255) / 256), dim3(256), 0, st, b->coef + row0,
+                         active, nrows);
+      live = b->coef + row0;
+    }
+    ProbHoDelta p = {v, row0, nrows, live};
     launch_gemm<true, true, ProbHoDelta>(st, p, b->slab, sh->H, sh->O, nkt, ks, T_OTHER);
     hipLaunchKernelGGL(k_ho_delta_finalize, dim3((ho + 255) / 256), dim3(256), 0, st, v, b->slab,
                        ks, accumulate, ranges);
@@ -1548,8 +1587,6 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     launch_gemm<false, false, ProbExtras>(st, p, b->slab, M, nxp, nkt, ks, T_OTHER);
     hipLaunchKernelGGL(k_extras_finalize, dim3(M), dim3(64), 0, st, v, row0, nrows, nx, nxp, ks, tn);
   }
-  hipLaunchKernelGGL(k_esum_reduce, dim3((sh->D * nrows + 255) / 256), dim3(256), 0, st, v, row0,
-                     nrows, tn);
   hipLaunchKernelGGL(k_bptt_control, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows,
                      active, flags, tn);
   // weight deltas: one GEMM over (step, stream)

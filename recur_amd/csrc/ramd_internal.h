@@ -43,6 +43,7 @@ typedef struct RamdBuffers {
   float *ex;        /* [D+1][Scap][nxp] column 0 and the input columns of each step's error */
   float *esum_part; /* [D][tn+1][Scap] per-column-tile partial sums of squares         */
   float *zeros;     /* 256 bytes of zeros: source of out-of-range LDS-DMA chunks       */
+  float *ones;      /* [Scap] of 1.0: the "every stream takes part" mask               */
   float *slab;
   size_t slab_floats;
   int *idx;       /* [Scap] ring position                           */
@@ -74,10 +75,11 @@ void ramd_launch_advance(ramd_stream_t st, const RamdShape *sh, const RamdBuffer
 /* builds the input rows (recur-nn.c:104-115 + 68-81).  mode selects where the
  * real inputs come from; dense is a device pointer with leading dimension ld;
  * text_i is the text position for RAMD_IN_TEXT (also fills b->target); the
- * row's global stream number is global_first + (row - row0) of global_count. */
+ * row's global stream number is global_first + (row - row0) of global_count.
+ * advance != 0 steps each stream's ring index first (rnn_bptt_advance). */
 void ramd_launch_assemble(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                           int row0, int nrows, int mode, const float *dense, int ld,
-                          int text_i, int global_first, int global_count);
+                          int text_i, int global_first, int global_count, int advance);
 /* hidden = act(X . W_ih), out = hidden . W_ho (recur-nn.c:117-151) */
 void ramd_launch_forward(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                          int row0, int nrows);

@@ -146,7 +146,7 @@ static void engine_free_device(RamdEngine *e) {
   dev_free(b->ih_aux); dev_free(b->ho_aux); dev_free(e->delta_own);
   dev_free(b->arena); dev_free(b->hidden); dev_free(b->out); dev_free(b->o_error);
   dev_free(b->err_a); dev_free(b->err_b); dev_free(b->ehi); dev_free(b->esum);
-  dev_free(b->coef); dev_free(b->ex); dev_free(b->esum_part); dev_free(b->zeros); dev_free(b->slab); dev_free(b->idx); dev_free(b->lr); dev_free(b->mef);
+  dev_free(b->coef); dev_free(b->ex); dev_free(b->esum_part); dev_free(b->zeros); dev_free(b->ones); dev_free(b->slab); dev_free(b->idx); dev_free(b->lr); dev_free(b->mef);
   dev_free(b->ih_scale); dev_free(b->top_raw); dev_free(b->top_scaled); dev_free(b->bptt_err);
   dev_free(b->n_exec); dev_free(b->depth_log); dev_free(b->target); dev_free(b->hot);
   dev_free(b->active); dev_free(b->stat_err); dev_free(b->stat_ent); dev_free(b->stat_zero);
@@ -469,6 +469,14 @@ static void engine_ensure_device(RamdEngine *e) {
     b->ex = dev_alloc((D + 1) * S * nxp * fl);
     b->esum_part = dev_alloc(D * (tn + 1) * S * fl);
     b->zeros = dev_alloc(256);
+    b->ones = dev_alloc(S * fl);
+    {
+      float *one = malloc(S * fl);
+      for (size_t i = 0; i < S; i++) one[i] = 1.0f;
+      h2d(b->ones, one, S * fl);
+      dsync();
+      free(one);
+    }
   }
   /* split-K workspace: up to 16 slabs of the largest GEMM output */
   {
@@ -983,7 +991,7 @@ float *rnn_opinion(RecurNN *net, const float *inputs, float presynaptic_noise) {
   }
   h2d(d_slot + s->hidden_size + 1, net->real_inputs, sizeof(float) * s->input_size);
   set_uniform_idx(e, p->stream >= 0 ? p->stream : e->n_streams, p->stream >= 0 ? 1 : 0);
-  ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1);
+  ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1, 0);
   ramd_launch_forward(g_stream, s, &e->b, r, 1);
   d2h(net->input_layer, d_slot, sizeof(float) * s->I);
   d2h(net->hidden_layer, e->b.hidden + (size_t)r * s->H, sizeof(float) * s->H);
@@ -1316,16 +1324,21 @@ void rnn_amd_set_advance(RnnAmdSet *set) {
 }
 
 static void set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, int text_i,
-                        float *outputs) {
+                        float *outputs, int advance) {
   RamdEngine *e = set->eng;
   for (int j = 0; j < set->n; j++) {
     check_supported(set->nets[j], set->nets[j]->presynaptic_noise);
   }
   engine_need_dev(e, RNN_AMD_WEIGHTS);
   set_streams_to_dev(set);
+  if (advance) {
+    for (int j = 0; j < set->n; j++) {
+      host_advance(set->nets[j]); /* the device steps its copy inside the assemble kernel */
+    }
+  }
   set_uniform_idx(e, set->row0, set->n);
   ramd_launch_assemble(g_stream, &e->sh, &e->b, set->row0, set->n, mode, d_dense, ld, text_i,
-                       set->global_first, set->global_count);
+                       set->global_first, set->global_count, advance);
   ramd_launch_forward(g_stream, &e->sh, &e->b, set->row0, set->n);
   set_streams_dev_wrote(set);
   if (outputs) {
@@ -1341,9 +1354,9 @@ void rnn_amd_set_opinion(RnnAmdSet *set, const float *inputs, int ld_inputs, flo
     HIP_OK(hipMemcpy2DAsync(e->d_dense, w * sizeof(float), inputs, ld_inputs * sizeof(float),
                             w * sizeof(float), set->n, hipMemcpyHostToDevice, g_stream));
     dsync();
-    set_forward(set, RAMD_IN_DENSE, e->d_dense, w, 0, outputs);
+    set_forward(set, RAMD_IN_DENSE, e->d_dense, w, 0, outputs, 0);
   } else {
-    set_forward(set, RAMD_IN_KEEP, NULL, 0, 0, outputs);
+    set_forward(set, RAMD_IN_KEEP, NULL, 0, 0, outputs, 0);
   }
 }
 
@@ -1351,7 +1364,7 @@ void rnn_amd_set_one_hot_opinion(RnnAmdSet *set, const int *hot, float *outputs)
   RamdEngine *e = set->eng;
   h2d(e->b.hot + set->row0, hot, set->n * sizeof(int));
   dsync();
-  set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, outputs);
+  set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, outputs, 0);
 }
 
 void rnn_amd_set_put_o_error(RnnAmdSet *set, const float *o_error, int ld) {
@@ -1427,8 +1440,7 @@ void rnn_amd_set_char_step_deltas(RnnAmdSet *set, int i) {
     fprintf(stderr, "librecur_amd: rnn_amd_set_char_step without rnn_amd_set_load_text\n");
     abort();
   }
-  rnn_amd_set_advance(set);
-  set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL);
+  set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1); /* advance + one-hot opinion */
   ramd_launch_softmax_error(g_stream, &e->sh, &e->b, set->row0, set->n);
   rnn_amd_set_calc_deltas(set, 0, NULL, NULL);
 }
