@@ -60,9 +60,9 @@ __device__ __forceinline__ float *input_row(const View &v, int r, int back) {
   if (r < s.Scap) {
     int slot = (UNI ? v.b.uniform_idx : v.b.idx[r]) - back;
     if (slot < 0) slot += s.D;
-    return v.b.arena + ((size_t)slot * s.Scap + r) * s.I;
+    return v.b.arena + (slot * s.Scap + r) * s.I; /* 32-bit element offsets: checked on the host */
   }
-  return v.b.arena + ((size_t)s.D * s.Scap + (r - s.Scap)) * s.I;
+  return v.b.arena + (s.D * s.Scap + (r - s.Scap)) * s.I;
 }
 
 // recur-nn-helpers.h:104-113
@@ -485,7 +485,7 @@ template <bool UNI> struct ProbFwd {
   __device__ const float *b_ptr(int kt, int k, int n) const {
     k += kt * BK;
     bool ok = k < v.sh.I && n < v.sh.H;
-    return v.b.ih_w + (ok ? (size_t)k * v.sh.H + n : 0);
+    return v.b.ih_w + (ok ? k * v.sh.H + n : 0);
   }
   __device__ float4 b_fix(int kt, int k, int n, const Raw &r) const {
     return (k + kt * BK < v.sh.I && n < v.sh.H) ? r.v : zero4();
@@ -501,7 +501,7 @@ struct ProbOut {
   __device__ const float *a_ptr(int kt, int row, int k) const {
     k += kt * BK;
     bool ok = row < nrows && k < v.sh.H;
-    return v.b.hidden + (ok ? (size_t)(row0 + row) * v.sh.H + k : 0);
+    return v.b.hidden + (ok ? (row0 + row) * v.sh.H + k : 0);
   }
   __device__ float4 a_fix(int kt, int row, int k, const Raw &r) const {
     return (row < nrows && k + kt * BK < v.sh.H) ? r.v : zero4();
@@ -509,7 +509,7 @@ struct ProbOut {
   __device__ const float *b_ptr(int kt, int k, int n) const {
     k += kt * BK;
     bool ok = k < v.sh.H && n < v.sh.O;
-    return v.b.ho_w + (ok ? (size_t)k * v.sh.O + n : 0);
+    return v.b.ho_w + (ok ? k * v.sh.O + n : 0);
   }
   __device__ float4 b_fix(int kt, int k, int n, const Raw &r) const {
     return (k + kt * BK < v.sh.H && n < v.sh.O) ? r.v : zero4();
@@ -528,7 +528,7 @@ struct ProbHoDelta {
   __device__ const float *a_ptr(int kt, int k, int m) const {
     k += kt * BK;
     bool ok = k < nrows && m < v.sh.H;
-    return v.b.hidden + (ok ? (size_t)(row0 + k) * v.sh.H + m : 0);
+    return v.b.hidden + (ok ? (row0 + k) * v.sh.H + m : 0);
   }
   __device__ float4 a_fix(int kt, int k, int m, const Raw &r) const {
     return (k + kt * BK < nrows && m < v.sh.H) ? r.v : zero4();
@@ -536,7 +536,7 @@ struct ProbHoDelta {
   __device__ const float *b_ptr(int kt, int k, int n) const {
     k += kt * BK;
     bool ok = k < nrows && n < v.sh.O;
-    return v.b.o_error + (ok ? (size_t)(row0 + k) * v.sh.O + n : 0);
+    return v.b.o_error + (ok ? (row0 + k) * v.sh.O + n : 0);
   }
   __device__ const float *b_aux_ptr(int kt, int k) const {
     k += kt * BK;
@@ -562,7 +562,7 @@ struct ProbExtras {
     bool ok = m < M && k < v.sh.H;
     int mm = m < M ? m : 0;
     int t = mm / nrows, r = mm - t * nrows;
-    return v.b.ehi + ((size_t)t * v.sh.Scap + row0 + r) * v.sh.I + (ok ? k : 0);
+    return v.b.ehi + ((t * v.sh.Scap + row0 + r) * v.sh.I + (ok ? k : 0));
   }
   __device__ float4 a_fix(int kt, int m, int k, const Raw &r) const {
     return (m < v.sh.D * nrows && k + kt * BK < v.sh.H) ? r.v : zero4();
@@ -571,7 +571,7 @@ struct ProbExtras {
     k += kt * BK;
     bool ok = c < nx && k < v.sh.H;
     int n = (c == 0 || c >= nx) ? 0 : v.sh.hidden_size + c;
-    return v.b.ih_w + (size_t)n * v.sh.H + (ok ? k : 0);
+    return v.b.ih_w + (n * v.sh.H + (ok ? k : 0));
   }
   __device__ float4 b_fix(int kt, int c, int k, const Raw &r) const {
     return (c < nx && k + kt * BK < v.sh.H) ? r.v : zero4();
@@ -597,12 +597,12 @@ template <bool UNI> struct ProbDelta {
   __device__ const float *b_ptr(int kt, int k, int n) const {
     int t = kt / rtiles, s = (kt - t * rtiles) * BK + k;
     bool ok = s < nrows && n < v.sh.H;
-    size_t row = (size_t)t * v.sh.Scap + row0 + (s < nrows ? s : 0);
-    return v.b.ehi + row * v.sh.I + (ok ? n : 0);
+    int row = t * v.sh.Scap + row0 + (s < nrows ? s : 0);
+    return v.b.ehi + (row * v.sh.I + (ok ? n : 0));
   }
   __device__ const float *b_aux_ptr(int kt, int k) const {
     int t = kt / rtiles, s = (kt - t * rtiles) * BK + k;
-    return v.b.coef + (size_t)t * v.sh.Scap + row0 + (s < nrows ? s : 0);
+    return v.b.coef + (t * v.sh.Scap + row0 + (s < nrows ? s : 0));
   }
   __device__ float4 b_fix(int kt, int k, int n, const Raw &r) const {
     int t = kt / rtiles, s = (kt - t * rtiles) * BK + k;

@@ -440,6 +440,11 @@ static void engine_ensure_device(RamdEngine *e) {
   }
   size_t I = s->I, H = s->H, O = s->O, S = s->Scap, F = s->Fcap, D = s->D;
   size_t fl = sizeof(float);
+  if ((D + 1) * (S + F) * I >= ((size_t)1 << 31) || e->ih_size >= ((size_t)1 << 31)) {
+    fprintf(stderr, "librecur_amd: %zu streams x depth %zu x %zu inputs exceeds the 2^31-element "
+                    "offsets of the kernels\n", S, D, I);
+    abort();
+  }
   e->has_momentum = o->bptt && o->bptt->ih_momentum;
   e->has_aux = o->bptt && o->bptt->ih_aux;
   e->has_delta = o->bptt && o->bptt->ih_delta;
