@@ -1260,12 +1260,16 @@ RnnAmdSet *rnn_amd_set_open(RecurNN **nets, int n_nets) {
     return NULL;
   }
   RamdEngine *e = ramd_engine_of(nets[0]);
-  int row0 = ramd_priv(nets[0])->stream;
+  /* either training streams in rnn_new_training_set order, or forward-only clones
+   * (rnn_clone without bptt, e.g. gstrnnca.c's constructors) in creation order */
+  int fwd_only = ramd_priv(nets[0])->stream < 0;
+  int row0 = fwd_only ? ramd_priv(nets[0])->fwd : ramd_priv(nets[0])->stream;
   for (int j = 0; j < n_nets; j++) {
     RamdPriv *p = ramd_priv(nets[j]);
-    if (ramd_engine_of(nets[j]) != e || p->stream != row0 + j) {
+    int id = fwd_only ? p->fwd : p->stream;
+    if (ramd_engine_of(nets[j]) != e || id != row0 + j || (p->stream < 0) != fwd_only) {
       fprintf(stderr, "librecur_amd: rnn_amd_set_open: nets must be one training set in "
-                      "rnn_new_training_set order\n");
+                      "rnn_new_training_set order (or forward-only clones in creation order)\n");
       return NULL;
     }
   }
@@ -1275,6 +1279,7 @@ RnnAmdSet *rnn_amd_set_open(RecurNN **nets, int n_nets) {
   set->nets = nets;
   set->n = n_nets;
   set->row0 = row0;
+  set->fwd_only = fwd_only;
   set->global_first = 0;
   set->global_count = n_nets;
   return set;
@@ -1293,6 +1298,18 @@ int rnn_amd_set_size(const RnnAmdSet *set) { return set->n; }
 void rnn_amd_set_shard(RnnAmdSet *set, int global_first, int global_count) {
   set->global_first = global_first;
   set->global_count = global_count;
+}
+
+/* first state row of the set (forward-only rows sit after the Scap training rows) */
+static int set_state_row0(const RnnAmdSet *set) {
+  return set->fwd_only ? set->eng->sh.Scap + set->row0 : set->row0;
+}
+
+static void set_need_training(const RnnAmdSet *set, const char *what) {
+  if (set->fwd_only) {
+    fprintf(stderr, "librecur_amd: %s needs a training set (nets with bptt)\n", what);
+    abort();
+  }
 }
 
 static void set_streams_to_dev(RnnAmdSet *set) {
@@ -1321,6 +1338,7 @@ static void set_streams_dev_wrote(RnnAmdSet *set) {
 
 void rnn_amd_set_advance(RnnAmdSet *set) {
   RamdEngine *e = set->eng;
+  set_need_training(set, "rnn_amd_set_advance");
   set_streams_to_dev(set);
   for (int j = 0; j < set->n; j++) {
     host_advance(set->nets[j]); /* the index is deterministic: both sides step */
@@ -1337,17 +1355,23 @@ static void set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, 
   engine_need_dev(e, RNN_AMD_WEIGHTS);
   set_streams_to_dev(set);
   if (advance) {
+    set_need_training(set, "advancing");
     for (int j = 0; j < set->n; j++) {
       host_advance(set->nets[j]); /* the device steps its copy inside the assemble kernel */
     }
   }
-  set_uniform_idx(e, set->row0, set->n);
-  ramd_launch_assemble(g_stream, &e->sh, &e->b, set->row0, set->n, mode, d_dense, ld, text_i,
+  const int r0 = set_state_row0(set);
+  if (set->fwd_only) {
+    e->b.uniform_idx = -1;
+  } else {
+    set_uniform_idx(e, set->row0, set->n);
+  }
+  ramd_launch_assemble(g_stream, &e->sh, &e->b, r0, set->n, mode, d_dense, ld, text_i,
                        set->global_first, set->global_count, advance);
-  ramd_launch_forward(g_stream, &e->sh, &e->b, set->row0, set->n);
+  ramd_launch_forward(g_stream, &e->sh, &e->b, r0, set->n);
   set_streams_dev_wrote(set);
   if (outputs) {
-    d2h(outputs, e->b.out + (size_t)set->row0 * e->sh.O, (size_t)set->n * e->sh.O * sizeof(float));
+    d2h(outputs, e->b.out + (size_t)r0 * e->sh.O, (size_t)set->n * e->sh.O * sizeof(float));
     dsync();
   }
 }
@@ -1367,13 +1391,14 @@ void rnn_amd_set_opinion(RnnAmdSet *set, const float *inputs, int ld_inputs, flo
 
 void rnn_amd_set_one_hot_opinion(RnnAmdSet *set, const int *hot, float *outputs) {
   RamdEngine *e = set->eng;
-  h2d(e->b.hot + set->row0, hot, set->n * sizeof(int));
+  h2d(e->b.hot + set_state_row0(set), hot, set->n * sizeof(int));
   dsync();
   set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, outputs, 0);
 }
 
 void rnn_amd_set_put_o_error(RnnAmdSet *set, const float *o_error, int ld) {
   RamdEngine *e = set->eng;
+  set_need_training(set, "rnn_amd_set_put_o_error");
   set_streams_to_dev(set);
   HIP_OK(hipMemcpy2DAsync(e->b.o_error + (size_t)set->row0 * e->sh.O, e->sh.O * sizeof(float),
                           o_error, ld * sizeof(float), e->sh.O * sizeof(float), set->n,
@@ -1384,6 +1409,7 @@ void rnn_amd_set_put_o_error(RnnAmdSet *set, const float *o_error, int ld) {
 
 void rnn_amd_set_softmax_error(RnnAmdSet *set, const int *target) {
   RamdEngine *e = set->eng;
+  set_need_training(set, "rnn_amd_set_softmax_error");
   set_streams_to_dev(set);
   if (target) {
     h2d(e->b.target + set->row0, target, set->n * sizeof(int));
@@ -1396,6 +1422,7 @@ void rnn_amd_set_softmax_error(RnnAmdSet *set, const int *target) {
 void rnn_amd_set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ranges,
                              const u8 *active) {
   RamdEngine *e = set->eng;
+  set_need_training(set, "rnn_amd_set_calc_deltas");
   engine_need_dev(e, RNN_AMD_WEIGHTS | (accumulate ? RNN_AMD_DELTAS : 0));
   set_streams_to_dev(set);
   push_learn_rates(e, set->row0, set->n);
@@ -1457,6 +1484,7 @@ void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float mome
 
 void rnn_amd_set_read_stats(RnnAmdSet *set, RnnAmdStats *stats, int clear) {
   RamdEngine *e = set->eng;
+  set_need_training(set, "rnn_amd_set_read_stats");
   int n = set->n, r0 = set->row0;
   double *d = malloc(4 * n * sizeof(double));
   long long *l = malloc(2 * n * sizeof(long long));

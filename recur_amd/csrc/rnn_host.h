@@ -62,7 +62,8 @@ struct RnnAmdSet {
   RamdEngine *eng;
   RecurNN **nets;
   int n;
-  int row0;
+  int row0;     /* first training-stream row, or first forward-only index when fwd_only */
+  int fwd_only; /* the set is made of forward-only clones (no bptt): opinion calls only */
   int global_first, global_count;
 };
 

@@ -251,3 +251,38 @@ def test_full_size_optimiser_is_elementwise_exact(amd, full_set):
         want_m = (before[m] + t) * mom
         assert np.allclose(after[w], want_w, rtol=1e-6, atol=1e-9)  # the device contracts to fma
         assert np.allclose(after[m], want_m, rtol=1e-6, atol=1e-9)
+
+
+def test_forward_only_clone_set_matches_oracle(amd):
+    """batched rnn_opinion over forward-only, weight-borrowing clones (the shape of
+    rnnca's frame fill, gstrnnca.c:805-831: many cell-streams, no training)"""
+    lib = amd
+    n_cells, steps = 70, 5
+    net = lib.rnn_new(35, 128, 3, rc.FLAG_STANDARD, 8, None, 4, 1e-3, 0.9, 0.0, rc.RELU)
+    lib.rnn_randomise_weights_auto(net)
+    flags = net.contents.flags & ~(rc.FLAG_OWN_BPTT | rc.FLAG_OWN_WEIGHTS)
+    clones = (rc.NetP * n_cells)(*[lib.rnn_clone(net, flags, rc.SUBSEED, None) for _ in range(n_cells)])
+    h = lib.rnn_amd_set_open(clones, n_cells)
+    assert h
+    o = sc.OracleSet(input_size=35, hidden_size=128, output_size=3, S=n_cells, D=1, seed=8,
+                     shape=rc.DIST_UNIFORM, perforation=0.7)
+    a = o.arrays()
+    n = net.contents
+    assert np.array_equal(a["ih_w"], rc.view(n.ih_weights, n.i_size, n.h_size))
+    rs = np.random.default_rng(3)
+    out = np.zeros((n_cells, n.o_size), np.float32)
+    for _ in range(steps):
+        x = rs.standard_normal((n_cells, 35)).astype(np.float32)
+        lib.rnn_amd_set_opinion(h, rc.fptr(x), 35, rc.fptr(out))
+        for j in range(n_cells):
+            o.orc.orc_opinion(o.z, j, rc.fptr(np.ascontiguousarray(x[j])), 0.0)
+        assert rc.rel_err(out, a["output"]) < RTOL
+    # the per-net view of one clone agrees after a sync
+    lib.rnn_amd_sync_host(clones[5], rc.RNN_AMD_STREAM)
+    assert rc.rel_err(rc.view(clones[5].contents.hidden_layer, n.h_size), a["hidden"][5]) < RTOL
+    # training calls on such a set are refused loudly, not silently ignored
+    lib.rnn_amd_set_close(h)
+    for c in clones:
+        lib.rnn_delete_net(c)
+    lib.rnn_delete_net(net)
+    o.close()
