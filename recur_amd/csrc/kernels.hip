@@ -631,6 +631,48 @@ __global__ __launch_bounds__(256) void k_sum_slabs(float *dst, int ld_dst, const
   *reinterpret_cast<float4 *>(dst + (size_t)r * ld_dst + c) = a;
 }
 
+// ------------------------------------------------------ presynaptic noise --
+
+// recur-rng.h:22-31 (Jenkins small fast PRNG, 64 bit) and 179-200 (the sum of twelve
+// 16-bit fields), bit for bit: the noise a stream gets must be the one the reference
+// would draw from that stream's generator.
+struct DevRng {
+  unsigned long long a, b, c, d;
+};
+__device__ __forceinline__ unsigned long long rotl64(unsigned long long x, int k) {
+  return (x << k) | (x >> (64 - k));
+}
+__device__ __forceinline__ unsigned long long dev_rand64(DevRng &x) {
+  unsigned long long e = x.a - rotl64(x.b, 7);
+  x.a = x.b ^ rotl64(x.c, 13);
+  x.b = x.c + rotl64(x.d, 37);
+  x.c = x.d + e;
+  x.d = e + x.a;
+  return x.d;
+}
+__device__ __forceinline__ float dev_cheap_gaussian(DevRng &x) {
+  long long a = 0;
+  for (int w = 0; w < 3; w++) {
+    unsigned long long bits = dev_rand64(x);
+    a += (long long)(bits & 0xffff) + (long long)((bits >> 16) & 0xffff) +
+         (long long)((bits >> 32) & 0xffff) + (long long)(bits >> 48);
+  }
+  return (float)(a - 0xffff * 6) / (0xffff);
+}
+
+// MAYBE_ADD_ARRAY_NOISE on hidden[1..h_size) (recur-nn.c:120-121; the pad columns get
+// noise too).  The generator is sequential per stream, so one thread
+// walks each stream's row; the values are added to K slab 0 of the forward GEMM.
+__global__ void k_presynaptic_noise(View v, int row0, int nrows, float deviation) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nrows) return;
+  const RamdShape &s = v.sh;
+  DevRng g = reinterpret_cast<DevRng *>(v.b.rng)[row0 + j];
+  float *row = v.b.slab + (size_t)j * s.H;
+  for (int i = 1; i < s.H; i++) row[i] += dev_cheap_gaussian(g) * deviation;
+  reinterpret_cast<DevRng *>(v.b.rng)[row0 + j] = g;
+}
+
 // ---------------------------------------------------------- finalize: fwd --
 
 // sums the K slabs, applies the activation (recur-nn.c:123-148) and writes
@@ -1487,7 +1529,7 @@ extern "C" void ramd_launch_assemble(ramd_stream_t st_, const RamdShape *sh, con
 }
 
 extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
-                                    int row0, int nrows) {
+                                    int row0, int nrows, float noise) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   int tm = (nrows + BM - 1) / BM;
@@ -1501,6 +1543,9 @@ extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, cons
       ProbFwd<false> p = {v, row0, nrows};
       launch_gemm<false, true, ProbFwd<false>>(st, p, b->slab, nrows, sh->H, nkt, ks, T_FWD);
     }
+    if (noise != 0.0f)
+      hipLaunchKernelGGL(k_presynaptic_noise, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows,
+                         noise);
     int n4 = nrows * (sh->H / 4);
     hipLaunchKernelGGL(k_fwd_finalize, dim3((n4 + 255) / 256), dim3(256), 0, st, v, row0, nrows, ks);
   }

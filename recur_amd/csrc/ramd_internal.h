@@ -43,6 +43,7 @@ typedef struct RamdBuffers {
   float *ex;        /* [D+1][Scap][nxp] column 0 and the input columns of each step's error */
   float *esum_part; /* [D][tn+1][Scap] per-column-tile partial sums of squares         */
   float *zeros;     /* 256 bytes of zeros: source of out-of-range LDS-DMA chunks       */
+  unsigned long long *rng; /* [Scap+Fcap][4] each stream's generator (recur-rng.h:15-20)   */
   float *ones;      /* [Scap] of 1.0: the "every stream takes part" mask               */
   float *slab;
   size_t slab_floats;
@@ -82,7 +83,7 @@ void ramd_launch_assemble(ramd_stream_t st, const RamdShape *sh, const RamdBuffe
                           int text_i, int global_first, int global_count, int advance);
 /* hidden = act(X . W_ih), out = hidden . W_ho (recur-nn.c:117-151) */
 void ramd_launch_forward(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
-                         int row0, int nrows);
+                         int row0, int nrows, float presynaptic_noise);
 /* o_error = onehot(target) - softmax(out) and statistics
  * (charmodel-predict.c:18-27, 299-304) */
 void ramd_launch_softmax_error(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,

@@ -146,7 +146,7 @@ static void engine_free_device(RamdEngine *e) {
   dev_free(b->ih_aux); dev_free(b->ho_aux); dev_free(e->delta_own);
   dev_free(b->arena); dev_free(b->hidden); dev_free(b->out); dev_free(b->o_error);
   dev_free(b->err_a); dev_free(b->err_b); dev_free(b->ehi); dev_free(b->esum);
-  dev_free(b->coef); dev_free(b->ex); dev_free(b->esum_part); dev_free(b->zeros); dev_free(b->ones); dev_free(b->slab); dev_free(b->idx); dev_free(b->lr); dev_free(b->mef);
+  dev_free(b->coef); dev_free(b->ex); dev_free(b->esum_part); dev_free(b->zeros); dev_free(b->ones); dev_free(b->rng); dev_free(b->slab); dev_free(b->idx); dev_free(b->lr); dev_free(b->mef);
   dev_free(b->ih_scale); dev_free(b->top_raw); dev_free(b->top_scaled); dev_free(b->bptt_err);
   dev_free(b->n_exec); dev_free(b->depth_log); dev_free(b->target); dev_free(b->hot);
   dev_free(b->active); dev_free(b->stat_err); dev_free(b->stat_ent); dev_free(b->stat_zero);
@@ -247,6 +247,11 @@ static void stream_copy(RamdEngine *e, RecurNN *net, int to_device) {
   } while (0)
   COPY(b->hidden + (size_t)r * H, net->hidden_layer, H);
   COPY(b->out + (size_t)r * O, net->output_layer, O);
+  if (to_device) {
+    h2d((char *)b->rng + (size_t)r * sizeof(rand_ctx), &net->rng, sizeof(rand_ctx));
+  } else {
+    d2h(&net->rng, (char *)b->rng + (size_t)r * sizeof(rand_ctx), sizeof(rand_ctx));
+  }
   if (p->stream >= 0) {
     RecurNNBPTT *bp = net->bptt;
     int j = p->stream;
@@ -474,6 +479,7 @@ static void engine_ensure_device(RamdEngine *e) {
     b->ex = dev_alloc((D + 1) * S * nxp * fl);
     b->esum_part = dev_alloc(D * (tn + 1) * S * fl);
     b->zeros = dev_alloc(256);
+    b->rng = dev_alloc((S + F) * sizeof(rand_ctx));
     b->ones = dev_alloc(S * fl);
     {
       float *one = malloc(S * fl);
@@ -757,6 +763,10 @@ void rnn_set_log_file(RecurNN *net, const char *log_file, int append_dont_trunca
 /* recur-nn-init.c:296-350 */
 RecurNN *rnn_clone(RecurNN *parent, u32 flags, u64 rng_seed, const char *log_file) {
   if (rng_seed == RECUR_RNG_SUBSEED) {
+    if (ramd_priv(parent)->eng && !ramd_priv(parent)->host_valid) {
+      ramd_need_host(parent, RNN_AMD_STREAM);
+    }
+    ramd_priv(parent)->dev_valid = 0;
     do {
       rng_seed = ramd_rand64(&parent->rng);
     } while (rng_seed == RECUR_RNG_RANDOM_SEED);
@@ -955,10 +965,7 @@ static void check_supported(RecurNN *net, float noise) {
     fprintf(stderr, "librecur_amd: bottom layer not supported on the device yet\n");
     abort();
   }
-  if (noise != 0.0f) {
-    fprintf(stderr, "librecur_amd: presynaptic noise not supported on the device yet\n");
-    abort();
-  }
+  (void)noise;
 }
 
 /* recur-nn.h:310 */
@@ -997,7 +1004,13 @@ float *rnn_opinion(RecurNN *net, const float *inputs, float presynaptic_noise) {
   h2d(d_slot + s->hidden_size + 1, net->real_inputs, sizeof(float) * s->input_size);
   set_uniform_idx(e, p->stream >= 0 ? p->stream : e->n_streams, p->stream >= 0 ? 1 : 0);
   ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1, 0);
-  ramd_launch_forward(g_stream, s, &e->b, r, 1);
+  if (presynaptic_noise != 0.0f) { /* the host generator is the one the caller may have used */
+    h2d((char *)e->b.rng + (size_t)r * sizeof(rand_ctx), &net->rng, sizeof(rand_ctx));
+  }
+  ramd_launch_forward(g_stream, s, &e->b, r, 1, presynaptic_noise);
+  if (presynaptic_noise != 0.0f) {
+    d2h(&net->rng, (char *)e->b.rng + (size_t)r * sizeof(rand_ctx), sizeof(rand_ctx));
+  }
   d2h(net->input_layer, d_slot, sizeof(float) * s->I);
   d2h(net->hidden_layer, e->b.hidden + (size_t)r * s->H, sizeof(float) * s->H);
   d2h(net->output_layer, e->b.out + (size_t)r * s->O, sizeof(float) * s->O);
@@ -1161,9 +1174,11 @@ void rnn_condition_net(RecurNN *net) {
     engine_dev_wrote(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS);
     break;
   case RNN_COND_BIT_RAND: {
+    stream_need_host(e, net); /* the generator may have advanced on the device (noise) */
     int t = ramd_rand_small_int(&net->rng, net->ih_size + net->ho_size);
     float damage = (ramd_cheap_gaussian_noise(&net->rng) * RANDOM_DAMAGE_FACTOR * net->h_size *
                     net->bptt->learn_rate);
+    ramd_priv(net)->dev_valid = 0; /* and now it advanced on the host */
     engine_need_dev(e, RNN_AMD_WEIGHTS);
     if (t >= net->ih_size) {
       t -= net->ih_size;
@@ -1368,7 +1383,14 @@ static void set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, 
   }
   ramd_launch_assemble(g_stream, &e->sh, &e->b, r0, set->n, mode, d_dense, ld, text_i,
                        set->global_first, set->global_count, advance);
-  ramd_launch_forward(g_stream, &e->sh, &e->b, r0, set->n);
+  float noise = set->nets[0]->presynaptic_noise;
+  for (int j = 1; j < set->n; j++) {
+    if (set->nets[j]->presynaptic_noise != noise) {
+      fprintf(stderr, "librecur_amd: the nets of a set must share presynaptic_noise\n");
+      abort();
+    }
+  }
+  ramd_launch_forward(g_stream, &e->sh, &e->b, r0, set->n, noise);
   set_streams_dev_wrote(set);
   if (outputs) {
     d2h(outputs, e->b.out + (size_t)r0 * e->sh.O, (size_t)set->n * e->sh.O * sizeof(float));

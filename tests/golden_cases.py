@@ -33,6 +33,10 @@ TRAIN_CASES = {
     # a learn rate high enough that the error-gain clamp (ih_scale < 1) and the
     # adaptive early exit both fire (recur-nn.c:387-413)
     "hot_clamps": dict(hidden=39, S=4, D=12, act=rc.RELU, method=rc.WEIGHTED, lr=0.08, steps=40, seed=11),
+    # presynaptic noise: every stream draws from its own Jenkins generator
+    # (recur-nn.c:120-121), so the final generator states are part of the parity
+    "noisy": dict(hidden=39, S=4, D=6, act=rc.RELU, method=rc.WEIGHTED, lr=1e-2, steps=12, seed=15,
+                  noise=0.05),
     "depth1": dict(hidden=23, S=2, D=1, act=rc.RELU, method=rc.WEIGHTED, lr=1e-2, steps=6, seed=12),
 }
 
@@ -42,7 +46,8 @@ def case_kwargs(c):
     if c.get("aux"):
         flags |= rc.FLAG_AUX_ARRAYS
     return dict(input_size=42, hidden_size=c["hidden"], output_size=42, S=c["S"], D=c["D"],
-                activation=c["act"], learn_rate=c["lr"], seed=c["seed"], flags=flags)
+                activation=c["act"], learn_rate=c["lr"], seed=c["seed"], flags=flags,
+                noise=c.get("noise", 0.0))
 
 
 def synthetic_text_np(n=TEXT_LEN, alphabet=42, seed=7):

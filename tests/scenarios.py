@@ -31,11 +31,11 @@ class ApiSet:
     def __init__(self, lib, input_size, hidden_size, output_size, S, D, activation=rc.RELU,
                  flags=rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR, learn_rate=1e-3, seed=1,
                  momentum=0.95, variance=None, shape=rc.DIST_SEMICIRCLE, perforation=0.0,
-                 softmax_best_guess=None):
+                 softmax_best_guess=None, noise=0.0):
         self.lib = lib
         self.S, self.D = S, D
         net = lib.rnn_new(input_size, hidden_size, output_size, flags, seed, None, D,
-                          learn_rate, momentum, 0.0, activation)
+                          learn_rate, momentum, noise, activation)
         self.net = net
         n = net.contents
         self.I, self.H, self.O = n.i_size, n.h_size, n.o_size
@@ -140,7 +140,7 @@ class OracleSet:
     def __init__(self, input_size, hidden_size, output_size, S, D, activation=rc.RELU,
                  flags=rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR, learn_rate=1e-3, seed=1,
                  momentum=0.95, variance=None, shape=rc.DIST_SEMICIRCLE, perforation=0.0,
-                 fast=False):
+                 fast=False, noise=0.0):
         self.orc = orc = rc.load_oracle(fast=fast)
         self.z = orc.orc_set_new(input_size, hidden_size, output_size, S, D, activation, flags,
                                  learn_rate, seed)
@@ -151,6 +151,7 @@ class OracleSet:
             variance = np.float32(2.0) / np.float32(z.H)
         orc.orc_set_init_flat(self.z, variance, shape, perforation)
         orc.orc_set_seed_clones(self.z)
+        self.z.contents.presynaptic_noise = noise
 
     def close(self):
         self.orc.orc_set_free(self.z)

@@ -49,7 +49,7 @@ def test_batched_path_matches_reference_vectors(amd, name):
 
 
 @pytest.mark.parametrize("name", ["relu_weighted", "resqrt_weighted", "relu_adagrad", "single_step_h99",
-                                  "depth1"])
+                                  "depth1", "noisy"])
 def test_per_net_drop_in_calls_match_reference_vectors(amd, orc, name):
     got = replay.train_api(amd, name, batched=False, sbg=orc.orc_softmax_best_guess)
     replay.check(got, replay.golden_case(name), RTOL, exact=("index", "generation", "rng"))
