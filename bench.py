@@ -121,8 +121,14 @@ def main():
         raise SystemExit("bench.py needs a GPU (librecur_amd has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # RECUR_BENCH_FORCE_DIST=1 exercises the sharded path (RCCL group, external delta buffer,
+    # all-reduce) even with one rank: a single-GPU check of the multi-GPU plumbing
+    force_dist = os.environ.get("RECUR_BENCH_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     amd = rc.load_amd()
@@ -138,13 +144,13 @@ def main():
     first, _, total = shard_range(rank, world, S)
     amd.rnn_amd_set_shard(gpu.handle, first, total)
     delta = None
-    if world > 1:
+    if dist is not None:
         delta = torch.zeros(gpu.I * gpu.H + gpu.H * gpu.O, dtype=torch.float32, device="cuda")
         amd.rnn_amd_set_external_delta(gpu.handle, C.c_void_p(delta.data_ptr()))
 
     from recur_amd.dist import ShardedStep
     step = ShardedStep(lambda i: amd.rnn_amd_set_char_step_deltas(gpu.handle, i),
-                       (lambda: dist.all_reduce(delta)) if world > 1 else None,
+                       (lambda: dist.all_reduce(delta)) if dist is not None else None,
                        lambda: amd.rnn_apply_learning(gpu.net, rc.WEIGHTED, MOMENTUM))
 
     def fence():
@@ -244,11 +250,15 @@ def main():
         out["roofline"] = roofline
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rc, sc, amd, gpu, text, i, args.cpu_seconds)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio; push it out first so that the JSON
+        # line is the last thing on stdout
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
