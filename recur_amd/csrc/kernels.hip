@@ -1132,6 +1132,7 @@ __global__ void k_bptt_control(View v, int row0, int nrows, const unsigned char 
   const int D = s.D;
   if (active && !active[j]) {
     for (int k = 0; k < D; k++) v.b.coef[(size_t)k * s.Scap + r] = 0.0f;
+    v.b.n_exec[r] = 0; /* no step ran for this stream: k_err_writeback leaves its images alone */
     return;
   }
   float top = v.b.top_scaled[r];

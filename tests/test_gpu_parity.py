@@ -286,3 +286,76 @@ def test_forward_only_clone_set_matches_oracle(amd):
         lib.rnn_delete_net(c)
     lib.rnn_delete_net(net)
     o.close()
+
+
+def test_classify_shape_dense_inputs_active_mask_nesterov(amd):
+    """BASELINE.json configs[2] shape (gstclassify: 512 hidden, 128 streams, dense
+    features, 2 classes, Nesterov; train_channel only back-propagates the channels
+    whose group was trained, gstclassify.c:2070-2130): batched calls with an active
+    mask against the oracle's per-stream calls."""
+    lib = amd
+    S, D = 128, 12
+    kw = dict(input_size=32, hidden_size=512, output_size=2, S=S, D=D, learn_rate=3e-4, seed=6)
+    g = sc.AmdBatchedSet(lib, **kw)
+    o = sc.OracleSet(**kw)
+    a = o.arrays()
+    rs = np.random.default_rng(12)
+    compared = 0
+    for step in range(6):
+        x = (rs.standard_normal((S, 32)) * 0.5).astype(np.float32)
+        err = (rs.standard_normal((S, g.O)) * 0.05).astype(np.float32)
+        err[:, 2:] = 0
+        active = (rs.random(S) < 0.7).astype(np.uint8)
+        active[0] = 1
+        # gstclassify order: opinion, error, calc_deltas, then advance
+        lib.rnn_amd_set_opinion(g.handle, rc.fptr(x), 32, None)
+        lib.rnn_amd_set_put_o_error(g.handle, rc.fptr(err), g.O)
+        lib.rnn_bptt_clear_deltas(g.net)
+        lib.rnn_amd_set_calc_deltas(g.handle, 1, None, rc.u8ptr(active))
+        lib.rnn_amd_set_advance(g.handle)
+        lib.rnn_apply_learning(g.net, rc.NESTEROV, 0.9)
+        o.orc.orc_clear_deltas(o.z)
+        for j in range(S):
+            o.orc.orc_opinion(o.z, j, rc.fptr(np.ascontiguousarray(x[j])), 0.0)
+            a["o_error"][j, :] = err[j]
+            if active[j]:
+                o.orc.orc_calc_deltas(o.z, j, 1, None)
+            o.orc.orc_advance(o.z, j)
+        o.orc.orc_apply_learning(o.z, rc.NESTEROV, 0.9)
+        # Precondition of any fp32 comparison of this algorithm: no hidden unit sits within
+        # rounding of zero -- its ReLU mask, hence its whole back-propagated error, would
+        # depend on the summation order (seen: unit 505 of stream 121 was 3e-8 on the device
+        # and 0 on the CPU).  Steps where that happens are not compared; every step starts
+        # from the oracle's state so that they stay independent.
+        sg, so = g.snapshot(), o.snapshot()
+        flips = np.argwhere((sg["hidden"] != 0) != (so["hidden"] != 0))
+        if len(flips) == 0:
+            replay.check(sg, so, RTOL, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta",
+                                             "hidden", "output", "hist"], exact=("index", "generation"))
+            compared += 1
+        _load_state(amd, g, so)
+    assert compared >= 3
+    g.close()
+    o.close()
+
+
+def test_c_driver_trains_on_erewhon():
+    """tools/text_predict_amd.c (plain C against include/ + librecur_amd.so) at the
+    BASELINE.json configs[1] shape: 1024 hidden, 64 streams, depth 20."""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(rc.ROOT, "build", "text_predict_amd")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.join(rc.ROOT, "recur_amd", "csrc")], check=True)
+    r = subprocess.run([exe, "-f", rc.EREWHON, "-H", "1024", "-t", "64", "-d", "20", "-l", "3e-5", "-s", "300",
+                        "-r", "100", "-V", "1500"], capture_output=True, text=True, timeout=600,
+                       cwd=rc.ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = re.findall(r"generation\s+(\d+) t_entropy ([\d.]+) v_entropy ([\d.]+) accuracy ([\d.]+) depth ([\d.]+)\s+(\d+)/s",
+                      r.stdout)
+    assert [int(x[0]) for x in rows] == [100, 200, 300]
+    t = [float(x[1]) for x in rows]
+    v = [float(x[2]) for x in rows]
+    assert t[-1] < t[0] and v[-1] < v[0] and v[-1] < 5.0      # it learns (uniform = log2(42) = 5.39)
+    assert float(rows[-1][4]) > 10                              # BPTT runs deep
