@@ -34,6 +34,11 @@ HIDDEN, STREAMS, DEPTH, ALPHABET = 1024, 256, 20, 42
 LEARN_RATE, MOMENTUM = 1e-5, 0.95
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
+# HBM-side bytes per launch of the dominant kernel at the default shape, from the PMC passes
+# kept in profiles/r01_pmc_fetch_write_per_kernel.txt (2 x FETCH_SIZE + WRITE_SIZE, the gfx950
+# correction of MI355X_MICROARCH.md); it cannot be read live without the profiler.
+TRAFFIC_BYTES_PER_LAUNCH = {"bptt_chain_gemm": (2 * 7366.5 + 1312.0) * 1024,
+                            "delta_gemm": (2 * 100101.3 + 32452.5) * 1024}
 
 
 def parse():
@@ -45,7 +50,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=STREAMS, help="streams per GPU")
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
@@ -94,7 +99,7 @@ def cpu_baseline(rc, sc, amd, gpu_set, text, i_next, budget_s):
         cpu.char_step(text, i_next + gens, rc.WEIGHTED, MOMENTUM)
         gens += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or gens >= 200:
+        if el >= budget_s or gens >= 600:
             break
     cpu.close()
     return {
@@ -217,7 +222,10 @@ def main():
         achieved = flops[dom] / (avg_us * 1e-6) / 1e12 if n else 0.0
         roofline = {
             "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "traffic": (TRAFFIC_BYTES_PER_LAUNCH.get(dom)
+                        if (Hd, S, D) == (HIDDEN, STREAMS, DEPTH) else None),
+            "algorithmic_bytes": 4.0 * (I * H + 3 * S * I),  # W once, E in, X mask, E out
             "avg_launch_us": avg_us, "launches": n, "flop_per_launch": flops[dom],
             "classes_ms_per_step": {k: v[0] / n_roof for k, v in cls.items()},
             "steps": n_roof,
