@@ -1083,6 +1083,70 @@ __global__ __launch_bounds__(256) void k_chain_main(View v, int row0, int nrows,
     v.b.esum_part[((size_t)t * (tn + 1) + nt) * s.Scap + row0 + r] = sq;
 }
 
+// Chain "extras" without a GEMM: for every (step, stream) the error of the bias
+// row (column 0) and of the real-input rows, i.e. e = W_ih[y][:] . E_h[t][s][:] for
+// the rows y whose input value is non-zero -- the reference's zero-row skip
+// (recur-nn.c:338-341) is what makes this cheap: a one-hot text stream has two
+// such rows per step, a dense audio frame a few dozen.  One wave per (step,
+// stream): the error row sits in registers (5 float4 per lane at h_size 1028),
+// the wave walks the non-zero columns (ballot), each dot product is reduced with
+// xor shuffles in a fixed order.  It also closes the step's sum of squares:
+// the column-tile partials of k_chain_main in index order, then the extras.
+__global__ __launch_bounds__(256) void k_extras_gather(View v, int row0, int nrows, int nx, int nxp,
+                                                       int tn) {
+  const RamdShape &s = v.sh;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= s.D * nrows) return;
+  const int t = m / nrows, r = row0 + (m - t * nrows);
+  const float *erow = v.b.ehi + (t * s.Scap + r) * s.I;
+  const float *x = input_row<false>(v, r, t);
+  float *dst = v.b.ex + ((size_t)(t + 1) * s.Scap + r) * nxp;
+  constexpr int MAXQ = 8; /* float4 per lane: h_size up to 2048 */
+  const int nq = (s.H / 4 + 63) / 64;
+  float4 ev[MAXQ];
+#pragma unroll
+  for (int i = 0; i < MAXQ; i++) {
+    int k4 = lane + 64 * i;
+    ev[i] = (i < nq && 4 * k4 < s.H) ? ld4(erow + 4 * k4) : zero4();
+  }
+  float sq = 0.0f;
+  for (int c0 = 0; c0 < nx; c0 += 64) {
+    int c = c0 + lane;
+    int n = (c == 0) ? 0 : s.hidden_size + c;
+    float xi = (c < nx) ? x[n] : 0.0f;
+    bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
+    if (c < nx) dst[c] = 0.0f;
+    unsigned long long live = __ballot(on);
+    while (live) {
+      int l = __ffsll((long long)live) - 1;
+      live &= live - 1;
+      int cc = c0 + l;
+      int nn = (cc == 0) ? 0 : s.hidden_size + cc;
+      float xv = __shfl(xi, l, 64);
+      const float *w = v.b.ih_w + nn * s.H;
+      float acc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < MAXQ; i++) {
+        int k4 = lane + 64 * i;
+        if (i < nq && 4 * k4 < s.H) {
+          float4 wv = ld4(w + 4 * k4);
+          acc += ev[i].x * wv.x + ev[i].y * wv.y + ev[i].z * wv.z + ev[i].w * wv.w;
+        }
+      }
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (s.activation == 2) acc /= 2 * (xv + 1.0f);
+      if (lane == 0) dst[cc] = acc;
+      sq += acc * acc; /* identical in every lane */
+    }
+  }
+  if (lane == 0) {
+    float sum = 0.0f;
+    for (int p = 0; p < tn; p++) sum += v.b.esum_part[((size_t)t * (tn + 1) + p) * s.Scap + r];
+    v.b.esum[(size_t)t * s.Scap + r] = sum + sq;
+  }
+}
+
 // Finalize of the extras GEMM: applies the row rule to column 0 and the input
 // columns, keeps the raw values in ex[t+1][s][c] (for the h_error / i_error
 // images) and adds their squares as the last partial sum.  One wave per (t, s).
@@ -1629,9 +1693,14 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int M = sh->D * nrows;
     int etm = (M + BM - 1) / BM, etn = (nx + BN - 1) / BN, nkt = (sh->H + BK - 1) / BK;
     int ks = pick_ks(etm * etn, nkt, "RECUR_AMD_KS_EXTRAS", b->slab_floats, (size_t)M * nxp);
-    ProbExtras p = {v, row0, nrows, nx};
-    launch_gemm<false, false, ProbExtras>(st, p, b->slab, M, nxp, nkt, ks, T_OTHER);
-    hipLaunchKernelGGL(k_extras_finalize, dim3(M), dim3(64), 0, st, v, row0, nrows, nx, nxp, ks, tn);
+    if (sh->H <= 2048 && !env_int("RECUR_AMD_EXTRAS_GEMM", 0)) {
+      hipLaunchKernelGGL(k_extras_gather, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx, nxp,
+                         tn);
+    } else { /* very wide nets: the dense GEMM over all extra columns */
+      ProbExtras p = {v, row0, nrows, nx};
+      launch_gemm<false, false, ProbExtras>(st, p, b->slab, M, nxp, nkt, ks, T_OTHER);
+      hipLaunchKernelGGL(k_extras_finalize, dim3(M), dim3(64), 0, st, v, row0, nrows, nx, nxp, ks, tn);
+    }
   }
   hipLaunchKernelGGL(k_bptt_control, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows,
                      active, flags, tn);
