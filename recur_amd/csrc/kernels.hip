@@ -917,7 +917,7 @@ __device__ __forceinline__ f32x4 lds_read_b128(uint32_t addr) {
 }
 
 template <bool UNI>
-__global__ __launch_bounds__(256) void k_chain_main(View v, int row0, int nrows, int t, int tm,
+__global__ __launch_bounds__(512) void k_chain_main(View v, int row0, int nrows, int t, int tm,
                                                     int tn, int nstages, int ktail0) {
   __shared__ __attribute__((aligned(16))) float smem[C_STAGES * C_STAGE_FLOATS];
   const RamdShape &s = v.sh;
@@ -926,7 +926,12 @@ __global__ __launch_bounds__(256) void k_chain_main(View v, int row0, int nrows,
   const int mt = q % tm, nt = (q / tm) * 8 + xcd; /* the m tiles of one W panel share an XCD */
   if (nt >= tn) return;
   const int m0 = mt * CM, n0 = 1 + nt * CN;       /* output columns start at 1 */
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // 8 waves: 0-3 multiply (one quarter of every K stage each), 4-7 only feed the LDS
+  // ring.  An LDS-DMA instruction costs its issuing wave 100-200 cycles; on a wave of its
+  // own that cost overlaps the other waves' MFMAs instead of delaying them.
+  const int wave8 = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool loader = wave8 >= 4;
+  const int wave = wave8 & 3;
   const int lm = lane & 31, kh = lane >> 5;
   const float *ehi_t = v.b.ehi + ((size_t)t * s.Scap + row0) * s.I;
 
@@ -970,7 +975,8 @@ __global__ __launch_bounds__(256) void k_chain_main(View v, int row0, int nrows,
   // --- what the epilogue needs from global memory (this thread's 4 output columns of one
   // row: the input values that gate them, and the operands of a short K tail) is fetched
   // now, so that its latency hides under the main loop
-  const int erow_i = threadIdx.x >> 3, ec4 = (threadIdx.x & 7) * 4;
+  const int etid = threadIdx.x & 255; /* epilogue work is done by the compute waves */
+  const int erow_i = etid >> 3, ec4 = (etid & 7) * 4;
   const int er = m0 + erow_i < nrows ? m0 + erow_i : nrows - 1;
   const float *xrow = input_row<UNI>(v, row0 + er, t);
   float xin[4];
@@ -991,18 +997,26 @@ __global__ __launch_bounds__(256) void k_chain_main(View v, int row0, int nrows,
     et[1] = (s.H - ktail0 > 4) ? ld4(ehi_t + (size_t)er * s.I + ktail0 + 4) : zero4();
   }
 
+  if (loader) {
 #pragma unroll
-  for (int p = 0; p < C_STAGES - 1; p++)
-    if (p < nstages) issue(p);
+    for (int p = 0; p < C_STAGES - 1; p++)
+      if (p < nstages) issue(p);
+  }
   const uint32_t lds0 = lds_byte_addr(smem);
   const uint32_t rowoff = (uint32_t)lm * (CK * 4u);
   for (int st = 0; st < nstages; st++) {
-    // stages st+1 .. st+C_STAGES-2 may stay in flight (8 DMAs per stage and wave)
-    const int ahead = min(C_STAGES - 2, nstages - 1 - st);
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (loader) {
+      // stages st+1 .. st+C_STAGES-2 may stay in flight (8 DMAs per stage and loader wave)
+      const int ahead = min(C_STAGES - 2, nstages - 1 - st);
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier(); /* stage st has landed; stage st-1's buffer is free */
+    if (loader) {
+      if (st + C_STAGES - 1 < nstages) issue(st + C_STAGES - 1);
+      continue;
+    }
     const uint32_t abase = lds0 + (uint32_t)((st % C_STAGES) * C_STAGE_FLOATS) * 4u;
     const uint32_t bbase = abase + (uint32_t)(CM * CK) * 4u;
     f32x4 a[4], b[4];
@@ -1018,28 +1032,28 @@ __global__ __launch_bounds__(256) void k_chain_main(View v, int row0, int nrows,
     // refill the buffer everybody finished reading before this stage's barrier,
     // two DMA issues after every four MFMAs so that their address arithmetic sits
     // in the shadow of the dependent MFMA chain
-    const bool refill = st + C_STAGES - 1 < nstages;
 #pragma unroll
     for (int gi = 0; gi < 4; gi++) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].x, b[gi].x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].y, b[gi].y, acc, 0, 0, 0);
-      if (refill) issue_one(st + C_STAGES - 1, 2 * gi);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].z, b[gi].z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].w, b[gi].w, acc, 0, 0, 0);
-      if (refill) issue_one(st + C_STAGES - 1, 2 * gi + 1);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
   // --- sum the four waves' partial tiles through LDS
   __builtin_amdgcn_s_barrier();
   float *red = smem; /* [4][32][32] */
+  if (!loader) {
 #pragma unroll
-  for (int g = 0; g < 16; g++) {
-    int row = (g & 3) + 8 * (g >> 2) + 4 * kh;
-    red[(wave * CM + row) * CN + lm] = acc[g];
+    for (int g = 0; g < 16; g++) {
+      int row = (g & 3) + 8 * (g >> 2) + 4 * kh;
+      red[(wave * CM + row) * CN + lm] = acc[g];
+    }
   }
   __syncthreads();
-  const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+  if (loader) return;
+  const int row = etid >> 3, c4 = (etid & 7) * 4;
   float e[4];
   {
     float4 p0 = ld4(red + (0 * CM + row) * CN + c4), p1 = ld4(red + (1 * CM + row) * CN + c4);
@@ -1079,7 +1093,7 @@ __global__ __launch_bounds__(256) void k_chain_main(View v, int row0, int nrows,
   sq += __shfl_xor(sq, 1, 64);
   sq += __shfl_xor(sq, 2, 64);
   sq += __shfl_xor(sq, 4, 64);
-  if ((threadIdx.x & 7) == 0 && r < nrows)
+  if ((etid & 7) == 0 && r < nrows)
     v.b.esum_part[((size_t)t * (tn + 1) + nt) * s.Scap + row0 + r] = sq;
 }
 
@@ -1683,10 +1697,10 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int ev = timing_begin(st, T_CHAIN, sh->D);
     for (int t = 0; t < sh->D; t++) {
       if (b->uniform_idx >= 0)
-        hipLaunchKernelGGL(k_chain_main<true>, dim3(blocks), dim3(256), 0, st, v, row0, nrows, t, tm,
+        hipLaunchKernelGGL(k_chain_main<true>, dim3(blocks), dim3(512), 0, st, v, row0, nrows, t, tm,
                            tn, nstages, ktail0);
       else
-        hipLaunchKernelGGL(k_chain_main<false>, dim3(blocks), dim3(256), 0, st, v, row0, nrows, t,
+        hipLaunchKernelGGL(k_chain_main<false>, dim3(blocks), dim3(512), 0, st, v, row0, nrows, t,
                            tm, tn, nstages, ktail0);
     }
     timing_end(st, ev);
