@@ -1004,42 +1004,59 @@ __global__ __launch_bounds__(512) void k_chain_main(View v, int row0, int nrows,
   }
   const uint32_t lds0 = lds_byte_addr(smem);
   const uint32_t rowoff = (uint32_t)lm * (CK * 4u);
-  for (int st = 0; st < nstages; st++) {
-    if (loader) {
+  if (loader) {
+    for (int st = 0; st < nstages; st++) {
       // stages st+1 .. st+C_STAGES-2 may stay in flight (8 DMAs per stage and loader wave)
       const int ahead = min(C_STAGES - 2, nstages - 1 - st);
       if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier(); /* stage st has landed; stage st-1's buffer is free */
-    if (loader) {
+      __builtin_amdgcn_s_barrier(); /* stage st has landed; stage st-1's buffer is free */
       if (st + C_STAGES - 1 < nstages) issue(st + C_STAGES - 1);
-      continue;
     }
-    const uint32_t abase = lds0 + (uint32_t)((st % C_STAGES) * C_STAGE_FLOATS) * 4u;
-    const uint32_t bbase = abase + (uint32_t)(CM * CK) * 4u;
-    f32x4 a[4], b[4];
+  } else {
+    // Compute waves run one stage behind their own LDS reads: the fragments of stage
+    // st + 1 are requested right after its barrier and arrive while the 16 dependent
+    // MFMAs of stage st execute, so neither the ds_read latency nor the barrier sits
+    // between two MFMA blocks.
+    auto rd = [&](int st, f32x4 (&a)[4], f32x4 (&b)[4]) {
+      const uint32_t abase = lds0 + (uint32_t)((st % C_STAGES) * C_STAGE_FLOATS) * 4u;
+      const uint32_t bbase = abase + (uint32_t)(CM * CK) * 4u;
 #pragma unroll
-    for (int gi = 0; gi < 4; gi++) {
-      int c = 2 * (4 * wave + gi) + kh;               /* chunk = 4 consecutive k */
-      uint32_t off = rowoff + (uint32_t)((c ^ (lm & 15)) * 16);
-      a[gi] = lds_read_b128(abase + off);
-      b[gi] = lds_read_b128(bbase + off);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    // refill the buffer everybody finished reading before this stage's barrier,
-    // two DMA issues after every four MFMAs so that their address arithmetic sits
-    // in the shadow of the dependent MFMA chain
+      for (int gi = 0; gi < 4; gi++) {
+        int c = 2 * (4 * wave + gi) + kh;               /* chunk = 4 consecutive k */
+        uint32_t off = rowoff + (uint32_t)((c ^ (lm & 15)) * 16);
+        a[gi] = lds_read_b128(abase + off);
+        b[gi] = lds_read_b128(bbase + off);
+      }
+    };
+    auto step = [&](int st, f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&an)[4], f32x4 (&bn)[4]) {
+      /* every read issued so far has arrived: this stage's fragments are usable, and the
+       * loaders may overwrite its buffer after the next barrier */
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (st + 1 < nstages) {
+        __builtin_amdgcn_s_barrier(); /* stage st + 1 has landed */
+        rd(st + 1, an, bn);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int gi = 0; gi < 4; gi++) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].x, b[gi].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].y, b[gi].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].z, b[gi].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].w, b[gi].w, acc, 0, 0, 0);
+      for (int gi = 0; gi < 4; gi++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].x, b[gi].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].y, b[gi].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].z, b[gi].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].w, b[gi].w, acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    f32x4 a0[4], b0[4], a1[4], b1[4];
+    if (nstages > 0) {
+      __builtin_amdgcn_s_barrier(); /* stage 0 has landed */
+      rd(0, a0, b0);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    for (int st = 0; st < nstages; st += 2) {
+      step(st, a0, b0, a1, b1);
+      if (st + 1 < nstages) step(st + 1, a1, b1, a0, b0);
+    }
   }
   // --- sum the four waves' partial tiles through LDS
   __builtin_amdgcn_s_barrier();
