@@ -232,6 +232,22 @@ OrcSet *orc_set_new(int input_size, int hidden_size, int output_size, int S,
   return z;
 }
 
+/* rnn_new_extra_layer (recur-nn-init.c:158-192) */
+void orc_set_add_bottom(OrcSet *z, int n_inputs) {
+  z->b_in = n_inputs;
+  z->bI = (n_inputs + 1 + 3) & ~3;
+  z->bO = (z->input_size + 3) & ~3;
+  size_t n = (size_t)z->bI * z->bO;
+  z->b_w = zeros(n);
+  z->b_m = zeros(n);
+  z->b_aux = zeros(n);
+  z->b_delta = zeros(n);
+  z->b_inputs = zeros(z->bI);
+  z->b_outputs = zeros(z->bO);
+  z->b_o_error = zeros(z->bO);
+  z->b_learn_rate_scale = 1.0f;
+}
+
 /* rnn_clone's RECUR_RNG_SUBSEED branch (recur-nn-init.c:300-305), in the
  * order rnn_new_training_set clones (recur-nn-init.c:236-241). */
 void orc_set_seed_clones(OrcSet *z) {
@@ -258,6 +274,13 @@ void orc_set_free(OrcSet *z) {
   free(z->ih_delta);
   free(z->ho_delta);
   free(z->ih_delta_tmp);
+  free(z->b_w);
+  free(z->b_m);
+  free(z->b_aux);
+  free(z->b_delta);
+  free(z->b_inputs);
+  free(z->b_outputs);
+  free(z->b_o_error);
   free(z->hist);
   free(z->hidden);
   free(z->output);
@@ -312,7 +335,7 @@ static void fill_flat(OrcRng *rng, float *array, int width, int height, int stri
   }
 }
 
-/* randomise_weights_flat (recur-nn-init.c:547-573), no bottom layer */
+/* randomise_weights_flat (recur-nn-init.c:547-573) */
 void orc_set_init_flat(OrcSet *z, float variance, int shape, double perforation) {
   memset(z->ih_w, 0, sizeof(float) * z->I * z->H);
   memset(z->ho_w, 0, sizeof(float) * z->H * z->O);
@@ -325,6 +348,11 @@ void orc_set_init_flat(OrcSet *z, float variance, int shape, double perforation)
             z->H, 1, variance, shape, perforation);
   fill_flat(&z->rng[0], z->ho_w, z->output_size, z->hidden_size + 1, z->O, 0,
             variance, shape, perforation);
+  if (z->bI) { /* recur-nn-init.c:566-572 */
+    memset(z->b_w, 0, sizeof(float) * z->bI * z->bO);
+    fill_flat(&z->rng[0], z->b_w, z->input_size, z->b_in, z->bO, 1, variance, shape,
+              perforation);
+  }
 }
 
 /* ---------------------------------------------------------- forward pass -- */
@@ -355,13 +383,28 @@ static void interlayer(const float *in, int in_size, float *out, int out_size,
   }
 }
 
-/* rnn_opinion (recur-nn.c:83-154) without a bottom layer */
+/* rnn_opinion (recur-nn.c:83-154) */
 float *orc_opinion(OrcSet *z, int s, const float *inputs, float noise) {
   float *slot = slot_of(z, s);
   float *hid = z->hidden + (size_t)s * z->H;
   float *out = z->output + (size_t)s * z->O;
   int off = z->hidden_size + 1;
-  if (inputs) {
+  if (z->bI) { /* recur-nn.c:88-103 */
+    z->b_inputs[0] = 1.0f;
+    if (inputs) {
+      memcpy(z->b_inputs + 1, inputs, z->b_in * sizeof(float));
+    }
+    interlayer(z->b_inputs, z->bI, z->b_outputs, z->bO, z->b_w);
+    if (noise) {
+      for (int i = 1; i < z->input_size; i++) {
+        z->b_outputs[i] += orc_cheap_gaussian_noise(&z->rng[s]) * noise;
+      }
+    }
+    for (int i = 0; i < z->input_size; i++) {
+      float x = z->b_outputs[i];
+      slot[off + i] = (x > 0.0f) ? x : 0.0f;
+    }
+  } else if (inputs) {
     memcpy(slot + off, inputs, z->input_size * sizeof(float));
   }
   memcpy(slot, hid, off * sizeof(float));
@@ -407,6 +450,14 @@ float *orc_opinion(OrcSet *z, int s, const float *inputs, float noise) {
 
 /* one_hot_opinion (charmodel-helpers.h:16-33) */
 float *orc_one_hot_opinion(OrcSet *z, int s, int hot, float noise) {
+  if (z->bI) {
+    /* with a bottom layer the helper indexes from the layer's bias slot
+     * (charmodel-helpers.h:20-23, 30-31): symbol k lights input k - 1, symbol 0 only
+     * the bias that rnn_opinion sets anyway, and the last input is never cleared */
+    memset(z->b_inputs, 0, z->b_in * sizeof(float));
+    z->b_inputs[hot] = 1.0f;
+    return orc_opinion(z, s, NULL, noise);
+  }
   float *slot = slot_of(z, s);
   float *real = slot + z->hidden_size + 1;
   memset(real, 0, z->input_size * sizeof(float));
@@ -511,7 +562,8 @@ static void top_delta(const float *hid, int H, const float *o_err, int O,
 
 /* bptt_and_accumulate_error (recur-nn.c:303-450), VECTOR flavour of the inner
  * loop (four running partial sums, recur-nn.c:347-358). */
-static float bptt_accumulate(OrcSet *z, int s, float *ih_delta, float top_error_sum) {
+static float bptt_accumulate(OrcSet *z, int s, float *ih_delta, float *cumulative_input_error,
+                             float top_error_sum) {
   const int I = z->I, H = z->H, D = z->D;
   float *h_error = z->err_a + (size_t)s * I;
   float *i_error = z->err_b + (size_t)s * I;
@@ -554,6 +606,12 @@ static float bptt_accumulate(OrcSet *z, int s, float *ih_delta, float top_error_
         i_error[y] = 0;
       }
     }
+    if (cumulative_input_error) { /* recur-nn.c:377-382 */
+      const float *input_error = i_error + z->hidden_size + 1;
+      for (int y = 0; y < z->input_size; y++) {
+        cumulative_input_error[y] += input_error[y];
+      }
+    }
     float *tmp = h_error;
     h_error = i_error;
     i_error = tmp;
@@ -582,6 +640,10 @@ static float bptt_accumulate(OrcSet *z, int s, float *ih_delta, float top_error_
 void orc_clear_deltas(OrcSet *z) {
   memset(z->ih_delta, 0, sizeof(float) * z->I * z->H);
   memset(z->ho_delta, 0, sizeof(float) * z->H * z->O);
+  if (z->bI) {
+    memset(z->b_o_error, 0, sizeof(float) * z->bO);
+    memset(z->b_delta, 0, sizeof(float) * z->bI * z->bO);
+  }
 }
 
 /* rnn_bptt_calc_deltas (recur-nn.c:707-772) */
@@ -600,7 +662,7 @@ void orc_calc_deltas(OrcSet *z, int s, int accumulate, const int *ranges) {
   float bptt_err;
   if (accumulate) {
     memset(z->ih_delta_tmp, 0, sizeof(float) * ih);
-    bptt_err = bptt_accumulate(z, s, z->ih_delta_tmp, top_scaled);
+    bptt_err = bptt_accumulate(z, s, z->ih_delta_tmp, z->bI ? z->b_o_error : NULL, top_scaled);
     float scale = z->ih_scale[s];
     if (scale == 1.0f) { /* add_aligned_arrays, recur-nn-helpers.h:68-77 */
       for (size_t i = 0; i < ih; i++) {
@@ -613,13 +675,19 @@ void orc_calc_deltas(OrcSet *z, int s, int accumulate, const int *ranges) {
     }
   } else {
     memset(z->ih_delta, 0, sizeof(float) * ih);
-    bptt_err = bptt_accumulate(z, s, z->ih_delta, top_scaled);
+    bptt_err = bptt_accumulate(z, s, z->ih_delta, z->bI ? z->b_o_error : NULL, top_scaled);
     if (z->ih_scale[s] != 1.0f) {
       float scale = z->ih_scale[s];
       for (size_t i = 0; i < ih; i++) {
         z->ih_delta[i] *= scale;
       }
     }
+  }
+  if (z->bI) { /* recur-nn.c:750-757: nothing in here ever clears b_o_error */
+    if (!accumulate) {
+      memset(z->b_delta, 0, sizeof(float) * z->bI * z->bO);
+    }
+    top_delta(z->b_inputs, z->bI, z->b_o_error, z->bO, z->b_delta, NULL);
   }
   z->top_error_raw[s] = top;
   z->top_error_scaled[s] = top_scaled;
@@ -720,18 +788,24 @@ void orc_apply_learning(OrcSet *z, int method, float momentum) {
   size_t ih = (size_t)z->I * z->H, ho = (size_t)z->H * z->O;
   float lr = z->learn_rate[0];
   float lr_top = lr * z->ho_scale;
+  size_t bn = (size_t)z->bI * z->bO;
+  float lr_bottom = lr * z->b_learn_rate_scale;
   if (method == ORC_NESTEROV) {
     learn_nesterov(z->ho_w, z->ho_delta, z->ho_m, ho, lr_top, momentum);
     learn_nesterov(z->ih_w, z->ih_delta, z->ih_m, ih, lr, momentum);
+    if (bn) learn_nesterov(z->b_w, z->b_delta, z->b_m, bn, lr_bottom, momentum);
   } else if (method == ORC_ADAGRAD) {
     learn_adagrad(z->ho_w, z->ho_delta, z->ho_m, ho, lr_top);
     learn_adagrad(z->ih_w, z->ih_delta, z->ih_m, ih, lr);
+    if (bn) learn_adagrad(z->b_w, z->b_delta, z->b_m, bn, lr_bottom);
   } else if (method == ORC_ADADELTA) {
     learn_adadelta(z->ho_w, z->ho_delta, z->ho_m, z->ho_aux, ho, lr_top, momentum);
     learn_adadelta(z->ih_w, z->ih_delta, z->ih_m, z->ih_aux, ih, lr, momentum);
+    if (bn) learn_adadelta(z->b_w, z->b_delta, z->b_m, z->b_aux, bn, lr_bottom, momentum);
   } else if (method == ORC_RPROP) {
     learn_rprop(z->ho_w, z->ho_delta, z->ho_m, z->ho_aux, ho, lr_top, momentum);
     learn_rprop(z->ih_w, z->ih_delta, z->ih_m, z->ih_aux, ih, lr, momentum);
+    if (bn) learn_rprop(z->b_w, z->b_delta, z->b_m, z->b_aux, bn, lr_bottom, momentum);
   } else {
     float mw;
     if (method == ORC_SIMPLIFIED_NESTEROV) {
@@ -743,6 +817,7 @@ void orc_apply_learning(OrcSet *z, int method, float momentum) {
     }
     learn_momentum(z->ho_w, z->ho_delta, z->ho_m, ho, lr_top, momentum, mw);
     learn_momentum(z->ih_w, z->ih_delta, z->ih_m, ih, lr, momentum, mw);
+    if (bn) learn_momentum(z->b_w, z->b_delta, z->b_m, bn, lr_bottom, momentum, mw);
   }
 }
 
@@ -846,7 +921,7 @@ void orc_bptt_calculate(OrcSet *z, int s, unsigned batch_size, float momentum) {
   float bptt_err;
   if (batch_size > 1) { /* apply_sgd_with_bptt_batch */
     memset(z->ih_delta_tmp, 0, sizeof(float) * ih);
-    bptt_err = bptt_accumulate(z, s, z->ih_delta_tmp, top_scaled);
+    bptt_err = bptt_accumulate(z, s, z->ih_delta_tmp, NULL /* recur-nn.c:972, 986 */, top_scaled);
     float scale = z->ih_scale[s];
     if (scale == 1.0f) {
       for (size_t i = 0; i < ih; i++)
@@ -861,7 +936,7 @@ void orc_bptt_calculate(OrcSet *z, int s, unsigned batch_size, float momentum) {
     }
   } else { /* apply_sgd_with_bptt */
     memset(z->ih_delta, 0, sizeof(float) * ih);
-    bptt_err = bptt_accumulate(z, s, z->ih_delta, top_scaled);
+    bptt_err = bptt_accumulate(z, s, z->ih_delta, NULL /* recur-nn.c:972, 986 */, top_scaled);
     learn_momentum(z->ih_w, z->ih_delta, z->ih_m, ih, rate * z->ih_scale[s], momentum, mw);
   }
   z->top_error_raw[s] = top;

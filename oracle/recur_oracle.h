@@ -70,6 +70,13 @@ typedef struct OrcSet {
   double stat_error, stat_entropy;
   long stat_correct, stat_count;
   double stat_depth, stat_zeros;
+  /* optional bottom layer (recur-nn.h:211-227; orc_set_add_bottom): ONE layer struct is
+   * shared by the prototype and every clone (recur-nn-init.c:345-346), so there is one
+   * input buffer, one output buffer and one never-cleared error accumulator */
+  int b_in, bI, bO; /* real inputs; padded input (+ bias) and output sizes; 0 = none */
+  float *b_w, *b_m, *b_aux, *b_delta; /* [bI][bO] */
+  float *b_inputs, *b_outputs, *b_o_error;
+  float b_learn_rate_scale;
   /* when this set is one shard of a larger one: its streams are global streams
    * [global_first, global_first + S) of global_count (0 = not sharded) */
   int global_first, global_count;
@@ -99,6 +106,10 @@ OrcSet *orc_set_new(int input_size, int hidden_size, int output_size, int S,
                     int D, int activation, uint32_t flags, float learn_rate,
                     uint64_t seed);
 void orc_set_free(OrcSet *set);
+/* rnn_new_with_bottom_layer (recur-nn-init.c:158-219): call right after orc_set_new; the
+ * set's input_size is then the bottom layer's output size and orc_opinion's `inputs`
+ * are the n_inputs values that feed the bottom layer */
+void orc_set_add_bottom(OrcSet *set, int n_inputs);
 /* seeds streams 1..S-1 from stream 0's rng as rnn_new_training_set does */
 void orc_set_seed_clones(OrcSet *set);
 /* flat weight init (recur-nn-init.c:495-573) using stream 0's rng */

@@ -673,6 +673,112 @@ __global__ void k_presynaptic_noise(View v, int row0, int nrows, float deviation
   reinterpret_cast<DevRng *>(v.b.rng)[row0 + j] = g;
 }
 
+// ------------------------------------------------------- bottom layer --
+
+// The optional bottom layer of rnn_opinion (recur-nn.c:88-103): one workgroup per
+// stream.  The layer is small (tens to a few hundred nodes each side), so each output
+// column is one thread's sequential dot product down the rows, in the reference's
+// order (calculate_interlayer, recur-nn.c:18-65, skips zero inputs).  The noise comes
+// from the stream's own generator before the hidden layer draws from it.
+__global__ __launch_bounds__(256) void k_bottom_forward(View v, int row0, int mode,
+                                                        const float *dense, int ld, int text_i,
+                                                        int global_first, int n_set,
+                                                        float deviation) {
+  extern __shared__ float bsh[];
+  const RamdShape &s = v.sh;
+  float *sin = bsh, *sout = bsh + s.bI;
+  int j = blockIdx.x;
+  int r = row0 + j;
+  float *inp = v.b.binp + (size_t)r * s.bI;
+  int hot = -1;
+  if (mode == RAMD_IN_ONE_HOT) {
+    hot = v.b.hot[r];
+  } else if (mode == RAMD_IN_TEXT) { /* charmodel-predict.c:273, 295-298 */
+    int len = v.b.text_len;
+    int spacing = (len - 1) / n_set;
+    int o = text_i + (global_first + j) * spacing;
+    if (o >= len - 1) o -= len - 1;
+    hot = v.b.text[o];
+    if (threadIdx.x == 0) v.b.target[r] = v.b.text[o + 1];
+  }
+  for (int i = threadIdx.x; i < s.bI; i += 256) {
+    float x;
+    if (i == 0) x = 1.0f;
+    else if (i > s.b_in || mode == RAMD_IN_KEEP) x = inp[i];
+    else if (mode == RAMD_IN_DENSE) x = dense[(size_t)j * ld + (i - 1)];
+    /* one_hot_opinion's bottom-layer branch clears and indexes the layer's inputs from
+     * the bias slot (charmodel-helpers.h:20-23, 30-31): symbol k lights entry k, the
+     * last entry is never cleared */
+    else if (i == s.b_in) x = inp[i];
+    else x = (i == hot) ? 1.0f : 0.0f;
+    inp[i] = x;
+    sin[i] = x;
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < s.bO; x += 256) {
+    float acc = 0.0f;
+    for (int y = 0; y < s.bI; y++) {
+      float xi = sin[y];
+      if (xi != 0.0f) acc += xi * v.b.bw[y * s.bO + x];
+    }
+    sout[x] = acc;
+  }
+  __syncthreads();
+  if (deviation != 0.0f && threadIdx.x == 0) {
+    DevRng g = reinterpret_cast<DevRng *>(v.b.rng)[r];
+    for (int i = 1; i < s.input_size; i++) sout[i] += dev_cheap_gaussian(g) * deviation;
+    reinterpret_cast<DevRng *>(v.b.rng)[r] = g;
+  }
+  __syncthreads();
+  float *slot = input_row<false>(v, r, 0) + s.hidden_size + 1;
+  float *out = v.b.bout + (size_t)r * s.bO;
+  for (int x = threadIdx.x; x < s.bO; x += 256) {
+    float o = sout[x];
+    out[x] = o;
+    if (x < s.input_size) slot[x] = o > 0.0f ? o : 0.0f;
+  }
+}
+
+// cumulative_input_error of one stream (recur-nn.c:377-382): the input columns of
+// every executed step's error, summed in step order.  One workgroup per stream.
+__global__ __launch_bounds__(64) void k_bottom_error(View v, int row0, int nxp,
+                                                     const unsigned char *active) {
+  const RamdShape &s = v.sh;
+  int j = blockIdx.x, r = row0 + j;
+  int n = (active && !active[j]) ? 0 : v.b.n_exec[r];
+  for (int y = threadIdx.x; y < s.bO; y += 64) {
+    float sum = 0.0f;
+    if (y < s.input_size)
+      for (int k = 0; k < n; k++) sum += v.b.ex[((size_t)(k + 1) * s.Scap + r) * nxp + y + 1];
+    v.b.berr[(size_t)r * s.bO + y] = sum;
+  }
+}
+
+// single_layer_sgd on the bottom layer (recur-nn.c:750-757, 256-273) for the streams in
+// the reference's order.  bottom->o_error is shared by all the clones and only
+// rnn_bptt_clear_deltas ever zeroes it, so stream j's update uses the running total of
+// every stream before it (and of every earlier generation): carry_in + the prefix sum.
+// One thread per weight; the stream loop is sequential, as the reference's calls are.
+__global__ __launch_bounds__(256) void k_bottom_delta(View v, int row0, int nrows, int accumulate,
+                                                      const unsigned char *active,
+                                                      const float *carry_in, float *carry_out) {
+  const RamdShape &s = v.sh;
+  int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= s.bI * s.bO) return;
+  int yi = e / s.bO, x = e - yi * s.bO;
+  float cum = carry_in[x];
+  float acc = accumulate ? v.b.bdelta[e] : 0.0f;
+  for (int j = 0; j < nrows; j++) {
+    if (active && !active[j]) continue;
+    int r = row0 + j;
+    cum += v.b.berr[(size_t)r * s.bO + x];
+    float xi = v.b.binp[(size_t)r * s.bI + yi];
+    if (xi != 0.0f) acc += xi * cum;
+  }
+  v.b.bdelta[e] = acc;
+  if (yi == 0) carry_out[x] = cum;
+}
+
 // ---------------------------------------------------------- finalize: fwd --
 
 // sums the K slabs, applies the activation (recur-nn.c:123-148) and writes
@@ -1624,6 +1730,32 @@ extern "C" void ramd_launch_assemble(ramd_stream_t st_, const RamdShape *sh, con
                      global_first, n_set, advance);
 }
 
+extern "C" void ramd_launch_bottom_forward(ramd_stream_t st_, const RamdShape *sh,
+                                           const RamdBuffers *b, int row0, int nrows, int mode,
+                                           const float *dense, int ld, int text_i,
+                                           int global_first, int n_set, float noise) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  size_t shm = (size_t)(sh->bI + sh->bO) * sizeof(float);
+  hipLaunchKernelGGL(k_bottom_forward, dim3(nrows), dim3(256), shm, st, v, row0, mode, dense, ld,
+                     text_i, global_first, n_set, noise);
+}
+
+extern "C" void ramd_launch_bottom_deltas(ramd_stream_t st_, const RamdShape *sh, RamdBuffers *b,
+                                          int row0, int nrows, int accumulate,
+                                          const unsigned char *active) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  int nxp = (sh->I - sh->hidden_size + 3) & ~3;
+  hipLaunchKernelGGL(k_bottom_error, dim3(nrows), dim3(64), 0, st, v, row0, nxp, active);
+  int n = sh->bI * sh->bO;
+  const float *cin = b->bcarry + (size_t)b->bcarry_cur * sh->bO;
+  float *cout = b->bcarry + (size_t)(b->bcarry_cur ^ 1) * sh->bO;
+  hipLaunchKernelGGL(k_bottom_delta, dim3((n + 255) / 256), dim3(256), 0, st, v, row0, nrows,
+                     accumulate, active, cin, cout);
+  b->bcarry_cur ^= 1;
+}
+
 extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
                                     int row0, int nrows, float noise) {
   hipStream_t st = (hipStream_t)st_;
@@ -1670,6 +1802,11 @@ extern "C" void ramd_launch_clear_deltas(ramd_stream_t st_, const RamdShape *sh,
   size_t ih4 = (size_t)sh->I * sh->H / 4, ho4 = (size_t)sh->H * sh->O / 4;
   hipLaunchKernelGGL(k_zero_f4, dim3((unsigned)((ih4 + 255) / 256)), dim3(256), 0, st, b->ih_delta, ih4);
   hipLaunchKernelGGL(k_zero_f4, dim3((unsigned)((ho4 + 255) / 256)), dim3(256), 0, st, b->ho_delta, ho4);
+  if (sh->bI) { /* recur-nn.c:687-692 */
+    size_t b4 = (size_t)sh->bI * sh->bO / 4, c4 = (size_t)2 * sh->bO / 4;
+    hipLaunchKernelGGL(k_zero_f4, dim3((unsigned)((b4 + 255) / 256)), dim3(256), 0, st, b->bdelta, b4);
+    hipLaunchKernelGGL(k_zero_f4, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, st, b->bcarry, c4);
+  }
 }
 
 extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,

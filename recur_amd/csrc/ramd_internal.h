@@ -23,6 +23,9 @@ typedef struct RamdShape {
   int Scap;       /* capacity in training streams: row stride of a slot    */
   int Fcap;       /* capacity in forward-only streams                      */
   int activation; /* rnn_activation                                        */
+  /* optional bottom layer (recur-nn.h:211-227): b_in real inputs (+ bias) feed
+   * b_out = input_size rectified outputs; bI, bO are its padded sizes, 0 without one */
+  int b_in, b_out, bI, bO;
 } RamdShape;
 
 /* Device arrays.  "state row" r addresses hidden/out: r < Scap is training
@@ -61,6 +64,13 @@ typedef struct RamdBuffers {
   long long *stat_correct, *stat_count;                 /* [Scap]    */
   unsigned char *text;   /* encoded text for the host-free epoch loop */
   int text_len;
+  /* bottom layer: weights and their optimiser arrays [bI][bO]; each stream's input row
+   * binp [Scap+Fcap][bI] and raw output row bout [Scap+Fcap][bO]; berr [Scap][bO] the
+   * stream's input error summed over its executed BPTT steps; bcarry [2][bO] the
+   * reference's never-cleared bottom->o_error accumulator (ping-pong, bcarry_cur = the
+   * current one) */
+  float *bw, *bm, *baux, *bdelta, *binp, *bout, *berr, *bcarry;
+  int bcarry_cur;
   /* ring position shared by every training stream of the current call, or -1
    * when they differ (set by the host before each launch) */
   int uniform_idx;
@@ -81,6 +91,18 @@ void ramd_launch_advance(ramd_stream_t st, const RamdShape *sh, const RamdBuffer
 void ramd_launch_assemble(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                           int row0, int nrows, int mode, const float *dense, int ld,
                           int text_i, int global_first, int global_count, int advance);
+/* the bottom layer of rnn_opinion (recur-nn.c:88-103): fills each stream's bottom input
+ * row as `mode` says (as ramd_launch_assemble), multiplies it through the bottom
+ * weights, adds the presynaptic noise and writes the rectified result as the stream's
+ * real inputs.  The ring index must already be the current one. */
+void ramd_launch_bottom_forward(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
+                                int row0, int nrows, int mode, const float *dense, int ld,
+                                int text_i, int global_first, int global_count,
+                                float presynaptic_noise);
+/* the bottom layer's share of rnn_bptt_calc_deltas (recur-nn.c:377-382, 750-757) for
+ * rows that ramd_launch_calc_deltas has just processed; flips b->bcarry_cur */
+void ramd_launch_bottom_deltas(ramd_stream_t st, const RamdShape *sh, RamdBuffers *b, int row0,
+                               int nrows, int accumulate, const unsigned char *active);
 /* hidden = act(X . W_ih), out = hidden . W_ho (recur-nn.c:117-151) */
 void ramd_launch_forward(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                          int row0, int nrows, float presynaptic_noise);

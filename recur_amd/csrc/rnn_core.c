@@ -152,6 +152,8 @@ static void engine_free_device(RamdEngine *e) {
   dev_free(b->active); dev_free(b->stat_err); dev_free(b->stat_ent); dev_free(b->stat_zero);
   dev_free(b->stat_depth); dev_free(b->stat_correct); dev_free(b->stat_count);
   dev_free(b->text);
+  dev_free(b->bw); dev_free(b->bm); dev_free(b->baux); dev_free(b->bdelta);
+  dev_free(b->binp); dev_free(b->bout); dev_free(b->berr); dev_free(b->bcarry);
   dev_free(e->d_scratch); dev_free(e->d_ranges); dev_free(e->d_dense);
   free(e->lr_pushed);
   e->lr_pushed = NULL;
@@ -311,11 +313,22 @@ static void stream_need_dev(RamdEngine *e, RecurNN *net) {
 
 static void engine_need_host(RamdEngine *e, int what) {
   RecurNN *o = e->owner;
+  RecurExtraLayer *bl = e->sh.bI ? o->bottom_layer : NULL;
+  size_t bn = (size_t)e->sh.bI * e->sh.bO;
   int fetch = what & ~e->host_valid & (RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
   if (fetch && e->dev_ready) {
     if (fetch & RNN_AMD_WEIGHTS) {
       d2h(o->ih_weights, e->b.ih_w, e->ih_size * sizeof(float));
       d2h(o->ho_weights, e->b.ho_w, e->ho_size * sizeof(float));
+      if (bl) d2h(bl->weights, e->b.bw, bn * sizeof(float));
+    }
+    if ((fetch & RNN_AMD_MOMENTUMS) && bl) {
+      d2h(bl->momentums, e->b.bm, bn * sizeof(float));
+      if (bl->aux) d2h(bl->aux, e->b.baux, bn * sizeof(float));
+    }
+    if ((fetch & RNN_AMD_DELTAS) && bl) {
+      d2h(bl->delta, e->b.bdelta, bn * sizeof(float));
+      d2h(bl->o_error, e->b.bcarry + (size_t)e->b.bcarry_cur * e->sh.bO, e->sh.bO * sizeof(float));
     }
     if ((fetch & RNN_AMD_MOMENTUMS) && o->bptt) {
       if (e->has_momentum) {
@@ -338,6 +351,8 @@ static void engine_need_host(RamdEngine *e, int what) {
 
 static void engine_need_dev(RamdEngine *e, int what) {
   RecurNN *o = e->owner;
+  RecurExtraLayer *bl = e->sh.bI ? o->bottom_layer : NULL;
+  size_t bn = (size_t)e->sh.bI * e->sh.bO;
   int push = what & ~e->dev_valid & (RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
   if (!push) {
     return;
@@ -345,6 +360,15 @@ static void engine_need_dev(RamdEngine *e, int what) {
   if (push & RNN_AMD_WEIGHTS) {
     h2d(e->b.ih_w, o->ih_weights, e->ih_size * sizeof(float));
     h2d(e->b.ho_w, o->ho_weights, e->ho_size * sizeof(float));
+    if (bl) h2d(e->b.bw, bl->weights, bn * sizeof(float));
+  }
+  if ((push & RNN_AMD_MOMENTUMS) && bl) {
+    h2d(e->b.bm, bl->momentums, bn * sizeof(float));
+    if (bl->aux) h2d(e->b.baux, bl->aux, bn * sizeof(float));
+  }
+  if ((push & RNN_AMD_DELTAS) && bl) {
+    h2d(e->b.bdelta, bl->delta, bn * sizeof(float));
+    h2d(e->b.bcarry + (size_t)e->b.bcarry_cur * e->sh.bO, bl->o_error, e->sh.bO * sizeof(float));
   }
   if ((push & RNN_AMD_MOMENTUMS) && o->bptt) {
     if (e->has_momentum) {
@@ -415,7 +439,16 @@ void rnn_amd_host_written(RecurNN *net, int what) { ramd_host_wrote(net, what); 
  * device call. */
 static void engine_ensure_device(RamdEngine *e) {
   ramd_require_device("this call");
-  if (e->dev_ready && e->sh.Scap >= e->n_streams && e->sh.Fcap >= e->n_fwd) {
+  /* the bottom layer is attached after rnn_new returns (recur-nn-init.c:215) */
+  RecurExtraLayer *obl = e->owner->bottom_layer;
+  int bI = obl ? obl->i_size : 0, bO = obl ? obl->o_size : 0;
+  if (obl && (obl->output_size != e->sh.input_size || bI < 4 || bO < 4)) {
+    fprintf(stderr, "librecur_amd: bottom layer of %d outputs under a net of %d inputs\n",
+            obl->output_size, e->sh.input_size);
+    abort();
+  }
+  int same_bottom = bI == e->sh.bI && bO == e->sh.bO;
+  if (e->dev_ready && e->sh.Scap >= e->n_streams && e->sh.Fcap >= e->n_fwd && same_bottom) {
     return;
   }
   if (e->dev_ready) {
@@ -438,6 +471,10 @@ static void engine_ensure_device(RamdEngine *e) {
   RamdShape *s = &e->sh;
   RamdBuffers *b = &e->b;
   RecurNN *o = e->owner;
+  s->bI = bI;
+  s->bO = bO;
+  s->b_in = obl ? obl->input_size : 0;
+  s->b_out = obl ? obl->output_size : 0;
   s->Scap = RAMD_MAX(e->n_streams, 1);
   s->Fcap = RAMD_MAX(e->n_fwd, 1);
   if (s->D < 1) {
@@ -521,7 +558,19 @@ static void engine_ensure_device(RamdEngine *e) {
   b->stat_count = dev_alloc(S * sizeof(long long));
   e->d_scratch = dev_alloc(256 * 16);
   e->d_ranges = dev_alloc(130 * sizeof(int));
-  e->d_dense = dev_alloc((S + F) * (size_t)s->input_size * fl);
+  e->d_dense = dev_alloc((S + F) * (size_t)RAMD_MAX(s->input_size, s->b_in) * fl);
+  if (bI) {
+    size_t bn = (size_t)bI * bO;
+    b->bw = dev_alloc(bn * fl);
+    b->bm = dev_alloc(bn * fl);
+    b->baux = obl->aux ? dev_alloc(bn * fl) : NULL;
+    b->bdelta = dev_alloc(bn * fl);
+    b->binp = dev_alloc((S + F) * bI * fl);
+    b->bout = dev_alloc((S + F) * bO * fl);
+    b->berr = dev_alloc(S * bO * fl);
+    b->bcarry = dev_alloc(2 * (size_t)bO * fl);
+    b->bcarry_cur = 0;
+  }
   e->lr_pushed = ramd_zalloc(S * sizeof(float));
   e->dev_ready = 1;
   e->dev_valid = 0;
@@ -666,9 +715,8 @@ RecurNN *rnn_new(uint input_size, uint hidden_size, uint output_size, u32 flags,
                  learn_rate, momentum, presynaptic_noise, activation, NULL);
 }
 
-/* recur-nn-init.c:158-192.  The layer is allocated so that struct users find
- * what they expect; computing through it on the device is not done yet, so
- * rnn_new_with_bottom_layer refuses a non-zero size. */
+/* recur-nn-init.c:158-192.  Like the reference, nothing ever frees a layer: every
+ * clone borrows the pointer (recur-nn-init.c:345-346). */
 RecurExtraLayer *rnn_new_extra_layer(int input_size, int output_size, int overlap, u32 flags) {
   RecurExtraLayer *layer = ramd_zalloc(sizeof(RecurExtraLayer));
   layer->input_size = input_size;
@@ -701,15 +749,17 @@ RecurNN *rnn_new_with_bottom_layer(int n_inputs, int r_input_size, int hidden_si
                                    const char *log_file, int bptt_depth, float learn_rate,
                                    float momentum, float presynaptic_noise,
                                    rnn_activation activation, int convolutional_overlap) {
-  (void)convolutional_overlap;
   if (r_input_size == 0) {
     flags &= ~RNN_NET_FLAG_BOTTOM_LAYER;
     return rnn_new(n_inputs, hidden_size, output_size, flags, rng_seed, log_file, bptt_depth,
                    learn_rate, momentum, presynaptic_noise, activation);
   }
-  fprintf(stderr, "librecur_amd: a bottom layer (r_input_size %d) is not supported by the "
-                  "device core yet\n", r_input_size);
-  abort();
+  flags |= RNN_NET_FLAG_BOTTOM_LAYER;
+  RecurNN *net = rnn_new(r_input_size, hidden_size, output_size, flags, rng_seed, log_file,
+                         bptt_depth, learn_rate, momentum, presynaptic_noise, activation);
+  net->bottom_layer = rnn_new_extra_layer(n_inputs, r_input_size, convolutional_overlap,
+                                          net->flags);
+  return net;
 }
 
 /* recur-nn-init.c:145-155 */
@@ -960,14 +1010,6 @@ static void log_bptt(RamdEngine *e, RecurNN *net, float mef_before) {
 
 /* ---------------------------------------------------------- per-net hot path -- */
 
-static void check_supported(RecurNN *net, float noise) {
-  if (net->bottom_layer) {
-    fprintf(stderr, "librecur_amd: bottom layer not supported on the device yet\n");
-    abort();
-  }
-  (void)noise;
-}
-
 /* recur-nn.h:310 */
 void rnn_bptt_advance(RecurNN *net) {
   host_advance(net);
@@ -980,15 +1022,15 @@ void rnn_bptt_advance(RecurNN *net) {
 
 /* recur-nn.h:302 / recur-nn.c:83-154 for one stream */
 float *rnn_opinion(RecurNN *net, const float *inputs, float presynaptic_noise) {
-  check_supported(net, presynaptic_noise);
   RamdEngine *e = ramd_engine_of(net);
   RamdPriv *p = ramd_priv(net);
   engine_ensure_device(e);
   engine_need_dev(e, RNN_AMD_WEIGHTS);
   const RamdShape *s = &e->sh;
+  RecurExtraLayer *bl = s->bI ? net->bottom_layer : NULL;
   /* the caller's real inputs are authoritative: keep them across a refresh */
   float *keep = malloc(sizeof(float) * s->input_size);
-  memcpy(keep, inputs ? inputs : net->real_inputs, sizeof(float) * s->input_size);
+  memcpy(keep, (inputs && !bl) ? inputs : net->real_inputs, sizeof(float) * s->input_size);
   stream_need_host(e, net);
   stream_need_dev(e, net);
   memcpy(net->real_inputs, keep, sizeof(float) * s->input_size);
@@ -1001,12 +1043,23 @@ float *rnn_opinion(RecurNN *net, const float *inputs, float presynaptic_noise) {
   } else {
     d_slot = e->b.arena + ((size_t)s->D * s->Scap + p->fwd) * s->I;
   }
-  h2d(d_slot + s->hidden_size + 1, net->real_inputs, sizeof(float) * s->input_size);
-  set_uniform_idx(e, p->stream >= 0 ? p->stream : e->n_streams, p->stream >= 0 ? 1 : 0);
-  ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1, 0);
   if (presynaptic_noise != 0.0f) { /* the host generator is the one the caller may have used */
     h2d((char *)e->b.rng + (size_t)r * sizeof(rand_ctx), &net->rng, sizeof(rand_ctx));
   }
+  if (bl) { /* recur-nn.c:88-103: the layer's one input buffer is shared by every clone */
+    bl->inputs[0] = 1.0f;
+    if (inputs) {
+      memcpy(bl->inputs + 1, inputs, sizeof(float) * bl->input_size);
+    }
+    h2d(e->b.binp + (size_t)r * s->bI, bl->inputs, sizeof(float) * s->bI);
+    ramd_launch_bottom_forward(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1,
+                               presynaptic_noise);
+    d2h(bl->outputs, e->b.bout + (size_t)r * s->bO, sizeof(float) * s->bO);
+  } else {
+    h2d(d_slot + s->hidden_size + 1, net->real_inputs, sizeof(float) * s->input_size);
+  }
+  set_uniform_idx(e, p->stream >= 0 ? p->stream : e->n_streams, p->stream >= 0 ? 1 : 0);
+  ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1, 0);
   ramd_launch_forward(g_stream, s, &e->b, r, 1, presynaptic_noise);
   if (presynaptic_noise != 0.0f) {
     d2h(&net->rng, (char *)e->b.rng + (size_t)r * sizeof(rand_ctx), sizeof(rand_ctx));
@@ -1036,9 +1089,6 @@ static const int *push_ranges(RamdEngine *e, RecurErrorRange *ranges) {
 }
 
 static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *ranges, unsigned fused) {
-  if (net->bottom_layer) {
-    check_supported(net, 0);
-  }
   RamdEngine *e = ramd_engine_of(net);
   RamdPriv *p = ramd_priv(net);
   if (p->stream < 0) {
@@ -1076,6 +1126,14 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
   set_uniform_idx(e, j, 1);
   ramd_launch_calc_deltas(g_stream, s, &e->b, j, 1, accumulate, d_ranges, NULL,
                           net->flags | (fused ? 0x80000000u : 0));
+  if (s->bI && !fused) { /* the fused path passes no bottom error (recur-nn.c:972, 986) */
+    if (accumulate) {
+      engine_need_dev(e, RNN_AMD_DELTAS);
+    }
+    ramd_launch_bottom_deltas(g_stream, s, &e->b, j, 1, accumulate, NULL);
+    d2h(net->bottom_layer->o_error, e->b.bcarry + (size_t)e->b.bcarry_cur * s->bO,
+        sizeof(float) * s->bO);
+  }
   engine_dev_wrote(e, RNN_AMD_DELTAS);
   e->err_pending = 1;
   e->err_row0 = j;
@@ -1121,6 +1179,17 @@ static void apply_arrays(RamdEngine *e, int method, float lr, float lr_top, floa
                     momentum, mw, rate_scale_dev);
 }
 
+/* the bottom layer's share of rnn_apply_learning (recur-nn.c:611-615, 622-625, 634-638,
+ * 647-651, 672-676) */
+static void apply_bottom(RamdEngine *e, int method, float lr, float momentum, float mw) {
+  RamdBuffers *b = &e->b;
+  if (e->sh.bI) {
+    ramd_launch_apply(g_stream, method, b->bw, b->bdelta, b->bm, b->baux,
+                      (size_t)e->sh.bI * e->sh.bO,
+                      lr * e->owner->bottom_layer->learn_rate_scale, momentum, mw, NULL);
+  }
+}
+
 /* recur-nn.h:312 / recur-nn.c:601-678 */
 void rnn_apply_learning(RecurNN *net, int learning_method, float momentum) {
   RamdEngine *e = ramd_engine_of(net);
@@ -1143,6 +1212,7 @@ void rnn_apply_learning(RecurNN *net, int learning_method, float momentum) {
   }
   apply_arrays(e, kernel_method, bptt->learn_rate, bptt->learn_rate * bptt->ho_scale, momentum, mw,
                NULL);
+  apply_bottom(e, kernel_method, bptt->learn_rate, momentum, mw);
   engine_dev_wrote(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS);
 }
 
@@ -1364,9 +1434,6 @@ void rnn_amd_set_advance(RnnAmdSet *set) {
 static void set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, int text_i,
                         float *outputs, int advance) {
   RamdEngine *e = set->eng;
-  for (int j = 0; j < set->n; j++) {
-    check_supported(set->nets[j], set->nets[j]->presynaptic_noise);
-  }
   engine_need_dev(e, RNN_AMD_WEIGHTS);
   set_streams_to_dev(set);
   if (advance) {
@@ -1381,14 +1448,26 @@ static void set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, 
   } else {
     set_uniform_idx(e, set->row0, set->n);
   }
-  ramd_launch_assemble(g_stream, &e->sh, &e->b, r0, set->n, mode, d_dense, ld, text_i,
-                       set->global_first, set->global_count, advance);
   float noise = set->nets[0]->presynaptic_noise;
   for (int j = 1; j < set->n; j++) {
     if (set->nets[j]->presynaptic_noise != noise) {
       fprintf(stderr, "librecur_amd: the nets of a set must share presynaptic_noise\n");
       abort();
     }
+  }
+  if (e->sh.bI) {
+    /* the caller's inputs feed the bottom layer, whose rectified outputs become the real
+     * inputs of the current slot: the ring has to step before it runs */
+    if (advance) {
+      ramd_launch_advance(g_stream, &e->sh, &e->b, set->row0, set->n);
+    }
+    ramd_launch_bottom_forward(g_stream, &e->sh, &e->b, r0, set->n, mode, d_dense, ld, text_i,
+                               set->global_first, set->global_count, noise);
+    ramd_launch_assemble(g_stream, &e->sh, &e->b, r0, set->n, RAMD_IN_KEEP, NULL, 0, 0,
+                         set->global_first, set->global_count, 0);
+  } else {
+    ramd_launch_assemble(g_stream, &e->sh, &e->b, r0, set->n, mode, d_dense, ld, text_i,
+                         set->global_first, set->global_count, advance);
   }
   ramd_launch_forward(g_stream, &e->sh, &e->b, r0, set->n, noise);
   set_streams_dev_wrote(set);
@@ -1401,7 +1480,7 @@ static void set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, 
 void rnn_amd_set_opinion(RnnAmdSet *set, const float *inputs, int ld_inputs, float *outputs) {
   RamdEngine *e = set->eng;
   if (inputs) {
-    int w = e->sh.input_size;
+    int w = e->sh.bI ? e->sh.b_in : e->sh.input_size;
     HIP_OK(hipMemcpy2DAsync(e->d_dense, w * sizeof(float), inputs, ld_inputs * sizeof(float),
                             w * sizeof(float), set->n, hipMemcpyHostToDevice, g_stream));
     dsync();
@@ -1461,6 +1540,15 @@ void rnn_amd_set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ra
   set_uniform_idx(e, set->row0, set->n);
   ramd_launch_calc_deltas(g_stream, &e->sh, &e->b, set->row0, set->n, accumulate, d_ranges,
                           d_active, set->nets[0]->flags);
+  if (e->sh.bI) {
+    if (set->global_count != set->n || e->delta_external) {
+      fprintf(stderr, "librecur_amd: a bottom layer cannot be trained on a sharded set: its "
+                      "error accumulator runs through the streams in order "
+                      "(recur-nn.c:377-382)\n");
+      abort();
+    }
+    ramd_launch_bottom_deltas(g_stream, &e->sh, &e->b, set->row0, set->n, accumulate, d_active);
+  }
   e->err_pending = 1;
   e->err_row0 = set->row0;
   e->err_nrows = set->n;

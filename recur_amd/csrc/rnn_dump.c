@@ -68,6 +68,15 @@ void rnn_multi_pgm_dump(RecurNN *net, const char *dumpees, const char *basename)
               : v == 'd' ? bptt->ho_delta
               : (v == 'a' && aux) ? bptt->ho_aux
                                   : NULL;
+    } else if (in == 'b' && out == 'i' && net->bottom_layer) { /* recur-nn-init.c:792-808 */
+      RecurExtraLayer *bl = net->bottom_layer;
+      x = bl->o_size;
+      y = bl->i_size;
+      array = v == 'w' ? bl->weights
+              : v == 'm' ? bl->momentums
+              : v == 'd' ? bl->delta
+              : (v == 'a' && aux) ? bl->aux
+                                  : NULL;
     }
     if (array) {
       char name[200];

@@ -146,6 +146,12 @@ static void init_flat(RecurNN *net, float variance, rnn_init_distribution shape,
             perforation);
   fill_flat(&net->rng, net->ho_weights, net->output_size, net->hidden_size + 1, net->o_size, 0,
             variance, shape, perforation);
+  if (net->bottom_layer) { /* recur-nn-init.c:566-572: input_size rows, so not the last one */
+    RecurExtraLayer *bl = net->bottom_layer;
+    memset(bl->weights, 0, (size_t)bl->i_size * bl->o_size * sizeof(float));
+    fill_flat(&net->rng, bl->weights, bl->output_size, bl->input_size, bl->o_size, 1, variance,
+              shape, perforation);
+  }
 }
 
 /* ---------------------------------------------------------- fan-in init -- */
@@ -185,6 +191,12 @@ static void init_fan_in(RecurNN *net, float sum, float kurtosis, float margin,
   }
   fill_fan_in(&net->rng, net->ho_weights, net->output_size, net->hidden_size, net->o_size, sum,
               kurtosis, margin);
+  if (net->bottom_layer) { /* recur-nn-init.c:614-620 */
+    RecurExtraLayer *bl = net->bottom_layer;
+    memset(bl->weights, 0, (size_t)bl->i_size * bl->o_size * sizeof(float));
+    fill_fan_in(&net->rng, bl->weights, bl->output_size, bl->input_size + 1, bl->o_size, sum,
+                kurtosis, margin);
+  }
 }
 
 /* -------------------------------------------------------- runs / loops -- */
@@ -393,6 +405,17 @@ void rnn_weight_noise(RecurNN *net, float deviation) {
       row[i] += ramd_cheap_gaussian_noise(&net->rng) * deviation;
     }
   }
+  if (net->bottom_layer) {
+    /* recur-nn.c:877-882 walks the [i_size][o_size] matrix with a row stride of i_size
+     * and output_size rows; kept as it is */
+    RecurExtraLayer *bl = net->bottom_layer;
+    for (int y = 0; y < bl->output_size; y++) {
+      float *row = bl->weights + 1 + (size_t)y * bl->i_size;
+      for (int i = 0; i < bl->input_size; i++) {
+        row[i] += ramd_cheap_gaussian_noise(&net->rng) * deviation;
+      }
+    }
+  }
   ramd_host_wrote(net, RNN_AMD_WEIGHTS);
 }
 
@@ -407,6 +430,9 @@ void rnn_set_momentum_values(RecurNN *net, float x) {
   ramd_need_host(net, RNN_AMD_MOMENTUMS);
   fill(net->bptt->ho_momentum, net->ho_size, x);
   fill(net->bptt->ih_momentum, net->ih_size, x);
+  if (net->bottom_layer) {
+    fill(net->bottom_layer->momentums, (size_t)net->bottom_layer->i_size * net->bottom_layer->o_size, x);
+  }
   ramd_host_wrote(net, RNN_AMD_MOMENTUMS);
 }
 
@@ -415,6 +441,9 @@ void rnn_set_aux_values(RecurNN *net, float x) {
   ramd_need_host(net, RNN_AMD_MOMENTUMS);
   fill(net->bptt->ho_aux, net->ho_size, x);
   fill(net->bptt->ih_aux, net->ih_size, x);
+  if (net->bottom_layer && net->bottom_layer->aux) {
+    fill(net->bottom_layer->aux, (size_t)net->bottom_layer->i_size * net->bottom_layer->o_size, x);
+  }
   ramd_host_wrote(net, RNN_AMD_MOMENTUMS);
 }
 
@@ -551,4 +580,9 @@ void rnn_print_net_stats(RecurNN *net) {
                     net->h_size, 1, "ih_weights");
   mean_and_variance(net->ho_weights, net->output_size, net->hidden_size + 1, net->o_size, 0,
                     "ho_weights");
+  if (net->bottom_layer) {
+    RecurExtraLayer *bl = net->bottom_layer;
+    mean_and_variance(bl->weights, bl->output_size, bl->input_size, bl->o_size, 1,
+                      "bottom weights");
+  }
 }

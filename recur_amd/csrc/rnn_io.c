@@ -293,6 +293,16 @@ RecurNN *rnn_load_net(const char *filename) {
         fprintf(stderr, "error %d loading 'net.metadata'\ncontinuing anyway\n", rc);
       }
     }
+    if (net->bottom_layer) { /* recur-nn-io.c:341-344: the weights only; learn_rate_scale
+                              * keeps the constructor's 1.0 as in the reference */
+      RecurExtraLayer *bl = net->bottom_layer;
+      want = sizeof(float) * (size_t)bl->i_size * bl->o_size;
+      if (cdbr_find(&r, "bottom_layer.weights", 20, &v, &vlen) < 1 || vlen != want) {
+        fprintf(stderr, "array size mismatch on 'bottom_layer.weights'\n");
+        goto error;
+      }
+      memcpy(bl->weights, v, want);
+    }
   }
   ramd_host_wrote(net, RNN_AMD_WEIGHTS | RNN_AMD_STREAM);
   cdbr_close(&r);

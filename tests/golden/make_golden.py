@@ -80,6 +80,21 @@ def main():
         out[name + "_rng"] = np.array([n.rng.a, n.rng.b, n.rng.c, n.rng.d], dtype=np.uint64)
         ref.rnn_delete_net(net)
 
+    # ... and with a bottom layer, whose weights are drawn last (recur-nn-init.c:566-572)
+    for name, method in (("init_bottom_flat", rc.INIT_FLAT), ("init_bottom_fan_in", rc.INIT_FAN_IN)):
+        net = ref.rnn_new_with_bottom_layer(42, 16, 39, 42, rc.FLAG_STANDARD, 5, None, 10, 1e-3, 0.9,
+                                            0.0, rc.RELU, 0)
+        p = rc.InitParams()
+        ref.rnn_init_default_weight_parameters(net, C.byref(p))
+        p.method = method
+        ref.rnn_randomise_weights_clever(net, C.byref(p))
+        n = net.contents
+        bl = n.bottom_layer.contents
+        out[name + "_b_w"] = rc.view(bl.weights, bl.i_size, bl.o_size).copy()
+        out[name + "_ih_sum"] = np.array([rc.view(n.ih_weights, n.ih_size).astype(np.float64).sum()])
+        out[name + "_rng"] = np.array([n.rng.a, n.rng.b, n.rng.c, n.rng.d], dtype=np.uint64)
+        ref.rnn_delete_net(net)
+
     # G3/G4: training scenarios -----------------------------------------------------
     text = sc.synthetic_text(gc.TEXT_LEN)
     assert np.array_equal(text, gc.synthetic_text_np())

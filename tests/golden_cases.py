@@ -37,6 +37,13 @@ TRAIN_CASES = {
     # (recur-nn.c:120-121), so the final generator states are part of the parity
     "noisy": dict(hidden=39, S=4, D=6, act=rc.RELU, method=rc.WEIGHTED, lr=1e-2, steps=12, seed=15,
                   noise=0.05),
+    # a bottom layer under the net (text-predict --bottom-layer): 42 symbols -> 16
+    # rectified nodes -> 39 hidden.  bottom->o_error is never cleared on this path, so
+    # the bottom deltas integrate every earlier stream and generation (recur-nn.c:377-382)
+    "bottom_weighted": dict(hidden=39, S=4, D=8, act=rc.RELU, method=rc.WEIGHTED, lr=1e-2, steps=20,
+                            seed=16, bottom=16, bottom_rate_scale=0.5),
+    "bottom_adagrad_noisy": dict(hidden=39, S=3, D=6, act=rc.RESQRT, method=rc.ADAGRAD, lr=1e-2, steps=12,
+                                 seed=17, bottom=12, ballast=0.1, noise=0.03),
     "depth1": dict(hidden=23, S=2, D=1, act=rc.RELU, method=rc.WEIGHTED, lr=1e-2, steps=6, seed=12),
 }
 
@@ -45,9 +52,13 @@ def case_kwargs(c):
     flags = rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR
     if c.get("aux"):
         flags |= rc.FLAG_AUX_ARRAYS
-    return dict(input_size=42, hidden_size=c["hidden"], output_size=42, S=c["S"], D=c["D"],
-                activation=c["act"], learn_rate=c["lr"], seed=c["seed"], flags=flags,
-                noise=c.get("noise", 0.0))
+    kw = dict(input_size=42, hidden_size=c["hidden"], output_size=42, S=c["S"], D=c["D"],
+              activation=c["act"], learn_rate=c["lr"], seed=c["seed"], flags=flags,
+              noise=c.get("noise", 0.0))
+    if c.get("bottom"):
+        kw.update(input_size=c["bottom"], bottom_inputs=42,
+                  bottom_rate_scale=c.get("bottom_rate_scale", 1.0))
+    return kw
 
 
 def synthetic_text_np(n=TEXT_LEN, alphabet=42, seed=7):

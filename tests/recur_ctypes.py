@@ -156,6 +156,7 @@ FLAG_LOG_HIDDEN_SUM = 16
 FLAG_ADAPTIVE_MIN_ERROR = 64
 FLAG_NO_MOMENTUMS = 128
 FLAG_NO_DELTAS = 256
+FLAG_BOTTOM_LAYER = 1024
 FLAG_AUX_ARRAYS = 2048
 COND_USE_SCALE = 1 << 16
 COND_USE_ZERO = 1 << 18
@@ -318,6 +319,10 @@ class OrcSet(C.Structure):
         ("stat_error", C.c_double), ("stat_entropy", C.c_double),
         ("stat_correct", C.c_long), ("stat_count", C.c_long),
         ("stat_depth", C.c_double), ("stat_zeros", C.c_double),
+        ("b_in", C.c_int), ("bI", C.c_int), ("bO", C.c_int),
+        ("b_w", c_float_p), ("b_m", c_float_p), ("b_aux", c_float_p), ("b_delta", c_float_p),
+        ("b_inputs", c_float_p), ("b_outputs", c_float_p), ("b_o_error", c_float_p),
+        ("b_learn_rate_scale", C.c_float),
         ("global_first", C.c_int), ("global_count", C.c_int),
     ]
 
@@ -339,6 +344,7 @@ ORACLE_API = {
     "orc_set_new": (OrcP, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
                            C.c_float, C.c_uint64]),
     "orc_set_free": (None, [OrcP]),
+    "orc_set_add_bottom": (None, [OrcP, C.c_int]),
     "orc_set_seed_clones": (None, [OrcP]),
     "orc_set_init_flat": (None, [OrcP, C.c_float, C.c_int, C.c_double]),
     "orc_advance": (None, [OrcP, C.c_int]),

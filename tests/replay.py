@@ -43,6 +43,8 @@ def train_oracle(name):
 
     def set_m(x):
         a["ih_m"][:] = x
+        if "b_m" in a:
+            a["b_m"][:] = x
         a["ho_m"][:] = x
 
     def set_aux(x):

@@ -31,11 +31,21 @@ class ApiSet:
     def __init__(self, lib, input_size, hidden_size, output_size, S, D, activation=rc.RELU,
                  flags=rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR, learn_rate=1e-3, seed=1,
                  momentum=0.95, variance=None, shape=rc.DIST_SEMICIRCLE, perforation=0.0,
-                 softmax_best_guess=None, noise=0.0):
+                 softmax_best_guess=None, noise=0.0, bottom_inputs=0, bottom_rate_scale=1.0):
         self.lib = lib
         self.S, self.D = S, D
-        net = lib.rnn_new(input_size, hidden_size, output_size, flags, seed, None, D,
-                          learn_rate, momentum, noise, activation)
+        # with bottom_inputs the net sits on a bottom layer: `input_size` is that
+        # layer's output size and bottom_inputs its input size
+        # (rnn_new_with_bottom_layer, recur-nn-init.c:194-219)
+        self.bottom_inputs = bottom_inputs
+        if bottom_inputs:
+            net = lib.rnn_new_with_bottom_layer(bottom_inputs, input_size, hidden_size, output_size,
+                                                flags, seed, None, D, learn_rate, momentum, noise,
+                                                activation, 0)
+            net.contents.bottom_layer.contents.learn_rate_scale = bottom_rate_scale
+        else:
+            net = lib.rnn_new(input_size, hidden_size, output_size, flags, seed, None, D,
+                              learn_rate, momentum, noise, activation)
         self.net = net
         n = net.contents
         self.I, self.H, self.O = n.i_size, n.h_size, n.o_size
@@ -59,7 +69,12 @@ class ApiSet:
     # -- per-stream steps (the reference call sequence) --
     def one_hot_opinion(self, j, hot, noise=0.0):
         n = self.nets[j].contents
-        real = rc.view(n.real_inputs, self.input_size)
+        if self.bottom_inputs:
+            # the helper's bottom-layer branch indexes from the bias slot
+            # (charmodel-helpers.h:20-23, 30-31)
+            real = rc.view(n.bottom_layer.contents.inputs, self.bottom_inputs)
+        else:
+            real = rc.view(n.real_inputs, self.input_size)
         real[:] = 0
         real[hot] = 1.0
         return self.lib.rnn_opinion(self.nets[j], None, noise)
@@ -108,6 +123,12 @@ class ApiSet:
             "ih_delta": rc.view(b0.ih_delta, I, H).copy(),
             "ho_delta": rc.view(b0.ho_delta, H, O).copy(),
         }
+        if self.bottom_inputs:
+            bl = n0.bottom_layer.contents
+            snap.update(b_w=rc.view(bl.weights, bl.i_size, bl.o_size).copy(),
+                        b_m=rc.view(bl.momentums, bl.i_size, bl.o_size).copy(),
+                        b_delta=rc.view(bl.delta, bl.i_size, bl.o_size).copy(),
+                        b_o_error=rc.view(bl.o_error, bl.o_size).copy())
         hist = np.zeros((D, S, I), np.float32)
         hidden = np.zeros((S, H), np.float32)
         output = np.zeros((S, O), np.float32)
@@ -140,10 +161,14 @@ class OracleSet:
     def __init__(self, input_size, hidden_size, output_size, S, D, activation=rc.RELU,
                  flags=rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR, learn_rate=1e-3, seed=1,
                  momentum=0.95, variance=None, shape=rc.DIST_SEMICIRCLE, perforation=0.0,
-                 fast=False, noise=0.0):
+                 fast=False, noise=0.0, bottom_inputs=0, bottom_rate_scale=1.0):
         self.orc = orc = rc.load_oracle(fast=fast)
         self.z = orc.orc_set_new(input_size, hidden_size, output_size, S, D, activation, flags,
                                  learn_rate, seed)
+        self.bottom_inputs = bottom_inputs
+        if bottom_inputs:
+            orc.orc_set_add_bottom(self.z, bottom_inputs)
+            self.z.contents.b_learn_rate_scale = bottom_rate_scale
         z = self.z.contents
         self.S, self.D, self.I, self.H, self.O = S, D, z.I, z.H, z.O
         self.input_size, self.hidden_size, self.output_size = input_size, hidden_size, output_size
@@ -166,7 +191,14 @@ class OracleSet:
         """numpy VIEWS of the oracle's arrays (writable)."""
         z = self.z.contents
         S, D, I, H, O = self.S, self.D, self.I, self.H, self.O
+        bottom = {}
+        if self.bottom_inputs:
+            bottom = {"b_w": rc.view(z.b_w, z.bI, z.bO), "b_m": rc.view(z.b_m, z.bI, z.bO),
+                      "b_aux": rc.view(z.b_aux, z.bI, z.bO),
+                      "b_delta": rc.view(z.b_delta, z.bI, z.bO),
+                      "b_o_error": rc.view(z.b_o_error, z.bO)}
         return {
+            **bottom,
             "ih_w": rc.view(z.ih_w, I, H), "ho_w": rc.view(z.ho_w, H, O),
             "ih_m": rc.view(z.ih_m, I, H), "ho_m": rc.view(z.ho_m, H, O),
             "ih_aux": rc.view(z.ih_aux, I, H), "ho_aux": rc.view(z.ho_aux, H, O),
@@ -198,7 +230,7 @@ class OracleSet:
 
 
 FLOAT_KEYS = ["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hist", "hidden", "output",
-              "o_error", "min_error_factor", "ih_scale"]
+              "o_error", "min_error_factor", "ih_scale", "b_w", "b_m", "b_delta", "b_o_error"]
 EXACT_KEYS = ["index", "generation", "rng"]
 
 

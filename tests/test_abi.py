@@ -95,6 +95,62 @@ def test_weight_init_bit_exact_with_reference(name, hidden, shape, perf, seed):
     AMD.rnn_delete_net(net)
 
 
+@pytest.mark.parametrize("name,method", [("init_bottom_flat", rc.INIT_FLAT),
+                                         ("init_bottom_fan_in", rc.INIT_FAN_IN)])
+def test_bottom_layer_init_bit_exact_and_round_trips(name, method, tmp_path):
+    """rnn_new_with_bottom_layer (recur-nn-init.c:158-219): the layer's layout, its
+    weights drawn after the net's (recur-nn-init.c:566-572, 614-620), sharing by the
+    clones (345-346) and the CDB records (recur-nn-io.c:109-120, 341-344)."""
+    net = AMD.rnn_new_with_bottom_layer(42, 16, 39, 42, rc.FLAG_STANDARD, 5, None, 10, 1e-3, 0.9, 0.0,
+                                        rc.RELU, 0)
+    n = net.contents
+    assert n.flags & rc.FLAG_BOTTOM_LAYER and n.input_size == 16
+    bl = n.bottom_layer.contents
+    assert (bl.input_size, bl.output_size, bl.i_size, bl.o_size) == (42, 16, 44, 16)
+    assert bl.learn_rate_scale == 1.0 and not bl.aux
+    addr = lambda p: C.addressof(p.contents)
+    m = bl.i_size * bl.o_size  # the reference's carve-up of layer->mem (recur-nn-init.c:180-190)
+    assert addr(bl.momentums) == addr(bl.mem) and addr(bl.inputs) == addr(bl.mem) + 4 * m
+    assert addr(bl.weights) == addr(bl.inputs) + 4 * bl.i_size
+    assert addr(bl.outputs) == addr(bl.weights) + 4 * m and addr(bl.delta) == addr(bl.outputs) + 4 * bl.o_size
+    assert addr(bl.i_error) == addr(bl.delta) + 4 * m and addr(bl.o_error) == addr(bl.i_error) + 4 * bl.i_size
+    p = rc.InitParams()
+    AMD.rnn_init_default_weight_parameters(net, C.byref(p))
+    p.method = method
+    AMD.rnn_randomise_weights_clever(net, C.byref(p))
+    w = rc.view(bl.weights, bl.i_size, bl.o_size).copy()
+    assert np.array_equal(w, Z[name + "_b_w"])
+    assert rc.view(n.ih_weights, n.ih_size).astype(np.float64).sum() == Z[name + "_ih_sum"][0]
+    assert np.array_equal(np.array([n.rng.a, n.rng.b, n.rng.c, n.rng.d], dtype=np.uint64), Z[name + "_rng"])
+    nets = AMD.rnn_new_training_set(net, 3)
+    assert all(addr(nets[j].contents.bottom_layer) == addr(n.bottom_layer) for j in range(3))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert AMD.rnn_save_net(net, b"bottom.net", 1) == 0
+        again = AMD.rnn_load_net(b"bottom.net")
+        assert again
+        a = again.contents
+        al = a.bottom_layer.contents
+        assert (al.input_size, al.output_size, al.i_size, al.o_size) == (42, 16, 44, 16)
+        assert np.array_equal(rc.view(al.weights, al.i_size, al.o_size), w)
+        assert np.array_equal(rc.view(a.ih_weights, a.ih_size), rc.view(n.ih_weights, n.ih_size))
+        keys = [k for k, _ in cdb_keys("bottom.net")]
+        assert keys[-7:] == ["bottom_layer.input_size", "bottom_layer.output_size", "bottom_layer.i_size",
+                             "bottom_layer.o_size", "bottom_layer.learn_rate_scale",
+                             "bottom_layer.overlap", "bottom_layer.weights"]
+        AMD.rnn_delete_net(again)
+    finally:
+        os.chdir(cwd)
+    AMD.rnn_delete_training_set(nets, 3, 0)
+    # a zero-sized bottom layer is no bottom layer (recur-nn-init.c:201-207)
+    plain = AMD.rnn_new_with_bottom_layer(42, 0, 39, 42, rc.FLAG_STANDARD | rc.FLAG_BOTTOM_LAYER, 5, None,
+                                          10, 1e-3, 0.9, 0.0, rc.RELU, 0)
+    assert not plain.contents.bottom_layer and not (plain.contents.flags & rc.FLAG_BOTTOM_LAYER)
+    assert plain.contents.input_size == 42
+    AMD.rnn_delete_net(plain)
+
+
 def test_training_set_clones_share_and_seed_like_reference():
     c = replay.golden_case("relu_weighted")  # its rng snapshot is after 30 steps without noise == after cloning
     import golden_cases as gc

@@ -49,7 +49,7 @@ def test_batched_path_matches_reference_vectors(amd, name):
 
 
 @pytest.mark.parametrize("name", ["relu_weighted", "resqrt_weighted", "relu_adagrad", "single_step_h99",
-                                  "depth1", "noisy"])
+                                  "depth1", "noisy", "bottom_weighted", "bottom_adagrad_noisy"])
 def test_per_net_drop_in_calls_match_reference_vectors(amd, orc, name):
     got = replay.train_api(amd, name, batched=False, sbg=orc.orc_softmax_best_guess)
     replay.check(got, replay.golden_case(name), RTOL, exact=("index", "generation", "rng"))
@@ -335,6 +335,50 @@ def test_classify_shape_dense_inputs_active_mask_nesterov(amd):
             compared += 1
         _load_state(amd, g, so)
     assert compared >= 3
+    g.close()
+    o.close()
+
+
+def test_bottom_layer_dense_inputs_clear_deltas_active_mask(amd):
+    """A net on a bottom layer driven the gstclassify way (gstclassify.c:1101, 2070-2130,
+    2201): dense features into the bottom layer, rnn_bptt_clear_deltas every generation
+    (the only thing that ever zeroes bottom->o_error, recur-nn.c:687-692), an active
+    mask, Nesterov with a bottom learn-rate scale.  Batched calls against the oracle's
+    per-stream calls."""
+    lib = amd
+    S, D, NIN = 6, 6, 20
+    kw = dict(input_size=12, hidden_size=40, output_size=3, S=S, D=D, learn_rate=3e-3, seed=21,
+              bottom_inputs=NIN, bottom_rate_scale=0.25)
+    g = sc.AmdBatchedSet(lib, **kw)
+    o = sc.OracleSet(**kw)
+    a = o.arrays()
+    rs = np.random.default_rng(3)
+    for step in range(10):
+        x = (rs.standard_normal((S, NIN)) * 0.7).astype(np.float32)
+        err = (rs.standard_normal((S, g.O)) * 0.05).astype(np.float32)
+        err[:, 3:] = 0
+        active = (rs.random(S) < 0.7).astype(np.uint8)
+        active[0] = 1
+        lib.rnn_amd_set_opinion(g.handle, rc.fptr(x), NIN, None)
+        lib.rnn_amd_set_put_o_error(g.handle, rc.fptr(err), g.O)
+        lib.rnn_bptt_clear_deltas(g.net)
+        lib.rnn_amd_set_calc_deltas(g.handle, 1, None, rc.u8ptr(active))
+        lib.rnn_amd_set_advance(g.handle)
+        lib.rnn_apply_learning(g.net, rc.NESTEROV, 0.9)
+        o.orc.orc_clear_deltas(o.z)
+        for j in range(S):
+            o.orc.orc_opinion(o.z, j, rc.fptr(np.ascontiguousarray(x[j])), 0.0)
+            a["o_error"][j, :] = err[j]
+            if active[j]:
+                o.orc.orc_calc_deltas(o.z, j, 1, None)
+            o.orc.orc_advance(o.z, j)
+        o.orc.orc_apply_learning(o.z, rc.NESTEROV, 0.9)
+        sg, so = g.snapshot(), o.snapshot()
+        assert np.array_equal(sg["hidden"] != 0, so["hidden"] != 0)
+        replay.check(sg, so, RTOL, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden",
+                                         "output", "hist", "b_w", "b_m", "b_delta", "b_o_error"],
+                     exact=("index", "generation"))
+    assert np.abs(so["b_delta"]).max() > 0 and np.abs(so["b_o_error"]).max() > 0
     g.close()
     o.close()
 
