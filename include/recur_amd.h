@@ -430,6 +430,13 @@ void rnn_amd_set_shard(RnnAmdSet *set, int global_first, int global_count);
 /* Split rnn_amd_set_char_step for that use: everything up to and including
  * calc_deltas, then the update. */
 void rnn_amd_set_char_step_deltas(RnnAmdSet *set, int i);
+/* One net run over an encoded text without leaving the device: a one-hot opinion
+ * (charmodel-helpers.h:16-33) of text[i] for every i < len - 1, and from i = skip on
+ * the log2 of the softmax probability of text[i + 1] (capped at -100 like
+ * capped_log2f).  Returns the sum of the logs: get_cross_entropy's loop
+ * (charmodel-predict.c:62-76) without its final division; with skip >= len - 1 it is
+ * rnn_char_prime's loop (407-416).  Works for nets with or without bptt. */
+double rnn_amd_run_text(RecurNN *net, const u8 *text, int len, int skip);
 /* Block until all queued device work of the library has finished. */
 void rnn_amd_synchronize(void);
 

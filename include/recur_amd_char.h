@@ -48,6 +48,117 @@ u8 *rnn_char_load_new_encoded_text(const char *filename, RnnCharAlphabet *alphab
                                    int *encoded_len, int quietness);
 int rnn_char_alloc_file_contents(const char *filename, char **contents, int *len); /* charmodel.h:159 */
 
+
+/* ------------------------------------------------------------------------
+ * The prediction layer (charmodel-predict.c): epoch loop, validation
+ * entropy, learn-rate schedule, confabulation.  Struct layouts are the
+ * reference's (charmodel.h:15-73), because its callers fill them in directly
+ * (text-predict.c:545-600).
+ * ------------------------------------------------------------------------ */
+
+/* pgm_dump.h:227-237 defines this; callers that use the image fields include that header
+ * themselves (C11 lets the typedef repeat) */
+typedef struct _TemporalPPM TemporalPPM;
+
+typedef struct _RnnCharSchedule RnnCharSchedule;
+typedef struct _RnnCharModel RnnCharModel;
+
+typedef struct _RnnCharImageSettings { /* charmodel.h:18-24 */
+  char *basename;
+  bool temporal_pgm_dump;
+  TemporalPPM *input_ppm;
+  TemporalPPM *error_ppm;
+  char *periodic_pgm_dump_string;
+} RnnCharImageSettings;
+
+struct _RnnCharSchedule { /* charmodel.h:26-34 */
+  float *recent;
+  int recent_len;
+  int timeout;
+  float learn_rate_mul;
+  float learn_rate_min;
+  int adjust_noise;
+  void (*eval)(RnnCharModel *m, float score, int verbose);
+};
+
+typedef struct _RnnCharVentropy { /* charmodel.h:36-45 */
+  RecurNN *net;
+  int counter;
+  float *history;
+  const u8 *text;
+  int len;
+  int lap;
+  int lapsize;
+  float entropy;
+} RnnCharVentropy;
+
+struct _RnnCharModel { /* charmodel.h:56-73 */
+  RecurNN *net;
+  RecurNN **training_nets;
+  int n_training_nets;
+  uint batch_size;
+  char *filename;
+  float momentum;
+  float momentum_soft_start;
+  int learning_style;
+  float periodic_weight_noise;
+  uint report_interval;
+  bool save_net;
+  bool use_multi_tap_path;
+  RnnCharAlphabet *alphabet;
+  RnnCharSchedule schedule;
+  RnnCharImageSettings images;
+};
+
+typedef struct RnnCharMetadata { /* charmodel.h:75-81 */
+  char *alphabet; /* utf-8 or byte string */
+  char *collapse_chars;
+  bool utf8;
+  bool case_insensitive;
+  bool collapse_space;
+} RnnCharMetadata;
+
+/* charmodel.h:185-186; charmodel-predict.c:120-135 */
+void rnn_char_init_schedule(RnnCharSchedule *s, int recent_len, float learn_rate_min,
+                            float learn_rate_mul, int adjust_noise);
+/* charmodel.h:188, 194-197; charmodel-predict.c:208-258 */
+float rnn_char_calc_ventropy(RnnCharModel *model, RnnCharVentropy *v, int lap);
+void rnn_char_delete_ventropy(RnnCharVentropy *v);
+void rnn_char_init_ventropy(RnnCharVentropy *v, RecurNN *net, const u8 *text, const int len,
+                            const int lap);
+/* charmodel.h:190-192; charmodel-predict.c:137-181.  Returns the bytes written. */
+int rnn_char_confabulate(RecurNN *net, char *dest, int char_len, int byte_len, RnnCharAlphabet *a,
+                         float bias, int *prev_char, int start_point, int stop_point);
+/* charmodel.h:199-204; charmodel-predict.c:261-405.  One pass over the text from
+ * `start`; returns 1 when `stop` generations were reached, else 0.  The multi-tap
+ * branch runs as batched device generations (rnn_amd_set_char_step) whenever
+ * model->training_nets is one rnn_new_training_set. */
+int rnn_char_epoch(RnnCharModel *model, RecurNN *confab_net, RnnCharVentropy *v, const u8 *text,
+                   const int len, const int start, const int stop, float confab_bias,
+                   int confab_size, int confab_line_end, int quietness,
+                   uint diagonal_only_section, uint diagonal_only_friends);
+/* charmodel.h:234-239; charmodel-predict.c:407-431 */
+int rnn_char_prime(RecurNN *net, RnnCharAlphabet *alphabet, const u8 *text, const int len);
+double rnn_char_cross_entropy(RecurNN *net, RnnCharAlphabet *alphabet, const u8 *text,
+                              const int len, const int ignore_first, const u8 *prefix_text,
+                              const int prefix_len);
+
+/* ---- metadata and names (charmodel.h:206-227; charmodel-init.c:440-800) ---- */
+char *rnn_char_uncollapse_text(RnnCharAlphabet *alphabet, const u8 *orig, int len, int *dest_len);
+void rnn_char_dump_collapsed_text(const u8 *text, int len, const char *name, const char *alphabet);
+char *rnn_char_construct_metadata(const struct RnnCharMetadata *m);
+int rnn_char_load_metadata(const char *metadata, struct RnnCharMetadata *m);
+void rnn_char_free_metadata_items(struct RnnCharMetadata *m);
+char *rnn_char_construct_net_filename(struct RnnCharMetadata *m, const char *basename,
+                                      int input_size, int bottom_size, int hidden_size,
+                                      int output_size);
+int rnn_char_check_metadata(RecurNN *net, struct RnnCharMetadata *m, bool trust_file_metadata,
+                            bool force_metadata);
+void rnn_char_copy_metadata_items(struct RnnCharMetadata *src, struct RnnCharMetadata *dest);
+void rnn_char_dump_alphabet(RnnCharAlphabet *alphabet);
+int rnn_char_get_codepoint(RnnCharAlphabet *a, const char *s);
+RnnCharAlphabet *rnn_char_new_alphabet_from_net(RecurNN *net);
+
 #ifdef __cplusplus
 }
 #endif

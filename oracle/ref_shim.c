@@ -11,6 +11,7 @@
 #include "recur-nn.h"
 #include "recur-nn-helpers.h"
 #include "badmaths.h"
+#include "utf8.h"
 
 u64 ref_rand64(rand_ctx *x) { return rand64(x); }
 void ref_init_rand64(rand_ctx *x, u64 seed) { init_rand64(x, seed); }
@@ -25,3 +26,14 @@ int ref_softmax_best_guess(float *error, const float *src, int len) {
 float ref_soft_clip(float sum, float halfmax) { return soft_clip(sum, halfmax); }
 int ref_sizeof_net(void) { return (int)sizeof(RecurNN); }
 int ref_sizeof_bptt(void) { return (int)sizeof(RecurNNBPTT); }
+void ref_biased_softmax(float *dest, const float *src, int len, float bias) {
+  biased_softmax(dest, src, len, bias);
+}
+u32 ref_hash32(const char *s) { return rnn_hash32(s); }
+int ref_write_utf8_char(uint code, char *s) { return write_utf8_char(code, s); }
+int ref_read_utf8_char(const char *s, int *consumed) {
+  const char *p = s;
+  int c = read_utf8_char(&p);
+  *consumed = (int)(p - s);
+  return c;
+}

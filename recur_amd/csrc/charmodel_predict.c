@@ -1,0 +1,561 @@
+/* charmodel_predict.c -- the caller side of the text hot path: the epoch loop,
+ * validation entropy, learn-rate schedule and confabulation of the reference's
+ * charmodel-predict.c, written against this library's own public API
+ * (include/recur_amd.h) so that the reference's text tools keep working when they
+ * link librecur_amd instead of recur-nn.o + charmodel-predict.o.
+ *
+ * What differs from the reference is where the loops run.  The multi-tap branch of
+ * rnn_char_epoch (charmodel-predict.c:288-311) becomes one rnn_amd_set_char_step per
+ * generation with the loss statistics kept on the device, and get_cross_entropy
+ * (62-80) becomes rnn_amd_run_text; both fall back to the per-net calls (still on the
+ * device) when the nets are not one training set.  Host C, gnu11.
+ */
+#include "rnn_host.h"
+#include "recur_amd_char.h"
+#include <time.h>
+
+#define C_NORMAL "\033[00m"
+#define C_GREY "\033[00;37m"
+#define C_CYAN "\033[00;36m"
+#define C_YELLOW "\033[01;33m"
+
+/* pgm_dump.h:227-237.  Only touched when the caller has put such an object into
+ * model->images (text-predict.c:575-600 does so with pgm_dump.h's constructor). */
+struct _TemporalPPM {
+  float *im;
+  int width;
+  int height;
+  int y;
+  int id;
+  char *basename;
+  int counter;
+  int mode;
+  float **source;
+};
+enum { TEMPORAL_GREY = 0, TEMPORAL_COLOUR = 1 }; /* pgm_dump.h:222-225 */
+
+/* rnn_dump.c */
+void ramd_write_signed_ppm(const float *a, int width, int height, const char *name);
+void ramd_write_abs_pgm(const float *a, int width, int height, const char *name);
+
+/* temporal_ppm_add_row + temporal_ppm_write (pgm_dump.h:262-288) */
+static void temporal_add_row(TemporalPPM *ppm, const float *row) {
+  memcpy(ppm->im + (size_t)ppm->y * ppm->width, row, ppm->width * sizeof(float));
+  ppm->y++;
+  if (ppm->y == ppm->height) {
+    char name[200];
+    snprintf(name, sizeof(name), "images/%s-%d-%08d-%dx%d.ppm", ppm->basename, ppm->id,
+             ppm->counter, ppm->width, ppm->height);
+    if (ppm->mode == TEMPORAL_GREY) {
+      ramd_write_abs_pgm(ppm->im, ppm->width, ppm->height, name);
+    } else {
+      ramd_write_signed_ppm(ppm->im, ppm->width, ppm->height, name);
+    }
+    ppm->y = 0;
+    ppm->counter += ppm->height;
+  }
+}
+
+/* ---------------------------------------------------------------- small maths -- */
+
+static inline float capped_log2f(float x) { /* charmodel-helpers.h:11-14 */
+  return (x < 1e-30f) ? -100.0f : log2f(x);
+}
+
+/* badmaths.h:71-111 */
+static void softmax_host(float *dest, const float *src, int len) {
+  float lo = src[0], hi = src[0];
+  for (int i = 1; i < len; i++) {
+    hi = RAMD_MAX(hi, src[i]);
+    lo = RAMD_MIN(lo, src[i]);
+  }
+  float adj = 0.0f;
+  if (hi > 50.0f) {
+    adj = 50.0f - hi;
+  } else if (lo < -60.0f) {
+    adj = RAMD_MIN(-60.0f - lo, 50.0f - hi);
+  }
+  float sum = 0.0f;
+  for (int i = 0; i < len; i++) {
+    float x = ramd_fast_expf(src[i] + adj);
+    sum += x;
+    dest[i] = x;
+  }
+  for (int i = 0; i < len; i++) {
+    dest[i] /= sum;
+  }
+}
+
+/* badmaths.h:113-141: writes -softmax into `error`, returns the arg max */
+static int softmax_best_guess_host(float *error, const float *src, int len) {
+  softmax_host(error, src, len);
+  int best = 0;
+  float best_e = error[0];
+  error[0] = -best_e;
+  for (int i = 1; i < len; i++) {
+    float e = error[i];
+    if (e > best_e) {
+      best_e = e;
+      best = i;
+    }
+    error[i] = -e;
+  }
+  return best;
+}
+
+/* badmaths.h:143-156 */
+static void biased_softmax_host(float *dest, const float *src, int len, float bias) {
+  if (bias == 0) {
+    softmax_host(dest, src, len);
+    return;
+  }
+  float *tmp = malloc(len * sizeof(float));
+  softmax_host(tmp, src, len);
+  for (int i = 0; i < len; i++) {
+    tmp[i] = tmp[i] * bias + src[i];
+  }
+  softmax_host(dest, tmp, len);
+  free(tmp);
+}
+
+/* charmodel-helpers.h:16-33, including its bottom-layer branch that indexes the
+ * layer's inputs from the bias slot */
+static float *one_hot_opinion(RecurNN *net, int hot, float presynaptic_noise) {
+  float *inputs;
+  int len;
+  if (net->bottom_layer) {
+    inputs = net->bottom_layer->inputs;
+    len = net->bottom_layer->input_size;
+  } else {
+    inputs = net->real_inputs;
+    len = net->input_size;
+  }
+  memset(inputs, 0, len * sizeof(float));
+  inputs[hot] = 1.0f;
+  return rnn_opinion(net, NULL, presynaptic_noise);
+}
+
+/* charmodel-predict.c:18-27 */
+static float net_error_bptt(RecurNN *net, float *error, int c, int next, int *correct) {
+  float *answer = one_hot_opinion(net, c, net->presynaptic_noise);
+  int winner = softmax_best_guess_host(error, answer, net->output_size);
+  *correct = (winner == next);
+  error[next] += 1.0f;
+  return error[next];
+}
+
+/* charmodel-predict.c:29-60: sample (or, for a huge bias, pick) the next symbol */
+static int guess_next_character(RecurNN *net, int hot, float bias) {
+  float *answer = one_hot_opinion(net, hot, 0);
+  int len = net->output_size;
+  if (bias >= 100) {
+    int best = 0;
+    float best_score = answer[0];
+    for (int i = 1; i < len; i++) {
+      if (answer[i] >= best_score) {
+        best_score = answer[i];
+        best = i;
+      }
+    }
+    return best;
+  }
+  float *p = malloc(len * sizeof(float));
+  biased_softmax_host(p, answer, len, bias);
+  /* the draw comes from the net's own generator (rnn_opinion has just refreshed the host
+   * struct); the device copy follows */
+  int result = -1;
+  while (result < 0) {
+    float r = ramd_rand_double(&net->rng);
+    float accum = 0.0f;
+    for (int i = 0; i < len; i++) {
+      accum += p[i];
+      if (r < accum) {
+        result = i;
+        break;
+      }
+    }
+  }
+  ramd_rng_from_host(net);
+  free(p);
+  return result;
+}
+
+/* ------------------------------------------------------------- cross entropy -- */
+
+/* get_cross_entropy (charmodel-predict.c:62-80) */
+static double get_cross_entropy(RecurNN *net, const u8 *text, int len, int skip) {
+  double entropy = rnn_amd_run_text(net, text, len, skip);
+  entropy /= -(len - skip - 1);
+  return entropy;
+}
+
+int rnn_char_prime(RecurNN *net, RnnCharAlphabet *alphabet, const u8 *text, const int len) {
+  (void)alphabet;
+  if (!text || !len) {
+    return 0;
+  }
+  rnn_amd_run_text(net, text, len, len);
+  return text[len - 1];
+}
+
+double rnn_char_cross_entropy(RecurNN *net, RnnCharAlphabet *alphabet, const u8 *text,
+                              const int len, const int skip, const u8 *prefix_text,
+                              const int prefix_len) {
+  if (prefix_text) {
+    rnn_char_prime(net, alphabet, prefix_text, prefix_len);
+  }
+  return get_cross_entropy(net, text, len, skip);
+}
+
+/* ------------------------------------------------------------------ schedule -- */
+
+/* charmodel-predict.c:82-118: when the validation score is no better than any of a
+ * third of the remembered scores, cut the learn rate */
+static void eval_simple(RnnCharModel *model, float score, int verbose) {
+  RecurNN *net = model->net;
+  RnnCharSchedule *s = &model->schedule;
+  RecurNNBPTT *bptt = net->bptt;
+  if (s->recent_len == 0 || bptt->learn_rate <= s->learn_rate_min) {
+    return;
+  }
+  int sample_size = s->recent_len / 3;
+  ramd_rng_to_host(net);
+  int i = ramd_rand_small_int(&net->rng, s->recent_len);
+  ramd_rng_from_host(net);
+  s->recent[i] = score;
+  if (s->timeout) {
+    s->timeout--;
+    return;
+  }
+  i++;
+  for (int j = 0; j < sample_size; j++, i++) {
+    if (i >= s->recent_len) {
+      i = 0;
+    }
+    if (score < s->recent[i]) {
+      return;
+    }
+  }
+  s->timeout = s->recent_len;
+  bptt->learn_rate = RAMD_MAX(s->learn_rate_min, bptt->learn_rate * s->learn_rate_mul);
+  if (s->adjust_noise) {
+    net->presynaptic_noise *= s->learn_rate_mul;
+    model->periodic_weight_noise *= s->learn_rate_mul;
+  }
+  if (verbose) {
+    fprintf(stderr, "generation %7d: entropy %.4g exceeds %d recent samples."
+                    " setting learn_rate to %.3g. momentum %.3g\n",
+            net->generation, score, sample_size, bptt->learn_rate, net->bptt->momentum);
+  }
+}
+
+void rnn_char_init_schedule(RnnCharSchedule *s, int recent_len, float learn_rate_min,
+                            float learn_rate_mul, int adjust_noise) {
+  s->recent_len = recent_len;
+  if (recent_len) {
+    s->recent = ramd_zalloc(recent_len * sizeof(float));
+    s->learn_rate_min = learn_rate_min;
+    s->learn_rate_mul = learn_rate_mul;
+    for (int i = 0; i < recent_len; i++) {
+      s->recent[i] = 1e10;
+    }
+  }
+  s->timeout = s->recent_len;
+  s->eval = eval_simple;
+  s->adjust_noise = adjust_noise;
+}
+
+/* ------------------------------------------------------- validation entropy -- */
+
+void rnn_char_delete_ventropy(RnnCharVentropy *v) { free(v->history); }
+
+void rnn_char_init_ventropy(RnnCharVentropy *v, RecurNN *net, const u8 *text, const int len,
+                            const int lap) {
+  v->net = net;
+  v->text = text;
+  v->len = len;
+  v->lap = lap;
+  v->lapsize = len / lap;
+  v->history = calloc(lap, sizeof(float));
+  v->entropy = 0;
+  v->counter = 0;
+}
+
+/* charmodel-predict.c:227-258: either the whole validation text, or one lap of it per
+ * call with the mean of the laps seen so far */
+float rnn_char_calc_ventropy(RnnCharModel *model, RnnCharVentropy *v, int lap) {
+  (void)model;
+  if (v->len > 0) {
+    if (v->lap > 1 && lap) {
+      v->counter++;
+      if (v->counter == v->lap) {
+        v->counter = 0;
+      }
+      int skip = RAMD_MIN(v->lapsize / 10, 5);
+      v->history[v->counter] =
+          get_cross_entropy(v->net, v->text + v->lapsize * v->counter, v->lapsize, skip);
+      float sum = 0.0f;
+      float div = v->lap;
+      for (int j = 0; j < v->lap; j++) {
+        div -= v->history[j] == 0;
+        sum += v->history[j];
+      }
+      v->entropy = div ? sum / div : 0;
+    } else {
+      int skip = RAMD_MIN(v->len / 10, 5);
+      v->entropy = get_cross_entropy(v->net, v->text, v->len, skip);
+      v->history[0] = v->entropy;
+    }
+  }
+  return v->entropy;
+}
+
+/* ------------------------------------------------------------ confabulation -- */
+
+/* utf8.h:31-65 */
+static int write_code_point(int c, char *dest, int utf8) {
+  unsigned code = (unsigned)c;
+  if (!utf8 || code < 0x80) {
+    dest[0] = (char)c;
+    return 1;
+  }
+  if (code < 0x800) {
+    dest[0] = (char)(0xC0 | (code >> 6));
+    dest[1] = (char)(0x80 | (code & 63));
+    return 2;
+  }
+  if (code < 0x10000) {
+    dest[0] = (char)(0xE0 | (code >> 12));
+    dest[1] = (char)(0x80 | ((code >> 6) & 63));
+    dest[2] = (char)(0x80 | (code & 63));
+    return 3;
+  }
+  if (code < 0x200000) {
+    dest[0] = (char)(0xF0 | (code >> 18));
+    dest[1] = (char)(0x80 | ((code >> 12) & 63));
+    dest[2] = (char)(0x80 | ((code >> 6) & 63));
+    dest[3] = (char)(0x80 | (code & 63));
+    return 4;
+  }
+  return 0;
+}
+
+int rnn_char_confabulate(RecurNN *net, char *dest, int char_len, int byte_len, RnnCharAlphabet *a,
+                         float bias, int *prev_char, int start_point, int stop_point) {
+  int n = *prev_char;
+  int utf8 = (a->flags & RNN_CHAR_FLAG_UTF8) != 0;
+  const int *alphabet = a->points;
+  int safe_end = byte_len - (utf8 ? 5 : 1);
+  if (safe_end <= 0) {
+    fprintf(stderr, "insufficient space to confabulate (%d bytes)\n", byte_len);
+    if (byte_len) {
+      *dest = 0;
+    }
+    return 0;
+  }
+  int i, j = 0;
+  if (start_point >= 0 && char_len > 0) {
+    /* run until the requested first character turns up */
+    for (i = 0; i < 1000000 && n != start_point; i++) {
+      n = guess_next_character(net, n, bias);
+    }
+    j = write_code_point(alphabet[n], dest, utf8);
+    dest[j] = 0;
+    if (n != start_point) {
+      fprintf(stderr, "start char '%s' not found in first %d characters, giving up\n", dest, i);
+    } else {
+      fprintf(stderr, "start char '%s' found after %d others\n", dest, i);
+    }
+  }
+  for (i = 0; i < char_len && j < safe_end; i++) {
+    n = guess_next_character(net, n, bias);
+    j += write_code_point(alphabet[n], dest + j, utf8);
+    if (n == stop_point) {
+      break;
+    }
+  }
+  dest[j] = 0;
+  *prev_char = n;
+  return j;
+}
+
+/* charmodel-predict.c:184-206: one line to a stream, ending at end_code */
+static int fconfab_variable(FILE *f, RecurNN *net, const int end_code, int *prev_char, int max_len,
+                            RnnCharAlphabet *a, float bias) {
+  int n = *prev_char;
+  int utf8 = (a->flags & RNN_CHAR_FLAG_UTF8) != 0;
+  int i;
+  for (i = 0; i < max_len; i++) {
+    n = guess_next_character(net, n, bias);
+    if (n == end_code) {
+      break;
+    }
+    char s[5];
+    int w = write_code_point(a->points[n], s, utf8);
+    s[w] = 0;
+    fputs(s, f);
+  }
+  if (i == max_len) {
+    fputs(C_YELLOW "\\" C_NORMAL, f);
+  }
+  fputc('\n', f);
+  *prev_char = n;
+  return i;
+}
+
+/* --------------------------------------------------------------------- epoch -- */
+
+int rnn_char_epoch(RnnCharModel *model, RecurNN *confab_net, RnnCharVentropy *v, const u8 *text,
+                   const int len, const int start, const int stop, float confab_bias,
+                   int confab_size, int confab_line_end, int quietness,
+                   uint diagonal_only_section, uint diagonal_only_friends) {
+  float error = 0.0f, entropy = 0.0f;
+  int correct = 0;
+  int n_nets = model->n_training_nets;
+  int spacing = (len - 1) / n_nets;
+  RecurNN *net = model->net;
+  RecurNN **nets = model->training_nets;
+  uint report_counter = net->generation % model->report_interval;
+  float report_scale = 1.0f / ((model->report_interval - report_counter) * n_nets);
+  int confab_char = 0;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  if (diagonal_only_section) {
+    rnn_clear_diagonal_only_section(net, diagonal_only_section, diagonal_only_friends);
+  }
+  const int multi_tap = n_nets > 1 || model->learning_style != RNN_MOMENTUM_WEIGHTED ||
+                        model->use_multi_tap_path;
+  /* the whole set per call when the nets are one training set; the text goes to the
+   * device once per epoch */
+  RnnAmdSet *set = NULL;
+  if (multi_tap && nets && nets[0] == net) {
+    set = rnn_amd_set_open(nets, n_nets);
+    if (set) {
+      RnnAmdStats drop;
+      rnn_amd_set_load_text(set, text, len);
+      rnn_amd_set_read_stats(set, &drop, 1);
+    }
+  }
+  const int want_rows = model->images.input_ppm || model->images.error_ppm;
+  int result = 0;
+  for (int i = start; i < len - 1; i++) {
+    float momentum = rnn_calculate_momentum_soft_start(net->generation, model->momentum,
+                                                       model->momentum_soft_start);
+    if (set) {
+      rnn_amd_set_char_step(set, i, model->learning_style, momentum);
+    } else if (multi_tap) {
+      for (int j = 0; j < n_nets; j++) {
+        RecurNN *n = nets[j];
+        int offset = i + j * spacing;
+        if (offset >= len - 1) {
+          offset -= len - 1;
+        }
+        int c;
+        rnn_bptt_advance(n);
+        float e = net_error_bptt(n, n->bptt->o_error, text[offset], text[offset + 1], &c);
+        correct += c;
+        error += e;
+        entropy += capped_log2f(1.0f - e);
+        rnn_bptt_calc_deltas(n, j ? 1 : 0, NULL);
+      }
+      rnn_apply_learning(net, model->learning_style, momentum);
+    } else {
+      int c;
+      RecurNNBPTT *bptt = net->bptt;
+      bptt->momentum = momentum;
+      rnn_bptt_advance(net);
+      float e = net_error_bptt(net, bptt->o_error, text[i], text[i + 1], &c);
+      rnn_bptt_calculate(net, model->batch_size);
+      correct += c;
+      error += e;
+      entropy += capped_log2f(1.0f - e);
+    }
+    if (diagonal_only_section) { /* a no-op for section 0 in the reference too */
+      rnn_clear_diagonal_only_section(net, diagonal_only_section, diagonal_only_friends);
+    }
+    if (want_rows) {
+      if (set) {
+        rnn_amd_sync_host(net, RNN_AMD_STREAM);
+      }
+      if (model->images.input_ppm) {
+        temporal_add_row(model->images.input_ppm, net->input_layer);
+      }
+      if (model->images.error_ppm) {
+        temporal_add_row(model->images.error_ppm, net->bptt->o_error);
+      }
+    }
+    report_counter++;
+    if (report_counter >= model->report_interval) {
+      report_counter = 0;
+      if (set) {
+        RnnAmdStats st;
+        rnn_amd_set_read_stats(set, &st, 1); /* waits for the device */
+        error = (float)st.error;
+        entropy = (float)st.entropy;
+        correct = (int)st.correct;
+      } else {
+        rnn_amd_synchronize();
+      }
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      double elapsed = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+      t0 = t1;
+      float ventropy = rnn_char_calc_ventropy(model, v, 1);
+      {
+        int k = net->generation >> 10;
+        entropy *= -report_scale;
+        error *= report_scale;
+        float accuracy = correct * report_scale;
+        double per_sec = 1.0 / report_scale / elapsed;
+        if (confab_net && confab_size && quietness < 1) {
+          if (confab_line_end >= 0) {
+            fprintf(stderr, C_GREY "%5dk t%.2f " C_CYAN "v%.2f" C_GREY " %.0f/s |" C_NORMAL, k,
+                    entropy, ventropy, per_sec + 0.5);
+            fconfab_variable(stderr, confab_net, confab_line_end, &confab_char, confab_size,
+                             model->alphabet, confab_bias);
+          } else {
+            fprintf(stderr, C_GREY "%5dk e.%02d t%.2f v" C_CYAN "%.2f" C_GREY " a.%02d %.0f/s |" C_NORMAL,
+                    k, (int)(error * 100 + 0.5), entropy, ventropy, (int)(accuracy * 100 + 0.5),
+                    per_sec + 0.5);
+            int alloc_size = confab_size * 4;
+            char *confab = malloc(alloc_size + 1);
+            rnn_char_confabulate(confab_net, confab, confab_size, alloc_size, model->alphabet,
+                                 confab_bias, &confab_char, -1, -1);
+            fprintf(stderr, "%s" C_GREY "|\n", confab);
+            free(confab);
+          }
+        }
+        rnn_log_float(net, "t_error", error);
+        rnn_log_float(net, "t_entropy", entropy);
+        rnn_log_float(net, "v_entropy", ventropy);
+        rnn_log_float(net, "momentum", net->bptt->momentum);
+        rnn_log_float(net, "accuracy", accuracy);
+        rnn_log_float(net, "learn-rate", net->bptt->learn_rate);
+        rnn_log_float(net, "per_second", per_sec);
+        correct = 0;
+        error = 0.0f;
+        entropy = 0.0f;
+        report_scale = 1.0f / (model->report_interval * n_nets);
+      }
+      if (model->save_net && model->filename) {
+        rnn_save_net(net, model->filename, 1);
+      }
+      if (model->images.periodic_pgm_dump_string) {
+        rnn_multi_pgm_dump(net, model->images.periodic_pgm_dump_string, model->images.basename);
+      }
+      model->schedule.eval(model, ventropy, quietness < 2);
+      if (model->periodic_weight_noise) {
+        rnn_weight_noise(net, model->periodic_weight_noise);
+      }
+    }
+    if (stop && (int)net->generation >= stop) {
+      result = 1;
+      break;
+    }
+  }
+  if (set) {
+    /* statistics gathered since the last report are dropped at the end of an epoch, as
+     * the reference's locals are */
+    rnn_amd_set_close(set);
+  }
+  return result;
+}

@@ -893,6 +893,35 @@ __global__ __launch_bounds__(64) void k_softmax_error(View v, int row0, int nrow
   v.b.stat_count[r] += 1;
   v.b.stat_zero[r] += zeros / (double)s.hidden_size;
 }
+// get_cross_entropy's inner step (charmodel-predict.c:71-76): softmax of one state
+// row's outputs (badmaths.h:71-111, sums in the reference's order), the probability of
+// the row's target symbol, capped_log2f of it added to the row's running total.
+__global__ __launch_bounds__(64) void k_xent_accumulate(View v, int r, int count_it) {
+  extern __shared__ float ex[];
+  const RamdShape &s = v.sh;
+  const float *src = v.b.out + (size_t)r * s.O;
+  int len = s.output_size;
+  float lo = src[0], hi = src[0];
+  for (int i = threadIdx.x; i < len; i += 64) {
+    hi = fmaxf(hi, src[i]);
+    lo = fminf(lo, src[i]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    lo = fminf(lo, __shfl_xor(lo, off, 64));
+  }
+  float adj = 0.0f;
+  if (hi > 50.0f) adj = 50.0f - hi;
+  else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+  for (int i = threadIdx.x; i < len; i += 64) ex[i] = fast_expf_dev(src[i] + adj);
+  __syncthreads();
+  if (threadIdx.x != 0 || !count_it) return;
+  float sum = 0.0f;
+  for (int i = 0; i < len; i++) sum += ex[i];
+  float e = ex[v.b.target[r]] / sum;
+  v.b.xent[r] += (double)((e < 1e-30f) ? -100.0f : log2f(e));
+}
+
 #pragma clang fp contract(fast)
 
 // ---------------------------------------------------- K5/K6: top backprop --
@@ -1794,6 +1823,14 @@ extern "C" void ramd_launch_softmax_error(ramd_stream_t st_, const RamdShape *sh
   View v = make_view(sh, b);
   hipLaunchKernelGGL(k_softmax_error, dim3(nrows), dim3(64), (size_t)sh->output_size * sizeof(float), st, v,
                      row0, nrows);
+}
+
+extern "C" void ramd_launch_xent_accumulate(ramd_stream_t st_, const RamdShape *sh,
+                                            const RamdBuffers *b, int row, int count_it) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  hipLaunchKernelGGL(k_xent_accumulate, dim3(1), dim3(64), (size_t)sh->output_size * sizeof(float),
+                     st, v, row, count_it);
 }
 
 extern "C" void ramd_launch_clear_deltas(ramd_stream_t st_, const RamdShape *sh,

@@ -56,7 +56,8 @@ typedef struct RamdBuffers {
   float *ih_scale, *top_raw, *top_scaled, *bptt_err; /* [Scap]       */
   int *n_exec;    /* [Scap] executed BPTT steps                      */
   int *depth_log; /* [Scap] "depth - t" as the reference logs it     */
-  int *target;    /* [Scap] class the loss kernel scores against     */
+  int *target;    /* [Scap+Fcap] class the loss kernels score against */
+  double *xent;   /* [Scap+Fcap] running sum of log2 p(target), k_xent_accumulate */
   int *hot;       /* [Scap+Fcap] one-hot input index scratch         */
   unsigned char *active; /* [Scap] scratch for the active mask       */
   /* per-stream loss statistics (single writer per entry: deterministic) */
@@ -110,6 +111,11 @@ void ramd_launch_forward(ramd_stream_t st, const RamdShape *sh, const RamdBuffer
  * (charmodel-predict.c:18-27, 299-304) */
 void ramd_launch_softmax_error(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                                int row0, int nrows);
+
+/* one step of get_cross_entropy (charmodel-predict.c:71-76) for state row `row`: adds
+ * capped_log2f(softmax(out)[target]) to b->xent[row] when count_it */
+void ramd_launch_xent_accumulate(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
+                                 int row, int count_it);
 
 /* ---- backward ---- */
 /* ranges: device array of (start,len) pairs ending with start < 0, or NULL;

@@ -149,6 +149,7 @@ static void engine_free_device(RamdEngine *e) {
   dev_free(b->coef); dev_free(b->ex); dev_free(b->esum_part); dev_free(b->zeros); dev_free(b->ones); dev_free(b->rng); dev_free(b->slab); dev_free(b->idx); dev_free(b->lr); dev_free(b->mef);
   dev_free(b->ih_scale); dev_free(b->top_raw); dev_free(b->top_scaled); dev_free(b->bptt_err);
   dev_free(b->n_exec); dev_free(b->depth_log); dev_free(b->target); dev_free(b->hot);
+  dev_free(b->xent);
   dev_free(b->active); dev_free(b->stat_err); dev_free(b->stat_ent); dev_free(b->stat_zero);
   dev_free(b->stat_depth); dev_free(b->stat_correct); dev_free(b->stat_count);
   dev_free(b->text);
@@ -431,6 +432,25 @@ void ramd_host_wrote(RecurNN *net, int what) {
   }
 }
 
+/* A host-side draw from net->rng (charmodel-predict.c:52, 93) while the stream's state
+ * lives on the device: fetch only the generator before, push only it back after. */
+void ramd_rng_to_host(RecurNN *net) {
+  RamdPriv *p = ramd_priv(net);
+  RamdEngine *e = p->eng;
+  if (e && e->dev_ready && p->dev_valid && !p->host_valid) {
+    d2h(&net->rng, (char *)e->b.rng + (size_t)state_row(e, p) * sizeof(rand_ctx), sizeof(rand_ctx));
+    dsync();
+  }
+}
+void ramd_rng_from_host(RecurNN *net) {
+  RamdPriv *p = ramd_priv(net);
+  RamdEngine *e = p->eng;
+  if (e && e->dev_ready && p->dev_valid) {
+    h2d((char *)e->b.rng + (size_t)state_row(e, p) * sizeof(rand_ctx), &net->rng, sizeof(rand_ctx));
+    dsync();
+  }
+}
+
 void rnn_amd_sync_host(RecurNN *net, int what) { ramd_need_host(net, what); }
 void rnn_amd_host_written(RecurNN *net, int what) { ramd_host_wrote(net, what); }
 
@@ -547,7 +567,8 @@ static void engine_ensure_device(RamdEngine *e) {
   b->bptt_err = dev_alloc(S * fl);
   b->n_exec = dev_alloc(S * sizeof(int));
   b->depth_log = dev_alloc(S * sizeof(int));
-  b->target = dev_alloc(S * sizeof(int));
+  b->target = dev_alloc((S + F) * sizeof(int));
+  b->xent = dev_alloc((S + F) * sizeof(double));
   b->hot = dev_alloc((S + F) * sizeof(int));
   b->active = dev_alloc(S);
   b->stat_err = dev_alloc(S * sizeof(double));
@@ -1336,6 +1357,57 @@ void rnn_log_net(RecurNN *net) {
     rnn_log_float(net, "output_error", top_error);
     rnn_log_float(net, "hidden_error", hidden_error);
   }
+}
+
+/* ------------------------------------------------ text through one net -- */
+
+/* Runs one net over an encoded text without leaving the device: for every i < len - 1
+ * a one_hot_opinion of text[i] (charmodel-helpers.h:16-33) and, from i = skip on, the
+ * log2 probability the softmax gives text[i + 1].  Returns the sum of those logs
+ * (get_cross_entropy's loop, charmodel-predict.c:62-76; with count == 0 it is
+ * rnn_char_prime's loop, 407-416).  The net's state rows stay on the device. */
+double rnn_amd_run_text(RecurNN *net, const u8 *text, int len, int skip) {
+  RamdEngine *e = ramd_engine_of(net);
+  RamdPriv *p = ramd_priv(net);
+  engine_ensure_device(e);
+  engine_need_dev(e, RNN_AMD_WEIGHTS);
+  stream_need_dev(e, net);
+  if (len < 2) {
+    return 0.0;
+  }
+  const RamdShape *s = &e->sh;
+  int r = state_row(e, p);
+  unsigned char *d_text = dev_alloc(len);
+  h2d(d_text, text, len);
+  HIP_OK(hipMemsetAsync(e->b.xent + r, 0, sizeof(double), g_stream));
+  if (p->stream >= 0) {
+    h2d(e->b.idx + p->stream, &net->bptt->index, sizeof(int));
+  }
+  dsync();
+  unsigned char *old_text = e->b.text;
+  int old_len = e->b.text_len;
+  e->b.text = d_text;
+  e->b.text_len = len;
+  set_uniform_idx(e, p->stream >= 0 ? p->stream : e->n_streams, p->stream >= 0 ? 1 : 0);
+  for (int i = 0; i < len - 1; i++) {
+    if (s->bI) {
+      ramd_launch_bottom_forward(g_stream, s, &e->b, r, 1, RAMD_IN_TEXT, NULL, 0, i, 0, 1, 0.0f);
+      ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1, 0);
+    } else {
+      ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_TEXT, NULL, 0, i, 0, 1, 0);
+    }
+    ramd_launch_forward(g_stream, s, &e->b, r, 1, 0.0f);
+    ramd_launch_xent_accumulate(g_stream, s, &e->b, r, i >= skip);
+  }
+  double sum = 0.0;
+  d2h(&sum, e->b.xent + r, sizeof(double));
+  dsync();
+  e->b.text = old_text;
+  e->b.text_len = old_len;
+  dev_free(d_text);
+  p->dev_valid = 1;
+  p->host_valid = 0;
+  return sum;
 }
 
 /* ================================================================ batched == */

@@ -6,7 +6,7 @@
  * largest magnitude is 255).  Cold path, host only. */
 #include "rnn_host.h"
 
-static void write_signed_ppm(const float *a, int width, int height, const char *name) {
+void ramd_write_signed_ppm(const float *a, int width, int height, const char *name) {
   size_t n = (size_t)width * height;
   float biggest = 1e-35f;
   for (size_t i = 0; i < n; i++) {
@@ -33,6 +33,29 @@ static void write_signed_ppm(const float *a, int width, int height, const char *
       px[2] = 180;
     }
     fwrite(px, 1, 3, fh);
+  }
+  fclose(fh);
+}
+
+/* pgm_dump.h:64-81: grey image of magnitudes, scaled so the largest is 255 */
+void ramd_write_abs_pgm(const float *a, int width, int height, const char *name) {
+  size_t n = (size_t)width * height;
+  float biggest = 1e-35f;
+  for (size_t i = 0; i < n; i++) {
+    float f = fabsf(a[i]);
+    if (f > biggest) {
+      biggest = f;
+    }
+  }
+  float scale = 255.99f / biggest;
+  FILE *fh = fopen(name, "w");
+  if (fh == NULL) {
+    fprintf(stderr, "could not open '%s' for writing\n", name);
+    return;
+  }
+  fprintf(fh, "P5\n%u %u\n255\n", width, height);
+  for (size_t i = 0; i < n; i++) {
+    fputc((unsigned char)(fabs(a[i]) * scale), fh);
   }
   fclose(fh);
 }
@@ -83,7 +106,7 @@ void rnn_multi_pgm_dump(RecurNN *net, const char *dumpees, const char *basename)
       snprintf(name, sizeof(name), "images/%s-%s-%08d-%dx%d.ppm",
                (basename && basename[0]) ? basename : "untitled", token, (int)net->generation, x,
                y);
-      write_signed_ppm(array, x, y, name);
+      ramd_write_signed_ppm(array, x, y, name);
     }
   }
   free(copy);

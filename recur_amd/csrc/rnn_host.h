@@ -82,6 +82,8 @@ RamdEngine *ramd_engine_of(RecurNN *net);
 void ramd_need_host(RecurNN *net, int what);
 void ramd_host_wrote(RecurNN *net, int what);
 void ramd_require_device(const char *what);
+void ramd_rng_to_host(RecurNN *net);
+void ramd_rng_from_host(RecurNN *net);
 
 /* rnn_init.c: Jenkins PRNG (recur-rng.h) */
 uint64_t ramd_rand64(rand_ctx *x);

@@ -58,6 +58,37 @@ def main():
     out["soft_start"] = np.array([ref.rnn_calculate_momentum_soft_start(g, 0.95, x)
                                   for g in (0, 10, 1000, 1e6) for x in (0, 1, 2000)], dtype=np.float32)
 
+    # strings around the character models: the hash in net file names (recur-common.h:207-216),
+    # UTF-8 in both directions (utf8.h), the confabulation softmax (badmaths.h:143-156)
+    samples = [b"", b"a", b"alphabet 8%20etaonihsrdlucmwfygpb,v.k-;x\"qj'?:z)(_!*&\ncollapse_chars "
+               b"10872}{659/34][@\nutf8 0\ncollapse_space 1\ncase_insensitive 1\n",
+               bytes(range(1, 256)), b"The quick brown fox" * 7]
+    out["hash32_inputs"] = np.frombuffer(b"\0".join(samples), dtype=np.uint8).copy()
+    out["hash32_input_lens"] = np.array([len(x) for x in samples], np.int32)
+    out["hash32_values"] = np.array([ref.ref_hash32(x) for x in samples], dtype=np.uint32)
+    codes = [0x24, 0x7f, 0x80, 0xe9, 0x7ff, 0x800, 0x20ac, 0xffff, 0x10000, 0x1f600, 0x1fffff, 0x200000]
+    enc = []
+    for code in codes:
+        buf = C.create_string_buffer(8)
+        n = ref.ref_write_utf8_char(code, buf)
+        enc.append([n] + list(buf.raw[:4]))
+    out["utf8_codes"] = np.array(codes, np.uint32)
+    out["utf8_encoded"] = np.array(enc, np.int32)
+    seqs = [b"A", b"\xc3\xa9", b"\xe2\x82\xac", b"\xf0\x9f\x98\x80", b"\x80", b"\xc0\xaf", b"\xe0\x80\xaf",
+            b"\xf8\x88\x80\x80", b"\xc3", b"\xe2\x82", b"\xf0\x80\x80\x80", b"\xdf\xbf", b"\xef\xbf\xbf"]
+    dec = []
+    for q in seqs:
+        used = C.c_int(0)
+        dec.append([ref.ref_read_utf8_char(q + b"\0\0\0\0", C.byref(used)), used.value])
+    out["utf8_sequences"] = np.array([list(q.ljust(4, b"\0")) for q in seqs], np.uint8)
+    out["utf8_decoded"] = np.array(dec, np.int32)
+    bs_in = (np.random.default_rng(8).standard_normal(42) * 3).astype(np.float32)
+    out["biased_softmax_in"] = bs_in
+    for bias in (0.0, 1.0, 7.5):
+        o = np.zeros(42, np.float32)
+        ref.ref_biased_softmax(rc.fptr(o), rc.fptr(bs_in), 42, bias)
+        out["biased_softmax_%g" % bias] = o
+
     # G2: weight initialisation ------------------------------------------------
     for name, (hidden, shape, perf, seed) in {
         "init_semicircle_h99": (99, rc.DIST_SEMICIRCLE, 0.0, 1),

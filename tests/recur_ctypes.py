@@ -235,6 +235,7 @@ AMD_API = {
     "rnn_amd_set_external_delta": (None, [C.c_void_p, C.c_void_p]),
     "rnn_amd_set_char_step_deltas": (None, [C.c_void_p, C.c_int]),
     "rnn_amd_set_shard": (None, [C.c_void_p, C.c_int, C.c_int]),
+    "rnn_amd_run_text": (C.c_double, [NetP, c_u8_p, C.c_int, C.c_int]),
     "rnn_amd_synchronize": (None, []),
     "rnn_amd_kernel_time_enable": (None, [C.c_int]),
     "rnn_amd_kernel_time_ms": (C.c_double, [C.c_int, C.POINTER(C.c_long), C.c_int]),
@@ -252,6 +253,10 @@ REF_SHIM_API = {
     "ref_softmax": (None, [c_float_p, c_float_p, C.c_int]),
     "ref_softmax_best_guess": (C.c_int, [c_float_p, c_float_p, C.c_int]),
     "ref_soft_clip": (C.c_float, [C.c_float, C.c_float]),
+    "ref_biased_softmax": (None, [c_float_p, c_float_p, C.c_int, C.c_float]),
+    "ref_hash32": (C.c_uint32, [C.c_char_p]),
+    "ref_write_utf8_char": (C.c_int, [C.c_uint, C.c_char_p]),
+    "ref_read_utf8_char": (C.c_int, [C.c_char_p, c_int_p]),
     "ref_sizeof_net": (C.c_int, []),
     "ref_sizeof_bptt": (C.c_int, []),
 }
@@ -417,7 +422,66 @@ class CharAlphabet(C.Structure):
 
 
 AlphaP = C.POINTER(CharAlphabet)
+
+
+class CharModel(C.Structure):
+    pass
+
+
+class CharSchedule(C.Structure):  # charmodel.h:26-34
+    _fields_ = [("recent", c_float_p), ("recent_len", C.c_int), ("timeout", C.c_int),
+                ("learn_rate_mul", C.c_float), ("learn_rate_min", C.c_float), ("adjust_noise", C.c_int),
+                ("eval", C.CFUNCTYPE(None, C.POINTER(CharModel), C.c_float, C.c_int))]
+
+
+class CharImageSettings(C.Structure):  # charmodel.h:18-24
+    _fields_ = [("basename", C.c_char_p), ("temporal_pgm_dump", C.c_bool), ("input_ppm", C.c_void_p),
+                ("error_ppm", C.c_void_p), ("periodic_pgm_dump_string", C.c_char_p)]
+
+
+CharModel._fields_ = [  # charmodel.h:56-73
+    ("net", NetP), ("training_nets", C.POINTER(NetP)), ("n_training_nets", C.c_int),
+    ("batch_size", C.c_uint), ("filename", C.c_char_p), ("momentum", C.c_float),
+    ("momentum_soft_start", C.c_float), ("learning_style", C.c_int),
+    ("periodic_weight_noise", C.c_float), ("report_interval", C.c_uint), ("save_net", C.c_bool),
+    ("use_multi_tap_path", C.c_bool), ("alphabet", AlphaP), ("schedule", CharSchedule),
+    ("images", CharImageSettings)]
+
+
+class CharVentropy(C.Structure):  # charmodel.h:36-45
+    _fields_ = [("net", NetP), ("counter", C.c_int), ("history", c_float_p), ("text", c_u8_p),
+                ("len", C.c_int), ("lap", C.c_int), ("lapsize", C.c_int), ("entropy", C.c_float)]
+
+
+class CharMetadata(C.Structure):  # charmodel.h:75-81
+    _fields_ = [("alphabet", C.c_char_p), ("collapse_chars", C.c_char_p), ("utf8", C.c_bool),
+                ("case_insensitive", C.c_bool), ("collapse_space", C.c_bool)]
+
+
+MetaP = C.POINTER(CharMetadata)
 CHAR_API = {
+    "rnn_char_init_schedule": (None, [C.POINTER(CharSchedule), C.c_int, C.c_float, C.c_float, C.c_int]),
+    "rnn_char_calc_ventropy": (C.c_float, [C.POINTER(CharModel), C.POINTER(CharVentropy), C.c_int]),
+    "rnn_char_delete_ventropy": (None, [C.POINTER(CharVentropy)]),
+    "rnn_char_init_ventropy": (None, [C.POINTER(CharVentropy), NetP, c_u8_p, C.c_int, C.c_int]),
+    "rnn_char_confabulate": (C.c_int, [NetP, C.c_char_p, C.c_int, C.c_int, AlphaP, C.c_float, c_int_p,
+                                       C.c_int, C.c_int]),
+    "rnn_char_epoch": (C.c_int, [C.POINTER(CharModel), NetP, C.POINTER(CharVentropy), c_u8_p, C.c_int,
+                                 C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_uint,
+                                 C.c_uint]),
+    "rnn_char_prime": (C.c_int, [NetP, AlphaP, c_u8_p, C.c_int]),
+    "rnn_char_cross_entropy": (C.c_double, [NetP, AlphaP, c_u8_p, C.c_int, C.c_int, c_u8_p, C.c_int]),
+    "rnn_char_uncollapse_text": (C.c_void_p, [AlphaP, c_u8_p, C.c_int, c_int_p]),
+    "rnn_char_dump_collapsed_text": (None, [c_u8_p, C.c_int, C.c_char_p, C.c_char_p]),
+    "rnn_char_construct_metadata": (C.c_void_p, [MetaP]),
+    "rnn_char_load_metadata": (C.c_int, [C.c_char_p, MetaP]),
+    "rnn_char_free_metadata_items": (None, [MetaP]),
+    "rnn_char_construct_net_filename": (C.c_void_p, [MetaP, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rnn_char_check_metadata": (C.c_int, [NetP, MetaP, C.c_bool, C.c_bool]),
+    "rnn_char_copy_metadata_items": (None, [MetaP, MetaP]),
+    "rnn_char_dump_alphabet": (None, [AlphaP]),
+    "rnn_char_get_codepoint": (C.c_int, [AlphaP, C.c_char_p]),
+    "rnn_char_new_alphabet_from_net": (AlphaP, [NetP]),
     "rnn_char_new_alphabet": (AlphaP, []),
     "rnn_char_free_alphabet": (None, [AlphaP]),
     "rnn_char_alphabet_set_flags": (None, [AlphaP, C.c_bool, C.c_bool, C.c_bool]),
