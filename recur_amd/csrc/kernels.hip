@@ -834,6 +834,39 @@ __device__ float fast_expf_dev(float x) {
   return a;
 }
 
+// The output layer of rnn_opinion (recur-nn.c:150-151): out = hidden . W_ho for one state
+// row per workgroup.  O is small (tens to a few thousand columns) against H, so this is
+// not worth an MFMA launch plus a slab pass: thread (seg, col) walks a quarter of the
+// hidden units down one column of W_ho (rows of W_ho are contiguous in col, so a wave
+// reads whole rows), and the four segments are added in order.
+__global__ __launch_bounds__(256) void k_out_layer(View v, int row0) {
+  extern __shared__ float osh[]; /* [H] hidden row, then [4][64] partial sums */
+  const RamdShape &s = v.sh;
+  const int r = row0 + blockIdx.x;
+  const float *hid = v.b.hidden + (size_t)r * s.H;
+  for (int i = threadIdx.x; i < s.H; i += 256) osh[i] = hid[i];
+  __syncthreads();
+  float *part = osh + s.H;
+  const int seg = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per = (s.H + 3) / 4;
+  const int y0 = seg * per, y1 = min(s.H, y0 + per);
+  float *out = v.b.out + (size_t)r * s.O;
+  for (int c0 = 0; c0 < s.O; c0 += 64) {
+    int col = c0 + lane;
+    float acc = 0.0f;
+    if (col < s.O) {
+      const float *w = v.b.ho_w + col;
+#pragma unroll 8
+      for (int y = y0; y < y1; y++) acc += osh[y] * w[(size_t)y * s.O];
+    }
+    part[seg * 64 + lane] = acc;
+    __syncthreads();
+    if (seg == 0 && col < s.O)
+      out[col] = ((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane];
+    __syncthreads();
+  }
+}
+
 // net_error_bptt's loss (charmodel-predict.c:18-27): softmax (badmaths.h:71-111),
 // best guess and negation (badmaths.h:113-141), +1 on the target; plus the
 // running statistics of the epoch loop (charmodel-predict.c:302-304).  One
@@ -869,23 +902,32 @@ __global__ __launch_bounds__(64) void k_softmax_error(View v, int row0, int nrow
   // the exponentials in parallel, their sum in the reference's order (lane 0)
   for (int i = threadIdx.x; i < len; i += 64) ex[i] = fast_expf_dev(src[i] + adj);
   __syncthreads();
-  if (threadIdx.x != 0) return;
+  // every lane adds the exponentials in the reference's order (the same value in all of
+  // them); the divisions and the arg max (first of equal maxima, badmaths.h:126-139) are
+  // spread over the lanes
   float sum = 0.0f;
   for (int i = 0; i < len; i++) sum += ex[i];
-  int best_i = 0;
-  float best_e = ex[0] / sum;
-  err[0] = -best_e;
-  for (int i = 1; i < len; i++) {
+  float best_e = -1.0f;
+  int best_i = 0x7fffffff;
+  const int target = v.b.target[r];
+  for (int i = threadIdx.x; i < len; i += 64) {
     float e = ex[i] / sum;
+    err[i] = (i == target) ? -e + 1.0f : -e; /* error[next] += 1.0f, charmodel-predict.c:25 */
     if (e > best_e) {
       best_e = e;
       best_i = i;
     }
-    err[i] = -e;
   }
-  int target = v.b.target[r];
-  err[target] += 1.0f;
-  float e = err[target];
+  for (int off = 32; off > 0; off >>= 1) {
+    float oe = __shfl_xor(best_e, off, 64);
+    int oi = __shfl_xor(best_i, off, 64);
+    if (oe > best_e || (oe == best_e && oi < best_i)) {
+      best_e = oe;
+      best_i = oi;
+    }
+  }
+  if (threadIdx.x != 0) return;
+  float e = -(ex[target] / sum) + 1.0f;
   float l = 1.0f - e;
   v.b.stat_err[r] += e;
   v.b.stat_ent[r] += (l < 1e-30f) ? -100.0f : log2f(l); /* charmodel-helpers.h:11-13 */
@@ -957,7 +999,14 @@ __global__ __launch_bounds__(256) void k_top_backprop(View v, int row0, const in
           sum += fabsf(e); /* once per range, e keeps running: recur-nn.c:178-191 */
         }
       } else {
-        for (int x = 0; x < s.O; x++) e += row[x] * oerr[x];
+        /* a row is O contiguous floats (O % 4 == 0): whole rows as float4, same order */
+        for (int x = 0; x < s.O; x += 4) {
+          float4 w = ld4(row + x);
+          e += w.x * oerr[x];
+          e += w.y * oerr[x + 1];
+          e += w.z * oerr[x + 2];
+          e += w.w * oerr[x + 3];
+        }
         sum += fabsf(e);
       }
     } else {
@@ -1349,20 +1398,22 @@ __global__ __launch_bounds__(64) void k_extras_finalize(View v, int row0, int nr
 // ----------------------------------------------------- K9: BPTT control --
 
 // The data-dependent part of bptt_and_accumulate_error (recur-nn.c:317-330,
-// 383-413), one thread per stream: walks the per-step error sums, finds the
-// step at which the reference's loop would have stopped, derives ih_scale and
-// the adaptive min_error_factor, and publishes coef[t][r] = ih_scale while the
-// step counts, 0 afterwards.
-__global__ void k_bptt_control(View v, int row0, int nrows, const unsigned char *active,
-                               unsigned flags, int tn) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
+// 383-413), one wave per stream: lane k holds the error sum of step k, a ballot finds
+// the step at which the reference's loop would have stopped, lane 0 derives ih_scale
+// and the adaptive min_error_factor, and the lanes publish coef[t][r] = ih_scale while
+// the step counts, 0 afterwards.
+__global__ __launch_bounds__(256) void k_bptt_control(View v, int row0, int nrows,
+                                                      const unsigned char *active, unsigned flags,
+                                                      int tn) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= nrows) return;
   const RamdShape &s = v.sh;
-  int r = row0 + j;
+  const int r = row0 + j;
   const int D = s.D;
   if (active && !active[j]) {
-    for (int k = 0; k < D; k++) v.b.coef[(size_t)k * s.Scap + r] = 0.0f;
-    v.b.n_exec[r] = 0; /* no step ran for this stream: k_err_writeback leaves its images alone */
+    for (int k = lane; k < D; k += 64) v.b.coef[(size_t)k * s.Scap + r] = 0.0f;
+    if (lane == 0) v.b.n_exec[r] = 0; /* no step ran: k_err_writeback leaves its images alone */
     return;
   }
   float top = v.b.top_scaled[r];
@@ -1373,17 +1424,24 @@ __global__ void k_bptt_control(View v, int row0, int nrows, const unsigned char 
   /* MIN(a, b) of the reference is (a < b) ? a : b: keep NaN behaviour aligned */
   float mef_rate = mef / v.b.lr[r];
   float min_error_sum = (mef_rate < min_error_gain) ? mef_rate : min_error_gain;
+  /* the first step whose sum leaves [min, max] ends the loop (recur-nn.c:387-389) */
+  int n_exec = D;
   float error_sum = 0.0f;
-  int t = D, n_exec = 0;
-  for (int k = 0; k < D; k++) {
-    error_sum = v.b.esum[(size_t)k * s.Scap + r];
-    n_exec = k + 1;
-    if (error_sum <= min_error_sum || error_sum > max_error_sum) {
-      t = D - k;
+  for (int k0 = 0; k0 < D; k0 += 64) {
+    int k = k0 + lane;
+    float es = (k < D) ? v.b.esum[(size_t)k * s.Scap + r] : 0.0f;
+    bool stop = k < D && (es <= min_error_sum || es > max_error_sum);
+    unsigned long long hit = __ballot(stop);
+    int last = hit ? __ffsll((long long)hit) - 1 : min(63, D - 1 - k0);
+    error_sum = __shfl(es, last, 64);
+    if (hit) {
+      n_exec = k0 + last + 1;
       break;
     }
-    t = D - k - 1;
   }
+  /* the reference's t counts down from D and is not decremented on a break */
+  bool broke = n_exec < D || (error_sum <= min_error_sum || error_sum > max_error_sum);
+  int t = broke ? D - n_exec + 1 : 0;
   float scale;
   if (error_sum > error_sum_ceiling) {
     scale = soft_clip_dev(error_sum, max_error_sum);
@@ -1397,13 +1455,15 @@ __global__ void k_bptt_control(View v, int row0, int nrows, const unsigned char 
       mef = (mef >= ABS_MIN_ERROR_FACTOR_F) ? mef : ABS_MIN_ERROR_FACTOR_F;
     }
   }
-  v.b.mef[r] = mef;
-  v.b.ih_scale[r] = scale;
-  v.b.bptt_err[r] = error_sum;
-  v.b.n_exec[r] = n_exec;
-  v.b.depth_log[r] = D - t;
-  v.b.stat_depth[r] += (double)(D - t);
-  for (int k = 0; k < D; k++) v.b.coef[(size_t)k * s.Scap + r] = (k < n_exec) ? scale : 0.0f;
+  if (lane == 0) {
+    v.b.mef[r] = mef;
+    v.b.ih_scale[r] = scale;
+    v.b.bptt_err[r] = error_sum;
+    v.b.n_exec[r] = n_exec;
+    v.b.depth_log[r] = D - t;
+    v.b.stat_depth[r] += (double)(D - t);
+  }
+  for (int k = lane; k < D; k += 64) v.b.coef[(size_t)k * s.Scap + r] = (k < n_exec) ? scale : 0.0f;
 }
 
 // ------------------------------------------------------- finalize: delta --
@@ -1463,12 +1523,26 @@ __global__ __launch_bounds__(256) void k_err_writeback(View v, int row0, int nxp
 // The seven update rules of rnn_apply_learning (recur-nn.c:454-593) as one
 // float4-wide elementwise kernel.  `rs` optionally points at a device float
 // that multiplies the rate (ih_scale of the fused single-net path).
+// Up to three arrays per launch (top layer, recurrent layer, bottom layer), each with its
+// own rate: segment g owns blocks [first[g], first[g + 1]).
+struct ApplySegs {
+  float *w[3];
+  const float *delta[3];
+  float *m[3];
+  float *aux[3];
+  size_t n4[3];
+  float rate[3];
+  unsigned first[4];
+};
 template <int METHOD>
-__global__ __launch_bounds__(256) void k_apply(float *w, const float *delta, float *m, float *aux,
-                                               size_t n4, float rate, float momentum, float mw,
+__global__ __launch_bounds__(256) void k_apply(ApplySegs sg, float momentum, float mw,
                                                const float *rs) {
-  size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (q >= n4) return;
+  const int g = (blockIdx.x >= sg.first[2]) ? 2 : (blockIdx.x >= sg.first[1]) ? 1 : 0;
+  size_t q = (size_t)(blockIdx.x - sg.first[g]) * 256 + threadIdx.x;
+  if (q >= sg.n4[g]) return;
+  float *w = sg.w[g], *m = sg.m[g], *aux = sg.aux[g];
+  const float *delta = sg.delta[g];
+  float rate = sg.rate[g];
   if (rs) rate *= *rs;
   float4 W = ld4(w + 4 * q), Dl = ld4(delta + 4 * q), M = ld4(m + 4 * q);
   float4 A = (METHOD == 5 || METHOD == 6) ? ld4(aux + 4 * q) : zero4();
@@ -1806,7 +1880,10 @@ extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, cons
     int n4 = nrows * (sh->H / 4);
     hipLaunchKernelGGL(k_fwd_finalize, dim3((n4 + 255) / 256), dim3(256), 0, st, v, row0, nrows, ks);
   }
-  {
+  if (sh->O <= 256 && !env_int("RECUR_AMD_OUT_GEMM", 0)) {
+    hipLaunchKernelGGL(k_out_layer, dim3(nrows), dim3(256), (size_t)(sh->H + 256) * sizeof(float), st,
+                       v, row0);
+  } else { /* wide output layers (multi-head nets, O in the thousands): the MFMA GEMM */
     int tn = (sh->O + BN - 1) / BN, nkt = (sh->H + BK - 1) / BK;
     int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_OUT", b->slab_floats, (size_t)nrows * sh->O);
     ProbOut p = {v, row0, nrows};
@@ -1907,7 +1984,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       hipLaunchKernelGGL(k_extras_finalize, dim3(M), dim3(64), 0, st, v, row0, nrows, nx, nxp, ks, tn);
     }
   }
-  hipLaunchKernelGGL(k_bptt_control, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows,
+  hipLaunchKernelGGL(k_bptt_control, dim3((nrows + 3) / 4), dim3(256), 0, st, v, row0, nrows,
                      active, flags, tn);
   // weight deltas: one GEMM over (step, stream)
   {
@@ -1952,21 +2029,43 @@ extern "C" void ramd_launch_err_writeback(ramd_stream_t st_, const RamdShape *sh
   hipLaunchKernelGGL(k_err_writeback, dim3(nrows), dim3(256), 0, st, v, row0, nxp);
 }
 
+extern "C" void ramd_launch_apply_multi(ramd_stream_t st_, int method, int nseg, float *const *w,
+                                        const float *const *delta, float *const *m,
+                                        float *const *aux, const size_t *n, const float *rate,
+                                        float momentum, float mw, const float *rs) {
+  hipStream_t st = (hipStream_t)st_;
+  ApplySegs sg = {};
+  unsigned blocks = 0;
+  for (int g = 0; g < 3; g++) {
+    sg.first[g] = blocks;
+    if (g < nseg) {
+      sg.w[g] = w[g];
+      sg.delta[g] = delta[g];
+      sg.m[g] = m[g];
+      sg.aux[g] = aux[g];
+      sg.n4[g] = n[g] / 4;
+      sg.rate[g] = rate[g];
+      blocks += (unsigned)((sg.n4[g] + 255) / 256);
+    }
+  }
+  sg.first[3] = blocks;
+  for (int g = nseg; g < 3; g++) sg.first[g] = 0xffffffffu; /* never selected */
+  dim3 gr(blocks), bl(256);
+  int ev = timing_begin(st, T_APPLY);
+  switch (method) {
+  case 1: hipLaunchKernelGGL(k_apply<1>, gr, bl, 0, st, sg, momentum, mw, rs); break;
+  case 4: hipLaunchKernelGGL(k_apply<4>, gr, bl, 0, st, sg, momentum, mw, rs); break;
+  case 5: hipLaunchKernelGGL(k_apply<5>, gr, bl, 0, st, sg, momentum, mw, rs); break;
+  case 6: hipLaunchKernelGGL(k_apply<6>, gr, bl, 0, st, sg, momentum, mw, rs); break;
+  default: hipLaunchKernelGGL(k_apply<0>, gr, bl, 0, st, sg, momentum, mw, rs); break;
+  }
+  timing_end(st, ev);
+}
+
 extern "C" void ramd_launch_apply(ramd_stream_t st_, int method, float *w, const float *delta,
                                   float *m, float *aux, size_t n, float rate, float momentum,
                                   float mw, const float *rs) {
-  hipStream_t st = (hipStream_t)st_;
-  size_t n4 = n / 4;
-  dim3 g((unsigned)((n4 + 255) / 256)), bl(256);
-  int ev = timing_begin(st, T_APPLY);
-  switch (method) {
-  case 1: hipLaunchKernelGGL(k_apply<1>, g, bl, 0, st, w, delta, m, aux, n4, rate, momentum, mw, rs); break;
-  case 4: hipLaunchKernelGGL(k_apply<4>, g, bl, 0, st, w, delta, m, aux, n4, rate, momentum, mw, rs); break;
-  case 5: hipLaunchKernelGGL(k_apply<5>, g, bl, 0, st, w, delta, m, aux, n4, rate, momentum, mw, rs); break;
-  case 6: hipLaunchKernelGGL(k_apply<6>, g, bl, 0, st, w, delta, m, aux, n4, rate, momentum, mw, rs); break;
-  default: hipLaunchKernelGGL(k_apply<0>, g, bl, 0, st, w, delta, m, aux, n4, rate, momentum, mw, rs); break;
-  }
-  timing_end(st, ev);
+  ramd_launch_apply_multi(st_, method, 1, &w, &delta, &m, &aux, &n, &rate, momentum, mw, rs);
 }
 
 extern "C" void ramd_launch_top_apply_now(ramd_stream_t st_, const RamdShape *sh,

@@ -133,6 +133,11 @@ void ramd_launch_clear_deltas(ramd_stream_t st, const RamdShape *sh, const RamdB
 void ramd_launch_apply(ramd_stream_t st, int method, float *w, const float *delta, float *m,
                        float *aux, size_t n, float rate, float momentum,
                        float momentum_weight, const float *rate_scale_dev);
+/* the same for up to three arrays in one launch (top, recurrent, bottom) */
+void ramd_launch_apply_multi(ramd_stream_t st, int method, int nseg, float *const *w,
+                             const float *const *delta, float *const *m, float *const *aux,
+                             const size_t *n, const float *rate, float momentum,
+                             float momentum_weight, const float *rate_scale_dev);
 /* conditioning pieces (recur-nn.c:782-855) */
 void ramd_launch_scale(ramd_stream_t st, float *a, size_t n, float scale);
 void ramd_launch_zero_small(ramd_stream_t st, float *a, size_t n);

@@ -1186,29 +1186,29 @@ float rnn_calculate_momentum_soft_start(float generation, float max_momentum, fl
   return RAMD_MIN(max_momentum, 1.0f - x / (1.0f + generation + 2.0f * x));
 }
 
-static void apply_arrays(RamdEngine *e, int method, float lr, float lr_top, float momentum,
-                         float mw, const float *rate_scale_dev) {
-  RamdBuffers *b = &e->b;
+static void check_method_arrays(RamdEngine *e, int method) {
   if ((method == RNN_ADADELTA || method == RNN_RPROP) && !e->has_aux) {
     fprintf(stderr, "librecur_amd: learning method %d needs RNN_NET_FLAG_AUX_ARRAYS\n", method);
     abort();
   }
-  /* top layer first, then the recurrent layer, as recur-nn.c:606-676 */
-  ramd_launch_apply(g_stream, method, b->ho_w, b->ho_delta, b->ho_m, b->ho_aux, e->ho_size,
-                    lr_top, momentum, mw, rate_scale_dev);
-  ramd_launch_apply(g_stream, method, b->ih_w, b->ih_delta, b->ih_m, b->ih_aux, e->ih_size, lr,
-                    momentum, mw, rate_scale_dev);
 }
 
-/* the bottom layer's share of rnn_apply_learning (recur-nn.c:611-615, 622-625, 634-638,
- * 647-651, 672-676) */
-static void apply_bottom(RamdEngine *e, int method, float lr, float momentum, float mw) {
+/* rnn_apply_learning's arrays in one launch: top layer, recurrent layer and, when there
+ * is one, the bottom layer with its own rate scale (recur-nn.c:606-676; the arrays are
+ * disjoint, so the reference's order between them does not matter) */
+static void apply_all(RamdEngine *e, int method, float lr, float lr_top, float momentum,
+                      float mw) {
   RamdBuffers *b = &e->b;
-  if (e->sh.bI) {
-    ramd_launch_apply(g_stream, method, b->bw, b->bdelta, b->bm, b->baux,
-                      (size_t)e->sh.bI * e->sh.bO,
-                      lr * e->owner->bottom_layer->learn_rate_scale, momentum, mw, NULL);
-  }
+  check_method_arrays(e, method);
+  float *w[3] = {b->ho_w, b->ih_w, b->bw};
+  const float *d[3] = {b->ho_delta, b->ih_delta, b->bdelta};
+  float *m[3] = {b->ho_m, b->ih_m, b->bm};
+  float *aux[3] = {b->ho_aux, b->ih_aux, b->baux};
+  size_t n[3] = {e->ho_size, e->ih_size, (size_t)e->sh.bI * e->sh.bO};
+  float rate[3] = {lr_top, lr,
+                   e->sh.bI ? lr * e->owner->bottom_layer->learn_rate_scale : 0.0f};
+  ramd_launch_apply_multi(g_stream, method, e->sh.bI ? 3 : 2, w, d, m, aux, n, rate, momentum, mw,
+                          NULL);
 }
 
 /* recur-nn.h:312 / recur-nn.c:601-678 */
@@ -1231,9 +1231,7 @@ void rnn_apply_learning(RecurNN *net, int learning_method, float momentum) {
       learning_method < 0) {
     kernel_method = RNN_MOMENTUM_WEIGHTED;
   }
-  apply_arrays(e, kernel_method, bptt->learn_rate, bptt->learn_rate * bptt->ho_scale, momentum, mw,
-               NULL);
-  apply_bottom(e, kernel_method, bptt->learn_rate, momentum, mw);
+  apply_all(e, kernel_method, bptt->learn_rate, bptt->learn_rate * bptt->ho_scale, momentum, mw);
   engine_dev_wrote(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS);
 }
 
