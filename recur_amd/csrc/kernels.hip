@@ -195,6 +195,7 @@ struct GemmOut {
   int nkt;       // K tiles in total
   int tm, tn, ks;
   int col0;      // first output column (tiles start here; columns below are not produced)
+  int row0m;     // first output row (k_gemm only; rows below are not produced)
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) {
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void k_gemm(Prob p, GemmOut o) {
   const int mt = q % o.tm, panel = (q / o.tm) * 8 + xcd;
   if (panel >= o.tn * o.ks) return;
   const int nt = panel % o.tn, z = panel / o.tn;
-  const int m0 = mt * BM, n0 = o.col0 + nt * BN;
+  const int m0 = o.row0m + mt * BM, n0 = o.col0 + nt * BN;
   const int kt0 = (int)(((long)o.nkt * z) / o.ks), kt1 = (int)(((long)o.nkt * (z + 1)) / o.ks);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 1, wn = wave & 1;
@@ -835,34 +836,44 @@ __device__ float fast_expf_dev(float x) {
 }
 
 // The output layer of rnn_opinion (recur-nn.c:150-151): out = hidden . W_ho for one state
-// row per workgroup.  O is small (tens to a few thousand columns) against H, so this is
-// not worth an MFMA launch plus a slab pass: thread (seg, col) walks a quarter of the
-// hidden units down one column of W_ho (rows of W_ho are contiguous in col, so a wave
-// reads whole rows), and the four segments are added in order.
-__global__ __launch_bounds__(256) void k_out_layer(View v, int row0) {
-  extern __shared__ float osh[]; /* [H] hidden row, then [4][64] partial sums */
+// row per workgroup.  O is small (tens to a few hundred columns) against H, so this is
+// not worth an MFMA launch plus a slab pass: thread (seg, col) walks one sixteenth of the
+// hidden units down one column of W_ho (a wave reads whole contiguous rows), sixteen
+// waves keep enough rows in flight to cover the L2 latency, and the segments are added
+// in order.
+constexpr int OUT_SEGS = 16;
+__global__ __launch_bounds__(1024) void k_out_layer(View v, int row0) {
+  extern __shared__ float osh[]; /* [H] hidden row, then [OUT_SEGS][64] partial sums */
   const RamdShape &s = v.sh;
   const int r = row0 + blockIdx.x;
   const float *hid = v.b.hidden + (size_t)r * s.H;
-  for (int i = threadIdx.x; i < s.H; i += 256) osh[i] = hid[i];
+  for (int i = threadIdx.x; i < s.H; i += 1024) osh[i] = hid[i];
   __syncthreads();
   float *part = osh + s.H;
   const int seg = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int per = (s.H + 3) / 4;
+  const int per = (s.H + OUT_SEGS - 1) / OUT_SEGS;
   const int y0 = seg * per, y1 = min(s.H, y0 + per);
   float *out = v.b.out + (size_t)r * s.O;
   for (int c0 = 0; c0 < s.O; c0 += 64) {
     int col = c0 + lane;
-    float acc = 0.0f;
+    float acc0 = 0.0f, acc1 = 0.0f;
     if (col < s.O) {
       const float *w = v.b.ho_w + col;
-#pragma unroll 8
-      for (int y = y0; y < y1; y++) acc += osh[y] * w[(size_t)y * s.O];
+      int y = y0;
+#pragma unroll 4
+      for (; y + 1 < y1; y += 2) {
+        acc0 += osh[y] * w[(size_t)y * s.O];
+        acc1 += osh[y + 1] * w[(size_t)(y + 1) * s.O];
+      }
+      if (y < y1) acc0 += osh[y] * w[(size_t)y * s.O];
     }
-    part[seg * 64 + lane] = acc;
+    part[seg * 64 + lane] = acc0 + acc1;
     __syncthreads();
-    if (seg == 0 && col < s.O)
-      out[col] = ((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane];
+    if (seg == 0 && col < s.O) {
+      float sum = part[lane];
+      for (int g = 1; g < OUT_SEGS; g++) sum += part[g * 64 + lane];
+      out[col] = sum;
+    }
     __syncthreads();
   }
 }
@@ -1395,6 +1406,177 @@ __global__ __launch_bounds__(64) void k_extras_finalize(View v, int row0, int nr
   }
 }
 
+// ------------------------------------------------ weight-delta GEMM by LDS-DMA --
+//
+// ih_delta[m][n] = sum over (step t, stream r) of X_t[r][m] * coef[t][r] * E_t[r][n]
+// (recur-nn.c:343-358 for every executed step of every stream, with the stream's
+// ih_scale folded in).  Both operands are K-major: a K tile is 32 streams of one step, a
+// row of it 128 consecutive floats of a history slot (A) or of an error plane (B).
+//
+// Workgroup = 8 waves on one CU: waves 0-3 own a 64 x 64 quadrant of the 128 x 128 tile
+// each (2 x 2 accumulators, 64 MFMAs per K tile and wave); waves 4-7 only move data:
+// each K tile is 32 + 1 LDS-DMA wave instructions (16 KB of A, 16 KB of B, the tile's 32
+// coefficients) into a four-deep ring, three tiles in flight.  One raw s_barrier per K
+// tile; nothing else couples the two groups.  A K tile costs a compute wave 64 MFMAs
+// (4096 cycles), so the barrier and the LDS read latency between tiles are a few per cent.
+// The per-row coefficient is applied to the B fragments after the LDS read (select on
+// zero: rows of steps a stream did not execute may hold anything).
+//
+// Preconditions (checked by the launcher, which otherwise uses k_gemm2): every stream at
+// the same ring position, nrows % 32 == 0, hidden_size % 128 == 0, not RECLIP20.  Only
+// whole 128-row tiles are computed here; the remaining rows (bias row 0 is in tile 0; the
+// input rows above the last whole tile) go through the generic k_gemm with a row offset.
+constexpr int DD_STAGES = 4;
+constexpr int DD_STAGE_FLOATS = 2 * BK * 128 + 64; /* A, B, 32 coefficients (+ pad) */
+
+__global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, GemmOut o) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  const RamdShape &s = v.sh;
+  const int L = blockIdx.x;
+  // K slice z lives on 8 / ks XCDs (ks divides 8), so each XCD's L2 sees one slice of X
+  // and E only; within a slice consecutive tiles alternate between its XCDs
+  const int xcd = L & 7, q = L >> 3;
+  const int per = 8 / o.ks;
+  const int z = xcd / per, tile = q * per + (xcd % per);
+  if (tile >= o.tm * o.tn) return;
+  const int mt = tile / o.tn, nt = tile % o.tn;
+  const int m0 = mt * 128, n0 = o.col0 + nt * 128;
+  const int kt0 = (int)(((long)o.nkt * z) / o.ks), kt1 = (int)(((long)o.nkt * (z + 1)) / o.ks);
+  const int nst = kt1 - kt0;
+  const int wave8 = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rtiles = nrows / BK;
+
+  if (wave8 >= 4) {
+    // ---------------------------------------------------------------- loaders
+    const int w = wave8 - 4;
+    // instruction i (0..31): rows 2 (i & 15), +1 of A (i < 16) or B; wave w issues i = 8 w + j
+    const int rk = lane >> 5, c4 = (lane & 31) * 4;
+    auto issue = [&](int st) {
+      const int kt = kt0 + st;
+      const int t = kt / rtiles, sb = (kt - t * rtiles) * BK;
+      int slot = v.b.uniform_idx - t;
+      if (slot < 0) slot += s.D;
+      const float *xa = v.b.arena + ((size_t)slot * s.Scap + row0 + sb) * s.I + m0 + c4;
+      const float *eb = v.b.ehi + ((size_t)t * s.Scap + row0 + sb) * s.I + n0 + c4;
+      float *dst = dsm + (st % DD_STAGES) * DD_STAGE_FLOATS;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int i = w * 8 + j;
+        const int row = 2 * (i & 15) + rk;
+        const float *g = (i < 16 ? xa : eb) + (size_t)row * s.I;
+        float *d = dst + (i < 16 ? 0 : BK * 128) + (i & 15) * 256;
+        __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)d, 16, 0, 0);
+      }
+      if (w == 0) { /* the 32 coefficients of the tile: lanes 32-63 repeat them */
+        const float *g = v.b.coef + (size_t)t * s.Scap + row0 + sb + (lane & 31);
+        __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(dst + 2 * BK * 128), 4, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int p = 0; p < DD_STAGES - 1; p++)
+      if (p < nst) issue(p);
+    for (int st = 0; st < nst; st++) {
+      // stages st+1 .. st+DD_STAGES-2 may stay in flight (8 or 9 DMAs per stage)
+      const int ahead = min(DD_STAGES - 2, nst - 1 - st);
+      if (w == 0) {
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier(); /* stage st has landed; stage st-1's buffer is free */
+      if (st + DD_STAGES - 1 < nst) issue(st + DD_STAGES - 1);
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ compute
+  const int wm = wave8 >> 1, wn = wave8 & 1;
+  const int lm = lane & 31, kh = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
+  // The fragments of K group u + 1 (8 k: four MFMA steps of two k each) are read from LDS
+  // before the 16 MFMAs of group u are issued and used after them, so the LDS latency
+  // and, at a stage boundary, the barrier sit in the shadow of the matrix pipe.
+  struct Frag {
+    float a[2][4], e[2][4];
+    float4 cf;
+  };
+  const int lane_off = 4 * kh * 128 + lm;
+  auto rd = [&](int st, int g, Frag &f) {
+    const float *la = dsm + (st % DD_STAGES) * DD_STAGE_FLOATS + 8 * g * 128 + lane_off;
+    const float *lb = la + BK * 128;
+    f.cf = *reinterpret_cast<const float4 *>(dsm + (st % DD_STAGES) * DD_STAGE_FLOATS + 2 * BK * 128 +
+                                             8 * g + 4 * kh);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) {
+        f.a[i][jj] = la[jj * 128 + wm * 64 + i * 32];
+        f.e[i][jj] = lb[jj * 128 + wn * 64 + i * 32];
+      }
+  };
+  auto mm = [&](const Frag &f) {
+    const float cfv[4] = {f.cf.x, f.cf.y, f.cf.z, f.cf.w};
+    float b[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) b[i][jj] = (cfv[jj] == 0.0f) ? 0.0f : f.e[i][jj] * cfv[jj];
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][jj], b[jn][jj], acc[i][jn], 0, 0, 0);
+  };
+  auto step = [&](int st, int g, Frag &cur, Frag &nxt) {
+    if (g < 3) {
+      rd(st, g + 1, nxt);
+    } else if (st + 1 < nst) {
+      __builtin_amdgcn_s_barrier(); /* stage st + 1 has landed; stage st - 1's buffer is free */
+      asm volatile("" ::: "memory");
+      rd(st + 1, 0, nxt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mm(cur);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  Frag f0, f1;
+  if (nst > 0) {
+    __builtin_amdgcn_s_barrier(); /* stage 0 has landed */
+    asm volatile("" ::: "memory");
+    rd(0, 0, f0);
+  }
+  for (int st = 0; st < nst; st++) {
+    step(st, 0, f0, f1);
+    step(st, 1, f1, f0);
+    step(st, 2, f0, f1);
+    step(st, 3, f1, f0);
+  }
+  float *c = o.slab + (size_t)z * o.M * o.ldc;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int jn = 0; jn < 2; jn++) {
+      const int col = n0 + wn * 64 + jn * 32 + lm;
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+        int row = m0 + wm * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
+        c[(size_t)row * o.ldc + col] = acc[i][jn][g];
+      }
+    }
+}
+
 // ----------------------------------------------------- K9: BPTT control --
 
 // The data-dependent part of bptt_and_accumulate_error (recur-nn.c:317-330,
@@ -1472,9 +1654,12 @@ __global__ __launch_bounds__(256) void k_bptt_control(View v, int row0, int nrow
 // ih_scale already multiplies the error rows that went into the GEMM)
 __global__ __launch_bounds__(256) void k_delta_finalize(float *delta, const float *slab,
                                                         size_t n4, size_t n, int ks,
-                                                        int accumulate, int H, int hidden_size) {
+                                                        int accumulate, int H, int hidden_size,
+                                                        int rows_core, int ks_rest) {
   size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (q >= n4) return;
+  /* rows below rows_core were produced with ks K slices, the others with ks_rest */
+  if ((int)((4 * q) / (size_t)H) >= rows_core) ks = ks_rest;
   float4 a = accumulate ? ld4(delta + 4 * q) : zero4();
   float4 sum = zero4();
   for (int z = 0; z < ks; z++) {
@@ -1779,14 +1964,15 @@ static int pick_ks(int tiles, int nkt, const char *env, size_t slab_floats, size
 
 template <bool A_KM, bool B_KM, class Prob>
 static void launch_gemm(hipStream_t st, const Prob &p, float *slab, int M, int N, int nkt, int ks,
-                        int cls, int col0 = 0, int ldc = 0) {
+                        int cls, int col0 = 0, int ldc = 0, int row0m = 0) {
   GemmOut o;
   o.slab = slab;
   o.M = M;
   o.N = N;
   o.ldc = ldc > 0 ? ldc : N;
   o.nkt = nkt;
-  o.tm = (M + BM - 1) / BM;
+  o.row0m = row0m;
+  o.tm = (M - row0m + BM - 1) / BM;
   o.tn = (N - col0 + BN - 1) / BN;
   o.ks = ks;
   o.col0 = col0;
@@ -1810,6 +1996,7 @@ static void launch_gemm2(hipStream_t st, const Prob &p, float *slab, int M, int 
   o.tn = (N - col0 + BN2 - 1) / BN2;
   o.ks = ks;
   o.col0 = col0;
+  o.row0m = 0;
   int panels = o.tn * ks;
   int blocks = ((panels + 7) / 8) * 8 * o.tm;
   int ev = timing_begin(st, cls);
@@ -1881,8 +2068,8 @@ extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, cons
     hipLaunchKernelGGL(k_fwd_finalize, dim3((n4 + 255) / 256), dim3(256), 0, st, v, row0, nrows, ks);
   }
   if (sh->O <= 256 && !env_int("RECUR_AMD_OUT_GEMM", 0)) {
-    hipLaunchKernelGGL(k_out_layer, dim3(nrows), dim3(256), (size_t)(sh->H + 256) * sizeof(float), st,
-                       v, row0);
+    hipLaunchKernelGGL(k_out_layer, dim3(nrows), dim3(1024),
+                       (size_t)(sh->H + OUT_SEGS * 64) * sizeof(float), st, v, row0);
   } else { /* wide output layers (multi-head nets, O in the thousands): the MFMA GEMM */
     int tn = (sh->O + BN - 1) / BN, nkt = (sh->H + BK - 1) / BK;
     int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_OUT", b->slab_floats, (size_t)nrows * sh->O);
@@ -2002,7 +2189,52 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       int tm2 = (sh->I + BM2 - 1) / BM2, tn2 = (ncol - 1 + BN2 - 1) / BN2;
       ks = pick_ks(tm2 * tn2, nkt, "RECUR_AMD_KS_DELTA", b->slab_floats, n);
     }
-    if (big && b->uniform_idx >= 0) {
+    int rows_core = sh->I, ks_rest = ks;
+    const bool dma = b->uniform_idx >= 0 && nrows % BK == 0 && sh->hidden_size % 128 == 0 &&
+                     sh->I >= 128 && sh->activation != 5 && env_int("RECUR_AMD_DELTA_DMA", 1);
+    if (dma) {
+      /* whole 128-row tiles by LDS-DMA, one workgroup per CU; the rows above them (the
+       * input rows of a text net) by the generic kernel with its own K split */
+      static bool attr_set = false;
+      const size_t shm = (size_t)DD_STAGES * DD_STAGE_FLOATS * sizeof(float);
+      if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_delta_dma,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        attr_set = true;
+      }
+      rows_core = (sh->I / 128) * 128;
+      GemmOut o;
+      o.slab = b->slab;
+      o.M = sh->I;
+      o.N = ncol;
+      o.ldc = sh->H;
+      o.nkt = nkt;
+      o.tm = rows_core / 128;
+      o.tn = sh->hidden_size / 128;
+      o.col0 = 1;
+      o.row0m = 0;
+      int tiles = o.tm * o.tn;
+      int kd = env_int("RECUR_AMD_KS_DELTA", 0);
+      if (kd != 1 && kd != 2 && kd != 4 && kd != 8) {
+        kd = 8;
+        while (kd > 1 && tiles * kd > 256) kd >>= 1;
+      }
+      while (kd > 1 && (kd > nkt || (size_t)kd * n > b->slab_floats)) kd >>= 1;
+      o.ks = ks = kd;
+      const int per = 8 / kd;
+      int blocks = ((tiles + per - 1) / per) * 8;
+      int ev = timing_begin(st, T_DELTA);
+      hipLaunchKernelGGL(k_delta_dma, dim3(blocks), dim3(512), shm, st, v, row0, nrows, o);
+      timing_end(st, ev);
+      ks_rest = 0;
+      if (rows_core < sh->I) {
+        int tmr = (sh->I - rows_core + BM - 1) / BM, tnr = (ncol - 1 + BN - 1) / BN;
+        ks_rest = pick_ks(tmr * tnr, nkt, "RECUR_AMD_KS_DELTA_REST", b->slab_floats, n);
+        ProbDelta<true> p = {v, row0, nrows, rtiles};
+        launch_gemm<true, true, ProbDelta<true>>(st, p, b->slab, sh->I, ncol, nkt, ks_rest, T_DELTA, 1,
+                                                 sh->H, rows_core);
+      }
+    } else if (big && b->uniform_idx >= 0) {
       ProbDelta<true> p = {v, row0, nrows, rtiles};
       launch_gemm2<ProbDelta<true>>(st, p, b->slab, sh->I, ncol, nkt, ks, T_DELTA, 1, sh->H);
     } else if (big) {
@@ -2017,7 +2249,8 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     }
     size_t n4 = n / 4;
     hipLaunchKernelGGL(k_delta_finalize, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
-                       b->ih_delta, b->slab, n4, n, ks, accumulate, sh->H, sh->hidden_size);
+                       b->ih_delta, b->slab, n4, n, ks, accumulate, sh->H, sh->hidden_size, rows_core,
+                       ks_rest);
   }
 }
 
