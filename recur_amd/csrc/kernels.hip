@@ -946,6 +946,154 @@ __global__ __launch_bounds__(64) void k_softmax_error(View v, int row0, int nrow
   v.b.stat_count[r] += 1;
   v.b.stat_zero[r] += zeros / (double)s.hidden_size;
 }
+// The top of a text generation in one launch, one workgroup (16 waves) per stream: the
+// output layer (k_out_layer), the softmax loss against the stream's target
+// (k_softmax_error) and the top-layer backprop with its soft clip (k_top_backprop, dense
+// form), each exactly as in the separate kernels -- same operation order per value -- with
+// the hidden row, the outputs and the output error passed through LDS instead of HBM.
+__global__ __launch_bounds__(1024) void k_text_top(View v, int row0) {
+  extern __shared__ float tsh[];
+  __shared__ float tred[16];
+  const RamdShape &s = v.sh;
+  const int r = row0 + blockIdx.x;
+  float *shid = tsh;                   /* [H] hidden row                    */
+  float *part = shid + s.H;            /* [OUT_SEGS][64] output partial sums */
+  float *sout = part + OUT_SEGS * 64;  /* [O] outputs                        */
+  float *sex = sout + s.O;             /* [O] exponentials                   */
+  float *serr = sex + s.O;             /* [O] output error                   */
+  const float *hid = v.b.hidden + (size_t)r * s.H;
+  for (int i = threadIdx.x; i < s.H; i += 1024) shid[i] = hid[i];
+  __syncthreads();
+  const int seg = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // ---- output layer (recur-nn.c:150-151)
+  {
+    const int per = (s.H + OUT_SEGS - 1) / OUT_SEGS;
+    const int y0 = seg * per, y1 = min(s.H, y0 + per);
+    float *out = v.b.out + (size_t)r * s.O;
+    for (int c0 = 0; c0 < s.O; c0 += 64) {
+      int col = c0 + lane;
+      float acc0 = 0.0f, acc1 = 0.0f;
+      if (col < s.O) {
+        const float *w = v.b.ho_w + col;
+        int y = y0;
+#pragma unroll 4
+        for (; y + 1 < y1; y += 2) {
+          acc0 += shid[y] * w[(size_t)y * s.O];
+          acc1 += shid[y + 1] * w[(size_t)(y + 1) * s.O];
+        }
+        if (y < y1) acc0 += shid[y] * w[(size_t)y * s.O];
+      }
+      part[seg * 64 + lane] = acc0 + acc1;
+      __syncthreads();
+      if (seg == 0 && col < s.O) {
+        float sum = part[lane];
+        for (int g = 1; g < OUT_SEGS; g++) sum += part[g * 64 + lane];
+        out[col] = sum;
+        sout[col] = sum;
+      }
+      __syncthreads();
+    }
+  }
+  // ---- softmax loss (charmodel-predict.c:18-27, badmaths.h:71-141): wave 0
+  if (seg == 0) {
+    const int len = s.output_size;
+    float *err = v.b.o_error + (size_t)r * s.O;
+    int zeros = 0;
+    for (int i = lane; i < s.H; i += 64) zeros += (shid[i] == 0.0f);
+    for (int off = 32; off > 0; off >>= 1) zeros += __shfl_down(zeros, off, 64);
+    float lo = sout[0], hi = sout[0];
+    for (int i = lane; i < len; i += 64) {
+      hi = fmaxf(hi, sout[i]);
+      lo = fminf(lo, sout[i]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+      lo = fminf(lo, __shfl_xor(lo, off, 64));
+    }
+    float adj = 0.0f;
+    if (hi > 50.0f) adj = 50.0f - hi;
+    else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+    for (int i = lane; i < len; i += 64) sex[i] = fast_expf_dev(sout[i] + adj);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* one wave: its LDS writes are ordered */
+    float sum = 0.0f;
+    for (int i = 0; i < len; i++) sum += sex[i];
+    float best_e = -1.0f;
+    int best_i = 0x7fffffff;
+    const int target = v.b.target[r];
+    for (int i = lane; i < s.O; i += 64) {
+      float oe;
+      if (i < len) {
+        float e = sex[i] / sum;
+        oe = (i == target) ? -e + 1.0f : -e;
+        err[i] = oe;
+        if (e > best_e) {
+          best_e = e;
+          best_i = i;
+        }
+      } else {
+        oe = err[i]; /* the pad of o_error stays what it was (zero) */
+      }
+      serr[i] = oe;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      float oe = __shfl_xor(best_e, off, 64);
+      int oi = __shfl_xor(best_i, off, 64);
+      if (oe > best_e || (oe == best_e && oi < best_i)) {
+        best_e = oe;
+        best_i = oi;
+      }
+    }
+    if (lane == 0) {
+      float e = -(sex[target] / sum) + 1.0f;
+      float l = 1.0f - e;
+      v.b.stat_err[r] += e;
+      v.b.stat_ent[r] += (l < 1e-30f) ? -100.0f : log2f(l);
+      v.b.stat_correct[r] += (best_i == target);
+      v.b.stat_count[r] += 1;
+      v.b.stat_zero[r] += zeros / (double)s.hidden_size;
+    }
+  }
+  __syncthreads();
+  // ---- top-layer backprop + soft clip (recur-nn.c:199-228, 719-721)
+  float sum = 0.0f;
+  float ev[2] = {0.0f, 0.0f}; /* h_size <= 2048 per launch condition */
+  for (int q = 0, y = threadIdx.x; y < s.H; y += 1024, q++) {
+    float e = 0.0f;
+    if (y != 0 && shid[y] != 0.0f) {
+      const float *row = v.b.ho_w + (size_t)y * s.O;
+      for (int x = 0; x < s.O; x += 4) {
+        float4 w = ld4(row + x);
+        e += w.x * serr[x];
+        e += w.y * serr[x + 1];
+        e += w.z * serr[x + 2];
+        e += w.w * serr[x + 3];
+      }
+      sum += fabsf(e);
+    }
+    ev[q] = e;
+  }
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if (lane == 0) tred[seg] = sum;
+  __syncthreads();
+  /* the same tree as block_sum_256 within each group of four waves, then the four groups */
+  float g0 = (tred[0] + tred[1]) + (tred[2] + tred[3]), g1 = (tred[4] + tred[5]) + (tred[6] + tred[7]);
+  float g2 = (tred[8] + tred[9]) + (tred[10] + tred[11]), g3 = (tred[12] + tred[13]) + (tred[14] + tred[15]);
+  sum = (g0 + g1) + (g2 + g3);
+  float halfmax = s.H * MAX_TOP_ERROR_FACTOR_F;
+  float scaled = sum, scale = 1.0f;
+  if (sum > halfmax) {
+    scale = soft_clip_dev(sum, halfmax);
+    scaled = scale * sum;
+  }
+  float *dst = v.b.ehi + (size_t)r * s.I; /* step 0 plane */
+  for (int q = 0, y = threadIdx.x; y < s.H; y += 1024, q++)
+    dst[y] = (y == 0 || y > s.hidden_size) ? 0.0f : (sum > halfmax) ? ev[q] * scale : ev[q];
+  if (threadIdx.x == 0) {
+    v.b.top_raw[r] = sum;
+    v.b.top_scaled[r] = scaled;
+  }
+}
+
 // get_cross_entropy's inner step (charmodel-predict.c:71-76): softmax of one state
 // row's outputs (badmaths.h:71-111, sums in the reference's order), the probability of
 // the row's target symbol, capped_log2f of it added to the row's running total.
@@ -2046,8 +2194,44 @@ extern "C" void ramd_launch_bottom_deltas(ramd_stream_t st_, const RamdShape *sh
   b->bcarry_cur ^= 1;
 }
 
+extern "C" int ramd_text_top_ok(const RamdShape *sh) {
+  return sh->O <= 256 && sh->H <= 2048 && !env_int("RECUR_AMD_NO_TEXT_TOP", 0);
+}
+
+extern "C" void ramd_launch_text_top(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
+                                     int row0, int nrows) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  size_t shm = (size_t)(sh->H + OUT_SEGS * 64 + 3 * sh->O) * sizeof(float);
+  hipLaunchKernelGGL(k_text_top, dim3(nrows), dim3(1024), shm, st, v, row0);
+}
+
+extern "C" void ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh,
+                                           const RamdBuffers *b, int row0, int nrows, float noise);
+
 extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
                                     int row0, int nrows, float noise) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  ramd_launch_forward_hidden(st_, sh, b, row0, nrows, noise);
+  if (sh->O <= 256 && !env_int("RECUR_AMD_OUT_GEMM", 0)) {
+    hipLaunchKernelGGL(k_out_layer, dim3(nrows), dim3(1024),
+                       (size_t)(sh->H + OUT_SEGS * 64) * sizeof(float), st, v, row0);
+  } else { /* wide output layers (multi-head nets, O in the thousands): the MFMA GEMM */
+    int tm = (nrows + BM - 1) / BM;
+    int tn = (sh->O + BN - 1) / BN, nkt = (sh->H + BK - 1) / BK;
+    int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_OUT", b->slab_floats, (size_t)nrows * sh->O);
+    ProbOut p = {v, row0, nrows};
+    launch_gemm<false, true, ProbOut>(st, p, b->slab, nrows, sh->O, nkt, ks, T_OTHER);
+    int n4 = nrows * (sh->O / 4);
+    hipLaunchKernelGGL(k_sum_slabs, dim3((n4 + 255) / 256), dim3(256), 0, st,
+                       b->out + (size_t)row0 * sh->O, sh->O, b->slab, nrows, sh->O, ks, 0);
+  }
+}
+
+/* the hidden layer only: hidden = act(X . W_ih) (recur-nn.c:117-148) */
+extern "C" void ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh,
+                                           const RamdBuffers *b, int row0, int nrows, float noise) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   int tm = (nrows + BM - 1) / BM;
@@ -2066,18 +2250,6 @@ extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, cons
                          noise);
     int n4 = nrows * (sh->H / 4);
     hipLaunchKernelGGL(k_fwd_finalize, dim3((n4 + 255) / 256), dim3(256), 0, st, v, row0, nrows, ks);
-  }
-  if (sh->O <= 256 && !env_int("RECUR_AMD_OUT_GEMM", 0)) {
-    hipLaunchKernelGGL(k_out_layer, dim3(nrows), dim3(1024),
-                       (size_t)(sh->H + OUT_SEGS * 64) * sizeof(float), st, v, row0);
-  } else { /* wide output layers (multi-head nets, O in the thousands): the MFMA GEMM */
-    int tn = (sh->O + BN - 1) / BN, nkt = (sh->H + BK - 1) / BK;
-    int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_OUT", b->slab_floats, (size_t)nrows * sh->O);
-    ProbOut p = {v, row0, nrows};
-    launch_gemm<false, true, ProbOut>(st, p, b->slab, nrows, sh->O, nkt, ks, T_OTHER);
-    int n4 = nrows * (sh->O / 4);
-    hipLaunchKernelGGL(k_sum_slabs, dim3((n4 + 255) / 256), dim3(256), 0, st,
-                       b->out + (size_t)row0 * sh->O, sh->O, b->slab, nrows, sh->O, ks, 0);
   }
 }
 
@@ -2118,7 +2290,8 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   View v = make_view(sh, b);
   // top layer
   size_t shm = (size_t)(sh->O + sh->H) * sizeof(float);
-  hipLaunchKernelGGL(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges, active);
+  if (!(flags & 0x40000000u)) /* ramd_launch_text_top has already done the top backprop */
+    hipLaunchKernelGGL(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges, active);
   if (!(flags & 0x80000000u)) { /* the fused single-net path updates W_ho directly */
     int tm = (sh->H + BM - 1) / BM, tn = (sh->O + BN - 1) / BN;
     int nkt = (nrows + BK - 1) / BK;

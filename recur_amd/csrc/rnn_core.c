@@ -1502,7 +1502,7 @@ void rnn_amd_set_advance(RnnAmdSet *set) {
 }
 
 static void set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, int text_i,
-                        float *outputs, int advance) {
+                        float *outputs, int advance, int hidden_only) {
   RamdEngine *e = set->eng;
   engine_need_dev(e, RNN_AMD_WEIGHTS);
   set_streams_to_dev(set);
@@ -1539,7 +1539,11 @@ static void set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, 
     ramd_launch_assemble(g_stream, &e->sh, &e->b, r0, set->n, mode, d_dense, ld, text_i,
                          set->global_first, set->global_count, advance);
   }
-  ramd_launch_forward(g_stream, &e->sh, &e->b, r0, set->n, noise);
+  if (hidden_only) {
+    ramd_launch_forward_hidden(g_stream, &e->sh, &e->b, r0, set->n, noise);
+  } else {
+    ramd_launch_forward(g_stream, &e->sh, &e->b, r0, set->n, noise);
+  }
   set_streams_dev_wrote(set);
   if (outputs) {
     d2h(outputs, e->b.out + (size_t)r0 * e->sh.O, (size_t)set->n * e->sh.O * sizeof(float));
@@ -1554,9 +1558,9 @@ void rnn_amd_set_opinion(RnnAmdSet *set, const float *inputs, int ld_inputs, flo
     HIP_OK(hipMemcpy2DAsync(e->d_dense, w * sizeof(float), inputs, ld_inputs * sizeof(float),
                             w * sizeof(float), set->n, hipMemcpyHostToDevice, g_stream));
     dsync();
-    set_forward(set, RAMD_IN_DENSE, e->d_dense, w, 0, outputs, 0);
+    set_forward(set, RAMD_IN_DENSE, e->d_dense, w, 0, outputs, 0, 0);
   } else {
-    set_forward(set, RAMD_IN_KEEP, NULL, 0, 0, outputs, 0);
+    set_forward(set, RAMD_IN_KEEP, NULL, 0, 0, outputs, 0, 0);
   }
 }
 
@@ -1564,7 +1568,7 @@ void rnn_amd_set_one_hot_opinion(RnnAmdSet *set, const int *hot, float *outputs)
   RamdEngine *e = set->eng;
   h2d(e->b.hot + set_state_row0(set), hot, set->n * sizeof(int));
   dsync();
-  set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, outputs, 0);
+  set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, outputs, 0, 0);
 }
 
 void rnn_amd_set_put_o_error(RnnAmdSet *set, const float *o_error, int ld) {
@@ -1590,8 +1594,16 @@ void rnn_amd_set_softmax_error(RnnAmdSet *set, const int *target) {
   set_streams_dev_wrote(set);
 }
 
+static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ranges,
+                            const u8 *active, unsigned extra_flags);
+
 void rnn_amd_set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ranges,
                              const u8 *active) {
+  set_calc_deltas(set, accumulate, ranges, active, 0);
+}
+
+static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ranges,
+                            const u8 *active, unsigned extra_flags) {
   RamdEngine *e = set->eng;
   set_need_training(set, "rnn_amd_set_calc_deltas");
   engine_need_dev(e, RNN_AMD_WEIGHTS | (accumulate ? RNN_AMD_DELTAS : 0));
@@ -1609,7 +1621,7 @@ void rnn_amd_set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ra
   }
   set_uniform_idx(e, set->row0, set->n);
   ramd_launch_calc_deltas(g_stream, &e->sh, &e->b, set->row0, set->n, accumulate, d_ranges,
-                          d_active, set->nets[0]->flags);
+                          d_active, set->nets[0]->flags | extra_flags);
   if (e->sh.bI) {
     if (set->global_count != set->n || e->delta_external) {
       fprintf(stderr, "librecur_amd: a bottom layer cannot be trained on a sharded set: its "
@@ -1652,9 +1664,16 @@ void rnn_amd_set_char_step_deltas(RnnAmdSet *set, int i) {
     fprintf(stderr, "librecur_amd: rnn_amd_set_char_step without rnn_amd_set_load_text\n");
     abort();
   }
-  set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1); /* advance + one-hot opinion */
-  ramd_launch_softmax_error(g_stream, &e->sh, &e->b, set->row0, set->n);
-  rnn_amd_set_calc_deltas(set, 0, NULL, NULL);
+  if (ramd_text_top_ok(&e->sh)) {
+    /* advance + hidden layer, then output layer, loss and top backprop in one launch */
+    set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 1);
+    ramd_launch_text_top(g_stream, &e->sh, &e->b, set->row0, set->n);
+    set_calc_deltas(set, 0, NULL, NULL, RAMD_TOP_DONE);
+  } else {
+    set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 0); /* advance + one-hot opinion */
+    ramd_launch_softmax_error(g_stream, &e->sh, &e->b, set->row0, set->n);
+    set_calc_deltas(set, 0, NULL, NULL, 0);
+  }
 }
 
 void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float momentum) {
