@@ -183,6 +183,39 @@ def test_empty_and_edge_inputs(amd):
     lib.rnn_delete_net(net)
 
 
+@pytest.mark.parametrize("label,kw,steps", [
+    # more BPTT steps than a wave has lanes: k_bptt_control walks the sums in chunks of 64
+    ("depth70", dict(input_size=42, hidden_size=39, output_size=42, S=3, D=70, learn_rate=3e-3, seed=31), 80),
+    # an output layer wider than the direct kernels take (multi-head nets): the MFMA output
+    # GEMM, the stand-alone softmax and top backprop
+    ("wide_output", dict(input_size=42, hidden_size=64, output_size=300, S=4, D=5, learn_rate=1e-3, seed=32), 8),
+    # h_size above 2048: the extras of the chain as a GEMM, no fused text top
+    ("wide_hidden", dict(input_size=42, hidden_size=2112, output_size=42, S=2, D=3, learn_rate=1e-4, seed=33), 4),
+    # the LDS-DMA delta GEMM at its smallest shape (hidden 128, 32 streams) plus its rest rows,
+    # and with a second generation accumulated on top (accumulate = 1 is the per-net path only,
+    # so this one checks the non-accumulating batched form twice)
+    ("dma_small", dict(input_size=42, hidden_size=128, output_size=42, S=32, D=6, learn_rate=1e-3, seed=34), 9),
+])
+def test_fallback_and_boundary_shapes_match_oracle(amd, label, kw, steps):
+    text = sc.synthetic_text(4000)
+    g = sc.AmdBatchedSet(amd, **kw)
+    o = sc.OracleSet(**kw)
+    for i in range(steps):
+        g.char_step(text, i, rc.WEIGHTED, 0.9)
+        o.char_step(text, i, rc.WEIGHTED, 0.9)
+    sg, so = g.snapshot(), o.snapshot()
+    assert np.array_equal(sg["hidden"] != 0, so["hidden"] != 0)
+    replay.check(sg, so, RTOL, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "output",
+                                     "hist", "o_error", "min_error_factor", "ih_scale"],
+                 exact=("index", "generation"))
+    st = g.stats()
+    z = o.z.contents
+    assert st.count == steps * kw["S"] and st.correct == z.stat_correct
+    assert abs(st.entropy - z.stat_entropy) <= 1e-4 * abs(z.stat_entropy)
+    g.close()
+    o.close()
+
+
 # ------------------------------------------------------------ full size --
 
 FULL = dict(input_size=42, hidden_size=1024, output_size=42, S=256, D=20, learn_rate=1e-5, seed=1)
