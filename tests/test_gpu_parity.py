@@ -438,3 +438,48 @@ def test_c_driver_trains_on_erewhon():
     # run away over 1500 symbols (the oracle shows the same spikes), so only the best one is checked
     assert t[-1] < t[0] and min(v) < 5.39
     assert float(rows[-1][4]) > 10                              # BPTT runs deep
+
+
+def test_text_tools_train_save_score_and_sample(tmp_path):
+    """tools/text_predict_amd -> net file with the alphabet in its metadata ->
+    tools/text_cross_entropy_amd and tools/text_confabulate_amd (the reference's
+    text-cross-entropy.c:125-207 and text-confabulate.c:50-103 flows)."""
+    import os
+    import subprocess
+    build = os.path.join(rc.ROOT, "build")
+    subprocess.run(["make", "-s", "-C", os.path.join(rc.ROOT, "recur_amd", "csrc")], check=True)
+    net = str(tmp_path / "erewhon.net")
+    r = subprocess.run([os.path.join(build, "text_predict_amd"), "-f", rc.EREWHON, "-H", "99", "-t", "16", "-d", "10",
+                        "-l", "1e-3", "-s", "600", "-r", "300", "-V", "1500", "-n", net],
+                       capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0 and os.path.exists(net), r.stderr[-2000:]
+    excerpt = tmp_path / "excerpt.txt"
+    excerpt.write_bytes(open(rc.EREWHON, "rb").read()[20000:26000])
+    noise = tmp_path / "noise.txt"
+    noise.write_bytes(bytes(np.random.default_rng(0).choice(list(b"zqxj;:()_"), 3000).astype(np.uint8)))
+    r = subprocess.run([os.path.join(build, "text_cross_entropy_amd"), "-f", net, "-i", "10", str(excerpt), str(noise)],
+                       capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = dict(line.rsplit(" ", 1) for line in r.stdout.strip().splitlines())
+    english, junk = float(rows[str(excerpt)]), float(rows[str(noise)])
+    assert 1.0 < english < 5.0 and junk > english + 1.0        # a 600-generation net already knows English from junk
+    # the same number through the library in-process (alphabet from the net's metadata)
+    lib = rc.bind_char(rc.load_amd())
+    n = lib.rnn_load_net(net.encode())
+    a = lib.rnn_char_new_alphabet_from_net(n)
+    assert a.contents.len == 42 and a.contents.flags == (rc.CHAR_CASE_INSENSITIVE | rc.CHAR_COLLAPSE_SPACE)
+    raw = excerpt.read_bytes()
+    ln = C.c_int(0)
+    enc = lib.rnn_char_alloc_encoded_text(a, raw, len(raw), C.byref(ln), None, False)
+    got = lib.rnn_char_cross_entropy(n, a, enc, ln.value, 10, None, 0)
+    assert abs(got - english) < 1e-4
+    lib.rnn_char_free_alphabet(a)
+    lib.rnn_delete_net(n)
+    # sampling: deterministic for a seed, only alphabet characters, the requested length
+    runs = [subprocess.run([os.path.join(build, "text_confabulate_amd"), "-f", net, "-n", "80", "-B", "1.5", "-r", "7",
+                            "-p", "the "], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+            for _ in range(2)]
+    assert all(x.returncode == 0 for x in runs), runs[0].stderr[-2000:]
+    out = runs[0].stdout.rstrip("\n")
+    assert out == runs[1].stdout.rstrip("\n") and len(out) == 80
+    assert set(out.encode()) <= set(rc.DEFAULT_CHARSET)

@@ -16,7 +16,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <math.h>
 #include <time.h>
 #include <unistd.h>
 #include "recur-nn.h"
@@ -24,61 +23,17 @@
 
 #define DEFAULT_CHARSET "8 etaonihsrdlucmwfygpb,v.k-;x\"qj'?:z)(_!*&" /* text-predict.c:44 */
 
-/* badmaths.h:14-29 and 71-111: the caller-side softmax of get_cross_entropy */
-static float fast_expf(float x) {
-  int count = 0;
-  while (fabsf(x) > 0.2) {
-    x *= 0.125;
-    count++;
-  }
-  float a = ((x + 3) * (x + 3) + 3) / ((x - 3) * (x - 3) + 3);
-  for (; count; count--) {
-    a *= a;
-    a *= a;
-    a *= a;
-  }
-  return a;
-}
+#define DEFAULT_COLLAPSE_CHARS "10872}{659/34][@"                    /* text-predict.c:45 */
 
-static void softmax(float *dest, const float *src, int len) {
-  float lo = src[0], hi = src[0], adj = 0, sum = 0;
-  for (int i = 1; i < len; i++) {
-    hi = src[i] > hi ? src[i] : hi;
-    lo = src[i] < lo ? src[i] : lo;
-  }
-  if (hi > 50.0f) {
-    adj = 50.0f - hi;
-  } else if (lo < -60.0f) {
-    adj = (-60.0f - lo) < (50.0f - hi) ? (-60.0f - lo) : (50.0f - hi);
-  }
-  for (int i = 0; i < len; i++) {
-    dest[i] = fast_expf(src[i] + adj);
-    sum += dest[i];
-  }
-  for (int i = 0; i < len; i++) {
-    dest[i] /= sum;
-  }
-}
-
-/* get_cross_entropy (charmodel-predict.c:62-80) on a forward-only clone */
-static double cross_entropy(RecurNN *net, const u8 *text, int len, int skip) {
+/* the validation pass of text-predict (text-predict.c:538-541, charmodel-predict.c:62-80):
+ * a forward-only clone that borrows the weights, run over the text on the device */
+static double cross_entropy(RecurNN *net, RnnCharAlphabet *alphabet, const u8 *text, int len,
+                            int skip) {
   RecurNN *v = rnn_clone(net, net->flags & ~(RNN_NET_FLAG_OWN_BPTT | RNN_NET_FLAG_OWN_WEIGHTS),
                          RECUR_RNG_SUBSEED, NULL);
-  float *p = malloc(sizeof(float) * v->o_size);
-  double entropy = 0;
-  for (int i = 0; i < len - 1; i++) {
-    memset(v->real_inputs, 0, v->input_size * sizeof(float));
-    v->real_inputs[text[i]] = 1.0f;
-    float *answer = rnn_opinion(v, NULL, 0);
-    if (i >= skip) {
-      softmax(p, answer, v->output_size);
-      float e = p[text[i + 1]];
-      entropy += (e < 1e-30f) ? -100.0f : log2f(e);
-    }
-  }
-  free(p);
+  double entropy = rnn_char_cross_entropy(v, alphabet, text, len, skip, NULL, 0);
   rnn_delete_net(v);
-  return entropy / -(len - skip - 1);
+  return entropy;
 }
 
 int main(int argc, char **argv) {
@@ -145,7 +100,7 @@ int main(int argc, char **argv) {
       rnn_amd_set_read_stats(set, &st, 1);
       clock_gettime(CLOCK_MONOTONIC, &t1);
       double secs = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
-      double v = cross_entropy(net, vtext, validate, 5);
+      double v = cross_entropy(net, alphabet, vtext, validate, 5);
       printf("generation %6u t_entropy %.4f v_entropy %.4f accuracy %.3f depth %.1f  %.0f/s\n",
              net->generation, -st.entropy / st.count, v, (double)st.correct / st.count,
              st.bptt_depth_sum / st.count, st.count / secs);
@@ -154,6 +109,11 @@ int main(int argc, char **argv) {
     }
   }
   if (save) {
+    /* the alphabet travels in the net's metadata (text-predict.c:486-497), which is what
+     * text_cross_entropy_amd and text_confabulate_amd rebuild it from */
+    struct RnnCharMetadata m = {DEFAULT_CHARSET, DEFAULT_COLLAPSE_CHARS, 0, 1, 1};
+    free(net->metadata);
+    net->metadata = rnn_char_construct_metadata(&m);
     if (rnn_save_net(net, save, 1)) {
       return 1;
     }
