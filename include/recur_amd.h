@@ -395,6 +395,18 @@ void rnn_amd_set_softmax_error(RnnAmdSet *set, const int *target);
 void rnn_amd_set_calc_deltas(RnnAmdSet *set, int accumulate,
                              RecurErrorRange *top_error_ranges, const u8 *active);
 
+/* One generation of the multi-head text model (charmodel-multi-predict.c:17-58, 244-256) for
+ * every stream of the set: rnn_bptt_advance, a one-hot opinion of hot[j] with the net's
+ * presynaptic noise, the multi-head softmax error against next[j] -- the head
+ * target_class[j] always, every other head with probability `leakage` drawn from the
+ * stream's own generator --, and rnn_bptt_calc_deltas with the error ranges that loss
+ * produces.  accumulate applies to the first stream; the others accumulate.  The output
+ * layer is output_size / alphabet_len heads (at most 64).  Loss statistics of the own
+ * head go to the accumulators rnn_amd_set_read_stats reads (error, entropy, count). */
+void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *next,
+                                   const int *target_class, int alphabet_len, float leakage,
+                                   int accumulate);
+
 /* Text on the device, for a host-free epoch loop (charmodel-predict.c:288-311). */
 void rnn_amd_set_load_text(RnnAmdSet *set, const u8 *text, int len);
 /* One generation of rnn_char_epoch's multi-tap branch for text position i:

@@ -475,6 +475,47 @@ float orc_net_error_bptt(OrcSet *z, int s, int c, int next, int *correct) {
   return error[next];
 }
 
+/* multi_softmax_error (charmodel-multi-predict.c:17-58): opinion, then every class head
+ * of alphabet_len outputs is either trained (its own head always, the others when a draw
+ * from the stream's generator falls under leakage) or left at zero; ranges_out receives
+ * the merged, aligned (start, len) pairs and the terminator.  Returns the own head's
+ * error on the next symbol. */
+float orc_multi_softmax_error(OrcSet *z, int s, int c, int next, int target_class,
+                              int alphabet_len, float leakage, int *ranges_out) {
+  float *error = z->o_error + (size_t)s * z->O;
+  float *answer = orc_one_hot_opinion(z, s, c, z->presynaptic_noise);
+  int n_classes = z->output_size / alphabet_len;
+  float err = 0;
+  int j = 0;
+  uint64_t threshold = leakage * UINT64_MAX;
+  memset(error, 0, z->output_size * sizeof(float));
+  for (int i = 0; i < n_classes; i++) {
+    int offset = i * alphabet_len;
+    if (i == target_class || orc_rand64(&z->rng[s]) < threshold) {
+      orc_softmax_best_guess(error + offset, answer + offset, alphabet_len);
+      error[offset + next] += 1.0f;
+      if (i == target_class) {
+        err = error[offset + next];
+      }
+      int range_start = offset & ~3;
+      int range_end = (offset + alphabet_len + 3) & ~3;
+      if (j) {
+        int pstart = ranges_out[2 * (j - 1)], plen = ranges_out[2 * (j - 1) + 1];
+        if (pstart + plen >= range_start) {
+          ranges_out[2 * (j - 1) + 1] = range_end - pstart;
+          continue;
+        }
+      }
+      ranges_out[2 * j] = range_start;
+      ranges_out[2 * j + 1] = range_end - range_start;
+      j++;
+    }
+  }
+  ranges_out[2 * j] = -1;
+  ranges_out[2 * j + 1] = 0;
+  return err;
+}
+
 /* get_cross_entropy (charmodel-predict.c:62-80) */
 double orc_cross_entropy(OrcSet *z, int s, const uint8_t *text, int len, int skip) {
   float *error = malloc(sizeof(float) * z->output_size);

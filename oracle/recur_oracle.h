@@ -120,6 +120,9 @@ void orc_advance(OrcSet *set, int s);                                 /* recur-n
 float *orc_opinion(OrcSet *set, int s, const float *inputs, float noise); /* recur-nn.c:83-154 */
 float *orc_one_hot_opinion(OrcSet *set, int s, int hot, float noise); /* charmodel-helpers.h:16-33 */
 float orc_net_error_bptt(OrcSet *set, int s, int c, int next, int *correct); /* charmodel-predict.c:18-27 */
+/* charmodel-multi-predict.c:17-58; ranges_out: room for n_classes + 1 pairs */
+float orc_multi_softmax_error(OrcSet *set, int s, int c, int next, int target_class,
+                              int alphabet_len, float leakage, int *ranges_out);
 /* ranges: pairs (start, len) ending with start < 0, or NULL */
 void orc_calc_deltas(OrcSet *set, int s, int accumulate, const int *ranges); /* recur-nn.c:707-772 */
 void orc_clear_deltas(OrcSet *set);                                    /* recur-nn.c:681-693 */

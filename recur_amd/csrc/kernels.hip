@@ -1094,6 +1094,82 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0) {
   }
 }
 
+// multi_softmax_error (charmodel-multi-predict.c:17-58) after the opinion: the output row is
+// n_classes heads of alphabet_len symbols.  The head of the stream's own class is always
+// trained; every other head with probability `leakage`, decided by a draw from the
+// stream's generator (none for the own head: the || short-circuits).  A trained head gets
+// -softmax with +1 on the next symbol; the others stay zero.  The (start, len) ranges
+// the reference builds for rnn_bptt_calc_deltas -- aligned, merged when they touch -- are
+// left in ranges[j].  One wave per stream; every lane runs the generator redundantly so
+// that the decisions are uniform.
+__global__ __launch_bounds__(64) void k_multi_softmax_error(View v, int row0, int alen, int ncls,
+                                                            unsigned long long threshold,
+                                                            const int *tclass, int *ranges,
+                                                            int range_stride) {
+  extern __shared__ float ex[]; /* [alen] */
+  const RamdShape &s = v.sh;
+  const int j = blockIdx.x, r = row0 + j, lane = threadIdx.x;
+  const float *src = v.b.out + (size_t)r * s.O;
+  float *err = v.b.o_error + (size_t)r * s.O;
+  for (int i = lane; i < s.output_size; i += 64) err[i] = 0.0f;
+  const int next = v.b.target[r], own = tclass[j];
+  int *rg = ranges + (size_t)j * range_stride;
+  DevRng g = reinterpret_cast<DevRng *>(v.b.rng)[r];
+  int nr = 0, prev_start = 0, prev_len = 0;
+  float own_err = 0.0f;
+  for (int c = 0; c < ncls; c++) {
+    const int offset = c * alen;
+    bool train = (c == own);
+    if (!train) train = dev_rand64(g) < threshold;
+    if (!train) continue;
+    const float *gs = src + offset;
+    float lo = gs[0], hi = gs[0];
+    for (int i = lane; i < alen; i += 64) {
+      hi = fmaxf(hi, gs[i]);
+      lo = fminf(lo, gs[i]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+      lo = fminf(lo, __shfl_xor(lo, off, 64));
+    }
+    float adj = 0.0f;
+    if (hi > 50.0f) adj = 50.0f - hi;
+    else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+    __syncthreads();
+    for (int i = lane; i < alen; i += 64) ex[i] = fast_expf_dev(gs[i] + adj);
+    __syncthreads();
+    float sum = 0.0f;
+    for (int i = 0; i < alen; i++) sum += ex[i];
+    for (int i = lane; i < alen; i += 64) {
+      float e = ex[i] / sum;
+      err[offset + i] = (i == next) ? -e + 1.0f : -e;
+    }
+    if (c == own) own_err = -(ex[next] / sum) + 1.0f;
+    int start = offset & ~3, end = (offset + alen + 3) & ~3;
+    if (nr && prev_start + prev_len >= start) {
+      prev_len = end - prev_start;
+      if (lane == 0) rg[2 * (nr - 1) + 1] = prev_len;
+    } else {
+      prev_start = start;
+      prev_len = end - start;
+      if (lane == 0) {
+        rg[2 * nr] = prev_start;
+        rg[2 * nr + 1] = prev_len;
+      }
+      nr++;
+    }
+  }
+  if (lane == 0) {
+    rg[2 * nr] = -1;
+    rg[2 * nr + 1] = 0;
+    reinterpret_cast<DevRng *>(v.b.rng)[r] = g;
+    float l = 1.0f - own_err;
+    v.b.stat_err[r] += own_err;
+    v.b.stat_ent[r] += (l < 1e-30f) ? -100.0f : log2f(l);
+    v.b.stat_count[r] += 1;
+  }
+}
+
 // get_cross_entropy's inner step (charmodel-predict.c:71-76): softmax of one state
 // row's outputs (badmaths.h:71-111, sums in the reference's order), the probability of
 // the row's target symbol, capped_log2f of it added to the row's running total.
@@ -1131,12 +1207,14 @@ __global__ __launch_bounds__(64) void k_xent_accumulate(View v, int r, int count
 // 719-721).  One workgroup per stream.  Writes the (scaled) error both to
 // ehi[0] (what the BPTT chain reads) and leaves err_a for the lazy write-back.
 __global__ __launch_bounds__(256) void k_top_backprop(View v, int row0, const int *ranges,
+                                                      int range_stride,
                                                       const unsigned char *active) {
   extern __shared__ float sh[];
   __shared__ float red[4];
   const RamdShape &s = v.sh;
   int j = blockIdx.x, r = row0 + j;
   if (active && !active[j]) return;
+  if (ranges) ranges += (size_t)j * range_stride; /* 0: one list for every stream */
   float *oerr = sh;          /* [O] */
   float *herr = sh + s.O;    /* [H] */
   for (int i = threadIdx.x; i < s.O; i += 256) oerr[i] = v.b.o_error[(size_t)r * s.O + i];
@@ -2269,6 +2347,17 @@ extern "C" void ramd_launch_xent_accumulate(ramd_stream_t st_, const RamdShape *
                      st, v, row, count_it);
 }
 
+extern "C" void ramd_launch_multi_softmax_error(ramd_stream_t st_, const RamdShape *sh,
+                                                const RamdBuffers *b, int row0, int nrows,
+                                                int alphabet_len, int n_classes,
+                                                unsigned long long threshold, const int *tclass,
+                                                int *ranges, int range_stride) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  hipLaunchKernelGGL(k_multi_softmax_error, dim3(nrows), dim3(64), (size_t)alphabet_len * sizeof(float),
+                     st, v, row0, alphabet_len, n_classes, threshold, tclass, ranges, range_stride);
+}
+
 extern "C" void ramd_launch_clear_deltas(ramd_stream_t st_, const RamdShape *sh,
                                          const RamdBuffers *b) {
   hipStream_t st = (hipStream_t)st_;
@@ -2284,14 +2373,15 @@ extern "C" void ramd_launch_clear_deltas(ramd_stream_t st_, const RamdShape *sh,
 
 extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
                                         const RamdBuffers *b, int row0, int nrows, int accumulate,
-                                        const int *ranges, const unsigned char *active,
-                                        unsigned flags) {
+                                        const int *ranges, int range_stride,
+                                        const unsigned char *active, unsigned flags) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   // top layer
   size_t shm = (size_t)(sh->O + sh->H) * sizeof(float);
   if (!(flags & 0x40000000u)) /* ramd_launch_text_top has already done the top backprop */
-    hipLaunchKernelGGL(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges, active);
+    hipLaunchKernelGGL(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges,
+                       range_stride, active);
   if (!(flags & 0x80000000u)) { /* the fused single-net path updates W_ho directly */
     int tm = (sh->H + BM - 1) / BM, tn = (sh->O + BN - 1) / BN;
     int nkt = (nrows + BK - 1) / BK;
@@ -2307,8 +2397,10 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     }
     ProbHoDelta p = {v, row0, nrows, live};
     launch_gemm<true, true, ProbHoDelta>(st, p, b->slab, sh->H, sh->O, nkt, ks, T_OTHER);
+    /* with one range list per stream the set of touched columns differs per stream; the
+     * error is zero outside a stream's own ranges, so every column may take its sum */
     hipLaunchKernelGGL(k_ho_delta_finalize, dim3((ho + 255) / 256), dim3(256), 0, st, v, b->slab,
-                       ks, accumulate, ranges);
+                       ks, accumulate, range_stride ? nullptr : ranges);
   }
   // BPTT chain: D dependent steps, one launch each, then the extras of all steps
   const int tn = (sh->hidden_size + CN - 1) / CN;

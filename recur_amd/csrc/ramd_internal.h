@@ -134,7 +134,15 @@ void ramd_launch_xent_accumulate(ramd_stream_t st, const RamdShape *sh, const Ra
  * first.  This is rnn_bptt_calc_deltas (recur-nn.c:707-772) for the rows. */
 void ramd_launch_calc_deltas(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                              int row0, int nrows, int accumulate, const int *ranges,
-                             const unsigned char *active, unsigned flags);
+                             int range_stride, const unsigned char *active, unsigned flags);
+/* multi_softmax_error (charmodel-multi-predict.c:17-58) for rows whose opinion has been
+ * formed: b->target holds each stream's next symbol, tclass[j] its own class head;
+ * writes o_error and, per stream, the merged (start, len) range list (terminated by
+ * start < 0) at ranges + j * range_stride */
+void ramd_launch_multi_softmax_error(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
+                                     int row0, int nrows, int alphabet_len, int n_classes,
+                                     unsigned long long threshold, const int *tclass, int *ranges,
+                                     int range_stride);
 /* rebuilds err_a / err_b (bptt->h_error, i_error) from ehi after a calc_deltas */
 void ramd_launch_err_writeback(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                                int row0, int nrows);

@@ -156,6 +156,9 @@ static void engine_free_device(RamdEngine *e) {
   dev_free(b->bw); dev_free(b->bm); dev_free(b->baux); dev_free(b->bdelta);
   dev_free(b->binp); dev_free(b->bout); dev_free(b->berr); dev_free(b->bcarry);
   dev_free(e->d_scratch); dev_free(e->d_ranges); dev_free(e->d_dense);
+  dev_free(e->d_mranges); dev_free(e->d_mclass);
+  e->d_mranges = NULL;
+  e->d_mclass = NULL;
   free(e->lr_pushed);
   e->lr_pushed = NULL;
   memset(b, 0, sizeof(*b));
@@ -1145,7 +1148,7 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
     err_flush(e);
   }
   set_uniform_idx(e, j, 1);
-  ramd_launch_calc_deltas(g_stream, s, &e->b, j, 1, accumulate, d_ranges, NULL,
+  ramd_launch_calc_deltas(g_stream, s, &e->b, j, 1, accumulate, d_ranges, 0, NULL,
                           net->flags | (fused ? 0x80000000u : 0));
   if (s->bI && !fused) { /* the fused path passes no bottom error (recur-nn.c:972, 986) */
     if (accumulate) {
@@ -1595,33 +1598,38 @@ void rnn_amd_set_softmax_error(RnnAmdSet *set, const int *target) {
 }
 
 static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ranges,
-                            const u8 *active, unsigned extra_flags);
+                            const u8 *active, unsigned extra_flags, const int *dev_ranges,
+                            int range_stride);
 
 void rnn_amd_set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ranges,
                              const u8 *active) {
-  set_calc_deltas(set, accumulate, ranges, active, 0);
+  set_calc_deltas(set, accumulate, ranges, active, 0, NULL, 0);
 }
 
+/* dev_ranges: one range list per stream already on the device (range_stride ints apart),
+ * instead of the shared host list `ranges` */
 static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ranges,
-                            const u8 *active, unsigned extra_flags) {
+                            const u8 *active, unsigned extra_flags, const int *dev_ranges,
+                            int range_stride) {
   RamdEngine *e = set->eng;
   set_need_training(set, "rnn_amd_set_calc_deltas");
   engine_need_dev(e, RNN_AMD_WEIGHTS | (accumulate ? RNN_AMD_DELTAS : 0));
   set_streams_to_dev(set);
   push_learn_rates(e, set->row0, set->n);
-  const int *d_ranges = push_ranges(e, ranges);
+  const int *d_ranges = dev_ranges ? dev_ranges : push_ranges(e, ranges);
   const unsigned char *d_active = NULL;
   if (active) {
     h2d(e->b.active, active, set->n);
     dsync();
     d_active = e->b.active;
   }
-  if (e->err_pending && (ranges || e->err_row0 != set->row0 || e->err_nrows != set->n)) {
+  if (e->err_pending && (d_ranges || e->err_row0 != set->row0 || e->err_nrows != set->n)) {
     err_flush(e);
   }
   set_uniform_idx(e, set->row0, set->n);
   ramd_launch_calc_deltas(g_stream, &e->sh, &e->b, set->row0, set->n, accumulate, d_ranges,
-                          d_active, set->nets[0]->flags | extra_flags);
+                          dev_ranges ? range_stride : 0, d_active,
+                          set->nets[0]->flags | extra_flags);
   if (e->sh.bI) {
     if (set->global_count != set->n || e->delta_external) {
       fprintf(stderr, "librecur_amd: a bottom layer cannot be trained on a sharded set: its "
@@ -1648,6 +1656,40 @@ static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ran
   }
 }
 
+/* One generation of the multi-head text model for the whole set: what
+ * charmodel-multi-predict.c:244-256 does per net (rnn_bptt_advance, multi_softmax_error
+ * with its one_hot_opinion, rnn_bptt_calc_deltas with the error ranges), stream j
+ * accumulating on top of stream j - 1. */
+void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *next,
+                                   const int *target_class, int alphabet_len, float leakage,
+                                   int accumulate) {
+  RamdEngine *e = set->eng;
+  set_need_training(set, "rnn_amd_set_multi_step_deltas");
+  const RamdShape *s = &e->sh;
+  int n_classes = s->output_size / alphabet_len;
+  if (alphabet_len < 1 || n_classes < 1 || n_classes > 64) {
+    fprintf(stderr, "librecur_amd: %d outputs as heads of %d: 1 to 64 heads are supported\n",
+            s->output_size, alphabet_len);
+    abort();
+  }
+  const int stride = 2 * (64 + 1);
+  if (!e->d_mranges) {
+    e->d_mranges = dev_alloc((size_t)s->Scap * stride * sizeof(int));
+    e->d_mclass = dev_alloc((size_t)s->Scap * sizeof(int));
+  }
+  h2d(e->b.hot + set->row0, hot, set->n * sizeof(int));
+  h2d(e->b.target + set->row0, next, set->n * sizeof(int));
+  h2d(e->d_mclass, target_class, set->n * sizeof(int));
+  dsync();
+  set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, NULL, 1, 0);
+  /* u64 threshold = leakage * UINT64_MAX (charmodel-multi-predict.c:27): float arithmetic */
+  float tf = leakage * (float)UINT64_MAX;
+  unsigned long long threshold = tf >= 18446744073709551615.0f ? UINT64_MAX : (unsigned long long)tf;
+  ramd_launch_multi_softmax_error(g_stream, s, &e->b, set->row0, set->n, alphabet_len, n_classes,
+                                  threshold, e->d_mclass, e->d_mranges, stride);
+  set_calc_deltas(set, accumulate, NULL, NULL, 0, e->d_mranges, stride);
+}
+
 void rnn_amd_set_load_text(RnnAmdSet *set, const u8 *text, int len) {
   RamdEngine *e = set->eng;
   dsync();
@@ -1668,11 +1710,11 @@ void rnn_amd_set_char_step_deltas(RnnAmdSet *set, int i) {
     /* advance + hidden layer, then output layer, loss and top backprop in one launch */
     set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 1);
     ramd_launch_text_top(g_stream, &e->sh, &e->b, set->row0, set->n);
-    set_calc_deltas(set, 0, NULL, NULL, RAMD_TOP_DONE);
+    set_calc_deltas(set, 0, NULL, NULL, RAMD_TOP_DONE, NULL, 0);
   } else {
     set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 0); /* advance + one-hot opinion */
     ramd_launch_softmax_error(g_stream, &e->sh, &e->b, set->row0, set->n);
-    set_calc_deltas(set, 0, NULL, NULL, 0);
+    set_calc_deltas(set, 0, NULL, NULL, 0, NULL, 0);
   }
 }
 

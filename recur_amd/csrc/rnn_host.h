@@ -48,6 +48,8 @@ typedef struct RamdEngine {
   /* device scratch */
   void *d_scratch;      /* 256 (value,index) pairs for tall poppy + ranges */
   int *d_ranges;        /* up to 64 (start,len) pairs                       */
+  int *d_mranges;       /* [Scap][65] pairs: one range list per stream (multi-head loss) */
+  int *d_mclass;        /* [Scap] each stream's own class head                */
   float *d_dense;       /* staging for dense inputs, [Scap+Fcap][input_size] */
   float *delta_own;     /* library-owned ih_delta||ho_delta                */
   int delta_external;

@@ -483,3 +483,44 @@ def test_text_tools_train_save_score_and_sample(tmp_path):
     out = runs[0].stdout.rstrip("\n")
     assert out == runs[1].stdout.rstrip("\n") and len(out) == 80
     assert set(out.encode()) <= set(rc.DEFAULT_CHARSET)
+
+
+@pytest.mark.parametrize("leakage,noise", [(0.0, 0.0), (0.35, 0.0), (0.9, 0.02)])
+def test_multi_head_generation_matches_oracle(amd, leakage, noise):
+    """BASELINE.json configs[3] shape class (charmodel multi-head): the output layer is n_classes
+    heads of alphabet_len symbols, each stream trains its own head and, with probability
+    `leakage`, the others (charmodel-multi-predict.c:17-58), and the top layer is back-propagated
+    through the per-stream error ranges that loss produces (recur-nn.c:156-196, 275-301,
+    including the stale-entry behaviour of the sparse path).  The batched device step against
+    the oracle's per-stream restatement; generator states bit-exact (they decide the leakage).
+    The restatement of multi_softmax_error itself is not pinned by the reference (that file needs
+    the generated path.h); its parts are (softmax, generator, ranged calc_deltas)."""
+    lib = amd
+    A, NC, S, D = 10, 5, 6, 6
+    kw = dict(input_size=A, hidden_size=40, output_size=A * NC, S=S, D=D, learn_rate=3e-3, seed=41, noise=noise,
+              activation=rc.RESQRT)
+    g = sc.AmdBatchedSet(lib, **kw)
+    o = sc.OracleSet(**kw)
+    rs = np.random.default_rng(17)
+    ranges = (C.c_int * (2 * (NC + 1)))()
+    for step in range(12):
+        hot = rs.integers(0, A, S).astype(np.int32)
+        nxt = rs.integers(0, A, S).astype(np.int32)
+        cls = rs.integers(0, NC, S).astype(np.int32)
+        lib.rnn_amd_set_multi_step_deltas(g.handle, rc.iptr(hot), rc.iptr(nxt), rc.iptr(cls), A, leakage, 0)
+        lib.rnn_apply_learning(g.net, rc.NESTEROV if step % 2 else rc.WEIGHTED, 0.9)
+        for j in range(S):
+            o.orc.orc_advance(o.z, j)
+            o.orc.orc_multi_softmax_error(o.z, j, int(hot[j]), int(nxt[j]), int(cls[j]), A, leakage, ranges)
+            o.orc.orc_calc_deltas(o.z, j, 1 if j else 0, ranges)
+        o.orc.orc_apply_learning(o.z, rc.NESTEROV if step % 2 else rc.WEIGHTED, 0.9)
+    sg, so = g.snapshot(), o.snapshot()
+    assert np.array_equal(sg["hidden"] != 0, so["hidden"] != 0)
+    replay.check(sg, so, RTOL, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "output",
+                                     "hist", "o_error", "min_error_factor", "ih_scale"],
+                 exact=("index", "generation", "rng"))
+    if leakage == 0.35:       # some, not all, foreign heads were trained in the last generation
+        trained = (np.abs(so["o_error"]).reshape(S, -1)[:, :A * NC].reshape(S, NC, A).sum(axis=2) > 0).sum(axis=1)
+        assert trained.min() >= 1 and trained.max() > 1 and trained.min() < NC
+    g.close()
+    o.close()
