@@ -395,6 +395,19 @@ void rnn_amd_set_softmax_error(RnnAmdSet *set, const int *target);
 void rnn_amd_set_calc_deltas(RnnAmdSet *set, int accumulate,
                              RecurErrorRange *top_error_ranges, const u8 *active);
 
+/* The loss of gstclassify's train_channel (gstclassify.c:2070-2119) for every stream, on
+ * the device, after an rnn_amd_set_opinion: the outputs are n_groups class groups
+ * (group i = outputs [group_offset[i], group_offset[i] + group_size[i])); for stream j and
+ * group i with 0 <= targets[j * n_groups + i] < group_size[i] the group's error becomes
+ * -softmax with +1 on the target, otherwise zeros (the caller passes -1 where the reference
+ * skips a group: unknown target, ignored windows, the balanced-sampling draw); if any group
+ * of a stream was trained its whole error row is multiplied by error_weight (may be NULL).
+ * trained[j] (may be NULL) receives whether stream j has anything to back-propagate: pass
+ * it to rnn_amd_set_calc_deltas as the active mask.  Wins, wrongness and trained groups
+ * add to the correct / error / count accumulators of rnn_amd_set_read_stats. */
+void rnn_amd_set_grouped_softmax_error(RnnAmdSet *set, int n_groups, const int *group_offset,
+                                       const int *group_size, const int *targets,
+                                       const float *error_weight, u8 *trained);
 /* One generation of the multi-head text model (charmodel-multi-predict.c:17-58, 244-256) for
  * every stream of the set: rnn_bptt_advance, a one-hot opinion of hot[j] with the net's
  * presynaptic noise, the multi-head softmax error against next[j] -- the head

@@ -475,6 +475,36 @@ float orc_net_error_bptt(OrcSet *z, int s, int c, int next, int *correct) {
   return error[next];
 }
 
+/* the loss of train_channel (gstclassify.c:2070-2119) after the opinion; returns the
+ * number of groups trained */
+int orc_grouped_softmax_error(OrcSet *z, int s, int n_groups, const int *group_offset,
+                              const int *group_size, const int *targets, const float *weight,
+                              int *wins, float *wrongness) {
+  float *error = z->o_error + (size_t)s * z->O;
+  const float *answer = z->output + (size_t)s * z->O;
+  int trained = 0;
+  for (int i = 0; i < n_groups; i++) {
+    int o = group_offset[i], n = group_size[i], target = targets[i];
+    if (target < 0 || target >= n) {
+      for (int j = 0; j < n; j++) {
+        error[o + j] = 0;
+      }
+      continue;
+    }
+    int winner = orc_softmax_best_guess(error + o, answer + o, n);
+    *wins += winner == target;
+    error[o + target] += 1.0f;
+    *wrongness += error[o + target];
+    trained++;
+  }
+  if (trained && weight) {
+    for (int i = 0; i < z->output_size; i++) {
+      error[i] *= weight[i];
+    }
+  }
+  return trained;
+}
+
 /* multi_softmax_error (charmodel-multi-predict.c:17-58): opinion, then every class head
  * of alphabet_len outputs is either trained (its own head always, the others when a draw
  * from the stream's generator falls under leakage) or left at zero; ranges_out receives

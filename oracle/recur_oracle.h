@@ -120,6 +120,10 @@ void orc_advance(OrcSet *set, int s);                                 /* recur-n
 float *orc_opinion(OrcSet *set, int s, const float *inputs, float noise); /* recur-nn.c:83-154 */
 float *orc_one_hot_opinion(OrcSet *set, int s, int hot, float noise); /* charmodel-helpers.h:16-33 */
 float orc_net_error_bptt(OrcSet *set, int s, int c, int next, int *correct); /* charmodel-predict.c:18-27 */
+/* gstclassify.c:2070-2119 after the opinion; targets[i] < 0: group i is not trained */
+int orc_grouped_softmax_error(OrcSet *set, int s, int n_groups, const int *group_offset,
+                              const int *group_size, const int *targets, const float *weight,
+                              int *wins, float *wrongness);
 /* charmodel-multi-predict.c:17-58; ranges_out: room for n_classes + 1 pairs */
 float orc_multi_softmax_error(OrcSet *set, int s, int c, int next, int target_class,
                               int alphabet_len, float leakage, int *ranges_out);

@@ -1170,6 +1170,79 @@ __global__ __launch_bounds__(64) void k_multi_softmax_error(View v, int row0, in
   }
 }
 
+// train_channel's loss (gstclassify.c:2070-2119) for every stream: the output row is a
+// few class groups; a group whose target is valid gets -softmax with +1 on the target,
+// the others zeros; if any group was trained the whole error row is multiplied by the
+// per-output error weights.  One wave per stream.  gt[j * ngroups + i] < 0 (or out of
+// range) = "no training for this group" -- the caller decides that (target unknown,
+// ignored windows, the balanced-sampling draw), as the reference's caller does.
+__global__ __launch_bounds__(64) void k_grouped_softmax_error(View v, int row0, int ngroups,
+                                                              const int *goff, const int *gsize,
+                                                              const int *gt, const float *weight) {
+  extern __shared__ float ex[]; /* [largest group] */
+  const RamdShape &s = v.sh;
+  const int j = blockIdx.x, r = row0 + j, lane = threadIdx.x;
+  const float *src = v.b.out + (size_t)r * s.O;
+  float *err = v.b.o_error + (size_t)r * s.O;
+  int trained = 0, wins = 0;
+  float wrong = 0.0f;
+  for (int i = 0; i < ngroups; i++) {
+    const int o = goff[i], n = gsize[i], target = gt[(size_t)j * ngroups + i];
+    if (target < 0 || target >= n) {
+      for (int q = lane; q < n; q += 64) err[o + q] = 0.0f;
+      continue;
+    }
+    const float *gs = src + o;
+    float lo = gs[0], hi = gs[0];
+    for (int q = lane; q < n; q += 64) {
+      hi = fmaxf(hi, gs[q]);
+      lo = fminf(lo, gs[q]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+      lo = fminf(lo, __shfl_xor(lo, off, 64));
+    }
+    float adj = 0.0f;
+    if (hi > 50.0f) adj = 50.0f - hi;
+    else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+    __syncthreads();
+    for (int q = lane; q < n; q += 64) ex[q] = fast_expf_dev(gs[q] + adj);
+    __syncthreads();
+    float sum = 0.0f;
+    for (int q = 0; q < n; q++) sum += ex[q];
+    float best_e = -1.0f;
+    int best_i = 0x7fffffff;
+    for (int q = lane; q < n; q += 64) {
+      float e = ex[q] / sum;
+      err[o + q] = (q == target) ? -e + 1.0f : -e;
+      if (e > best_e) {
+        best_e = e;
+        best_i = q;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      float oe = __shfl_xor(best_e, off, 64);
+      int oi = __shfl_xor(best_i, off, 64);
+      if (oe > best_e || (oe == best_e && oi < best_i)) {
+        best_e = oe;
+        best_i = oi;
+      }
+    }
+    wins += (best_i == target);
+    wrong += -(ex[target] / sum) + 1.0f;
+    trained++;
+  }
+  if (trained && weight) {
+    __syncthreads(); /* one wave: its own stores are ordered; this keeps the compiler honest */
+    for (int q = lane; q < s.output_size; q += 64) err[q] *= weight[q];
+  }
+  if (lane == 0 && trained) {
+    v.b.stat_err[r] += wrong;
+    v.b.stat_correct[r] += wins;
+    v.b.stat_count[r] += trained;
+  }
+}
+
 // get_cross_entropy's inner step (charmodel-predict.c:71-76): softmax of one state
 // row's outputs (badmaths.h:71-111, sums in the reference's order), the probability of
 // the row's target symbol, capped_log2f of it added to the row's running total.
@@ -2356,6 +2429,17 @@ extern "C" void ramd_launch_multi_softmax_error(ramd_stream_t st_, const RamdSha
   View v = make_view(sh, b);
   hipLaunchKernelGGL(k_multi_softmax_error, dim3(nrows), dim3(64), (size_t)alphabet_len * sizeof(float),
                      st, v, row0, alphabet_len, n_classes, threshold, tclass, ranges, range_stride);
+}
+
+extern "C" void ramd_launch_grouped_softmax_error(ramd_stream_t st_, const RamdShape *sh,
+                                                  const RamdBuffers *b, int row0, int nrows,
+                                                  int ngroups, int largest, const int *goff,
+                                                  const int *gsize, const int *gt,
+                                                  const float *weight) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  hipLaunchKernelGGL(k_grouped_softmax_error, dim3(nrows), dim3(64), (size_t)largest * sizeof(float), st,
+                     v, row0, ngroups, goff, gsize, gt, weight);
 }
 
 extern "C" void ramd_launch_clear_deltas(ramd_stream_t st_, const RamdShape *sh,

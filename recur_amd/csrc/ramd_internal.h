@@ -135,6 +135,13 @@ void ramd_launch_xent_accumulate(ramd_stream_t st, const RamdShape *sh, const Ra
 void ramd_launch_calc_deltas(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                              int row0, int nrows, int accumulate, const int *ranges,
                              int range_stride, const unsigned char *active, unsigned flags);
+/* train_channel's loss (gstclassify.c:2070-2119): softmax error per class group against
+ * gt[row][group] (< 0: the group is not trained), then the per-output error weights; all
+ * arrays are device pointers, `largest` the largest group size */
+void ramd_launch_grouped_softmax_error(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
+                                       int row0, int nrows, int ngroups, int largest,
+                                       const int *goff, const int *gsize, const int *gt,
+                                       const float *weight);
 /* multi_softmax_error (charmodel-multi-predict.c:17-58) for rows whose opinion has been
  * formed: b->target holds each stream's next symbol, tclass[j] its own class head;
  * writes o_error and, per stream, the merged (start, len) range list (terminated by

@@ -156,7 +156,9 @@ static void engine_free_device(RamdEngine *e) {
   dev_free(b->bw); dev_free(b->bm); dev_free(b->baux); dev_free(b->bdelta);
   dev_free(b->binp); dev_free(b->bout); dev_free(b->berr); dev_free(b->bcarry);
   dev_free(e->d_scratch); dev_free(e->d_ranges); dev_free(e->d_dense);
-  dev_free(e->d_mranges); dev_free(e->d_mclass);
+  dev_free(e->d_mranges); dev_free(e->d_mclass); dev_free(e->d_group);
+  e->d_group = NULL;
+  e->d_group_bytes = 0;
   e->d_mranges = NULL;
   e->d_mclass = NULL;
   free(e->lr_pushed);
@@ -1653,6 +1655,56 @@ static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ran
     log_bptt(e, set->nets[0], set->nets[0]->bptt->min_error_factor);
     pull_scalars(e, set->row0, 1);
     rnn_log_int(set->nets[0], "generation", set->nets[0]->generation);
+  }
+}
+
+/* gstclassify's loss for the whole set (gstclassify.c:2070-2119), see recur_amd.h */
+void rnn_amd_set_grouped_softmax_error(RnnAmdSet *set, int n_groups, const int *group_offset,
+                                       const int *group_size, const int *targets,
+                                       const float *error_weight, u8 *trained) {
+  RamdEngine *e = set->eng;
+  set_need_training(set, "rnn_amd_set_grouped_softmax_error");
+  const RamdShape *s = &e->sh;
+  int largest = 1;
+  for (int i = 0; i < n_groups; i++) {
+    if (group_offset[i] < 0 || group_size[i] < 1 || group_offset[i] + group_size[i] > s->output_size) {
+      fprintf(stderr, "librecur_amd: class group %d (%d + %d) outside the %d outputs\n", i,
+              group_offset[i], group_size[i], s->output_size);
+      abort();
+    }
+    largest = RAMD_MAX(largest, group_size[i]);
+  }
+  set_streams_to_dev(set);
+  /* one staging block: offsets, sizes, targets, then the weights */
+  size_t ints = (size_t)2 * n_groups + (size_t)set->n * n_groups;
+  size_t bytes = ints * sizeof(int) + (error_weight ? (size_t)s->output_size * sizeof(float) : 0);
+  if (bytes > e->d_group_bytes) {
+    dsync();
+    dev_free(e->d_group);
+    e->d_group = dev_alloc(bytes);
+    e->d_group_bytes = bytes;
+  }
+  int *d = (int *)e->d_group;
+  h2d(d, group_offset, n_groups * sizeof(int));
+  h2d(d + n_groups, group_size, n_groups * sizeof(int));
+  h2d(d + 2 * n_groups, targets, (size_t)set->n * n_groups * sizeof(int));
+  float *dw = NULL;
+  if (error_weight) {
+    dw = (float *)(d + ints);
+    h2d(dw, error_weight, (size_t)s->output_size * sizeof(float));
+  }
+  dsync();
+  ramd_launch_grouped_softmax_error(g_stream, s, &e->b, set->row0, set->n, n_groups, largest, d,
+                                    d + n_groups, d + 2 * n_groups, dw);
+  set_streams_dev_wrote(set);
+  if (trained) { /* a stream is trained if any of its groups has a usable target */
+    for (int j = 0; j < set->n; j++) {
+      trained[j] = 0;
+      for (int i = 0; i < n_groups; i++) {
+        int t = targets[(size_t)j * n_groups + i];
+        trained[j] |= (t >= 0 && t < group_size[i]);
+      }
+    }
   }
 }
 

@@ -50,6 +50,8 @@ typedef struct RamdEngine {
   int *d_ranges;        /* up to 64 (start,len) pairs                       */
   int *d_mranges;       /* [Scap][65] pairs: one range list per stream (multi-head loss) */
   int *d_mclass;        /* [Scap] each stream's own class head                */
+  void *d_group;        /* staging of the class-group loss: offsets, sizes, targets, weights */
+  size_t d_group_bytes;
   float *d_dense;       /* staging for dense inputs, [Scap+Fcap][input_size] */
   float *delta_own;     /* library-owned ih_delta||ho_delta                */
   int delta_external;

@@ -236,6 +236,8 @@ AMD_API = {
     "rnn_amd_set_char_step_deltas": (None, [C.c_void_p, C.c_int]),
     "rnn_amd_set_shard": (None, [C.c_void_p, C.c_int, C.c_int]),
     "rnn_amd_run_text": (C.c_double, [NetP, c_u8_p, C.c_int, C.c_int]),
+    "rnn_amd_set_grouped_softmax_error": (None, [C.c_void_p, C.c_int, c_int_p, c_int_p, c_int_p, c_float_p,
+                                                 c_u8_p]),
     "rnn_amd_set_multi_step_deltas": (None, [C.c_void_p, c_int_p, c_int_p, c_int_p, C.c_int, C.c_float, C.c_int]),
     "rnn_amd_synchronize": (None, []),
     "rnn_amd_kernel_time_enable": (None, [C.c_int]),
@@ -358,6 +360,8 @@ ORACLE_API = {
     "orc_one_hot_opinion": (c_float_p, [OrcP, C.c_int, C.c_int, C.c_float]),
     "orc_net_error_bptt": (C.c_float, [OrcP, C.c_int, C.c_int, C.c_int, c_int_p]),
     "orc_calc_deltas": (None, [OrcP, C.c_int, C.c_int, c_int_p]),
+    "orc_grouped_softmax_error": (C.c_int, [OrcP, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, c_float_p,
+                                            c_int_p, c_float_p]),
     "orc_multi_softmax_error": (C.c_float, [OrcP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_int_p]),
     "orc_clear_deltas": (None, [OrcP]),
     "orc_apply_learning": (None, [OrcP, C.c_int, C.c_float]),

@@ -524,3 +524,55 @@ def test_multi_head_generation_matches_oracle(amd, leakage, noise):
         assert trained.min() >= 1 and trained.max() > 1 and trained.min() < NC
     g.close()
     o.close()
+
+
+def test_class_group_loss_on_device_matches_oracle(amd):
+    """gstclassify's train_channel (gstclassify.c:2070-2130) with two class groups, unknown
+    targets for some groups and streams, per-output error weights, Nesterov: opinion, grouped
+    softmax error on the device, calc_deltas over the streams that trained something, advance,
+    one update per generation after rnn_bptt_clear_deltas."""
+    lib = amd
+    S, D, NIN = 8, 5, 12
+    goff, gsize = np.array([0, 3], np.int32), np.array([3, 4], np.int32)
+    kw = dict(input_size=NIN, hidden_size=48, output_size=7, S=S, D=D, learn_rate=3e-3, seed=51)
+    g = sc.AmdBatchedSet(lib, **kw)
+    o = sc.OracleSet(**kw)
+    rs = np.random.default_rng(23)
+    weight = (0.5 + rs.random(7)).astype(np.float32)
+    wins_o, wrong_o, count_o = C.c_int(0), C.c_float(0), 0
+    for step in range(10):
+        x = (rs.standard_normal((S, NIN)) * 0.6).astype(np.float32)
+        targets = np.stack([rs.integers(-1, 3, S), rs.integers(-1, 4, S)], axis=1).astype(np.int32)
+        targets[0] = (1, 2)
+        targets[1] = (-1, -1)                                   # nothing to train for this stream
+        trained = np.zeros(S, np.uint8)
+        lib.rnn_bptt_clear_deltas(g.net)
+        lib.rnn_amd_set_opinion(g.handle, rc.fptr(x), NIN, None)
+        lib.rnn_amd_set_grouped_softmax_error(g.handle, 2, rc.iptr(goff), rc.iptr(gsize), rc.iptr(targets),
+                                              rc.fptr(weight) if step % 2 else None, rc.u8ptr(trained))
+        lib.rnn_amd_set_calc_deltas(g.handle, 1, None, rc.u8ptr(trained))
+        lib.rnn_amd_set_advance(g.handle)
+        lib.rnn_apply_learning(g.net, rc.NESTEROV, 0.9)
+        o.orc.orc_clear_deltas(o.z)
+        for j in range(S):
+            o.orc.orc_opinion(o.z, j, rc.fptr(np.ascontiguousarray(x[j])), 0.0)
+            n = o.orc.orc_grouped_softmax_error(o.z, j, 2, rc.iptr(goff), rc.iptr(gsize),
+                                                rc.iptr(np.ascontiguousarray(targets[j])),
+                                                rc.fptr(weight) if step % 2 else None,
+                                                C.byref(wins_o), C.byref(wrong_o))
+            count_o += n
+            assert bool(n) == bool(trained[j])
+            if n:
+                o.orc.orc_calc_deltas(o.z, j, 1, None)
+            o.orc.orc_advance(o.z, j)
+        o.orc.orc_apply_learning(o.z, rc.NESTEROV, 0.9)
+        assert trained[0] == 1 and trained[1] == 0
+    sg, so = g.snapshot(), o.snapshot()
+    assert np.array_equal(sg["hidden"] != 0, so["hidden"] != 0)
+    replay.check(sg, so, RTOL, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "output",
+                                     "hist", "o_error"], exact=("index", "generation"))
+    st = g.stats()
+    assert st.count == count_o and st.correct == wins_o.value
+    assert abs(st.error - wrong_o.value) < 1e-4 * abs(wrong_o.value)
+    g.close()
+    o.close()
