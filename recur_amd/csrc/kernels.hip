@@ -1617,6 +1617,7 @@ __global__ __launch_bounds__(512) void k_chain_main(View v, int row0, int nrows,
 // the wave walks the non-zero columns (ballot), each dot product is reduced with
 // xor shuffles in a fixed order.  It also closes the step's sum of squares:
 // the column-tile partials of k_chain_main in index order, then the extras.
+template <int MAXQ> /* float4 per lane: 5 covers h_size <= 1280, 8 h_size <= 2048 */
 __global__ __launch_bounds__(256) void k_extras_gather(View v, int row0, int nrows, int nx, int nxp,
                                                        int tn) {
   const RamdShape &s = v.sh;
@@ -1627,7 +1628,6 @@ __global__ __launch_bounds__(256) void k_extras_gather(View v, int row0, int nro
   const float *erow = v.b.ehi + (t * s.Scap + r) * s.I;
   const float *x = input_row<false>(v, r, t);
   float *dst = v.b.ex + ((size_t)(t + 1) * s.Scap + r) * nxp;
-  constexpr int MAXQ = 8; /* float4 per lane: h_size up to 2048 */
   const int nq = (s.H / 4 + 63) / 64;
   float4 ev[MAXQ];
 #pragma unroll
@@ -1643,33 +1643,59 @@ __global__ __launch_bounds__(256) void k_extras_gather(View v, int row0, int nro
     bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
     if (c < nx) dst[c] = 0.0f;
     unsigned long long live = __ballot(on);
+    /* two live columns per round, so that both weight rows are in flight together (a
+     * one-hot text stream has exactly two: the bias row and the symbol's row) */
     while (live) {
-      int l = __ffsll((long long)live) - 1;
+      int la = __ffsll((long long)live) - 1;
       live &= live - 1;
-      int cc = c0 + l;
-      int nn = (cc == 0) ? 0 : s.hidden_size + cc;
-      float xv = __shfl(xi, l, 64);
-      const float *w = v.b.ih_w + nn * s.H;
-      float acc = 0.0f;
+      int lb = live ? __ffsll((long long)live) - 1 : -1;
+      if (lb >= 0) live &= live - 1;
+      int ca = c0 + la, cb = c0 + (lb >= 0 ? lb : la);
+      int na = (ca == 0) ? 0 : s.hidden_size + ca;
+      int nb = (cb == 0) ? 0 : s.hidden_size + cb;
+      float xa = __shfl(xi, la, 64), xb = __shfl(xi, lb >= 0 ? lb : la, 64);
+      const float *wa = v.b.ih_w + na * s.H;
+      const float *wb = v.b.ih_w + nb * s.H;
+      float4 wva[MAXQ], wvb[MAXQ];
 #pragma unroll
       for (int i = 0; i < MAXQ; i++) {
         int k4 = lane + 64 * i;
-        if (i < nq && 4 * k4 < s.H) {
-          float4 wv = ld4(w + 4 * k4);
-          acc += ev[i].x * wv.x + ev[i].y * wv.y + ev[i].z * wv.z + ev[i].w * wv.w;
-        }
+        bool in = i < nq && 4 * k4 < s.H;
+        wva[i] = in ? ld4(wa + 4 * k4) : zero4();
+        wvb[i] = in ? ld4(wb + 4 * k4) : zero4();
       }
-      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-      if (s.activation == 2) acc /= 2 * (xv + 1.0f);
-      if (lane == 0) dst[cc] = acc;
-      sq += acc * acc; /* identical in every lane */
+      float acca = 0.0f, accb = 0.0f;
+#pragma unroll
+      for (int i = 0; i < MAXQ; i++) {
+        acca += ev[i].x * wva[i].x + ev[i].y * wva[i].y + ev[i].z * wva[i].z + ev[i].w * wva[i].w;
+        accb += ev[i].x * wvb[i].x + ev[i].y * wvb[i].y + ev[i].z * wvb[i].z + ev[i].w * wvb[i].w;
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        acca += __shfl_xor(acca, off, 64);
+        accb += __shfl_xor(accb, off, 64);
+      }
+      if (s.activation == 2) {
+        acca /= 2 * (xa + 1.0f);
+        accb /= 2 * (xb + 1.0f);
+      }
+      if (lane == 0) {
+        dst[ca] = acca;
+        if (lb >= 0) dst[cb] = accb;
+      }
+      sq += acca * acca; /* identical in every lane */
+      if (lb >= 0) sq += accb * accb;
     }
   }
-  if (lane == 0) {
-    float sum = 0.0f;
-    for (int p = 0; p < tn; p++) sum += v.b.esum_part[((size_t)t * (tn + 1) + p) * s.Scap + r];
-    v.b.esum[(size_t)t * s.Scap + r] = sum + sq;
+  // the step's total: the column-tile partials of k_chain_main in index order (each lane
+  // fetches one, lane 0 adds them in order), then the extras
+  float sum = 0.0f;
+  for (int p0 = 0; p0 < tn; p0 += 64) {
+    int p = p0 + lane;
+    float pv = (p < tn) ? v.b.esum_part[((size_t)t * (tn + 1) + p) * s.Scap + r] : 0.0f;
+    int cnt = min(64, tn - p0);
+    for (int i = 0; i < cnt; i++) sum += __shfl(pv, i, 64);
   }
+  if (lane == 0) v.b.esum[(size_t)t * s.Scap + r] = sum + sq;
 }
 
 // Finalize of the extras GEMM: applies the row rule to column 0 and the input
@@ -2512,8 +2538,13 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int etm = (M + BM - 1) / BM, etn = (nx + BN - 1) / BN, nkt = (sh->H + BK - 1) / BK;
     int ks = pick_ks(etm * etn, nkt, "RECUR_AMD_KS_EXTRAS", b->slab_floats, (size_t)M * nxp);
     if (sh->H <= 2048 && !env_int("RECUR_AMD_EXTRAS_GEMM", 0)) {
-      hipLaunchKernelGGL(k_extras_gather, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx, nxp,
-                         tn);
+      const int nq = (sh->H / 4 + 63) / 64;
+      if (nq <= 5)
+        hipLaunchKernelGGL(k_extras_gather<5>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
+                           nxp, tn);
+      else
+        hipLaunchKernelGGL(k_extras_gather<8>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
+                           nxp, tn);
     } else { /* very wide nets: the dense GEMM over all extra columns */
       ProbExtras p = {v, row0, nrows, nx};
       launch_gemm<false, false, ProbExtras>(st, p, b->slab, M, nxp, nkt, ks, T_OTHER);
