@@ -576,3 +576,88 @@ def test_class_group_loss_on_device_matches_oracle(amd):
     assert abs(st.error - wrong_o.value) < 1e-4 * abs(wrong_o.value)
     g.close()
     o.close()
+
+
+def test_mixed_call_sequences_keep_host_and_device_coherent(amd, orc):
+    """One training set driven through everything a caller may interleave: batched device
+    generations, the per-net drop-in calls, host-side edits of the big arrays
+    (rnn_amd_sync_host / rnn_amd_host_written, text-predict.c:467), rnn_forget_history on one
+    stream, a forward-only clone created after the device image exists (the engine regrows),
+    cross-entropy through that clone, deleting it, and on.  Against the oracle throughout."""
+    lib = rc.bind_char(amd)
+    text = sc.synthetic_text(3000)
+    kw = dict(input_size=42, hidden_size=48, output_size=42, S=5, D=6, learn_rate=3e-3, seed=61)
+    g = sc.AmdBatchedSet(lib, softmax_best_guess=orc.orc_softmax_best_guess, **kw)
+    o = sc.OracleSet(**kw)
+    a = o.arrays()
+    keys = ["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "output", "hist", "o_error",
+            "min_error_factor", "ih_scale"]
+
+    def same(tag):
+        sg, so = g.snapshot(), o.snapshot()
+        assert np.array_equal(sg["hidden"] != 0, so["hidden"] != 0), tag
+        bad = sc.compare(sg, so, RTOL, keys=keys, exact=["index", "generation"])
+        assert not bad, (tag, bad)
+
+    i = 0
+    for _ in range(3):                                   # batched
+        g.char_step(text, i, rc.WEIGHTED, 0.9)
+        o.char_step(text, i, rc.WEIGHTED, 0.9)
+        i += 1
+    same("batched")
+    for _ in range(2):                                   # the reference's own per-stream loop
+        sc.ApiSet.char_step(g, text, i, rc.WEIGHTED, 0.9)
+        o.char_step(text, i, rc.WEIGHTED, 0.9)
+        i += 1
+    same("per-net")
+    g.char_step(text, i, rc.NESTEROV, 0.9)               # and back
+    o.char_step(text, i, rc.NESTEROV, 0.9)
+    i += 1
+    # a host-side edit of the weights, the way text-predict boosts its diagonal
+    lib.rnn_amd_sync_host(g.net, rc.RNN_AMD_WEIGHTS)
+    n0 = g.net.contents
+    rc.view(n0.ih_weights, g.I, g.H)[7, 9] += 0.05
+    rc.view(n0.ho_weights, g.H, g.O)[3, 2] -= 0.02
+    lib.rnn_amd_host_written(g.net, rc.RNN_AMD_WEIGHTS)
+    a["ih_w"][7, 9] += 0.05
+    a["ho_w"][3, 2] -= 0.02
+    # one stream forgets its hidden state (recur-nn.c:8-16)
+    lib.rnn_forget_history(g.nets[2], 0)
+    a["hidden"][2, :] = 0
+    a["hist"][int(a["index"][2]), 2, :kw["hidden_size"] + 1] = 0
+    for _ in range(2):
+        g.char_step(text, i, rc.WEIGHTED, 0.9)
+        o.char_step(text, i, rc.WEIGHTED, 0.9)
+        i += 1
+    same("after host edits")
+    # a forward-only clone made now: the device image has to grow by one row
+    clone = lib.rnn_clone(g.net, n0.flags & ~(rc.FLAG_OWN_BPTT | rc.FLAG_OWN_WEIGHTS), rc.SUBSEED, None)
+    seg = np.ascontiguousarray(text[500:800])
+    got = lib.rnn_char_cross_entropy(clone, None, rc.u8ptr(seg), len(seg), 3, None, 0)
+    v = sc.OracleSet(input_size=42, hidden_size=48, output_size=42, S=1, D=1, learn_rate=1e-3, seed=1)
+    v.arrays()["ih_w"][:] = a["ih_w"]
+    v.arrays()["ho_w"][:] = a["ho_w"]
+    want = v.orc.orc_cross_entropy(v.z, 0, rc.u8ptr(seg), len(seg), 3)
+    v.close()
+    assert abs(got - want) < 1e-4 * want
+    g.char_step(text, i, rc.WEIGHTED, 0.9)
+    o.char_step(text, i, rc.WEIGHTED, 0.9)
+    i += 1
+    same("with a clone alive")
+    lib.rnn_delete_net(clone)
+    # the fused single-net call on the prototype in between (recur-nn.c:999-1019)
+    lib.rnn_bptt_advance(g.net)
+    g.net_error_bptt(0, int(text[7]), int(text[8]))
+    g.net.contents.bptt.contents.momentum = 0.9
+    lib.rnn_bptt_calculate(g.net, 1)
+    o.orc.orc_advance(o.z, 0)
+    o.orc.orc_net_error_bptt(o.z, 0, int(text[7]), int(text[8]), C.byref(C.c_int(0)))
+    o.orc.orc_bptt_calculate(o.z, 0, 1, 0.9)
+    same("fused single net")
+    for _ in range(2):
+        g.char_step(text, i, rc.WEIGHTED, 0.9)
+        o.char_step(text, i, rc.WEIGHTED, 0.9)
+        i += 1
+    same("end")
+    g.close()
+    o.close()
