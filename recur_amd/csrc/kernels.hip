@@ -2234,8 +2234,8 @@ static void timing_collect() {
     HIP_CHECK(hipEventElapsedTime(&ms, g_ev[i].a, g_ev[i].b));
     g_ms[g_ev[i].cls] += ms;
     g_launches[g_ev[i].cls] += g_ev[i].count;
-    hipEventDestroy(g_ev[i].a);
-    hipEventDestroy(g_ev[i].b);
+    HIP_CHECK(hipEventDestroy(g_ev[i].a));
+    HIP_CHECK(hipEventDestroy(g_ev[i].b));
   }
   g_nev = 0;
 }
