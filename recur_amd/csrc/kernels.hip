@@ -951,7 +951,7 @@ __global__ __launch_bounds__(64) void k_softmax_error(View v, int row0, int nrow
 // (k_softmax_error) and the top-layer backprop with its soft clip (k_top_backprop, dense
 // form), each exactly as in the separate kernels -- same operation order per value -- with
 // the hidden row, the outputs and the output error passed through LDS instead of HBM.
-__global__ __launch_bounds__(1024) void k_text_top(View v, int row0) {
+__global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, int fwd_ks) {
   extern __shared__ float tsh[];
   __shared__ float tred[16];
   const RamdShape &s = v.sh;
@@ -961,8 +961,29 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0) {
   float *sout = part + OUT_SEGS * 64;  /* [O] outputs                        */
   float *sex = sout + s.O;             /* [O] exponentials                   */
   float *serr = sex + s.O;             /* [O] output error                   */
-  const float *hid = v.b.hidden + (size_t)r * s.H;
-  for (int i = threadIdx.x; i < s.H; i += 1024) shid[i] = hid[i];
+  float *hid = v.b.hidden + (size_t)r * s.H;
+  if (fwd_ks > 0) {
+    // the forward GEMM's K slabs are still in the workspace: sum them, apply the
+    // activation and write the hidden row here (what k_fwd_finalize does, recur-nn.c:123-148)
+    const float *p = v.b.slab + (size_t)blockIdx.x * s.H;
+    for (int i = threadIdx.x; i < s.H; i += 1024) {
+      float x = p[i];
+      for (int z = 1; z < fwd_ks; z++) x += p[(size_t)z * nrows * s.H + i];
+      if (s.activation == 2) {
+        x = (x > 0.0f) ? sqrtf(x + 1.0f) - 1.0f : 0.0f;
+      } else if (s.activation == 5) {
+        x = x < 20.0f ? x : 20.0f;
+        x = (x > 0.0f) ? x : 0.0f;
+      } else {
+        x = (x > 0.0f) ? x : 0.0f;
+      }
+      if (i == 0) x = 1.0f; /* the bias node, recur-nn.c:148 */
+      hid[i] = x;
+      shid[i] = x;
+    }
+  } else {
+    for (int i = threadIdx.x; i < s.H; i += 1024) shid[i] = hid[i];
+  }
   __syncthreads();
   const int seg = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // ---- output layer (recur-nn.c:150-151)
@@ -2376,21 +2397,22 @@ extern "C" int ramd_text_top_ok(const RamdShape *sh) {
 }
 
 extern "C" void ramd_launch_text_top(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
-                                     int row0, int nrows) {
+                                     int row0, int nrows, int fwd_ks) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   size_t shm = (size_t)(sh->H + OUT_SEGS * 64 + 3 * sh->O) * sizeof(float);
-  hipLaunchKernelGGL(k_text_top, dim3(nrows), dim3(1024), shm, st, v, row0);
+  hipLaunchKernelGGL(k_text_top, dim3(nrows), dim3(1024), shm, st, v, row0, nrows, fwd_ks);
 }
 
-extern "C" void ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh,
-                                           const RamdBuffers *b, int row0, int nrows, float noise);
+extern "C" int ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh,
+                                          const RamdBuffers *b, int row0, int nrows, float noise,
+                                          int leave_slabs);
 
 extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
                                     int row0, int nrows, float noise) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  ramd_launch_forward_hidden(st_, sh, b, row0, nrows, noise);
+  ramd_launch_forward_hidden(st_, sh, b, row0, nrows, noise, 0);
   if (sh->O <= 256 && !env_int("RECUR_AMD_OUT_GEMM", 0)) {
     hipLaunchKernelGGL(k_out_layer, dim3(nrows), dim3(1024),
                        (size_t)(sh->H + OUT_SEGS * 64) * sizeof(float), st, v, row0);
@@ -2406,9 +2428,12 @@ extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, cons
   }
 }
 
-/* the hidden layer only: hidden = act(X . W_ih) (recur-nn.c:117-148) */
-extern "C" void ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh,
-                                           const RamdBuffers *b, int row0, int nrows, float noise) {
+/* the hidden layer only: hidden = act(X . W_ih) (recur-nn.c:117-148).  With leave_slabs the
+ * K slabs of the GEMM (noise included) stay in the workspace un-summed for
+ * ramd_launch_text_top; the return value is their number. */
+extern "C" int ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh,
+                                          const RamdBuffers *b, int row0, int nrows, float noise,
+                                          int leave_slabs) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   int tm = (nrows + BM - 1) / BM;
@@ -2425,9 +2450,11 @@ extern "C" void ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *s
     if (noise != 0.0f)
       hipLaunchKernelGGL(k_presynaptic_noise, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows,
                          noise);
+    if (leave_slabs) return ks;
     int n4 = nrows * (sh->H / 4);
     hipLaunchKernelGGL(k_fwd_finalize, dim3((n4 + 255) / 256), dim3(256), 0, st, v, row0, nrows, ks);
   }
+  return 0;
 }
 
 extern "C" void ramd_launch_softmax_error(ramd_stream_t st_, const RamdShape *sh,

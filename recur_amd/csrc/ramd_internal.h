@@ -108,8 +108,8 @@ void ramd_launch_bottom_deltas(ramd_stream_t st, const RamdShape *sh, RamdBuffer
 void ramd_launch_forward(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                          int row0, int nrows, float presynaptic_noise);
 /* the hidden layer only (the first half of ramd_launch_forward) */
-void ramd_launch_forward_hidden(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
-                                int row0, int nrows, float presynaptic_noise);
+int ramd_launch_forward_hidden(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
+                               int row0, int nrows, float presynaptic_noise, int leave_slabs);
 /* output layer + softmax error against b->target + dense top backprop in one launch (what
  * ramd_launch_forward's second half, ramd_launch_softmax_error and the first kernel of
  * ramd_launch_calc_deltas do); follow with ramd_launch_calc_deltas(flags | RAMD_TOP_DONE).
@@ -117,7 +117,7 @@ void ramd_launch_forward_hidden(ramd_stream_t st, const RamdShape *sh, const Ram
 #define RAMD_TOP_DONE 0x40000000u
 int ramd_text_top_ok(const RamdShape *sh);
 void ramd_launch_text_top(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0,
-                          int nrows);
+                          int nrows, int fwd_ks);
 /* o_error = onehot(target) - softmax(out) and statistics
  * (charmodel-predict.c:18-27, 299-304) */
 void ramd_launch_softmax_error(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,

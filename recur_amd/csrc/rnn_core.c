@@ -1506,8 +1506,10 @@ void rnn_amd_set_advance(RnnAmdSet *set) {
   ramd_launch_advance(g_stream, &e->sh, &e->b, set->row0, set->n);
 }
 
-static void set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, int text_i,
-                        float *outputs, int advance, int hidden_only) {
+/* hidden_only: stop after the hidden layer's GEMM and leave its K slabs for
+ * ramd_launch_text_top; returns their number (0 otherwise) */
+static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, int text_i,
+                       float *outputs, int advance, int hidden_only) {
   RamdEngine *e = set->eng;
   engine_need_dev(e, RNN_AMD_WEIGHTS);
   set_streams_to_dev(set);
@@ -1544,8 +1546,9 @@ static void set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, 
     ramd_launch_assemble(g_stream, &e->sh, &e->b, r0, set->n, mode, d_dense, ld, text_i,
                          set->global_first, set->global_count, advance);
   }
+  int fwd_ks = 0;
   if (hidden_only) {
-    ramd_launch_forward_hidden(g_stream, &e->sh, &e->b, r0, set->n, noise);
+    fwd_ks = ramd_launch_forward_hidden(g_stream, &e->sh, &e->b, r0, set->n, noise, 1);
   } else {
     ramd_launch_forward(g_stream, &e->sh, &e->b, r0, set->n, noise);
   }
@@ -1554,6 +1557,7 @@ static void set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, 
     d2h(outputs, e->b.out + (size_t)r0 * e->sh.O, (size_t)set->n * e->sh.O * sizeof(float));
     dsync();
   }
+  return fwd_ks;
 }
 
 void rnn_amd_set_opinion(RnnAmdSet *set, const float *inputs, int ld_inputs, float *outputs) {
@@ -1760,8 +1764,8 @@ void rnn_amd_set_char_step_deltas(RnnAmdSet *set, int i) {
   }
   if (ramd_text_top_ok(&e->sh)) {
     /* advance + hidden layer, then output layer, loss and top backprop in one launch */
-    set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 1);
-    ramd_launch_text_top(g_stream, &e->sh, &e->b, set->row0, set->n);
+    int fwd_ks = set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 1);
+    ramd_launch_text_top(g_stream, &e->sh, &e->b, set->row0, set->n, fwd_ks);
     set_calc_deltas(set, 0, NULL, NULL, RAMD_TOP_DONE, NULL, 0);
   } else {
     set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 0); /* advance + one-hot opinion */
