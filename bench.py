@@ -154,9 +154,15 @@ def main():
         amd.rnn_amd_set_external_delta(gpu.handle, C.c_void_p(delta.data_ptr()))
 
     from recur_amd.dist import ShardedStep
-    step = ShardedStep(lambda i: amd.rnn_amd_set_char_step_deltas(gpu.handle, i),
-                       (lambda: dist.all_reduce(delta)) if dist is not None else None,
-                       lambda: amd.rnn_apply_learning(gpu.net, rc.WEIGHTED, MOMENTUM))
+    if dist is not None:
+        step = ShardedStep(lambda i: amd.rnn_amd_set_char_step_deltas(gpu.handle, i),
+                           lambda: dist.all_reduce(delta),
+                           lambda: amd.rnn_apply_learning(gpu.net, rc.WEIGHTED, MOMENTUM))
+    else:
+        # one GPU: nothing happens between the deltas and the update, so the library's own
+        # generation call is used (same kernels; the delta slabs go straight into the update)
+        def step(i):
+            amd.rnn_amd_set_char_step(gpu.handle, i, rc.WEIGHTED, MOMENTUM)
 
     def fence():
         amd.rnn_amd_synchronize()

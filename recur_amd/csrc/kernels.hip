@@ -2064,6 +2064,9 @@ struct ApplySegs {
   size_t n4[3];
   float rate[3];
   unsigned first[4];
+  /* when pend.slab is set, segment 1's deltas have not been summed yet: the kernel does what
+   * k_delta_finalize would have (non-accumulating form) and stores them as well */
+  RamdPendingDelta pend;
 };
 template <int METHOD>
 __global__ __launch_bounds__(256) void k_apply(ApplySegs sg, float momentum, float mw,
@@ -2075,7 +2078,32 @@ __global__ __launch_bounds__(256) void k_apply(ApplySegs sg, float momentum, flo
   const float *delta = sg.delta[g];
   float rate = sg.rate[g];
   if (rs) rate *= *rs;
-  float4 W = ld4(w + 4 * q), Dl = ld4(delta + 4 * q), M = ld4(m + 4 * q);
+  float4 W = ld4(w + 4 * q), M = ld4(m + 4 * q), Dl;
+  if (g == 1 && sg.pend.slab) {
+    const RamdPendingDelta &pd = sg.pend;
+    const float *src = pd.slab;
+    size_t off = 4 * q, stride = pd.n;
+    int ks = pd.ks;
+    if ((int)(off / (size_t)pd.H) >= pd.rows_core) {
+      ks = pd.ks_rest;
+      src = pd.rest;
+      off -= (size_t)pd.rows_core * pd.H;
+      stride = pd.rest_stride;
+    }
+    float4 sum = zero4();
+    for (int z = 0; z < ks; z++) {
+      float4 t = ld4(src + (size_t)z * stride + off);
+      sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+    }
+    int c = (int)((4 * q) % (size_t)pd.H);
+    Dl.x = (c + 0 >= 1 && c + 0 <= pd.hidden_size) ? sum.x : 0.0f;
+    Dl.y = (c + 1 >= 1 && c + 1 <= pd.hidden_size) ? sum.y : 0.0f;
+    Dl.z = (c + 2 >= 1 && c + 2 <= pd.hidden_size) ? sum.z : 0.0f;
+    Dl.w = (c + 3 >= 1 && c + 3 <= pd.hidden_size) ? sum.w : 0.0f;
+    *reinterpret_cast<float4 *>(pd.delta_out + 4 * q) = Dl;
+  } else {
+    Dl = ld4(delta + 4 * q);
+  }
   float4 A = (METHOD == 5 || METHOD == 6) ? ld4(aux + 4 * q) : zero4();
   float wv[4] = {W.x, W.y, W.z, W.w}, dv[4] = {Dl.x, Dl.y, Dl.z, Dl.w};
   float mv[4] = {M.x, M.y, M.z, M.w}, av[4] = {A.x, A.y, A.z, A.w};
@@ -2511,7 +2539,8 @@ extern "C" void ramd_launch_clear_deltas(ramd_stream_t st_, const RamdShape *sh,
 extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
                                         const RamdBuffers *b, int row0, int nrows, int accumulate,
                                         const int *ranges, int range_stride,
-                                        const unsigned char *active, unsigned flags) {
+                                        const unsigned char *active, unsigned flags,
+                                        RamdPendingDelta *defer) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   // top layer
@@ -2655,6 +2684,20 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       launch_gemm<true, true, ProbDelta<false>>(st, p, b->slab, sh->I, ncol, nkt, ks, T_DELTA, 1, sh->H);
     }
     size_t n4 = n / 4;
+    if (defer && !accumulate) { /* the optimiser launch that follows sums the slabs itself */
+      defer->slab = b->slab;
+      defer->n = n;
+      defer->ks = ks;
+      defer->H = sh->H;
+      defer->hidden_size = sh->hidden_size;
+      defer->rows_core = rows_core;
+      defer->ks_rest = ks_rest;
+      defer->rest = b->slab + (size_t)rows_core * sh->H;
+      defer->rest_stride = n;
+      defer->delta_out = b->ih_delta;
+      return;
+    }
+    if (defer) defer->slab = nullptr;
     hipLaunchKernelGGL(k_delta_finalize, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
                        b->ih_delta, b->slab, n4, n, ks, accumulate, sh->H, sh->hidden_size, rows_core,
                        ks_rest);
@@ -2672,9 +2715,11 @@ extern "C" void ramd_launch_err_writeback(ramd_stream_t st_, const RamdShape *sh
 extern "C" void ramd_launch_apply_multi(ramd_stream_t st_, int method, int nseg, float *const *w,
                                         const float *const *delta, float *const *m,
                                         float *const *aux, const size_t *n, const float *rate,
-                                        float momentum, float mw, const float *rs) {
+                                        float momentum, float mw, const float *rs,
+                                        const RamdPendingDelta *pend) {
   hipStream_t st = (hipStream_t)st_;
   ApplySegs sg = {};
+  if (pend && nseg >= 2) sg.pend = *pend;
   unsigned blocks = 0;
   for (int g = 0; g < 3; g++) {
     sg.first[g] = blocks;
@@ -2705,7 +2750,7 @@ extern "C" void ramd_launch_apply_multi(ramd_stream_t st_, int method, int nseg,
 extern "C" void ramd_launch_apply(ramd_stream_t st_, int method, float *w, const float *delta,
                                   float *m, float *aux, size_t n, float rate, float momentum,
                                   float mw, const float *rs) {
-  ramd_launch_apply_multi(st_, method, 1, &w, &delta, &m, &aux, &n, &rate, momentum, mw, rs);
+  ramd_launch_apply_multi(st_, method, 1, &w, &delta, &m, &aux, &n, &rate, momentum, mw, rs, nullptr);
 }
 
 extern "C" void ramd_launch_top_apply_now(ramd_stream_t st_, const RamdShape *sh,

@@ -77,6 +77,17 @@ typedef struct RamdBuffers {
   int uniform_idx;
 } RamdBuffers;
 
+/* ih_delta left as un-summed K slabs by ramd_launch_calc_deltas, for the optimiser launch
+ * that follows immediately to sum (and store) itself; slab == NULL: nothing pending */
+typedef struct RamdPendingDelta {
+  const float *slab;   /* [ks][n] planes of the rows below rows_core                  */
+  size_t n;            /* plane stride = I * H                                        */
+  int ks, H, hidden_size, rows_core, ks_rest;
+  const float *rest;   /* planes of the rows from rows_core on: rest + z * rest_stride */
+  size_t rest_stride;
+  float *delta_out;    /* ih_delta                                                    */
+} RamdPendingDelta;
+
 enum { RAMD_IN_KEEP = 0, RAMD_IN_ONE_HOT = 1, RAMD_IN_DENSE = 2, RAMD_IN_TEXT = 3 };
 
 typedef void *ramd_stream_t;
@@ -134,7 +145,8 @@ void ramd_launch_xent_accumulate(ramd_stream_t st, const RamdShape *sh, const Ra
  * first.  This is rnn_bptt_calc_deltas (recur-nn.c:707-772) for the rows. */
 void ramd_launch_calc_deltas(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                              int row0, int nrows, int accumulate, const int *ranges,
-                             int range_stride, const unsigned char *active, unsigned flags);
+                             int range_stride, const unsigned char *active, unsigned flags,
+                             RamdPendingDelta *defer);
 /* train_channel's loss (gstclassify.c:2070-2119): softmax error per class group against
  * gt[row][group] (< 0: the group is not trained), then the per-output error weights; all
  * arrays are device pointers, `largest` the largest group size */
@@ -163,7 +175,8 @@ void ramd_launch_apply(ramd_stream_t st, int method, float *w, const float *delt
 void ramd_launch_apply_multi(ramd_stream_t st, int method, int nseg, float *const *w,
                              const float *const *delta, float *const *m, float *const *aux,
                              const size_t *n, const float *rate, float momentum,
-                             float momentum_weight, const float *rate_scale_dev);
+                             float momentum_weight, const float *rate_scale_dev,
+                             const RamdPendingDelta *pend);
 /* conditioning pieces (recur-nn.c:782-855) */
 void ramd_launch_scale(ramd_stream_t st, float *a, size_t n, float scale);
 void ramd_launch_zero_small(ramd_stream_t st, float *a, size_t n);

@@ -1151,7 +1151,7 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
   }
   set_uniform_idx(e, j, 1);
   ramd_launch_calc_deltas(g_stream, s, &e->b, j, 1, accumulate, d_ranges, 0, NULL,
-                          net->flags | (fused ? 0x80000000u : 0));
+                          net->flags | (fused ? 0x80000000u : 0), NULL);
   if (s->bI && !fused) { /* the fused path passes no bottom error (recur-nn.c:972, 986) */
     if (accumulate) {
       engine_need_dev(e, RNN_AMD_DELTAS);
@@ -1202,7 +1202,7 @@ static void check_method_arrays(RamdEngine *e, int method) {
  * is one, the bottom layer with its own rate scale (recur-nn.c:606-676; the arrays are
  * disjoint, so the reference's order between them does not matter) */
 static void apply_all(RamdEngine *e, int method, float lr, float lr_top, float momentum,
-                      float mw) {
+                      float mw, const RamdPendingDelta *pend) {
   RamdBuffers *b = &e->b;
   check_method_arrays(e, method);
   float *w[3] = {b->ho_w, b->ih_w, b->bw};
@@ -1213,11 +1213,19 @@ static void apply_all(RamdEngine *e, int method, float lr, float lr_top, float m
   float rate[3] = {lr_top, lr,
                    e->sh.bI ? lr * e->owner->bottom_layer->learn_rate_scale : 0.0f};
   ramd_launch_apply_multi(g_stream, method, e->sh.bI ? 3 : 2, w, d, m, aux, n, rate, momentum, mw,
-                          NULL);
+                          NULL, pend);
 }
 
 /* recur-nn.h:312 / recur-nn.c:601-678 */
+static void apply_learning(RecurNN *net, int learning_method, float momentum,
+                           const RamdPendingDelta *pend);
+
 void rnn_apply_learning(RecurNN *net, int learning_method, float momentum) {
+  apply_learning(net, learning_method, momentum, NULL);
+}
+
+static void apply_learning(RecurNN *net, int learning_method, float momentum,
+                           const RamdPendingDelta *pend) {
   RamdEngine *e = ramd_engine_of(net);
   engine_ensure_device(e);
   engine_need_dev(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
@@ -1236,7 +1244,8 @@ void rnn_apply_learning(RecurNN *net, int learning_method, float momentum) {
       learning_method < 0) {
     kernel_method = RNN_MOMENTUM_WEIGHTED;
   }
-  apply_all(e, kernel_method, bptt->learn_rate, bptt->learn_rate * bptt->ho_scale, momentum, mw);
+  apply_all(e, kernel_method, bptt->learn_rate, bptt->learn_rate * bptt->ho_scale, momentum, mw,
+            pend);
   engine_dev_wrote(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS);
 }
 
@@ -1605,18 +1614,18 @@ void rnn_amd_set_softmax_error(RnnAmdSet *set, const int *target) {
 
 static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ranges,
                             const u8 *active, unsigned extra_flags, const int *dev_ranges,
-                            int range_stride);
+                            int range_stride, RamdPendingDelta *defer);
 
 void rnn_amd_set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ranges,
                              const u8 *active) {
-  set_calc_deltas(set, accumulate, ranges, active, 0, NULL, 0);
+  set_calc_deltas(set, accumulate, ranges, active, 0, NULL, 0, NULL);
 }
 
 /* dev_ranges: one range list per stream already on the device (range_stride ints apart),
  * instead of the shared host list `ranges` */
 static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ranges,
                             const u8 *active, unsigned extra_flags, const int *dev_ranges,
-                            int range_stride) {
+                            int range_stride, RamdPendingDelta *defer) {
   RamdEngine *e = set->eng;
   set_need_training(set, "rnn_amd_set_calc_deltas");
   engine_need_dev(e, RNN_AMD_WEIGHTS | (accumulate ? RNN_AMD_DELTAS : 0));
@@ -1635,7 +1644,7 @@ static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ran
   set_uniform_idx(e, set->row0, set->n);
   ramd_launch_calc_deltas(g_stream, &e->sh, &e->b, set->row0, set->n, accumulate, d_ranges,
                           dev_ranges ? range_stride : 0, d_active,
-                          set->nets[0]->flags | extra_flags);
+                          set->nets[0]->flags | extra_flags, defer);
   if (e->sh.bI) {
     if (set->global_count != set->n || e->delta_external) {
       fprintf(stderr, "librecur_amd: a bottom layer cannot be trained on a sharded set: its "
@@ -1743,7 +1752,7 @@ void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *ne
   unsigned long long threshold = tf >= 18446744073709551615.0f ? UINT64_MAX : (unsigned long long)tf;
   ramd_launch_multi_softmax_error(g_stream, s, &e->b, set->row0, set->n, alphabet_len, n_classes,
                                   threshold, e->d_mclass, e->d_mranges, stride);
-  set_calc_deltas(set, accumulate, NULL, NULL, 0, e->d_mranges, stride);
+  set_calc_deltas(set, accumulate, NULL, NULL, 0, e->d_mranges, stride, NULL);
 }
 
 void rnn_amd_set_load_text(RnnAmdSet *set, const u8 *text, int len) {
@@ -1756,7 +1765,7 @@ void rnn_amd_set_load_text(RnnAmdSet *set, const u8 *text, int len) {
   dsync();
 }
 
-void rnn_amd_set_char_step_deltas(RnnAmdSet *set, int i) {
+static void char_step_deltas(RnnAmdSet *set, int i, RamdPendingDelta *defer) {
   RamdEngine *e = set->eng;
   if (!e->b.text) {
     fprintf(stderr, "librecur_amd: rnn_amd_set_char_step without rnn_amd_set_load_text\n");
@@ -1766,17 +1775,26 @@ void rnn_amd_set_char_step_deltas(RnnAmdSet *set, int i) {
     /* advance + hidden layer, then output layer, loss and top backprop in one launch */
     int fwd_ks = set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 1);
     ramd_launch_text_top(g_stream, &e->sh, &e->b, set->row0, set->n, fwd_ks);
-    set_calc_deltas(set, 0, NULL, NULL, RAMD_TOP_DONE, NULL, 0);
+    set_calc_deltas(set, 0, NULL, NULL, RAMD_TOP_DONE, NULL, 0, defer);
   } else {
     set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 0); /* advance + one-hot opinion */
     ramd_launch_softmax_error(g_stream, &e->sh, &e->b, set->row0, set->n);
-    set_calc_deltas(set, 0, NULL, NULL, 0, NULL, 0);
+    set_calc_deltas(set, 0, NULL, NULL, 0, NULL, 0, defer);
   }
 }
 
+void rnn_amd_set_char_step_deltas(RnnAmdSet *set, int i) { char_step_deltas(set, i, NULL); }
+
+static void apply_learning(RecurNN *net, int learning_method, float momentum,
+                           const RamdPendingDelta *pend);
+
 void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float momentum) {
-  rnn_amd_set_char_step_deltas(set, i);
-  rnn_apply_learning(set->nets[0], learning_style, momentum);
+  /* the deltas go straight from the GEMM's K slabs into the update (and into ih_delta) when
+   * nothing can look at them in between: library-owned storage, no log on the prototype */
+  RamdPendingDelta pend = {0};
+  int fuse = !set->eng->delta_external && !set->nets[0]->log;
+  char_step_deltas(set, i, fuse ? &pend : NULL);
+  apply_learning(set->nets[0], learning_style, momentum, pend.slab ? &pend : NULL);
 }
 
 void rnn_amd_set_read_stats(RnnAmdSet *set, RnnAmdStats *stats, int clear) {
