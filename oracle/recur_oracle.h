@@ -10,6 +10,12 @@
  * by the real reference compiled from /root/reference, see
  * tests/golden/make_golden.py) and, when oracle/_ref/librecur_ref.so is
  * present, against that library live (tests/test_oracle_vs_ref.py).
+ *
+ * Parity unpinned for two functions only: orc_multi_softmax_error and
+ * orc_grouped_softmax_error restate static functions of charmodel-multi-predict.c
+ * and gstclassify.c, files that cannot be compiled here (generated path.h, GStreamer);
+ * everything they call (softmax, generator, calc_deltas with and without ranges) is
+ * pinned.
  */
 #ifndef RECUR_ORACLE_H
 #define RECUR_ORACLE_H 1

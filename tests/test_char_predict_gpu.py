@@ -181,3 +181,41 @@ def test_confabulation_follows_the_nets_generator(amd):
     lib.rnn_delete_net(conf)
     o.close()
     a.close()
+
+
+def test_epoch_driver_single_net_branch_matches_oracle(amd, tmp_path):
+    """BASELINE.json configs[0] shape: text-predict's default path, one net, the fused
+    rnn_bptt_calculate branch of rnn_char_epoch (charmodel-predict.c:312-321) with temporal
+    batching, against the oracle's restatement of the same loop."""
+    lib = amd
+    text = np.ascontiguousarray(ec.encoded_text()[:4000])
+    for batch in (1, 5):
+        a = make_text_net(lib, hidden_size=39, S=1, D=8, learn_rate=3e-3, seed=71)
+        o = sc.OracleSet(input_size=42, hidden_size=39, output_size=42, S=1, D=8, learn_rate=3e-3, seed=71)
+        model = rc.CharModel()
+        model.net = a.net
+        model.training_nets = a.nets
+        model.n_training_nets = 1
+        model.batch_size = batch
+        model.momentum = 0.9
+        model.momentum_soft_start = 0.0
+        model.learning_style = rc.WEIGHTED
+        model.report_interval = 100
+        model.use_multi_tap_path = False
+        lib.rnn_char_init_schedule(C.byref(model.schedule), 0, 0.0, 1.0, 0)
+        v = rc.CharVentropy()
+        lib.rnn_char_init_ventropy(C.byref(v), a.net, rc.u8ptr(text), 0, 1)      # no validation text
+        done = lib.rnn_char_epoch(C.byref(model), None, C.byref(v), rc.u8ptr(text), len(text), 0, 150, 0.0, 0, -1,
+                                  2, 0, 0)
+        assert done == 1 and a.net.contents.generation == 150
+        for i in range(150):
+            o.orc.orc_advance(o.z, 0)
+            o.orc.orc_net_error_bptt(o.z, 0, int(text[i]), int(text[i + 1]), C.byref(C.c_int(0)))
+            o.orc.orc_bptt_calculate(o.z, 0, batch, 0.9)
+        sg, so = a.snapshot(), o.snapshot()
+        bad = sc.compare(sg, so, 1e-3, keys=["ih_w", "ho_w", "ih_m", "ho_m", "hidden", "output"],
+                         exact=["index", "generation"])
+        assert not bad, (batch, bad)
+        lib.rnn_char_delete_ventropy(C.byref(v))
+        a.close()
+        o.close()
