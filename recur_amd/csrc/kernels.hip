@@ -1401,18 +1401,19 @@ __global__ void k_ho_delta_finalize(View v, const float *slab, int ks, int accum
 // output tiles, (S/32) x (hidden/32) workgroups = 256 at the 1024 / 256 size,
 // one per CU, no split-K slabs and no separate finalize pass.  Column 0 (bias
 // row) and the real-input rows only feed the sum of squares and are done for
-// all steps together afterwards (ProbExtras).
+// all steps together afterwards (k_extras_gather, or the ProbExtras GEMM for very wide nets).
 //
-// Workgroup = 4 waves; each wave multiplies a quarter of every 128-deep K stage
-// (in-workgroup split-K, summed through LDS at the end).  Operand stages go
-// global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), three
-// stages deep, with counted s_waitcnt vmcnt and raw s_barrier so that two stages
-// stay in flight across barriers.  LDS rows are 128 floats; the 16-byte chunk c
+// Workgroup = 8 waves.  Waves 0-3 multiply: each takes a quarter of every 128-deep K
+// stage (in-workgroup split-K, summed through LDS at the end).  Waves 4-7 only move data:
+// operand stages go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round
+// trip), three stages deep, with counted s_waitcnt vmcnt and raw s_barrier so that two
+// stages stay in flight across barriers.  LDS rows are 128 floats; the 16-byte chunk c
 // of row r is stored at chunk position c ^ (r & 15), applied on the DMA's global
 // address (the LDS side of a DMA is lane-linear) and again on the ds_read_b128
 // address, which makes the 16-lane groups of ds_read_b128 conflict free.
-// Fragments are fetched with inline-asm ds_read_b128: hipcc would otherwise
-// drain vmcnt to 0 before any LDS read that may alias an LDS-DMA destination.
+// Fragments are fetched with inline-asm ds_read_b128 one stage ahead of the MFMAs that
+// use them (hipcc would otherwise drain vmcnt to 0 before any LDS read that may alias an
+// LDS-DMA destination, and would not overlap the reads with the previous stage's MFMAs).
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
