@@ -1432,83 +1432,12 @@ __device__ __forceinline__ f32x4 lds_read_b128(uint32_t addr) {
   return v;
 }
 
-// DEBUG: the microbenchmark's kernel on the library's own buffers
-__device__ __forceinline__ void mb_body(float *smem, const View &v, int t, int row0, float *out) {
-  constexpr int STAGES = 3, NST = 8, SF = 64 * 128, CKK = 128;
-  const int I = v.sh.I, H = v.sh.H;
-  const float *W = v.b.ih_w;
-  const float *A = v.b.ehi + ((size_t)t * v.sh.Scap + row0) * v.sh.I;
-  const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
-  const int mt = q % 8, nt = (q / 8) * 8 + xcd;
-  const int m0 = mt * 32, n0 = 1 + nt * 32;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const bool loader = wave >= 4;
-  const int lw = wave - 4;
-  constexpr int DPW = 8;
-  if (loader) {
-    const float *src[DPW];
-    for (int j = 0; j < DPW; j++) {
-      int i = lw * DPW + j;
-      int row = 2 * (i & 15) + (lane >> 5);
-      int c = (lane & 31) ^ (row & 15);
-      const float *base = (i < 16) ? A + (size_t)(m0 + row) * I : W + (size_t)(n0 + row) * H;
-      src[j] = base + 4 * c;
-    }
-    auto issue = [&](int st) {
-      for (int j = 0; j < DPW; j++) {
-        float *dst = smem + (st % STAGES) * SF + (lw * DPW + j) * 256;
-        const float *g = src[j] + st * CKK;
-        __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)dst, 16, 0, 0);
-      }
-    };
-    for (int p = 0; p < STAGES - 1; p++) issue(p);
-    for (int st = 0; st < NST; st++) {
-      int ahead = min(STAGES - 2, NST - 1 - st);
-      if (ahead >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (st + STAGES - 1 < NST) issue(st + STAGES - 1);
-    }
-  } else {
-    float acc = 0;
-    f32x16 c0;
-    for (int i = 0; i < 16; i++) c0[i] = 0;
-    for (int st = 0; st < NST; st++) {
-      __builtin_amdgcn_s_barrier();
-      const float *p = smem + (st % STAGES) * SF;
-      float4 a[4], b[4];
-      for (int gi = 0; gi < 4; gi++) {
-        int c = 2 * (4 * wave + gi) + (lane >> 5);
-        int lm = lane & 31;
-        a[gi] = *(const float4 *)(p + lm * CKK + ((c ^ (lm & 15)) * 4));
-        b[gi] = *(const float4 *)(p + 32 * CKK + lm * CKK + ((c ^ (lm & 15)) * 4));
-      }
-      for (int gi = 0; gi < 4; gi++) {
-        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].x, b[gi].x, c0, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].y, b[gi].y, c0, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].z, b[gi].z, c0, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].w, b[gi].w, c0, 0, 0, 0);
-      }
-    }
-    for (int i = 0; i < 16; i++) acc += c0[i];
-    if (acc == 12345.f) out[threadIdx.x] = acc;
-  }
-}
-
-
-template <int MODE>
-__global__ __launch_bounds__(512) void k_mb(View v, const float *A, int t, int row0, float *out) {
-  __shared__ __attribute__((aligned(16))) float smem[3 * 64 * 128];
-  mb_body(smem, v, t, row0, out);
-}
-
 template <bool UNI, int NS = 0> /* NS > 0: the number of K stages, known at compile time */
 __global__ __launch_bounds__(512) void k_chain_main(View v, int row0, int nrows, int t, int tm,
-                                                    int tn, int nstages_arg, int ktail0, int dbg) {
+                                                    int tn, int nstages_arg, int ktail0) {
   const int nstages = NS > 0 ? NS : nstages_arg;
   __shared__ __attribute__((aligned(16))) float smem[C_STAGES * C_STAGE_FLOATS];
   const RamdShape &s = v.sh;
-  if (dbg & 8) { mb_body(smem, v, t, row0, v.b.esum_part); return; }
   const int L = blockIdx.x;
   const int xcd = L & 7, q = L >> 3;
   const int mt = q % tm, nt = (q / tm) * 8 + xcd; /* the m tiles of one W panel share an XCD */
@@ -1578,32 +1507,15 @@ __global__ __launch_bounds__(512) void k_chain_main(View v, int row0, int nrows,
   float xin[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   float4 et[2] = {zero4(), zero4()}, wt[4][2];
   const bool tail = ktail0 < s.H;
-  if (dbg & 16) { mb_body(smem, v, t, row0, v.b.esum_part + (src[3] == nullptr) + (kcol[2] == 77)); return; }
-  if (loader && (dbg & 32)) {
-    // experiment: the microbenchmark's loader loop on this kernel's source pointers
-    auto issue2 = [&](int st) {
-      for (int j = 0; j < 8; j++) {
-        float *dst = smem + (st % 3) * C_STAGE_FLOATS + (wave * 8 + j) * 256;
-        const float *g = src[j] + st * CK;
-        __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)dst, 16, 0, 0);
-      }
-    };
-    for (int p = 0; p < 2; p++) issue2(p);
-    for (int st = 0; st < 8; st++) {
-      int ahead = min(1, 8 - 1 - st);
-      if (ahead >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (st + 2 < 8) issue2(st + 2);
-    }
-    return;
-  }
   if (loader) {
     /* the loaders' first stages go out before anything else in the workgroup touches memory */
 #pragma unroll
     for (int p = 0; p < C_STAGES - 1; p++)
       if (p < nstages) issue(p);
-  } else if (!(dbg & 2)) {
+  }
+  // what the epilogue needs from global memory, requested by the compute waves now so that
+  // it has arrived by the end of the loop (asking later, from inside the loop, gains nothing)
+  auto fetch_epilogue_operands = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       int n = n0 + ec4 + i;
@@ -1620,7 +1532,8 @@ __global__ __launch_bounds__(512) void k_chain_main(View v, int row0, int nrows,
       et[0] = ld4(ehi_t + (size_t)er * s.I + ktail0);
       et[1] = (s.H - ktail0 > 4) ? ld4(ehi_t + (size_t)er * s.I + ktail0 + 4) : zero4();
     }
-  }
+  };
+  if (!loader) fetch_epilogue_operands();
   const uint32_t lds0 = lds_byte_addr(smem);
   const uint32_t rowoff = (uint32_t)lm * (CK * 4u);
   if (loader) {
@@ -1669,26 +1582,6 @@ __global__ __launch_bounds__(512) void k_chain_main(View v, int row0, int nrows,
       __builtin_amdgcn_sched_barrier(0);
     };
     f32x4 a0[4], b0[4], a1[4], b1[4];
-    if (dbg & 4) { /* timing experiment: the plain structure of the microbenchmark */
-      for (int st = 0; st < nstages; st++) {
-        __builtin_amdgcn_s_barrier();
-        const float *p = smem + (st % C_STAGES) * C_STAGE_FLOATS;
-        float4 fa[4], fb[4];
-#pragma unroll
-        for (int gi = 0; gi < 4; gi++) {
-          int c = 2 * (4 * wave + gi) + kh;
-          fa[gi] = *(const float4 *)(p + lm * CK + ((c ^ (lm & 15)) * 4));
-          fb[gi] = *(const float4 *)(p + CM * CK + lm * CK + ((c ^ (lm & 15)) * 4));
-        }
-#pragma unroll
-        for (int gi = 0; gi < 4; gi++) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gi].x, fb[gi].x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gi].y, fb[gi].y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gi].z, fb[gi].z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gi].w, fb[gi].w, acc, 0, 0, 0);
-        }
-      }
-    } else {
     if (nstages > 0) {
       __builtin_amdgcn_s_barrier(); /* stage 0 has landed */
       rd(0, a0, b0);
@@ -1698,15 +1591,11 @@ __global__ __launch_bounds__(512) void k_chain_main(View v, int row0, int nrows,
       step(st, a0, b0, a1, b1);
       if (st + 1 < nstages) step(st + 1, a1, b1, a0, b0);
     }
-    }
   }
-  if (dbg & 1) {
-    if (!loader && acc[0] == 12345.0f) v.b.esum_part[0] = acc[1];
-    return;
-  }
-  // --- sum the four waves' partial tiles through LDS
-  __builtin_amdgcn_s_barrier();
-  float *red = smem; /* [4][32][32] */
+  // --- sum the four waves' partial tiles through LDS.  The ring buffer that stage
+  // `nstages` would have used holds stage nstages - 3, which every wave finished reading
+  // two barriers ago and no DMA targets any more: it can be overwritten without a barrier.
+  float *red = smem + (nstages % C_STAGES) * C_STAGE_FLOATS; /* [4][32][32] */
   if (!loader) {
 #pragma unroll
     for (int g = 0; g < 16; g++) {
@@ -2510,43 +2399,6 @@ static void launch_gemm2(hipStream_t st, const Prob &p, float *slab, int M, int 
 }
 
 
-extern "C" float ramd_debug_chain_only(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
-                                       int row0, int nrows, int reps) {
-  hipStream_t st = (hipStream_t)st_;
-  View v = make_view(sh, b);
-  const int tn = (sh->hidden_size + CN - 1) / CN;
-  int tm = (nrows + CM - 1) / CM;
-  int kfull = sh->H / CK, ktail = sh->H - kfull * CK;
-  int nstages = kfull + (ktail > 8 ? 1 : 0);
-  int ktail0 = ktail > 8 ? sh->H : kfull * CK;
-  int blocks = ((tn + 7) / 8) * 8 * tm;
-  hipEvent_t e0, e1;
-  HIP_CHECK(hipEventCreate(&e0));
-  HIP_CHECK(hipEventCreate(&e1));
-  float ms = 0;
-  for (int w = 0; w < 2; w++) {
-    HIP_CHECK(hipEventRecord(e0, st));
-    for (int r = 0; r < reps; r++)
-      for (int t = 0; t < sh->D; t++) {
-        if (env_int("RECUR_AMD_MB", 0))
-          hipLaunchKernelGGL(k_mb<1>, dim3(256), dim3(512), 0, st, v,
-                             b->ehi + ((size_t)t * sh->Scap + row0) * sh->I, t, row0, b->esum_part);
-        else
-          hipLaunchKernelGGL((k_chain_main<true, 8>), dim3(blocks), dim3(512), 0, st, v, row0, nrows, t, tm,
-                             tn, nstages, ktail0, env_int("RECUR_AMD_CH_DBG", 0));
-      }
-    HIP_CHECK(hipEventRecord(e1, st));
-    HIP_CHECK(hipEventSynchronize(e1));
-    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-  }
-  return 1e3f * ms / (reps * sh->D);
-}
-
-extern "C" void ramd_debug_read_slab(const RamdBuffers *b, size_t off_floats, void *dst, size_t bytes) {
-  HIP_CHECK(hipDeviceSynchronize());
-  HIP_CHECK(hipMemcpy(dst, b->slab + off_floats, bytes, hipMemcpyDeviceToHost));
-}
-
 extern "C" void ramd_launch_advance(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
                                     int row0, int nrows) {
   hipStream_t st = (hipStream_t)st_;
@@ -2753,13 +2605,13 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     for (int t = 0; t < sh->D; t++) {
       if (b->uniform_idx >= 0 && nstages == 8)
         hipLaunchKernelGGL((k_chain_main<true, 8>), dim3(blocks), dim3(512), 0, st, v, row0, nrows, t, tm,
-                           tn, nstages, ktail0, env_int("RECUR_AMD_CH_DBG", 0));
+                           tn, nstages, ktail0);
       else if (b->uniform_idx >= 0)
         hipLaunchKernelGGL(k_chain_main<true>, dim3(blocks), dim3(512), 0, st, v, row0, nrows, t, tm,
-                           tn, nstages, ktail0, env_int("RECUR_AMD_CH_DBG", 0));
+                           tn, nstages, ktail0);
       else
         hipLaunchKernelGGL(k_chain_main<false>, dim3(blocks), dim3(512), 0, st, v, row0, nrows, t,
-                           tm, tn, nstages, ktail0, env_int("RECUR_AMD_CH_DBG", 0));
+                           tm, tn, nstages, ktail0);
     }
     timing_end(st, ev);
     int M = sh->D * nrows;

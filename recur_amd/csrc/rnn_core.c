@@ -71,11 +71,6 @@ void rnn_amd_use_device(int device, void *hip_stream) {
 
 void *rnn_amd_current_stream(void) { return (void *)g_stream; }
 const char *rnn_amd_version(void) { return "recur_amd 0.1 (gfx950, fp32 MFMA)"; }
-void ramd_debug_read_slab(const RamdBuffers *b, size_t off_floats, void *dst, size_t bytes);
-void rnn_amd_debug_read_slab(RecurNN *net, size_t off_floats, void *dst, size_t bytes) {
-  ramd_debug_read_slab(&ramd_engine_of(net)->b, off_floats, dst, bytes);
-}
-
 void rnn_amd_synchronize(void) {
   if (g_device >= 0) {
     HIP_OK(hipStreamSynchronize(g_stream));
@@ -1847,12 +1842,4 @@ void rnn_amd_set_external_delta(RnnAmdSet *set, void *device_buffer) {
     e->b.ho_delta = dst + e->ih_size;
   }
   e->delta_external = device_buffer != NULL;
-}
-
-float ramd_debug_chain_only(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0,
-                            int nrows, int reps);
-float rnn_amd_debug_chain_only(RecurNN *net, int nrows, int reps) {
-  RamdEngine *e = ramd_engine_of(net);
-  set_uniform_idx(e, 0, nrows);
-  return ramd_debug_chain_only(g_stream, &e->sh, &e->b, 0, nrows, reps);
 }
