@@ -13,6 +13,7 @@
 // accumulate).  The top layer (O is 4..44 in the text and classify configs) and
 // the per-stream control logic are plain VALU kernels.
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1432,9 +1433,19 @@ __device__ __forceinline__ f32x4 lds_read_b128(uint32_t addr) {
   return v;
 }
 
+// stores the launch-invariant part of the kernel arguments in device memory (see below)
+__global__ void k_store_view(View v, View *dst) { *dst = v; }
+
+// The View is read from device memory instead of coming by value: 520 bytes of kernel
+// arguments per launch are fetched from the host-visible argument ring, and this kernel is
+// launched D times per generation.  Only the ring position changes between generations, and
+// that comes as a plain argument.
 template <bool UNI, int NS = 0> /* NS > 0: the number of K stages, known at compile time */
-__global__ __launch_bounds__(512) void k_chain_main(View v, int row0, int nrows, int t, int tm,
-                                                    int tn, int nstages_arg, int ktail0) {
+__global__ __launch_bounds__(512) void k_chain_main(const View *__restrict__ vp, int uniform_idx,
+                                                    int row0, int nrows, int t, int tm, int tn,
+                                                    int nstages_arg, int ktail0) {
+  View v = *vp;
+  v.b.uniform_idx = uniform_idx;
   const int nstages = NS > 0 ? NS : nstages_arg;
   __shared__ __attribute__((aligned(16))) float smem[C_STAGES * C_STAGE_FLOATS];
   const RamdShape &s = v.sh;
@@ -2601,17 +2612,31 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int blocks = ((tn + 7) / 8) * 8 * tm;
     /* one event pair around the D launches: the per-launch average then carries
      * 1/D of the event overhead instead of all of it */
+    /* the device copy of the View, rewritten only when it changes */
+    static View *d_view = nullptr;
+    static View h_view;
+    static bool have = false;
+    {
+      View cur = v;
+      cur.b.uniform_idx = 0;
+      if (!d_view) HIP_CHECK(hipMalloc(&d_view, sizeof(View)));
+      if (!have || memcmp(&cur, &h_view, sizeof(View)) != 0) {
+        hipLaunchKernelGGL(k_store_view, dim3(1), dim3(1), 0, st, cur, d_view);
+        h_view = cur;
+        have = true;
+      }
+    }
     int ev = timing_begin(st, T_CHAIN, sh->D);
     for (int t = 0; t < sh->D; t++) {
       if (b->uniform_idx >= 0 && nstages == 8)
-        hipLaunchKernelGGL((k_chain_main<true, 8>), dim3(blocks), dim3(512), 0, st, v, row0, nrows, t, tm,
-                           tn, nstages, ktail0);
+        hipLaunchKernelGGL((k_chain_main<true, 8>), dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx,
+                           row0, nrows, t, tm, tn, nstages, ktail0);
       else if (b->uniform_idx >= 0)
-        hipLaunchKernelGGL(k_chain_main<true>, dim3(blocks), dim3(512), 0, st, v, row0, nrows, t, tm,
-                           tn, nstages, ktail0);
+        hipLaunchKernelGGL(k_chain_main<true>, dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx, row0,
+                           nrows, t, tm, tn, nstages, ktail0);
       else
-        hipLaunchKernelGGL(k_chain_main<false>, dim3(blocks), dim3(512), 0, st, v, row0, nrows, t,
-                           tm, tn, nstages, ktail0);
+        hipLaunchKernelGGL(k_chain_main<false>, dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx,
+                           row0, nrows, t, tm, tn, nstages, ktail0);
     }
     timing_end(st, ev);
     int M = sh->D * nrows;
