@@ -1443,7 +1443,7 @@ __global__ void k_store_view(View v, View *dst) { *dst = v; }
 template <bool UNI, int NS = 0> /* NS > 0: the number of K stages, known at compile time */
 __global__ __launch_bounds__(512) void k_chain_main(const View *__restrict__ vp, int uniform_idx,
                                                     int row0, int nrows, int t, int tm, int tn,
-                                                    int nstages_arg, int ktail0) {
+                                                    int nstages_arg) {
   View v = *vp;
   v.b.uniform_idx = uniform_idx;
   const int nstages = NS > 0 ? NS : nstages_arg;
@@ -1480,19 +1480,21 @@ __global__ __launch_bounds__(512) void k_chain_main(const View *__restrict__ vp,
       int n = n0 + row;
       base = v.b.ih_w + (size_t)(n < s.I ? n : s.I - 1) * s.H;
     }
-    src[j] = base + 4 * c;
-    kcol[j] = 4 * c;
+    src[j] = base + 1 + 4 * c; /* K runs over the hidden columns 1..hidden_size */
+    kcol[j] = 1 + 4 * c;
   }
   // a stage whose 128 columns all lie inside K needs no per-chunk test
   auto issue_one = [&](int stage, int j) {
     float *dst = smem + (stage % C_STAGES) * C_STAGE_FLOATS + (wave * 8 + j) * 256;
     const int k0 = stage * CK;
     const float *g = src[j] + k0;
-    if (k0 + CK > s.H) g = (k0 + kcol[j] < s.H) ? g : v.b.zeros; /* last, partial stage only */
+    /* last, partial stage only: chunks wholly past the hidden columns come from a zero line
+     * (a chunk that straddles the end reads pad columns, which are zero in E) */
+    if (k0 + CK > s.hidden_size) g = (k0 + kcol[j] <= s.hidden_size) ? g : v.b.zeros;
     __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)dst, 16, 0, 0);
   };
   auto issue = [&](int stage) {
-    if (stage * CK + CK <= s.H) { /* a full stage: plain address arithmetic, nothing to select */
+    if (stage * CK + CK <= s.hidden_size) { /* a full stage: plain address arithmetic, nothing to select */
       float *dst = smem + (stage % C_STAGES) * C_STAGE_FLOATS + wave * 8 * 256;
 #pragma unroll
       for (int j = 0; j < 8; j++)
@@ -1516,35 +1518,21 @@ __global__ __launch_bounds__(512) void k_chain_main(const View *__restrict__ vp,
   const int er = m0 + erow_i < nrows ? m0 + erow_i : nrows - 1;
   const float *xrow = input_row<UNI>(v, row0 + er, t);
   float xin[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  float4 et[2] = {zero4(), zero4()}, wt[4][2];
-  const bool tail = ktail0 < s.H;
   if (loader) {
     /* the loaders' first stages go out before anything else in the workgroup touches memory */
 #pragma unroll
     for (int p = 0; p < C_STAGES - 1; p++)
       if (p < nstages) issue(p);
   }
-  // what the epilogue needs from global memory, requested by the compute waves now so that
-  // it has arrived by the end of the loop (asking later, from inside the loop, gains nothing)
-  auto fetch_epilogue_operands = [&]() {
+  // what the epilogue needs from global memory (the input values that gate this thread's four
+  // outputs), requested by the compute waves now so that it has arrived by the end of the loop
+  if (!loader) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       int n = n0 + ec4 + i;
-      n = n <= s.hidden_size ? n : s.hidden_size;
-      xin[i] = xrow[n];
-      wt[i][0] = zero4();
-      wt[i][1] = zero4();
-      if (tail) {
-        wt[i][0] = ld4(v.b.ih_w + (size_t)n * s.H + ktail0);
-        wt[i][1] = (s.H - ktail0 > 4) ? ld4(v.b.ih_w + (size_t)n * s.H + ktail0 + 4) : zero4();
-      }
+      xin[i] = xrow[n <= s.hidden_size ? n : s.hidden_size];
     }
-    if (tail) {
-      et[0] = ld4(ehi_t + (size_t)er * s.I + ktail0);
-      et[1] = (s.H - ktail0 > 4) ? ld4(ehi_t + (size_t)er * s.I + ktail0 + 4) : zero4();
-    }
-  };
-  if (!loader) fetch_epilogue_operands();
+  }
   const uint32_t lds0 = lds_byte_addr(smem);
   const uint32_t rowoff = (uint32_t)lm * (CK * 4u);
   if (loader) {
@@ -1630,20 +1618,11 @@ __global__ __launch_bounds__(512) void k_chain_main(const View *__restrict__ vp,
   float sq = 0.0f;
   if (r < nrows) {
     float *dst = v.b.ehi + ((size_t)(t + 1) * s.Scap + row0 + r) * s.I;
-    const int nt_tail = s.H - ktail0; /* 0..8 columns of K left over by the 128-wide stages */
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       int n = n0 + c4 + i;
       if (n <= s.hidden_size) {
         float ev = e[i];
-        if (tail) {
-          const float ek[8] = {et[0].x, et[0].y, et[0].z, et[0].w, et[1].x, et[1].y, et[1].z, et[1].w};
-          const float wk[8] = {wt[i][0].x, wt[i][0].y, wt[i][0].z, wt[i][0].w,
-                               wt[i][1].x, wt[i][1].y, wt[i][1].z, wt[i][1].w};
-#pragma unroll
-          for (int k = 0; k < 8; k++)
-            if (k < nt_tail) ev += ek[k] * wk[k];
-        }
         float xi = xin[i];
         bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
         ev = on ? ev : 0.0f;
@@ -2606,9 +2585,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   const int nxp = (nx + 3) & ~3;
   {
     int tm = (nrows + CM - 1) / CM;
-    int kfull = sh->H / CK, ktail = sh->H - kfull * CK;
-    int nstages = kfull + (ktail > 8 ? 1 : 0);
-    int ktail0 = ktail > 8 ? sh->H : kfull * CK; /* a short tail is added in the epilogue */
+    int nstages = (sh->hidden_size + CK - 1) / CK; /* K = the hidden columns 1..hidden_size */
     int blocks = ((tn + 7) / 8) * 8 * tm;
     /* one event pair around the D launches: the per-launch average then carries
      * 1/D of the event overhead instead of all of it */
@@ -2630,13 +2607,13 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     for (int t = 0; t < sh->D; t++) {
       if (b->uniform_idx >= 0 && nstages == 8)
         hipLaunchKernelGGL((k_chain_main<true, 8>), dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx,
-                           row0, nrows, t, tm, tn, nstages, ktail0);
+                           row0, nrows, t, tm, tn, nstages);
       else if (b->uniform_idx >= 0)
         hipLaunchKernelGGL(k_chain_main<true>, dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx, row0,
-                           nrows, t, tm, tn, nstages, ktail0);
+                           nrows, t, tm, tn, nstages);
       else
         hipLaunchKernelGGL(k_chain_main<false>, dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx,
-                           row0, nrows, t, tm, tn, nstages, ktail0);
+                           row0, nrows, t, tm, tn, nstages);
     }
     timing_end(st, ev);
     int M = sh->D * nrows;
