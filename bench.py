@@ -37,8 +37,8 @@ PEAK_HBM_GBS = 8000.0
 # HBM-side bytes per launch of the dominant kernel at the default shape, from the PMC passes
 # kept in profiles/r01_pmc_fetch_write_per_kernel.txt (2 x FETCH_SIZE + WRITE_SIZE, the gfx950
 # correction of MI355X_MICROARCH.md); it cannot be read live without the profiler.
-TRAFFIC_BYTES_PER_LAUNCH = {"bptt_chain_gemm": (2 * 7371.5 + 1312.0) * 1024,   # k_chain_main
-                            "delta_gemm": (2 * 33948.5 + 17414.2) * 1024}      # k_delta_dma
+TRAFFIC_BYTES_PER_LAUNCH = {"bptt_chain_gemm": (2 * 7398.5 + 1312.0) * 1024,   # k_chain_main
+                            "delta_gemm": (2 * 33946.5 + 17410.2) * 1024}      # k_delta_dma
 
 
 def parse():
