@@ -1,4 +1,5 @@
 """Development probe: generation rate of the batched text step at the BASELINE.json config shapes."""
+import sys
 import time
 import recur_ctypes as rc, scenarios as sc
 amd = rc.load_amd()
@@ -6,6 +7,8 @@ text = sc.synthetic_text(30000)
 for name, H, S, D in (("configs[1] text 1024/64/20", 1024, 64, 20), ("configs[2] classify-like 512/128/30", 512, 128, 30),
                       ("north star 1024/256/20", 1024, 256, 20), ("configs[4] rnnca-like 2048/512/10", 2048, 512, 10),
                       ("1024/512/20", 1024, 512, 20)):
+    if len(sys.argv) > 1 and sys.argv[1] not in name:
+        continue
     g = sc.AmdBatchedSet(amd, input_size=42, hidden_size=H, output_size=42, S=S, D=D, learn_rate=1e-5, seed=1)
     g.load_text(text)
     for i in range(D + 6):
