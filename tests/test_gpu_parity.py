@@ -249,6 +249,40 @@ def test_full_size_generation_matches_oracle(amd, full_set):
     o.close()
 
 
+@pytest.mark.parametrize("label,kw", [
+    ("configs1_text_1024_64_20", dict(input_size=42, hidden_size=1024, output_size=42, S=64, D=20)),
+    ("configs2_classify_like_512_128_30", dict(input_size=42, hidden_size=512, output_size=42, S=128, D=30)),
+    ("configs4_rnnca_like_2048_512_10", dict(input_size=42, hidden_size=2048, output_size=42, S=512, D=10)),
+])
+def test_baseline_config_shapes_one_generation_matches_oracle(amd, label, kw):
+    """BASELINE.json's other configurations at their full hidden / stream / depth sizes:
+    warm the ring up on the device, then one generation on both sides from the same state
+    (the generic-stage chain kernel, the delta DMA kernel at other tilings, and at hidden
+    2048 the dense extras GEMM and the unfused top layer)"""
+    kw = dict(kw, learn_rate=1e-5, seed=3)
+    g = sc.AmdBatchedSet(amd, **kw)
+    text = sc.synthetic_text(30000)
+    n = kw["D"] + 3
+    for i in range(n):
+        g.char_step(text, i, rc.WEIGHTED, 0.95)
+    snap = g.snapshot()
+    o = sc.OracleSet(**kw)
+    a = o.arrays()
+    for k in ("ih_w", "ho_w", "ih_m", "ho_m", "hist", "hidden", "index", "min_error_factor"):
+        a[k][:] = snap[k]
+    a["generation"][:] = snap["generation"]
+    g.stats(clear=True)
+    g.char_step(text, n, rc.WEIGHTED, 0.95)
+    o.char_step(text, n, rc.WEIGHTED, 0.95)
+    sg, so = g.snapshot(), o.snapshot()
+    assert np.array_equal(sg["hidden"] != 0, so["hidden"] != 0)
+    assert g.stats().bptt_depth_sum == float(so["bptt_depth"].sum())
+    replay.check(sg, so, RTOL, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "ih_m", "ho_m", "hidden",
+                                     "output", "o_error", "hist", "min_error_factor", "ih_scale"])
+    g.close()
+    o.close()
+
+
 def test_full_size_split_accumulation_property(amd, full_set):
     """size-independent property: the deltas of the whole set equal the deltas of
     its two halves accumulated (the reference's `j ? 1 : 0`, charmodel-predict.c:309)"""
