@@ -968,8 +968,17 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
     // activation and write the hidden row here (what k_fwd_finalize does, recur-nn.c:123-148)
     const float *p = v.b.slab + (size_t)blockIdx.x * s.H;
     for (int i = threadIdx.x; i < s.H; i += 1024) {
-      float x = p[i];
-      for (int z = 1; z < fwd_ks; z++) x += p[(size_t)z * nrows * s.H + i];
+      /* all the slabs' loads in flight at once (a loop with a run-time trip count issues
+       * them one L2 latency after another) */
+      const size_t plane = (size_t)nrows * s.H;
+      float xs[8];
+#pragma unroll
+      for (int z = 0; z < 8; z++) xs[z] = (z < fwd_ks) ? p[z * plane + i] : 0.0f;
+      float x = xs[0];
+#pragma unroll
+      for (int z = 1; z < 8; z++)
+        if (z < fwd_ks) x += xs[z];
+      for (int z = 8; z < fwd_ks; z++) x += p[z * plane + i];
       if (s.activation == 2) {
         x = (x > 0.0f) ? sqrtf(x + 1.0f) - 1.0f : 0.0f;
       } else if (s.activation == 5) {
@@ -998,6 +1007,17 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
       if (col < s.O) {
         const float *w = v.b.ho_w + col;
         int y = y0;
+        /* 32 rows' weights in flight per batch; the sums keep the order of the plain loop */
+        for (; y + 31 < y1; y += 32) {
+          float wv[32];
+#pragma unroll
+          for (int k = 0; k < 32; k++) wv[k] = w[(size_t)(y + k) * s.O];
+#pragma unroll
+          for (int k = 0; k < 32; k += 2) {
+            acc0 += shid[y + k] * wv[k];
+            acc1 += shid[y + k + 1] * wv[k + 1];
+          }
+        }
 #pragma unroll 4
         for (; y + 1 < y1; y += 2) {
           acc0 += shid[y] * w[(size_t)y * s.O];
@@ -2111,6 +2131,16 @@ __global__ __launch_bounds__(256) void k_apply(ApplySegs sg, float momentum, flo
     Dl.z = (c + 2 >= 1 && c + 2 <= pd.hidden_size) ? sum.z : 0.0f;
     Dl.w = (c + 3 >= 1 && c + 3 <= pd.hidden_size) ? sum.w : 0.0f;
     *reinterpret_cast<float4 *>(pd.delta_out + 4 * q) = Dl;
+  } else if (g == 0 && sg.pend.ho_slab) {
+    const RamdPendingDelta &pd = sg.pend;
+    float4 t[8];
+#pragma unroll
+    for (int z = 0; z < 8; z++) t[z] = (z < pd.ho_ks) ? ld4(pd.ho_slab + z * pd.ho_n + 4 * q) : zero4();
+    Dl = t[0];
+#pragma unroll
+    for (int z = 1; z < 8; z++)
+      if (z < pd.ho_ks) { Dl.x += t[z].x; Dl.y += t[z].y; Dl.z += t[z].z; Dl.w += t[z].w; }
+    *reinterpret_cast<float4 *>(pd.ho_delta_out + 4 * q) = Dl;
   } else {
     Dl = ld4(delta + 4 * q);
   }
@@ -2573,11 +2603,22 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       live = b->coef + row0;
     }
     ProbHoDelta p = {v, row0, nrows, live};
-    launch_gemm<true, true, ProbHoDelta>(st, p, b->slab, sh->H, sh->O, nkt, ks, T_OTHER);
-    /* with one range list per stream the set of touched columns differs per stream; the
-     * error is zero outside a stream's own ranges, so every column may take its sum */
-    hipLaunchKernelGGL(k_ho_delta_finalize, dim3((ho + 255) / 256), dim3(256), 0, st, v, b->slab,
-                       ks, accumulate, range_stride ? nullptr : ranges);
+    if (defer) defer->ho_slab = nullptr;
+    if (defer && !accumulate && !ranges && b->ho_slab) {
+      /* the optimiser launch that follows sums these slabs itself (and stores ho_delta) */
+      if (ks > 8) ks = 8;
+      launch_gemm<true, true, ProbHoDelta>(st, p, b->ho_slab, sh->H, sh->O, nkt, ks, T_OTHER);
+      defer->ho_slab = b->ho_slab;
+      defer->ho_n = (size_t)ho;
+      defer->ho_ks = ks;
+      defer->ho_delta_out = b->ho_delta;
+    } else {
+      launch_gemm<true, true, ProbHoDelta>(st, p, b->slab, sh->H, sh->O, nkt, ks, T_OTHER);
+      /* with one range list per stream the set of touched columns differs per stream; the
+       * error is zero outside a stream's own ranges, so every column may take its sum */
+      hipLaunchKernelGGL(k_ho_delta_finalize, dim3((ho + 255) / 256), dim3(256), 0, st, v, b->slab,
+                         ks, accumulate, range_stride ? nullptr : ranges);
+    }
   }
   // BPTT chain: D dependent steps, one launch each, then the extras of all steps
   const int tn = (sh->hidden_size + CN - 1) / CN;

@@ -49,6 +49,7 @@ typedef struct RamdBuffers {
   unsigned long long *rng; /* [Scap+Fcap][4] each stream's generator (recur-rng.h:15-20)   */
   float *ones;      /* [Scap] of 1.0: the "every stream takes part" mask               */
   float *slab;
+  float *ho_slab; /* 8 planes of H * O for the deferred top-layer delta sum, or NULL (very wide O) */
   size_t slab_floats;
   int *idx;       /* [Scap] ring position                           */
   float *lr;      /* [Scap] each stream's own learn_rate copy        */
@@ -86,6 +87,12 @@ typedef struct RamdPendingDelta {
   const float *rest;   /* planes of the rows from rows_core on: rest + z * rest_stride */
   size_t rest_stride;
   float *delta_out;    /* ih_delta                                                    */
+  /* the same for ho_delta (the top layer's GEMM keeps its slabs in b->ho_slab, which nothing
+   * else uses); ho_slab == NULL: ho_delta has been summed already */
+  const float *ho_slab;
+  size_t ho_n;         /* plane stride = H * O */
+  int ho_ks;
+  float *ho_delta_out;
 } RamdPendingDelta;
 
 enum { RAMD_IN_KEEP = 0, RAMD_IN_ONE_HOT = 1, RAMD_IN_DENSE = 2, RAMD_IN_TEXT = 3 };

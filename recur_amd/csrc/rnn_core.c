@@ -146,7 +146,7 @@ static void engine_free_device(RamdEngine *e) {
   dev_free(b->ih_aux); dev_free(b->ho_aux); dev_free(e->delta_own);
   dev_free(b->arena); dev_free(b->hidden); dev_free(b->out); dev_free(b->o_error);
   dev_free(b->err_a); dev_free(b->err_b); dev_free(b->ehi); dev_free(b->esum);
-  dev_free(b->coef); dev_free(b->ex); dev_free(b->esum_part); dev_free(b->zeros); dev_free(b->ones); dev_free(b->rng); dev_free(b->slab); dev_free(b->idx); dev_free(b->lr); dev_free(b->mef);
+  dev_free(b->coef); dev_free(b->ex); dev_free(b->esum_part); dev_free(b->zeros); dev_free(b->ones); dev_free(b->rng); dev_free(b->slab); dev_free(b->ho_slab); dev_free(b->idx); dev_free(b->lr); dev_free(b->mef);
   dev_free(b->ih_scale); dev_free(b->top_raw); dev_free(b->top_scaled); dev_free(b->bptt_err);
   dev_free(b->n_exec); dev_free(b->depth_log); dev_free(b->target); dev_free(b->hot);
   dev_free(b->xent);
@@ -562,6 +562,7 @@ static void engine_ensure_device(RamdEngine *e) {
     }
     b->slab_floats = per * slabs;
     b->slab = dev_alloc(b->slab_floats * fl);
+    b->ho_slab = e->ho_size <= ((size_t)1 << 20) ? dev_alloc(8 * e->ho_size * fl) : NULL;
   }
   b->idx = dev_alloc(S * sizeof(int));
   b->lr = dev_alloc(S * fl);
@@ -1794,7 +1795,7 @@ void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float mome
   RamdPendingDelta pend = {0};
   int fuse = !set->eng->delta_external && !set->nets[0]->log;
   char_step_deltas(set, i, fuse ? &pend : NULL);
-  apply_learning(set->nets[0], learning_style, momentum, pend.slab ? &pend : NULL);
+  apply_learning(set->nets[0], learning_style, momentum, (pend.slab || pend.ho_slab) ? &pend : NULL);
 }
 
 void rnn_amd_set_read_stats(RnnAmdSet *set, RnnAmdStats *stats, int clear) {
