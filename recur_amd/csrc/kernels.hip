@@ -1668,29 +1668,39 @@ __global__ __launch_bounds__(512) void k_chain_main(const View *__restrict__ vp,
 // the wave walks the non-zero columns (ballot), each dot product is reduced with
 // xor shuffles in a fixed order.  It also closes the step's sum of squares:
 // the column-tile partials of k_chain_main in index order, then the extras.
+// what one (step, stream) item reads before anything depends on anything: its error row,
+// this lane's input value of the first 64 extra columns, this lane's column-tile partial
+template <int MAXQ> struct ExtrasIn {
+  float4 ev[MAXQ];
+  float xi, pv;
+};
 template <int MAXQ> /* float4 per lane: 5 covers h_size <= 1280, 8 h_size <= 2048 */
-__global__ __launch_bounds__(256) void k_extras_gather(View v, int row0, int nrows, int nx, int nxp,
-                                                       int tn) {
+__device__ __forceinline__ void extras_load(const View &v, int t, int r, int nx, int tn, int lane,
+                                            ExtrasIn<MAXQ> &in) {
   const RamdShape &s = v.sh;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + wave;
-  if (m >= s.D * nrows) return;
-  const int t = m / nrows, r = row0 + (m - t * nrows);
   const float *erow = v.b.ehi + (t * s.Scap + r) * s.I;
   const float *x = input_row<false>(v, r, t);
-  float *dst = v.b.ex + ((size_t)(t + 1) * s.Scap + r) * nxp;
   const int nq = (s.H / 4 + 63) / 64;
-  float4 ev[MAXQ];
 #pragma unroll
   for (int i = 0; i < MAXQ; i++) {
     int k4 = lane + 64 * i;
-    ev[i] = (i < nq && 4 * k4 < s.H) ? ld4(erow + 4 * k4) : zero4();
+    in.ev[i] = (i < nq && 4 * k4 < s.H) ? ld4(erow + 4 * k4) : zero4();
   }
+  in.xi = (lane < nx) ? x[lane == 0 ? 0 : s.hidden_size + lane] : 0.0f;
+  in.pv = (lane < tn) ? v.b.esum_part[((size_t)t * (tn + 1) + lane) * s.Scap + r] : 0.0f;
+}
+template <int MAXQ>
+__device__ __forceinline__ float extras_compute(const View &v, int t, int r, int nx, int nxp, int tn,
+                                                int lane, const ExtrasIn<MAXQ> &in) {
+  const RamdShape &s = v.sh;
+  const float *x = input_row<false>(v, r, t);
+  float *dst = v.b.ex + ((size_t)(t + 1) * s.Scap + r) * nxp;
+  const int nq = (s.H / 4 + 63) / 64;
   float sq = 0.0f;
   for (int c0 = 0; c0 < nx; c0 += 64) {
     int c = c0 + lane;
     int n = (c == 0) ? 0 : s.hidden_size + c;
-    float xi = (c < nx) ? x[n] : 0.0f;
+    float xi = (c0 == 0) ? in.xi : ((c < nx) ? x[n] : 0.0f);
     bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
     if (c < nx) dst[c] = 0.0f;
     unsigned long long live = __ballot(on);
@@ -1711,15 +1721,15 @@ __global__ __launch_bounds__(256) void k_extras_gather(View v, int row0, int nro
 #pragma unroll
       for (int i = 0; i < MAXQ; i++) {
         int k4 = lane + 64 * i;
-        bool in = i < nq && 4 * k4 < s.H;
-        wva[i] = in ? ld4(wa + 4 * k4) : zero4();
-        wvb[i] = in ? ld4(wb + 4 * k4) : zero4();
+        bool inb = i < nq && 4 * k4 < s.H;
+        wva[i] = inb ? ld4(wa + 4 * k4) : zero4();
+        wvb[i] = inb ? ld4(wb + 4 * k4) : zero4();
       }
       float acca = 0.0f, accb = 0.0f;
 #pragma unroll
       for (int i = 0; i < MAXQ; i++) {
-        acca += ev[i].x * wva[i].x + ev[i].y * wva[i].y + ev[i].z * wva[i].z + ev[i].w * wva[i].w;
-        accb += ev[i].x * wvb[i].x + ev[i].y * wvb[i].y + ev[i].z * wvb[i].z + ev[i].w * wvb[i].w;
+        acca += in.ev[i].x * wva[i].x + in.ev[i].y * wva[i].y + in.ev[i].z * wva[i].z + in.ev[i].w * wva[i].w;
+        accb += in.ev[i].x * wvb[i].x + in.ev[i].y * wvb[i].y + in.ev[i].z * wvb[i].z + in.ev[i].w * wvb[i].w;
       }
       for (int off = 32; off > 0; off >>= 1) {
         acca += __shfl_xor(acca, off, 64);
@@ -1738,15 +1748,30 @@ __global__ __launch_bounds__(256) void k_extras_gather(View v, int row0, int nro
     }
   }
   // the step's total: the column-tile partials of k_chain_main in index order (each lane
-  // fetches one, lane 0 adds them in order), then the extras
+  // fetches one, every lane adds them in order), then the extras
   float sum = 0.0f;
   for (int p0 = 0; p0 < tn; p0 += 64) {
     int p = p0 + lane;
-    float pv = (p < tn) ? v.b.esum_part[((size_t)t * (tn + 1) + p) * s.Scap + r] : 0.0f;
+    float pv = (p0 == 0) ? in.pv
+                         : ((p < tn) ? v.b.esum_part[((size_t)t * (tn + 1) + p) * s.Scap + r] : 0.0f);
     int cnt = min(64, tn - p0);
     for (int i = 0; i < cnt; i++) sum += __shfl(pv, i, 64);
   }
-  if (lane == 0) v.b.esum[(size_t)t * s.Scap + r] = sum + sq;
+  return sum + sq; /* the same in every lane */
+}
+
+template <int MAXQ>
+__global__ __launch_bounds__(256) void k_extras_gather(View v, int row0, int nrows, int nx, int nxp,
+                                                       int tn) {
+  const RamdShape &s = v.sh;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= s.D * nrows) return;
+  const int t = m / nrows, r = row0 + (m - t * nrows);
+  ExtrasIn<MAXQ> in;
+  extras_load<MAXQ>(v, t, r, nx, tn, lane, in);
+  float es = extras_compute<MAXQ>(v, t, r, nx, nxp, tn, lane, in);
+  if (lane == 0) v.b.esum[(size_t)t * s.Scap + r] = es;
 }
 
 // Finalize of the extras GEMM: applies the row rule to column 0 and the input
@@ -1960,14 +1985,11 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
 // the step at which the reference's loop would have stopped, lane 0 derives ih_scale
 // and the adaptive min_error_factor, and the lanes publish coef[t][r] = ih_scale while
 // the step counts, 0 afterwards.
-__global__ __launch_bounds__(256) void k_bptt_control(View v, int row0, int nrows,
-                                                      const unsigned char *active, unsigned flags,
-                                                      int tn) {
-  const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= nrows) return;
+/* es: the stream's error sums by step, es[k * stride] */
+__device__ __forceinline__ void bptt_control_wave(const View &v, int r, int j, int lane,
+                                                  const unsigned char *active, unsigned flags,
+                                                  const float *es_src, size_t es_stride) {
   const RamdShape &s = v.sh;
-  const int r = row0 + j;
   const int D = s.D;
   if (active && !active[j]) {
     for (int k = lane; k < D; k += 64) v.b.coef[(size_t)k * s.Scap + r] = 0.0f;
@@ -1987,7 +2009,7 @@ __global__ __launch_bounds__(256) void k_bptt_control(View v, int row0, int nrow
   float error_sum = 0.0f;
   for (int k0 = 0; k0 < D; k0 += 64) {
     int k = k0 + lane;
-    float es = (k < D) ? v.b.esum[(size_t)k * s.Scap + r] : 0.0f;
+    float es = (k < D) ? es_src[(size_t)k * es_stride] : 0.0f;
     bool stop = k < D && (es <= min_error_sum || es > max_error_sum);
     unsigned long long hit = __ballot(stop);
     int last = hit ? __ffsll((long long)hit) - 1 : min(63, D - 1 - k0);
@@ -2022,6 +2044,45 @@ __global__ __launch_bounds__(256) void k_bptt_control(View v, int row0, int nrow
     v.b.stat_depth[r] += (double)(D - t);
   }
   for (int k = lane; k < D; k += 64) v.b.coef[(size_t)k * s.Scap + r] = (k < n_exec) ? scale : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_bptt_control(View v, int row0, int nrows,
+                                                      const unsigned char *active, unsigned flags,
+                                                      int tn) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= nrows) return;
+  const int r = row0 + j;
+  bptt_control_wave(v, r, j, lane, active, flags, v.b.esum + r, (size_t)v.sh.Scap);
+}
+
+// k_extras_gather and k_bptt_control in one launch, one workgroup per stream: the waves
+// share out the stream's steps, leave each step's error sum in LDS, and wave 0 then runs
+// the control logic on them (nothing else needs the sums of other streams).
+template <int MAXQ, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, int nrows, int nx,
+                                                            int nxp, int tn,
+                                                            const unsigned char *active,
+                                                            unsigned flags) {
+  extern __shared__ float es_sh[]; /* [D] */
+  const RamdShape &s = v.sh;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.x, r = row0 + j;
+  /* the next item's reads are requested before the current one is worked on */
+  ExtrasIn<MAXQ> cur, nxt;
+  if (wave < s.D) extras_load<MAXQ>(v, wave, r, nx, tn, lane, cur);
+  for (int t = wave; t < s.D; t += THREADS / 64) {
+    const int tnext = t + THREADS / 64;
+    if (tnext < s.D) extras_load<MAXQ>(v, tnext, r, nx, tn, lane, nxt);
+    float es = extras_compute<MAXQ>(v, t, r, nx, nxp, tn, lane, cur);
+    if (lane == 0) {
+      v.b.esum[(size_t)t * s.Scap + r] = es;
+      es_sh[t] = es;
+    }
+    cur = nxt;
+  }
+  __syncthreads();
+  if (wave == 0) bptt_control_wave(v, r, j, lane, active, flags, es_sh, 1);
 }
 
 // ------------------------------------------------------- finalize: delta --
@@ -2621,6 +2682,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     }
   }
   // BPTT chain: D dependent steps, one launch each, then the extras of all steps
+  bool control_done = false;
   const int tn = (sh->hidden_size + CN - 1) / CN;
   const int nx = sh->I - sh->hidden_size; /* column 0 + the input columns */
   const int nxp = (nx + 3) & ~3;
@@ -2662,20 +2724,33 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int ks = pick_ks(etm * etn, nkt, "RECUR_AMD_KS_EXTRAS", b->slab_floats, (size_t)M * nxp);
     if (sh->H <= 2048 && !env_int("RECUR_AMD_EXTRAS_GEMM", 0)) {
       const int nq = (sh->H / 4 + 63) / 64;
-      if (nq <= 5)
-        hipLaunchKernelGGL(k_extras_gather<5>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
-                           nxp, tn);
-      else
-        hipLaunchKernelGGL(k_extras_gather<8>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
-                           nxp, tn);
+      if (env_int("RECUR_AMD_EXTRAS_SPLIT", 0)) {
+        if (nq <= 5)
+          hipLaunchKernelGGL(k_extras_gather<5>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
+                             nxp, tn);
+        else
+          hipLaunchKernelGGL(k_extras_gather<8>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
+                             nxp, tn);
+      } else {
+        /* extras and control in one launch, one workgroup per stream */
+        const size_t shm = (size_t)sh->D * sizeof(float);
+        if (nq <= 5)
+          hipLaunchKernelGGL((k_extras_control<5, 1024>), dim3(nrows), dim3(1024), shm, st, v, row0, nrows,
+                             nx, nxp, tn, active, flags);
+        else
+          hipLaunchKernelGGL((k_extras_control<8, 512>), dim3(nrows), dim3(512), shm, st, v, row0, nrows,
+                             nx, nxp, tn, active, flags);
+        control_done = true;
+      }
     } else { /* very wide nets: the dense GEMM over all extra columns */
       ProbExtras p = {v, row0, nrows, nx};
       launch_gemm<false, false, ProbExtras>(st, p, b->slab, M, nxp, nkt, ks, T_OTHER);
       hipLaunchKernelGGL(k_extras_finalize, dim3(M), dim3(64), 0, st, v, row0, nrows, nx, nxp, ks, tn);
     }
   }
-  hipLaunchKernelGGL(k_bptt_control, dim3((nrows + 3) / 4), dim3(256), 0, st, v, row0, nrows,
-                     active, flags, tn);
+  if (!control_done)
+    hipLaunchKernelGGL(k_bptt_control, dim3((nrows + 3) / 4), dim3(256), 0, st, v, row0, nrows,
+                       active, flags, tn);
   // weight deltas: one GEMM over (step, stream)
   {
     /* only columns 1..hidden_size of the delta can be non-zero (h_error[0] and the pad are
