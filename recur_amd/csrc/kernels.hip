@@ -263,13 +263,17 @@ __device__ __forceinline__ float4 frag_read(const float *lds, int rc, int g, int
 // CU keep roughly 100-200 KB in flight per CU.
 constexpr int PF = 4;
 
+template <bool A_KM, bool B_KM> struct GemmLds {
+  static constexpr int A_FLOATS = A_KM ? BK * BM : BM * LDK;
+  static constexpr int B_FLOATS = B_KM ? BK * BN : BN * LDK;
+  static constexpr int STAGE = A_FLOATS + B_FLOATS;
+};
+
 template <bool A_KM, bool B_KM, class Prob>
-__global__ __launch_bounds__(256) void k_gemm(Prob p, GemmOut o) {
-  constexpr int A_FLOATS = A_KM ? BK * BM : BM * LDK;
-  constexpr int B_FLOATS = B_KM ? BK * BN : BN * LDK;
-  __shared__ __attribute__((aligned(16))) float lds[2][A_FLOATS + B_FLOATS];
+__device__ __forceinline__ void gemm_body(const Prob &p, const GemmOut &o, const int L,
+                                          float (*lds)[GemmLds<A_KM, B_KM>::STAGE]) {
+  constexpr int A_FLOATS = GemmLds<A_KM, B_KM>::A_FLOATS;
   // block id -> (m tile, panel = (n tile, K slice)), XCD aware
-  const int L = blockIdx.x;
   const int xcd = L & 7, q = L >> 3;
   const int mt = q % o.tm, panel = (q / o.tm) * 8 + xcd;
   if (panel >= o.tn * o.ks) return;
@@ -342,6 +346,24 @@ __global__ __launch_bounds__(256) void k_gemm(Prob p, GemmOut o) {
       if (row < o.M) c[(size_t)row * o.ldc + col] = acc[g];
     }
   }
+}
+
+template <bool A_KM, bool B_KM, class Prob>
+__global__ __launch_bounds__(256) void k_gemm(Prob p, GemmOut o) {
+  __shared__ __attribute__((aligned(16))) float lds[2][GemmLds<A_KM, B_KM>::STAGE];
+  gemm_body<A_KM, B_KM, Prob>(p, o, blockIdx.x, lds);
+}
+
+// Two independent small GEMMs (both operands K-major) in one launch: workgroups below
+// `first_b` work on problem A, the others on problem B.
+template <class ProbA, class ProbB>
+__global__ __launch_bounds__(256) void k_gemm_pair(ProbA pa, GemmOut oa, int first_b, ProbB pb,
+                                                   GemmOut ob) {
+  __shared__ __attribute__((aligned(16))) float lds[2][GemmLds<true, true>::STAGE];
+  if ((int)blockIdx.x < first_b)
+    gemm_body<true, true, ProbA>(pa, oa, blockIdx.x, lds);
+  else
+    gemm_body<true, true, ProbB>(pb, ob, blockIdx.x - first_b, lds);
 }
 
 
@@ -2437,9 +2459,8 @@ static int pick_ks(int tiles, int nkt, const char *env, size_t slab_floats, size
   return ks;
 }
 
-template <bool A_KM, bool B_KM, class Prob>
-static void launch_gemm(hipStream_t st, const Prob &p, float *slab, int M, int N, int nkt, int ks,
-                        int cls, int col0 = 0, int ldc = 0, int row0m = 0) {
+static GemmOut make_gemm_out(float *slab, int M, int N, int nkt, int ks, int col0, int ldc,
+                             int row0m, int *blocks) {
   GemmOut o;
   o.slab = slab;
   o.M = M;
@@ -2452,7 +2473,15 @@ static void launch_gemm(hipStream_t st, const Prob &p, float *slab, int M, int N
   o.ks = ks;
   o.col0 = col0;
   int panels = o.tn * ks;
-  int blocks = ((panels + 7) / 8) * 8 * o.tm;
+  *blocks = ((panels + 7) / 8) * 8 * o.tm;
+  return o;
+}
+
+template <bool A_KM, bool B_KM, class Prob>
+static void launch_gemm(hipStream_t st, const Prob &p, float *slab, int M, int N, int nkt, int ks,
+                        int cls, int col0 = 0, int ldc = 0, int row0m = 0) {
+  int blocks;
+  GemmOut o = make_gemm_out(slab, M, N, nkt, ks, col0, ldc, row0m, &blocks);
   int ev = timing_begin(st, cls);
   hipLaunchKernelGGL((k_gemm<A_KM, B_KM, Prob>), dim3(blocks), dim3(256), 0, st, p, o);
   timing_end(st, ev);
@@ -2650,6 +2679,15 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   if (!(flags & 0x40000000u)) /* ramd_launch_text_top has already done the top backprop */
     hipLaunchKernelGGL(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges,
                        range_stride, active);
+  /* the weight-delta GEMM's path is decided here already: when it ends with the small GEMM
+   * over the rows above the last whole 128-row tile, the top layer's equally small delta
+   * GEMM can share that launch (nothing before the optimiser needs its result) */
+  const bool dma = b->uniform_idx >= 0 && nrows % BK == 0 && sh->hidden_size % 128 == 0 &&
+                   sh->I >= 128 && sh->activation != 5 && env_int("RECUR_AMD_DELTA_DMA", 1);
+  const bool has_rest = dma && (sh->I / 128) * 128 < sh->I;
+  bool ho_paired = false;
+  ProbHoDelta ho_p = {};
+  int ho_nkt = 0, ho_ks = 0;
   if (!(flags & 0x80000000u)) { /* the fused single-net path updates W_ho directly */
     int tm = (sh->H + BM - 1) / BM, tn = (sh->O + BN - 1) / BN;
     int nkt = (nrows + BK - 1) / BK;
@@ -2668,7 +2706,14 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     if (defer && !accumulate && !ranges && b->ho_slab) {
       /* the optimiser launch that follows sums these slabs itself (and stores ho_delta) */
       if (ks > 8) ks = 8;
-      launch_gemm<true, true, ProbHoDelta>(st, p, b->ho_slab, sh->H, sh->O, nkt, ks, T_OTHER);
+      if (has_rest && !active && env_int("RECUR_AMD_PAIR_HO", 1)) {
+        ho_paired = true; /* launched together with the rest rows of the weight-delta GEMM */
+        ho_p = p;
+        ho_nkt = nkt;
+        ho_ks = ks;
+      } else {
+        launch_gemm<true, true, ProbHoDelta>(st, p, b->ho_slab, sh->H, sh->O, nkt, ks, T_OTHER);
+      }
       defer->ho_slab = b->ho_slab;
       defer->ho_n = (size_t)ho;
       defer->ho_ks = ks;
@@ -2768,8 +2813,6 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       ks = pick_ks(tm2 * tn2, nkt, "RECUR_AMD_KS_DELTA", b->slab_floats, n);
     }
     int rows_core = sh->I, ks_rest = ks;
-    const bool dma = b->uniform_idx >= 0 && nrows % BK == 0 && sh->hidden_size % 128 == 0 &&
-                     sh->I >= 128 && sh->activation != 5 && env_int("RECUR_AMD_DELTA_DMA", 1);
     if (dma) {
       /* whole 128-row tiles by LDS-DMA, one workgroup per CU; the rows above them (the
        * input rows of a text net) by the generic kernel with its own K split */
@@ -2809,8 +2852,19 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
         int tmr = (sh->I - rows_core + BM - 1) / BM, tnr = (ncol - 1 + BN - 1) / BN;
         ks_rest = pick_ks(tmr * tnr, nkt, "RECUR_AMD_KS_DELTA_REST", b->slab_floats, n);
         ProbDelta<true> p = {v, row0, nrows, rtiles};
-        launch_gemm<true, true, ProbDelta<true>>(st, p, b->slab, sh->I, ncol, nkt, ks_rest, T_DELTA, 1,
-                                                 sh->H, rows_core);
+        if (ho_paired) {
+          int blocks_a, blocks_b;
+          GemmOut oa = make_gemm_out(b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, 0, 0, 0, &blocks_a);
+          GemmOut ob = make_gemm_out(b->slab, sh->I, ncol, nkt, ks_rest, 1, sh->H, rows_core, &blocks_b);
+          int ev2 = timing_begin(st, T_DELTA);
+          hipLaunchKernelGGL((k_gemm_pair<ProbHoDelta, ProbDelta<true>>), dim3(blocks_a + blocks_b),
+                             dim3(256), 0, st, ho_p, oa, blocks_a, p, ob);
+          timing_end(st, ev2);
+          ho_paired = false;
+        } else {
+          launch_gemm<true, true, ProbDelta<true>>(st, p, b->slab, sh->I, ncol, nkt, ks_rest, T_DELTA, 1,
+                                                   sh->H, rows_core);
+        }
       }
     } else if (big && b->uniform_idx >= 0) {
       ProbDelta<true> p = {v, row0, nrows, rtiles};
