@@ -289,7 +289,7 @@ def load_ref(fast=False):
 def load_amd():
     if not os.path.exists(AMD_LIB):
         raise RuntimeError("librecur_amd.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
-    lib = C.CDLL(AMD_LIB)
+    lib = C.CDLL(os.environ.get("RECUR_AMD_LIB", AMD_LIB))  # development: an experimental build
     _bind(lib, RNN_API)
     _bind(lib, AMD_API)
     return lib

@@ -19,6 +19,9 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 #ifndef NST
 #define NST 8        // stages per launch
 #endif
+#ifndef MISALIGN
+#define MISALIGN 0   // 1: operand rows start at column 1 (4-byte-aligned 16-byte chunks), as in the real kernel
+#endif
 constexpr int CK = 128, SF = 64 * CK; // 32 KB stage
 struct Big { const float *p[60]; int n[16]; };
 template <int MODE>
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(64 * NLOAD + 256) void k(
       int c = (lane & 31) ^ (row & 15);
       const float *base = (i < 16) ? A + (size_t)(m0 + row) * I : W + (size_t)(n0 + row) * H;
       if (MODE == 2) base = A; // hot line: everything from the same few lines
-      src[j] = base + 4 * c;
+      src[j] = base + MISALIGN + 4 * c;
     }
     auto issue = [&](int st) {
       for (int j = 0; j < DPW; j++) {
@@ -69,7 +72,9 @@ __global__ __launch_bounds__(64 * NLOAD + 256) void k(
       if (MODE != 1) __builtin_amdgcn_s_barrier();
       if (st + STAGES - 1 < NST) issue(st + STAGES - 1);
     }
+#ifndef QUAD
     if (MODE == 6) __syncthreads();
+#endif
   } else {
     float acc = 0;
     for (int st = 0; st < NST && MODE < 4; st++) {
@@ -85,6 +90,48 @@ __global__ __launch_bounds__(64 * NLOAD + 256) void k(
         }
       }
     }
+#ifdef QUAD
+    // every compute wave owns a 16 x 16 quadrant of the tile over the whole K (16x16x4 MFMA):
+    // no cross-wave reduction at the end, twice the LDS fragment reads
+    if (MODE >= 4) {
+      typedef float f32x4v __attribute__((ext_vector_type(4)));
+      f32x4v c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+      const int wm = wave >> 1, wn = wave & 1, m = lane & 15, kq = lane >> 4;
+      for (int st = 0; st < NST; st++) {
+        __builtin_amdgcn_s_barrier();
+        const float *p = smem + (st % STAGES) * SF;
+        float4 a[8], b[8];
+        for (int i = 0; i < 8; i++) {
+          int c = 4 * i + kq;
+          int ra = wm * 16 + m, rb = wn * 16 + m;
+          a[i] = *(const float4 *)(p + ra * CK + ((c ^ (ra & 15)) * 4));
+          b[i] = *(const float4 *)(p + 32 * CK + rb * CK + ((c ^ (rb & 15)) * 4));
+        }
+        for (int i = 0; i < 8; i++) {
+          if (MODE == 4 || (i & 1) == 0) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, c0, 0, 0, 0);
+          } else {
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, c1, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, c1, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, c1, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, c1, 0, 0, 0);
+          }
+        }
+      }
+      for (int i = 0; i < 4; i++) acc += c0[i] + c1[i];
+      if (MODE == 6) {
+        // no workgroup-wide sum: each lane writes its four (row, column) values
+        float *pl = const_cast<float *>(A) + (size_t)256 * I;
+        for (int g = 0; g < 4; g++) {
+          int row = m0 + wm * 16 + 4 * kq + g, col = n0 + wn * 16 + m;
+          pl[(size_t)row * I + col] = (c0[g] + c1[g]) * 0.f;
+        }
+      }
+    }
+#else
     if (MODE >= 4) {
       typedef float f32x16 __attribute__((ext_vector_type(16)));
       f32x16 c0, c1;
@@ -122,6 +169,7 @@ __global__ __launch_bounds__(64 * NLOAD + 256) void k(
         dst[0] = acc * 0.f; dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f;
       }
     }
+#endif
     if (acc == 12345.f) out[threadIdx.x] = acc;
   }
 }
