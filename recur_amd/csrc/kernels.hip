@@ -985,10 +985,14 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
   float *sex = sout + s.O;             /* [O] exponentials                   */
   float *serr = sex + s.O;             /* [O] output error                   */
   float *hid = v.b.hidden + (size_t)r * s.H;
-  if (fwd_ks > 0) {
+  if (fwd_ks != 0) {
     // the forward GEMM's K slabs are still in the workspace: sum them, apply the
-    // activation and write the hidden row here (what k_fwd_finalize does, recur-nn.c:123-148)
+    // activation and write the hidden row here (what k_fwd_finalize does, recur-nn.c:123-148).
+    // fwd_ks < 0: k_fwd_fused left one plane of sums and, for the h_size padding columns,
+    // -fwd_ks per-tile partial sums in plane 1.
     const float *p = v.b.slab + (size_t)blockIdx.x * s.H;
+    const int npart = fwd_ks < 0 ? -fwd_ks : 0;
+    if (fwd_ks < 0) fwd_ks = 1;
     for (int i = threadIdx.x; i < s.H; i += 1024) {
       /* all the slabs' loads in flight at once (a loop with a run-time trip count issues
        * them one L2 latency after another) */
@@ -1001,6 +1005,7 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
       for (int z = 1; z < 8; z++)
         if (z < fwd_ks) x += xs[z];
       for (int z = 8; z < fwd_ks; z++) x += p[z * plane + i];
+      if (npart && i >= s.H - 4) continue; /* the tail columns: below */
       if (s.activation == 2) {
         x = (x > 0.0f) ? sqrtf(x + 1.0f) - 1.0f : 0.0f;
       } else if (s.activation == 5) {
@@ -1012,6 +1017,27 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
       if (i == 0) x = 1.0f; /* the bias node, recur-nn.c:148 */
       hid[i] = x;
       shid[i] = x;
+    }
+    if (npart && threadIdx.x < 256) {
+      /* k_fwd_fused's four tail columns (hidden value hidden_size and the padding of h_size):
+       * wave p adds column p's per-tile partial sums */
+      const int p4 = threadIdx.x >> 6, ln = threadIdx.x & 63;
+      const float *pd = v.b.slab + (size_t)nrows * s.H + (size_t)blockIdx.x * 4 + p4;
+      float x = 0.0f;
+      for (int t = ln; t < npart; t += 64) x += pd[(size_t)t * nrows * 4];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      if (s.activation == 2) {
+        x = (x > 0.0f) ? sqrtf(x + 1.0f) - 1.0f : 0.0f;
+      } else if (s.activation == 5) {
+        x = x < 20.0f ? x : 20.0f;
+        x = (x > 0.0f) ? x : 0.0f;
+      } else {
+        x = (x > 0.0f) ? x : 0.0f;
+      }
+      if (ln == 0) {
+        hid[s.H - 4 + p4] = x;
+        shid[s.H - 4 + p4] = x;
+      }
     }
   } else {
     for (int i = threadIdx.x; i < s.H; i += 1024) shid[i] = hid[i];
@@ -1622,15 +1648,37 @@ __global__ __launch_bounds__(512) void k_chain_main(const View *__restrict__ vp,
       }
       __builtin_amdgcn_sched_barrier(0);
     };
-    f32x4 a0[4], b0[4], a1[4], b1[4];
-    if (nstages > 0) {
+    if constexpr (NS > 0) {
+      f32x4 a0[4], b0[4], a1[4], b1[4];
       __builtin_amdgcn_s_barrier(); /* stage 0 has landed */
       rd(0, a0, b0);
-    }
 #pragma unroll
-    for (int st = 0; st < nstages; st += 2) {
-      step(st, a0, b0, a1, b1);
-      if (st + 1 < nstages) step(st + 1, a1, b1, a0, b0);
+      for (int st = 0; st < NS; st += 2) {
+        step(st, a0, b0, a1, b1);
+        if (st + 1 < NS) step(st + 1, a1, b1, a0, b0);
+      }
+    } else {
+      /* Any number of stages: read, wait, multiply, stage by stage.  The read-ahead form above
+       * is only used fully unrolled: in a rolled loop the compiler may copy the ping-pong
+       * fragment registers right after the ds_read that fills them -- before the data has
+       * arrived -- since it cannot see that an inline-asm load completes later. */
+      f32x4 a[4], b[4];
+      for (int st = 0; st < nstages; st++) {
+        __builtin_amdgcn_s_barrier(); /* stage st has landed */
+        rd(st, a, b);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]),
+                       "+v"(b[3])
+                     :
+                     : "memory");
+#pragma unroll
+        for (int gi = 0; gi < 4; gi++) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].x, b[gi].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].y, b[gi].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].z, b[gi].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].w, b[gi].w, acc, 0, 0, 0);
+        }
+      }
     }
   }
   // --- sum the four waves' partial tiles through LDS.  The ring buffer that stage
@@ -1679,6 +1727,301 @@ __global__ __launch_bounds__(512) void k_chain_main(const View *__restrict__ vp,
   sq += __shfl_xor(sq, 4, 64);
   if ((etid & 7) == 0 && r < nrows)
     v.b.esum_part[((size_t)t * (tn + 1) + nt) * s.Scap + row0 + r] = sq;
+}
+
+// ------------------------------------- assemble + hidden layer in one launch --
+//
+// The text step's forward pass shaped like a chain step (recur-nn.c:104-148): output tile =
+// 32 streams x 32 hidden columns, K = the previous hidden values 1..hidden_size in 128-deep
+// stages through the same LDS ring, loader and compute waves as k_chain_main.  What differs:
+//   * A = rows of `hidden` (the previous step's activations, K-contiguous, swizzled as in the
+//     chain); B = W_ih rows k, columns of the tile: K-major, so a stage is [128 k][32 columns]
+//     in LDS and a lane fetches its four k with two ds_read2_b32;
+//   * the bias row (input 0 is always 1) and the row of the stream's one-hot input are added in
+//     the epilogue -- the K loop never touches the input columns;
+//   * the workgroup does k_assemble's work for its block on the side: it writes its 32 x 32
+//     block of the new history slot (the previous hidden values), the workgroups of column tile
+//     0 also the bias, the input columns, the ring index and the text target; the row sum
+//     that decides the emergency soft clip (maybe_scale_inputs, recur-nn.c:68-81) falls out
+//     of the A fragments, and the clip is applied to the outputs and the stored row alike;
+//   * the pre-activation sums go to slab plane 0 for k_text_top (which applies the activation
+//     and writes `hidden`: the A operand must stay intact while other workgroups read it); the
+//     h_size padding columns, which only matter when W's padding is non-zero, come as per-tile
+//     partial sums in plane 1 ([tn][nrows][4]) that k_text_top adds up.
+// Launcher preconditions: every stream at the same ring position, one-hot or text input, no
+// presynaptic noise, no bottom layer, hidden_size a multiple of 32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+/* [k][col] and [k + 1][col] of a 32-column K-major stage; _hi: k + 2, k + 3.  The results are
+ * used as they come (sub-registers of the asm output): a copy the compiler is free to place
+ * before the s_waitcnt would read them too early */
+__device__ __forceinline__ f32x2 lds_read2_b32(uint32_t addr) {
+  f32x2 v;
+  asm volatile("ds_read2_b32 %0, %1 offset1:32" : "=v"(v) : "v"(addr));
+  return v;
+}
+__device__ __forceinline__ f32x2 lds_read2_b32_hi(uint32_t addr) {
+  f32x2 v;
+  asm volatile("ds_read2_b32 %0, %1 offset0:64 offset1:96" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+template <int NS = 0>
+__global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, int new_idx, int row0,
+                                                   int nrows, int tm, int tn, int nstages_arg,
+                                                   int mode, int text_i, int global_first,
+                                                   int n_set) {
+  View v = *vp;
+  const int nstages = NS > 0 ? NS : nstages_arg;
+  __shared__ __attribute__((aligned(16))) float smem[C_STAGES * C_STAGE_FLOATS];
+  __shared__ float rs_sh[4][CM];
+  const RamdShape &s = v.sh;
+  const int L = blockIdx.x;
+  const int xcd = L & 7, q = L >> 3;
+  const int mt = q % tm, nt = (q / tm) * 8 + xcd;
+  if (nt >= tn) return;
+  /* column tiles start at column 0 (16-byte aligned rows of W and of the outputs); column 0's
+   * sum is never used (the bias node), and the last four columns of h_size -- hidden value
+   * hidden_size and the padding -- are not in any tile: they come as partial sums */
+  const int m0 = mt * CM, n0 = nt * CN;
+  const int wave8 = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool loader = wave8 >= 4;
+  const int wave = wave8 & 3;
+  const int lm = lane & 31, kh = lane >> 5;
+  const float *hid0 = v.b.hidden + (size_t)row0 * s.H;
+
+  // --- LDS-DMA sources: instruction i < 16 fills rows 2 (i & 15), +1 of A; i >= 16 fills
+  // k rows 8 (i - 16) .. + 7 of B, eight lanes (32 columns) per k row
+  const float *src[8];
+  size_t stage_step[8];
+  int kfirst[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    int i = wave * 8 + j;
+    if (i < 16) {
+      int row = 2 * (i & 15) + (lane >> 5);
+      int c = (lane & 31) ^ (row & 15);
+      int r = m0 + row;
+      src[j] = hid0 + (size_t)(r < nrows ? r : nrows - 1) * s.H + 1 + 4 * c;
+      stage_step[j] = CK;
+      kfirst[j] = 1 + 4 * c;
+    } else {
+      int kr = 8 * (i - 16) + (lane >> 3);
+      src[j] = v.b.ih_w + (size_t)(1 + kr) * s.H + n0 + 4 * (lane & 7);
+      stage_step[j] = (size_t)CK * s.H;
+      kfirst[j] = 1 + kr;
+    }
+  }
+  auto issue = [&](int stage) {
+    float *dst = smem + (stage % C_STAGES) * C_STAGE_FLOATS + wave * 8 * 256;
+    const int k0 = stage * CK;
+    if (k0 + CK <= s.hidden_size) {
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(src[j] + stage * stage_step[j]),
+                                         (lds_void_t *)(dst + j * 256), 16, 0, 0);
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { /* last, partial stage: what lies past the hidden values is zero */
+      const float *g = (k0 + kfirst[j] <= s.hidden_size) ? src[j] + stage * stage_step[j] : v.b.zeros;
+      __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(dst + j * 256), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+
+  const int etid = threadIdx.x & 255;
+  const int erow = etid >> 3, ec4 = (etid & 7) * 4;
+  const int er = m0 + erow < nrows ? m0 + erow : nrows - 1; /* row within the set */
+  const int grow = row0 + er;
+  const int tail = s.H - 4; /* the four columns outside the tiles: hidden_size = tail or tail + 1 .. */
+  if (loader) {
+#pragma unroll
+    for (int p = 0; p < C_STAGES - 1; p++)
+      if (p < nstages) issue(p);
+  }
+  // --- what the epilogue needs (compute waves): the one-hot index, this thread's four input
+  // values x[n0 + ec4 ..] (column 0 is the bias node, 1), the bias row's and the input row's
+  // weights under its four columns, and the tail columns of W in the rows of its four inputs
+  int hot = -1, text_o = 0;
+  float4 a4 = zero4(), wb = zero4(), ws = zero4(), wt[4];
+  if (!loader) {
+    if (mode == RAMD_IN_TEXT) { /* charmodel-predict.c:273, 295-298 */
+      int len = v.b.text_len;
+      int spacing = (len - 1) / n_set;
+      text_o = text_i + (global_first + er) * spacing;
+      if (text_o >= len - 1) text_o -= len - 1;
+      hot = v.b.text[text_o];
+    } else {
+      hot = v.b.hot[grow];
+    }
+    if (hot < 0 || hot >= s.input_size) hot = -1;
+    a4 = ld4(hid0 + (size_t)er * s.H + n0 + ec4);
+    if (n0 + ec4 == 0) a4.x = 1.0f;
+    wb = ld4(v.b.ih_w + n0 + ec4);
+    ws = ld4(v.b.ih_w + (size_t)(hot >= 0 ? s.hidden_size + 1 + hot : 0) * s.H + n0 + ec4);
+#pragma unroll
+    for (int i = 0; i < 4; i++) wt[i] = ld4(v.b.ih_w + (size_t)(n0 + ec4 + i) * s.H + tail);
+  }
+  const uint32_t lds0 = lds_byte_addr(smem);
+  const uint32_t rowoff = (uint32_t)lm * (CK * 4u);
+  float rsum = 0.0f;
+  if (loader) {
+#pragma unroll
+    for (int st = 0; st < nstages; st++) {
+      const int ahead = min(C_STAGES - 2, nstages - 1 - st);
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (st + C_STAGES - 1 < nstages) issue(st + C_STAGES - 1);
+    }
+  } else {
+    struct BFrag {
+      f32x2 lo[4], hi[4];
+    };
+    auto rd = [&](int st, f32x4 (&a)[4], BFrag &b) {
+      const uint32_t abase = lds0 + (uint32_t)((st % C_STAGES) * C_STAGE_FLOATS) * 4u;
+      const uint32_t bbase = abase + (uint32_t)(CM * CK) * 4u;
+#pragma unroll
+      for (int gi = 0; gi < 4; gi++) {
+        int c = 2 * (4 * wave + gi) + kh; /* chunk = 4 consecutive k */
+        a[gi] = lds_read_b128(abase + rowoff + (uint32_t)((c ^ (lm & 15)) * 16));
+        const uint32_t baddr = bbase + (uint32_t)((4 * c) * CN + lm) * 4u;
+        b.lo[gi] = lds_read2_b32(baddr);
+        b.hi[gi] = lds_read2_b32_hi(baddr);
+      }
+    };
+    auto step = [&](int st, f32x4 (&a)[4], BFrag &b, f32x4 (&an)[4], BFrag &bn) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (st + 1 < nstages) {
+        __builtin_amdgcn_s_barrier();
+        rd(st + 1, an, bn);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int gi = 0; gi < 4; gi++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].x, b.lo[gi].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].y, b.lo[gi].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].z, b.hi[gi].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].w, b.hi[gi].y, acc, 0, 0, 0);
+        rsum += (a[gi].x + a[gi].y) + (a[gi].z + a[gi].w); /* the row's input sum, on the side */
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (NS > 0) {
+      f32x4 a0[4], a1[4];
+      BFrag b0, b1;
+      __builtin_amdgcn_s_barrier();
+      rd(0, a0, b0);
+#pragma unroll
+      for (int st = 0; st < NS; st += 2) {
+        step(st, a0, b0, a1, b1);
+        if (st + 1 < NS) step(st + 1, a1, b1, a0, b0);
+      }
+    } else { /* any number of stages: no read-ahead (see k_chain_main) */
+      f32x4 a[4];
+      BFrag b;
+      for (int st = 0; st < nstages; st++) {
+        __builtin_amdgcn_s_barrier();
+        rd(st, a, b);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b.lo[0]), "+v"(b.lo[1]),
+                       "+v"(b.lo[2]), "+v"(b.lo[3]), "+v"(b.hi[0]), "+v"(b.hi[1]), "+v"(b.hi[2]), "+v"(b.hi[3])
+                     :
+                     : "memory");
+#pragma unroll
+        for (int gi = 0; gi < 4; gi++) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].x, b.lo[gi].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].y, b.lo[gi].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].z, b.hi[gi].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi].w, b.hi[gi].y, acc, 0, 0, 0);
+          rsum += (a[gi].x + a[gi].y) + (a[gi].z + a[gi].w);
+        }
+      }
+    }
+  }
+  float *red = smem + (nstages % C_STAGES) * C_STAGE_FLOATS; /* [4][32][32] */
+  if (!loader) {
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+      int row = (g & 3) + 8 * (g >> 2) + 4 * kh;
+      red[(wave * CM + row) * CN + lm] = acc[g];
+    }
+    rsum += __shfl_xor(rsum, 32, 64);
+    if (kh == 0) rs_sh[wave][lm] = rsum;
+  }
+  __syncthreads();
+  if (loader) return;
+  const int row = erow, c4 = ec4;
+  float4 e;
+  {
+    float4 p0 = ld4(red + (0 * CM + row) * CN + c4), p1 = ld4(red + (1 * CM + row) * CN + c4);
+    float4 p2 = ld4(red + (2 * CM + row) * CN + c4), p3 = ld4(red + (3 * CM + row) * CN + c4);
+    e.x = (p0.x + p1.x) + (p2.x + p3.x);
+    e.y = (p0.y + p1.y) + (p2.y + p3.y);
+    e.z = (p0.z + p1.z) + (p2.z + p3.z);
+    e.w = (p0.w + p1.w) + (p2.w + p3.w);
+  }
+  // the row's input sum: bias + previous hidden values + the one-hot input
+  float sum = ((rs_sh[0][row] + rs_sh[1][row]) + (rs_sh[2][row] + rs_sh[3][row])) + 1.0f +
+              (hot >= 0 ? 1.0f : 0.0f);
+  const float softclip = s.I * INPUT_MEAN_SOFT_TOP_F;
+  const float scale = (sum > softclip) ? soft_clip_dev(sum, softclip) : 1.0f;
+  const bool live = m0 + row < nrows;
+  // this workgroup's share of the four tail columns: its 32 inputs x W[k][tail .. tail + 3]
+  float4 pp;
+  pp.x = ((a4.x * wt[0].x + a4.y * wt[1].x) + (a4.z * wt[2].x + a4.w * wt[3].x));
+  pp.y = ((a4.x * wt[0].y + a4.y * wt[1].y) + (a4.z * wt[2].y + a4.w * wt[3].y));
+  pp.z = ((a4.x * wt[0].z + a4.y * wt[1].z) + (a4.z * wt[2].z + a4.w * wt[3].z));
+  pp.w = ((a4.x * wt[0].w + a4.y * wt[1].w) + (a4.z * wt[2].w + a4.w * wt[3].w));
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    pp.x += __shfl_xor(pp.x, off, 64);
+    pp.y += __shfl_xor(pp.y, off, 64);
+    pp.z += __shfl_xor(pp.z, off, 64);
+    pp.w += __shfl_xor(pp.w, off, 64);
+  }
+  if (!live) return;
+  float *out = v.b.slab + (size_t)er * s.H;
+  float *slot = v.b.arena + ((size_t)new_idx * s.Scap + grow) * s.I;
+  {
+    float4 o;
+    o.x = ((e.x + wb.x) + (hot >= 0 ? ws.x : 0.0f)) * scale;
+    o.y = ((e.y + wb.y) + (hot >= 0 ? ws.y : 0.0f)) * scale;
+    o.z = ((e.z + wb.z) + (hot >= 0 ? ws.z : 0.0f)) * scale;
+    o.w = ((e.w + wb.w) + (hot >= 0 ? ws.w : 0.0f)) * scale;
+    *reinterpret_cast<float4 *>(out + n0 + c4) = o;
+    *reinterpret_cast<float4 *>(slot + n0 + c4) = make_float4(a4.x * scale, a4.y * scale, a4.z * scale, a4.w * scale);
+  }
+  if ((etid & 7) == 0) {
+    if (nt == 0) {
+      /* once per row: the inputs the tiles do not cover -- hidden values tail .. hidden_size and
+       * the one-hot input -- times their W rows */
+      for (int k = tail; k <= s.hidden_size; k++) {
+        float x = hid0[(size_t)er * s.H + k];
+        float4 w = ld4(v.b.ih_w + (size_t)k * s.H + tail);
+        pp.x += x * w.x; pp.y += x * w.y; pp.z += x * w.z; pp.w += x * w.w;
+        slot[k] = x * scale;
+      }
+      if (hot >= 0) {
+        float4 w = ld4(v.b.ih_w + (size_t)(s.hidden_size + 1 + hot) * s.H + tail);
+        pp.x += w.x; pp.y += w.y; pp.z += w.z; pp.w += w.w;
+      }
+    }
+    float *pd = v.b.slab + (size_t)nrows * s.H + ((size_t)nt * nrows + er) * 4;
+    *reinterpret_cast<float4 *>(pd) = make_float4(pp.x * scale, pp.y * scale, pp.z * scale, pp.w * scale);
+  }
+  if (nt == 0) { /* the rest of k_assemble's row: input columns, ring index, target */
+    const int sub = etid & 7;
+    if (sub == 0) {
+      v.b.idx[grow] = new_idx;
+      if (mode == RAMD_IN_TEXT) v.b.target[grow] = v.b.text[text_o + 1];
+    }
+    for (int k = sub; k < s.input_size; k += 8) slot[s.hidden_size + 1 + k] = (k == hot) ? scale : 0.0f;
+  }
 }
 
 // Chain "extras" without a GEMM: for every (step, stream) the error of the bias
@@ -2555,6 +2898,56 @@ extern "C" int ramd_text_top_ok(const RamdShape *sh) {
   return sh->O <= 256 && sh->H <= 2048 && !env_int("RECUR_AMD_NO_TEXT_TOP", 0);
 }
 
+/* the device copy of the View for the kernels that take it by pointer, rewritten only when
+ * it changes (the ring position is not part of it: those kernels get it as an argument) */
+static const View *device_view(hipStream_t st, const View &v) {
+  static View *d_view = nullptr;
+  static View h_view;
+  static bool have = false;
+  View cur = v;
+  cur.b.uniform_idx = 0;
+  if (!d_view) HIP_CHECK(hipMalloc(&d_view, sizeof(View)));
+  if (!have || memcmp(&cur, &h_view, sizeof(View)) != 0) {
+    hipLaunchKernelGGL(k_store_view, dim3(1), dim3(1), 0, st, cur, d_view);
+    h_view = cur;
+    have = true;
+  }
+  return d_view;
+}
+
+/* assemble + hidden layer in one launch for the text step (k_fwd_fused); returns what
+ * ramd_launch_text_top wants as fwd_ks (negative: one plane of sums + per-tile padding
+ * partials), or 0 when the preconditions do not hold and nothing was launched */
+extern "C" int ramd_launch_forward_fused(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
+                                         int row0, int nrows, int mode, int text_i,
+                                         int global_first, int n_set) {
+  if (b->uniform_idx < 0 || sh->bI || sh->hidden_size % CN != 0 || row0 + nrows > sh->Scap ||
+      (mode != RAMD_IN_TEXT && mode != RAMD_IN_ONE_HOT) || !ramd_text_top_ok(sh) ||
+      env_int("RECUR_AMD_NO_FWD_FUSED", 0))
+    return 0;
+  const int tm = (nrows + CM - 1) / CM, tn = sh->hidden_size / CN;
+  /* plane 0: sums; plane 1: [tn][nrows][4] padding partials */
+  if ((size_t)nrows * sh->H + (size_t)tn * nrows * 4 > b->slab_floats || tn * 4 > sh->H) return 0;
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  const View *d_view = device_view(st, v);
+  const int nstages = (sh->hidden_size + CK - 1) / CK;
+  const int blocks = ((tn + 7) / 8) * 8 * tm;
+  int ev = timing_begin(st, T_FWD);
+  const bool exact = sh->hidden_size % CK == 0 && !env_int("RECUR_AMD_FWD_NS0", 0);
+#define FWD_FUSED(NS)                                                                              \
+  hipLaunchKernelGGL((k_fwd_fused<NS>), dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx, row0, \
+                     nrows, tm, tn, nstages, mode, text_i, global_first, n_set)
+  if (exact && nstages == 8) FWD_FUSED(8);
+  else if (exact && nstages == 4) FWD_FUSED(4);
+  else if (exact && nstages == 2) FWD_FUSED(2);
+  else if (exact && nstages == 16) FWD_FUSED(16);
+  else FWD_FUSED(0);
+#undef FWD_FUSED
+  timing_end(st, ev);
+  return -tn;
+}
+
 extern "C" void ramd_launch_text_top(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
                                      int row0, int nrows, int fwd_ks) {
   hipStream_t st = (hipStream_t)st_;
@@ -2737,31 +3130,24 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int blocks = ((tn + 7) / 8) * 8 * tm;
     /* one event pair around the D launches: the per-launch average then carries
      * 1/D of the event overhead instead of all of it */
-    /* the device copy of the View, rewritten only when it changes */
-    static View *d_view = nullptr;
-    static View h_view;
-    static bool have = false;
-    {
-      View cur = v;
-      cur.b.uniform_idx = 0;
-      if (!d_view) HIP_CHECK(hipMalloc(&d_view, sizeof(View)));
-      if (!have || memcmp(&cur, &h_view, sizeof(View)) != 0) {
-        hipLaunchKernelGGL(k_store_view, dim3(1), dim3(1), 0, st, cur, d_view);
-        h_view = cur;
-        have = true;
-      }
-    }
+    const View *d_view = device_view(st, v);
     int ev = timing_begin(st, T_CHAIN, sh->D);
     for (int t = 0; t < sh->D; t++) {
-      if (b->uniform_idx >= 0 && nstages == 8)
-        hipLaunchKernelGGL((k_chain_main<true, 8>), dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx,
-                           row0, nrows, t, tm, tn, nstages);
+#define CHAIN_NS(NS)                                                                               \
+  hipLaunchKernelGGL((k_chain_main<true, NS>), dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx, \
+                     row0, nrows, t, tm, tn, nstages)
+      const bool exact = sh->hidden_size % CK == 0;
+      if (b->uniform_idx >= 0 && exact && nstages == 8) CHAIN_NS(8);
+      else if (b->uniform_idx >= 0 && exact && nstages == 4) CHAIN_NS(4);
+      else if (b->uniform_idx >= 0 && exact && nstages == 2) CHAIN_NS(2);
+      else if (b->uniform_idx >= 0 && exact && nstages == 16) CHAIN_NS(16);
       else if (b->uniform_idx >= 0)
         hipLaunchKernelGGL(k_chain_main<true>, dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx, row0,
                            nrows, t, tm, tn, nstages);
       else
         hipLaunchKernelGGL(k_chain_main<false>, dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx,
                            row0, nrows, t, tm, tn, nstages);
+#undef CHAIN_NS
     }
     timing_end(st, ev);
     int M = sh->D * nrows;

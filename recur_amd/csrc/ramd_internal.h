@@ -134,6 +134,8 @@ int ramd_launch_forward_hidden(ramd_stream_t st, const RamdShape *sh, const Ramd
  * ramd_text_top_ok says whether the shape allows it. */
 #define RAMD_TOP_DONE 0x40000000u
 int ramd_text_top_ok(const RamdShape *sh);
+int ramd_launch_forward_fused(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0,
+                              int nrows, int mode, int text_i, int global_first, int n_set);
 void ramd_launch_text_top(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0,
                           int nrows, int fwd_ks);
 /* o_error = onehot(target) - softmax(out) and statistics

@@ -1553,6 +1553,16 @@ static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, i
     ramd_launch_assemble(g_stream, &e->sh, &e->b, r0, set->n, RAMD_IN_KEEP, NULL, 0, 0,
                          set->global_first, set->global_count, 0);
   } else {
+    if (hidden_only && advance && noise == 0.0f && !set->fwd_only) {
+      /* the text step: building the input rows and the hidden layer's GEMM in one launch
+       * (the ring index the kernel stores is the host's, which has just stepped) */
+      int fused = ramd_launch_forward_fused(g_stream, &e->sh, &e->b, r0, set->n, mode, text_i,
+                                            set->global_first, set->global_count);
+      if (fused) {
+        set_streams_dev_wrote(set);
+        return fused;
+      }
+    }
     ramd_launch_assemble(g_stream, &e->sh, &e->b, r0, set->n, mode, d_dense, ld, text_i,
                          set->global_first, set->global_count, advance);
   }
