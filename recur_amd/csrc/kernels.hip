@@ -1084,6 +1084,18 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
       __syncthreads();
     }
   }
+  // the backprop below needs this thread's row of W_ho: request it now (narrow output layers),
+  // so that it arrives while wave 0 works out the softmax
+  constexpr int TOP_PF = 12; /* float4 per row: o_size <= 48 */
+  float4 wrow[TOP_PF];
+  const bool top_pf = s.O <= 4 * TOP_PF;
+  if (top_pf) {
+    const int y = threadIdx.x;
+    const bool need = y != 0 && y < s.H && shid[y] != 0.0f;
+    const float *rowp = v.b.ho_w + (size_t)(need ? y : 0) * s.O;
+#pragma unroll
+    for (int k = 0; k < TOP_PF; k++) wrow[k] = (need && 4 * k < s.O) ? ld4(rowp + 4 * k) : zero4();
+  }
   // ---- softmax loss (charmodel-predict.c:18-27, badmaths.h:71-141): wave 0
   if (seg == 0) {
     const int len = s.output_size;
@@ -1150,13 +1162,25 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
   for (int q = 0, y = threadIdx.x; y < s.H; y += 1024, q++) {
     float e = 0.0f;
     if (y != 0 && shid[y] != 0.0f) {
-      const float *row = v.b.ho_w + (size_t)y * s.O;
-      for (int x = 0; x < s.O; x += 4) {
-        float4 w = ld4(row + x);
-        e += w.x * serr[x];
-        e += w.y * serr[x + 1];
-        e += w.z * serr[x + 2];
-        e += w.w * serr[x + 3];
+      if (top_pf && q == 0) {
+#pragma unroll
+        for (int k = 0; k < TOP_PF; k++) {
+          if (4 * k < s.O) {
+            e += wrow[k].x * serr[4 * k];
+            e += wrow[k].y * serr[4 * k + 1];
+            e += wrow[k].z * serr[4 * k + 2];
+            e += wrow[k].w * serr[4 * k + 3];
+          }
+        }
+      } else {
+        const float *row = v.b.ho_w + (size_t)y * s.O;
+        for (int x = 0; x < s.O; x += 4) {
+          float4 w = ld4(row + x);
+          e += w.x * serr[x];
+          e += w.y * serr[x + 1];
+          e += w.z * serr[x + 2];
+          e += w.w * serr[x + 3];
+        }
       }
       sum += fabsf(e);
     }
