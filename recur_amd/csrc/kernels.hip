@@ -1798,6 +1798,7 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
   const int nstages = NS > 0 ? NS : nstages_arg;
   __shared__ __attribute__((aligned(16))) float smem[C_STAGES * C_STAGE_FLOATS];
   __shared__ float rs_sh[4][CM];
+  __shared__ float4 wt_sh[CN];
   const RamdShape &s = v.sh;
   const int L = blockIdx.x;
   const int xcd = L & 7, q = L >> 3;
@@ -1870,7 +1871,7 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
   // values x[n0 + ec4 ..] (column 0 is the bias node, 1), the bias row's and the input row's
   // weights under its four columns, and the tail columns of W in the rows of its four inputs
   int hot = -1, text_o = 0;
-  float4 a4 = zero4(), wb = zero4(), ws = zero4(), wt[4];
+  float4 a4 = zero4(), wb = zero4(), ws = zero4(), wt_mine = zero4();
   if (!loader) {
     if (mode == RAMD_IN_TEXT) { /* charmodel-predict.c:273, 295-298 */
       int len = v.b.text_len;
@@ -1886,8 +1887,9 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
     if (n0 + ec4 == 0) a4.x = 1.0f;
     wb = ld4(v.b.ih_w + n0 + ec4);
     ws = ld4(v.b.ih_w + (size_t)(hot >= 0 ? s.hidden_size + 1 + hot : 0) * s.H + n0 + ec4);
-#pragma unroll
-    for (int i = 0; i < 4; i++) wt[i] = ld4(v.b.ih_w + (size_t)(n0 + ec4 + i) * s.H + tail);
+    /* the tail columns of W in this tile's 32 input rows: one row per thread of the first half
+     * wave, shared through LDS at the end */
+    if (etid < CN) wt_mine = ld4(v.b.ih_w + (size_t)(n0 + etid) * s.H + tail);
   }
   const uint32_t lds0 = lds_byte_addr(smem);
   const uint32_t rowoff = (uint32_t)lm * (CK * 4u);
@@ -1976,10 +1978,14 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
     }
     rsum += __shfl_xor(rsum, 32, 64);
     if (kh == 0) rs_sh[wave][lm] = rsum;
+    if (etid < CN) wt_sh[etid] = wt_mine;
   }
   __syncthreads();
   if (loader) return;
   const int row = erow, c4 = ec4;
+  float4 wt[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) wt[i] = wt_sh[c4 + i];
   float4 e;
   {
     float4 p0 = ld4(red + (0 * CM + row) * CN + c4), p1 = ld4(red + (1 * CM + row) * CN + c4);
