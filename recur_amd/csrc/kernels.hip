@@ -2952,7 +2952,7 @@ extern "C" int ramd_launch_forward_fused(ramd_stream_t st_, const RamdShape *sh,
                                          int row0, int nrows, int mode, int text_i,
                                          int global_first, int n_set) {
   if (b->uniform_idx < 0 || sh->bI || sh->hidden_size % CN != 0 || row0 + nrows > sh->Scap ||
-      (mode != RAMD_IN_TEXT && mode != RAMD_IN_ONE_HOT) || !ramd_text_top_ok(sh) ||
+      mode != RAMD_IN_TEXT /* the only caller that stops after the hidden layer */ || !ramd_text_top_ok(sh) ||
       env_int("RECUR_AMD_NO_FWD_FUSED", 0))
     return 0;
   const int tm = (nrows + CM - 1) / CM, tn = sh->hidden_size / CN;

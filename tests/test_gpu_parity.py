@@ -283,6 +283,39 @@ def test_baseline_config_shapes_one_generation_matches_oracle(amd, label, kw):
     o.close()
 
 
+@pytest.mark.parametrize("hidden,act", [(64, rc.RELU), (128, rc.RESQRT), (96, rc.RELU)])
+def test_text_step_emergency_soft_clip_of_the_input_row(amd, hidden, act):
+    """maybe_scale_inputs (recur-nn.c:68-81): a hidden state large enough that the input row's
+    sum passes 16 * i_size; the fused assemble + forward launch (hidden 64, 128) and the
+    separate kernels (hidden 96: one partial stage) must both scale the stored row and the
+    sums like the reference"""
+    kw = dict(input_size=42, hidden_size=hidden, output_size=42, S=32, D=4, learn_rate=1e-4, seed=5,
+              activation=act)
+    g = sc.AmdBatchedSet(amd, **kw)
+    o = sc.OracleSet(**kw)
+    text = sc.synthetic_text(4000)
+    for i in range(2):
+        g.char_step(text, i, rc.WEIGHTED, 0.9)
+        o.char_step(text, i, rc.WEIGHTED, 0.9)
+    g.sync()
+    a = o.arrays()
+    big = (30.0 + np.arange(g.S * g.H, dtype=np.float32).reshape(g.S, g.H) % 7).astype(np.float32)
+    big[:, 0] = 1.0
+    big[:, hidden + 1:] = 0.0
+    for j in range(g.S):
+        rc.view(g.nets[j].contents.hidden_layer, g.H)[:] = big[j]
+        amd.rnn_amd_host_written(g.nets[j], rc.RNN_AMD_STREAM)
+    a["hidden"][:] = big
+    assert big[0].sum() + 1 > 16 * g.I          # the clip does trigger
+    for i in range(2, 4):
+        g.char_step(text, i, rc.WEIGHTED, 0.9)
+        o.char_step(text, i, rc.WEIGHTED, 0.9)
+    sg, so = g.snapshot(), o.snapshot()
+    replay.check(sg, so, RTOL, keys=["hist", "hidden", "output", "o_error", "ih_delta", "ho_delta", "ih_w", "ho_w"])
+    g.close()
+    o.close()
+
+
 def test_full_size_split_accumulation_property(amd, full_set):
     """size-independent property: the deltas of the whole set equal the deltas of
     its two halves accumulated (the reference's `j ? 1 : 0`, charmodel-predict.c:309)"""
