@@ -3108,7 +3108,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   const bool dma = b->uniform_idx >= 0 && nrows % BK == 0 && sh->hidden_size % 128 == 0 &&
                    sh->I >= 128 && sh->activation != 5 && env_int("RECUR_AMD_DELTA_DMA", 1);
   const bool has_rest = dma && (sh->I / 128) * 128 < sh->I;
-  bool ho_paired = false;
+  bool ho_paired = false, ho_finalize_after = false;
   ProbHoDelta ho_p = {};
   int ho_nkt = 0, ho_ks = 0;
   if (!(flags & 0x80000000u)) { /* the fused single-net path updates W_ho directly */
@@ -3141,6 +3141,15 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       defer->ho_n = (size_t)ho;
       defer->ho_ks = ks;
       defer->ho_delta_out = b->ho_delta;
+    } else if (has_rest && !active && b->ho_slab && env_int("RECUR_AMD_PAIR_HO", 1)) {
+      /* not deferred (the deltas are wanted as such: accumulation, an all-reduce between the
+       * ranks): still one launch with the rest rows, summed right after it */
+      if (ks > 8) ks = 8;
+      ho_paired = true;
+      ho_finalize_after = true;
+      ho_p = p;
+      ho_nkt = nkt;
+      ho_ks = ks;
     } else {
       launch_gemm<true, true, ProbHoDelta>(st, p, b->slab, sh->H, sh->O, nkt, ks, T_OTHER);
       /* with one range list per stream the set of touched columns differs per stream; the
@@ -3277,6 +3286,9 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
                              dim3(256), 0, st, ho_p, oa, blocks_a, p, ob);
           timing_end(st, ev2);
           ho_paired = false;
+          if (ho_finalize_after)
+            hipLaunchKernelGGL(k_ho_delta_finalize, dim3((sh->H * sh->O + 255) / 256), dim3(256), 0, st, v,
+                               b->ho_slab, ho_ks, accumulate, range_stride ? nullptr : ranges);
         } else {
           launch_gemm<true, true, ProbDelta<true>>(st, p, b->slab, sh->I, ncol, nkt, ks_rest, T_DELTA, 1,
                                                    sh->H, rows_core);
