@@ -2487,8 +2487,25 @@ __global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, in
 __global__ __launch_bounds__(256) void k_delta_finalize(float *delta, const float *slab,
                                                         size_t n4, size_t n, int ks,
                                                         int accumulate, int H, int hidden_size,
-                                                        int rows_core, int ks_rest) {
+                                                        int rows_core, int ks_rest,
+                                                        float *ho_delta, const float *ho_slab,
+                                                        size_t ho_n, int ho_ks) {
   size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t ih_threads = ((n4 + 255) / 256) * 256;
+  if (q >= ih_threads) {
+    /* the blocks past ih_delta: ho_delta (+)= its K slabs, when the caller has them pending
+     * (k_ho_delta_finalize without error ranges) */
+    size_t e = q - ih_threads;
+    if (ho_slab && 4 * e < ho_n) {
+      float4 a = accumulate ? ld4(ho_delta + 4 * e) : zero4();
+      for (int z = 0; z < ho_ks; z++) {
+        float4 t = ld4(ho_slab + (size_t)z * ho_n + 4 * e);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
+      *reinterpret_cast<float4 *>(ho_delta + 4 * e) = a;
+    }
+    return;
+  }
   if (q >= n4) return;
   /* rows below rows_core were produced with ks K slices, the others with ks_rest */
   if ((int)((4 * q) / (size_t)H) >= rows_core) ks = ks_rest;
@@ -3108,7 +3125,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   const bool dma = b->uniform_idx >= 0 && nrows % BK == 0 && sh->hidden_size % 128 == 0 &&
                    sh->I >= 128 && sh->activation != 5 && env_int("RECUR_AMD_DELTA_DMA", 1);
   const bool has_rest = dma && (sh->I / 128) * 128 < sh->I;
-  bool ho_paired = false, ho_finalize_after = false;
+  bool ho_paired = false, ho_finalize_after = false, ho_in_final = false;
   ProbHoDelta ho_p = {};
   int ho_nkt = 0, ho_ks = 0;
   if (!(flags & 0x80000000u)) { /* the fused single-net path updates W_ho directly */
@@ -3286,9 +3303,12 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
                              dim3(256), 0, st, ho_p, oa, blocks_a, p, ob);
           timing_end(st, ev2);
           ho_paired = false;
-          if (ho_finalize_after)
+          if (ho_finalize_after && !ranges) {
+            ho_in_final = true; /* summed by the k_delta_finalize launch below */
+          } else if (ho_finalize_after) {
             hipLaunchKernelGGL(k_ho_delta_finalize, dim3((sh->H * sh->O + 255) / 256), dim3(256), 0, st, v,
                                b->ho_slab, ho_ks, accumulate, range_stride ? nullptr : ranges);
+          }
         } else {
           launch_gemm<true, true, ProbDelta<true>>(st, p, b->slab, sh->I, ncol, nkt, ks_rest, T_DELTA, 1,
                                                    sh->H, rows_core);
@@ -3322,9 +3342,11 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       return;
     }
     if (defer) defer->slab = nullptr;
-    hipLaunchKernelGGL(k_delta_finalize, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
-                       b->ih_delta, b->slab, n4, n, ks, accumulate, sh->H, sh->hidden_size, rows_core,
-                       ks_rest);
+    const size_t ho_n = (size_t)sh->H * sh->O;
+    const unsigned fin_blocks = (unsigned)((n4 + 255) / 256) + (ho_in_final ? (unsigned)((ho_n / 4 + 255) / 256) : 0u);
+    hipLaunchKernelGGL(k_delta_finalize, dim3(fin_blocks), dim3(256), 0, st, b->ih_delta, b->slab, n4, n, ks,
+                       accumulate, sh->H, sh->hidden_size, rows_core, ks_rest, b->ho_delta,
+                       ho_in_final ? b->ho_slab : nullptr, ho_n, ho_ks);
   }
 }
 
