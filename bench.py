@@ -13,17 +13,23 @@ Workload (BASELINE.json configs / SURVEY.md section 8(d)): hidden 1024,
 flat semicircle init seed 1, weighted momentum 0.95 / 0.5, learn rate 1e-5,
 synthetic symbol stream (rand_small_int seed 7, 42 symbols).
 
-Multi-GPU: one process per GPU (torchrun), streams sharded over ranks (weak
-scaling: 256 streams per GPU), one RCCL all-reduce of ih_delta||ho_delta per
-generation, replicated optimiser step.
+Multi-GPU: one process per GPU, streams sharded over ranks (weak scaling: 256
+streams per GPU), ONE RCCL all-reduce of ih_delta||ho_delta per generation INSIDE
+the library (rnn_amd_dist_*; recur_amd/csrc/dist.c), replicated optimiser step.
+`--gpus N` without a launcher's WORLD_SIZE starts the N ranks itself (children are
+spawned before anything touches a GPU); under `python -m torch.distributed.run`
+the ranks are the launcher's.  No PyTorch in the data path (nor imported).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
+import mmap
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -34,11 +40,9 @@ HIDDEN, STREAMS, DEPTH, ALPHABET = 1024, 256, 20, 42
 LEARN_RATE, MOMENTUM = 1e-5, 0.95
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
-# HBM-side bytes per launch of the dominant kernel at the default shape, from the PMC passes
-# kept in profiles/r01_pmc_fetch_write_per_kernel.txt (2 x FETCH_SIZE + WRITE_SIZE, the gfx950
-# correction of MI355X_MICROARCH.md); it cannot be read live without the profiler.
-TRAFFIC_BYTES_PER_LAUNCH = {"bptt_chain_gemm": (2 * 7398.5 + 1312.0) * 1024,   # k_chain_main
-                            "delta_gemm": (2 * 33946.5 + 17410.2) * 1024}      # k_delta_dma
+# HBM-side bytes per launch come from the PMC passes of THIS round's kernels, summarised by
+# tools/pmc_summary.py into this file (rocprofv3 cannot run inside the timed process)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def parse():
@@ -50,18 +54,93 @@ def parse():
     ap.add_argument("--streams", type=int, default=STREAMS, help="streams per GPU")
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of EACH cpu leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dist", action="store_true",
+                    help="join an RCCL group even with one rank (exercises the exchange step)")
     return ap.parse_args()
 
 
-def cpu_baseline(rc, sc, amd, gpu_set, text, i_next, budget_s):
-    """Times the CPU path on the GPU box's host cores from the GPU's own
-    post-warm-up state (so the history ring is full and the zero-row skip sees
-    realistic sparsity).  Uses oracle/_ref (the real reference, -Ofast) when it
-    travelled here, else the repo's restatement.  Single-threaded like the
-    reference."""
-    import numpy as np
+# ------------------------------------------------------------------ launcher --
+
+def spawn_ranks(n):
+    """--gpus N with no launcher: start N ranks of this script (one per GPU) as child
+    processes, BEFORE this process touches a GPU, and relay rank 0's JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    out0 = tempfile.TemporaryFile()
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RECUR_BENCH_RUN_ID=str(os.getpid()))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    # a rank that dies would leave the others waiting in a collective: watch them all
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            time.sleep(2.0)
+            for r, p in enumerate(procs):
+                if p.poll() is None:
+                    p.kill()  # this exact child
+                rcs[r] = p.wait()
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        sys.exit(max(1, min(255, max(abs(rc) for _, rc in bad))))
+    sys.exit(0)
+
+
+def exchange_id(amd, rank, world):
+    """rank 0's RCCL id reaches the others through a file (single node): no PyTorch, and
+    the launcher's own store on MASTER_PORT is left alone."""
+    key = "%s_%s" % (os.environ.get("MASTER_PORT", "0"),
+                     os.environ.get("RECUR_BENCH_RUN_ID") or os.getppid())
+    path = os.path.join(tempfile.gettempdir(), "recur_amd_rccl_id_" + key)
+    buf = C.create_string_buffer(128)
+    if rank == 0:
+        if amd.rnn_amd_dist_get_id(buf) != 0:
+            raise SystemExit("bench.py: cannot get an RCCL id")
+        with open(path + ".tmp", "wb") as f:
+            f.write(buf.raw)
+        os.replace(path + ".tmp", path)
+    else:
+        t0 = time.time()
+        while True:
+            try:
+                if os.path.getsize(path) == 128 and os.path.getmtime(path) > t0 - 300:
+                    break
+            except OSError:
+                pass
+            if time.time() - t0 > 300:
+                raise SystemExit("bench.py: rank %d never saw rank 0's RCCL id" % rank)
+            time.sleep(0.02)
+        buf.raw = open(path, "rb").read()
+    if amd.rnn_amd_dist_init(rank, world, buf) != 0:
+        raise SystemExit("bench.py: rnn_amd_dist_init failed on rank %d" % rank)
+    if rank == 0:  # the init is collective: everybody has read the file
+        os.unlink(path)
+
+
+# --------------------------------------------------------------- CPU baseline --
+
+def cpu_one_core(rc, sc, gpu_set, text, i_next, budget_s):
+    """The CPU path on ONE host core (the reference is single-threaded), continued from
+    the GPU's own post-warm-up state (full history ring, realistic zero-row sparsity) on
+    32 of the streams.  Uses oracle/_ref (the real reference, -Ofast) when it travelled
+    here, else the repo's restatement."""
     S_cpu = min(32, gpu_set.S)
     kw = dict(input_size=ALPHABET, hidden_size=gpu_set.hidden_size, output_size=ALPHABET,
               S=S_cpu, D=gpu_set.D, learn_rate=LEARN_RATE, seed=1)
@@ -103,76 +182,168 @@ def cpu_baseline(rc, sc, amd, gpu_set, text, i_next, budget_s):
             break
     cpu.close()
     return {
-        "value": gens * S_cpu / el,
-        "unit": "stream-timesteps/s",
-        "cores": 1,
-        "kind": kind,
+        "value": gens * S_cpu / el, "unit": "stream-timesteps/s", "cores": 1, "kind": kind,
         "sample": "%d generations x %d streams (hidden %d, depth %d) continued from the GPU's "
                   "post-warm-up state, %.1f s" % (gens, S_cpu, gpu_set.hidden_size, gpu_set.D, el),
     }
 
 
+def _all_cores_worker(p, P, s_p, hidden, depth, text, n_floats, slabs_mm, result_mm, flags_mm, barrier,
+                      budget_s, q):
+    """One of P processes of the best-effort CPU run: s_p of the streams, a full replica of
+    the weights, per generation the deltas of its streams -> slab p; everybody sums one
+    1/P-th of the range over all slabs -> result; everybody applies the summed deltas."""
+    import numpy as np
+    import recur_ctypes as rc
+    import scenarios as sc
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[p % len(os.sched_getaffinity(0))]})
+    except (AttributeError, OSError):
+        pass
+    kw = dict(input_size=ALPHABET, hidden_size=hidden, output_size=ALPHABET, S=s_p, D=depth,
+              learn_rate=LEARN_RATE, seed=1)
+    if rc.have_ref() and os.path.exists(rc.REF_FAST_LIB):
+        kind = "reference"
+        ref = rc.load_ref(fast=True)
+        cpu = sc.ApiSet(ref, softmax_best_guess=ref.ref_softmax_best_guess, **kw)
+        cpu.global_first, cpu.global_count = p * s_p, P * s_p
+        b0 = cpu.net.contents.bptt.contents
+        ih, ho = rc.view(b0.ih_delta, cpu.I * cpu.H), rc.view(b0.ho_delta, cpu.H * cpu.O)
+        apply = lambda: ref.rnn_apply_learning(cpu.net, rc.WEIGHTED, MOMENTUM)
+    else:
+        kind = "port"
+        cpu = sc.OracleSet(fast=True, **kw)
+        cpu.z.contents.global_first, cpu.z.contents.global_count = p * s_p, P * s_p
+        a = cpu.arrays()
+        ih, ho = a["ih_delta"].reshape(-1), a["ho_delta"].reshape(-1)
+        apply = lambda: cpu.orc.orc_apply_learning(cpu.z, rc.WEIGHTED, MOMENTUM)
+    slabs = np.frombuffer(slabs_mm, dtype=np.float32).reshape(P, n_floats)
+    result = np.frombuffer(result_mm, dtype=np.float32)
+    flags = np.frombuffer(flags_mm, dtype=np.int32)  # [0]: stop
+    lo, hi = (n_floats * p) // P, (n_floats * (p + 1)) // P
+    warm = depth + 2
+    gens, t0, el = 0, None, 0.0
+    g = 0
+    while True:
+        if g == warm:
+            t0 = time.perf_counter()
+        cpu.char_step_deltas(text, g)
+        slabs[p, :ih.size] = ih
+        slabs[p, ih.size:] = ho
+        barrier.wait(timeout=600)
+        stop = int(flags[0])  # written before the barrier above, read after it: the same everywhere
+        result[lo:hi] = slabs[:, lo:hi].sum(axis=0, dtype=np.float32)
+        barrier.wait(timeout=600)
+        ih[:] = result[:ih.size]
+        ho[:] = result[ih.size:]
+        apply()
+        g += 1
+        if t0 is not None:
+            gens += 1
+            el = time.perf_counter() - t0
+        if stop:
+            break
+        if p == 0 and t0 is not None and (el >= budget_s or gens >= 400):
+            flags[0] = 1
+    q.put((p, kind, gens, el))
+
+
+def cpu_all_cores(args, text):
+    """Best-effort CPU figure: the SAME 256-stream
+    workload sharded over all host cores, one process per core, per-generation delta sum
+    through shared memory, replicated update.  Runs before this process touches the GPU."""
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    S = args.streams
+    P = 1
+    while P * 2 <= min(cores, S) and S % (P * 2) == 0:
+        P *= 2
+    s_p = S // P
+    I = (args.hidden + ALPHABET + 1 + 3) // 4 * 4
+    H = (args.hidden + 1 + 3) // 4 * 4
+    O = (ALPHABET + 3) // 4 * 4
+    n_floats = I * H + H * O
+    ctx = mp.get_context("fork")
+    slabs_mm = mmap.mmap(-1, P * n_floats * 4)
+    result_mm = mmap.mmap(-1, n_floats * 4)
+    flags_mm = mmap.mmap(-1, 64)
+    barrier = ctx.Barrier(P)
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_all_cores_worker,
+                         args=(p, P, s_p, args.hidden, args.depth, text, n_floats, slabs_mm, result_mm,
+                               flags_mm, barrier, args.cpu_seconds, q), daemon=True) for p in range(P)]
+    for pr in procs:
+        pr.start()
+    try:
+        got = [q.get(timeout=args.cpu_seconds * 6 + 240) for _ in range(P)]
+    except Exception as e:  # a worker died: report nothing rather than a wrong number
+        for pr in procs:
+            pr.terminate()
+        return {"cores_available": cores, "error": "all-core run failed: %r" % (e,)}
+    for pr in procs:
+        pr.join(timeout=30)
+    _, kind, gens, el = sorted(got)[0]
+    el = max(t[3] for t in got)
+    return {
+        "cores_available": cores,
+        "value": gens * S / el, "unit": "stream-timesteps/s", "cores": P, "kind": kind,
+        "sample": "%d generations x %d streams as %d processes x %d streams (hidden %d, depth %d), "
+                  "delta sum through shared memory every generation, after %d warm-up generations, "
+                  "%.1f s" % (gens, S, P, s_p, args.hidden, args.depth, args.depth + 2, el),
+    }
+
+
+# ------------------------------------------------------------------------ main --
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import numpy as np
-    import torch
+    import golden_cases as gc
     import recur_ctypes as rc
     import scenarios as sc
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (librecur_amd has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    # RECUR_BENCH_FORCE_DIST=1 exercises the sharded path (RCCL group, external delta buffer,
-    # all-reduce) even with one rank: a single-GPU check of the multi-GPU plumbing
-    force_dist = os.environ.get("RECUR_BENCH_FORCE_DIST", "0") == "1"
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    amd = rc.load_amd()
-    amd.rnn_amd_use_device(local_rank, C.c_void_p(torch.cuda.current_stream().cuda_stream))
-
     S, D, Hd = args.streams, args.depth, args.hidden
-    total_steps = args.warmup + args.steps + 260
-    text = sc.synthetic_text(max(20000, S * world * 40 + total_steps + 16), ALPHABET, 7)
-    gpu = sc.AmdBatchedSet(amd, input_size=ALPHABET, hidden_size=Hd, output_size=ALPHABET, S=S,
-                           D=D, learn_rate=LEARN_RATE, seed=1, momentum=MOMENTUM)
-    gpu.load_text(text)
-    from recur_amd.dist import shard_range
-    first, _, total = shard_range(rank, world, S)
-    amd.rnn_amd_set_shard(gpu.handle, first, total)
-    delta = None
-    if dist is not None:
-        delta = torch.zeros(gpu.I * gpu.H + gpu.H * gpu.O, dtype=torch.float32, device="cuda")
-        amd.rnn_amd_set_external_delta(gpu.handle, C.c_void_p(delta.data_ptr()))
+    prefill = D + 5  # untimed, before the warm-up: the history ring is full whatever --warmup is
+    total_steps = prefill + args.warmup + args.steps + 260
+    text = gc.synthetic_text_np(max(20000, S * world * 40 + total_steps + 16), ALPHABET, 7)
 
-    from recur_amd.dist import ShardedStep
-    if dist is not None:
-        step = ShardedStep(lambda i: amd.rnn_amd_set_char_step_deltas(gpu.handle, i),
-                           lambda: dist.all_reduce(delta),
-                           lambda: amd.rnn_apply_learning(gpu.net, rc.WEIGHTED, MOMENTUM))
-    else:
-        # one GPU: nothing happens between the deltas and the update, so the library's own
-        # generation call is used (same kernels; the delta slabs go straight into the update)
-        def step(i):
-            amd.rnn_amd_set_char_step(gpu.handle, i, rc.WEIGHTED, MOMENTUM)
+    all_cores = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        all_cores = cpu_all_cores(args, text)  # before this process initialises the GPU (it forks)
+
+    amd = rc.load_amd()
+    ndev = amd.rnn_amd_device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (librecur_amd has no CPU fallback)")
+    if local_rank >= ndev:
+        raise SystemExit("bench.py: rank %d of %d but only %d GPU(s) are visible" % (rank, world, ndev))
+    amd.rnn_amd_use_device(local_rank, None)
+    dist = world > 1 or args.dist or os.environ.get("RECUR_BENCH_FORCE_DIST", "0") == "1"
+    if dist:
+        exchange_id(amd, rank, world)
+        assert amd.rnn_amd_dist_world() == world and amd.rnn_amd_dist_rank() == rank
+
+    gpu = sc.AmdBatchedSet(amd, input_size=ALPHABET, hidden_size=Hd, output_size=ALPHABET, S=S,
+                           D=D, learn_rate=LEARN_RATE, seed=1, momentum=MOMENTUM,
+                           shard=(rank * S, world * S))
+    gpu.load_text(text)
+    amd.rnn_amd_set_shard(gpu.handle, rank * S, world * S)
+
+    def step(i):  # deltas -> (all-reduce over ranks, inside the library) -> update
+        amd.rnn_amd_set_char_step(gpu.handle, i, rc.WEIGHTED, MOMENTUM)
 
     def fence():
         amd.rnn_amd_synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        amd.rnn_amd_dist_barrier()
+        amd.rnn_amd_synchronize()
 
     i = 0
-    for _ in range(args.warmup):
+    for _ in range(prefill + args.warmup):
         step(i)
         i += 1
     fence()
@@ -185,18 +356,14 @@ def main():
         i += 1
     fence()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = amd.rnn_amd_dist_max(elapsed)  # max over ranks (identity for one rank)
     amd.rnn_amd_set_read_stats(gpu.handle, C.byref(st), 1)
     mean_depth = st.bptt_depth_sum / max(st.count, 1)
     zero_frac = st.hidden_zeros / max(st.count, 1)
     t_entropy = -st.entropy / max(st.count, 1)
 
-    # roofline leg: HIP events around every GEMM launch, on the launch stream,
-    # over a further short run of the same loop (kept out of the timed region so
-    # that the event records do not perturb `value`)
+    # roofline leg: HIP events around the GEMM launches, on the launch stream, over a further
+    # short run of the same loop (kept out of the timed region: the event records cost time)
     roofline = None
     if not args.no_roofline:
         I, H = gpu.I, gpu.H
@@ -217,22 +384,39 @@ def main():
         amd.rnn_amd_kernel_time_ms(0, None, 1)
         amd.rnn_amd_set_read_stats(gpu.handle, C.byref(st), 1)
         d_exec = st.bptt_depth_sum / max(st.count, 1)
-        flops = {
-            "bptt_chain_gemm": 2.0 * S * I * H,            # per launch: one BPTT step, all streams
-            "delta_gemm": 2.0 * I * H * S * d_exec,         # per launch: all executed steps
-            "forward_gemm": 2.0 * S * I * H,
+        # the kernels' OWN work per generation: the chain multiplies the hidden x hidden block
+        # (the extras' columns are another kernel's), the delta GEMM every row of W
+        per_gen_flops = {
+            "bptt_chain_gemm": 2.0 * S * Hd * Hd * D,
+            "delta_gemm": 2.0 * I * Hd * S * d_exec,
         }
-        dom = max(("bptt_chain_gemm", "delta_gemm"), key=lambda k: cls[k][0])
+        per_gen_bytes = {  # algorithmic: W once per step, E in, X mask, E out / X, E, dW once
+            "bptt_chain_gemm": 4.0 * (Hd * Hd + 3 * S * Hd) * D,
+            "delta_gemm": 4.0 * (2 * S * D * Hd + I * Hd),
+        }
+        dom = max(per_gen_flops, key=lambda k: cls[k][0])
         ms, n = cls[dom]
+        launches_per_gen = max(n, 1) / n_roof
         avg_us = 1e3 * ms / max(n, 1)
-        achieved = flops[dom] / (avg_us * 1e-6) / 1e12 if n else 0.0
+        flop_launch = per_gen_flops[dom] / launches_per_gen
+        bytes_launch = per_gen_bytes[dom] / launches_per_gen
+        achieved = flop_launch / (avg_us * 1e-6) / 1e12 if n else 0.0
+        frac_mfma = achieved / PEAK_FP32_MFMA_TFLOPS
+        frac_hbm = bytes_launch / (avg_us * 1e-6) / 1e9 / PEAK_HBM_GBS if n else 0.0
+        traffic, traffic_src = None, None
+        if (Hd, S, D) == (HIDDEN, STREAMS, DEPTH) and os.path.exists(TRAFFIC_FILE):
+            t = json.load(open(TRAFFIC_FILE)).get(dom)
+            if t:
+                traffic = t["bytes_per_launch"] * t.get("launches_per_generation", launches_per_gen) / launches_per_gen
+                traffic_src = "profiles/%s (rocprofv3 --pmc passes of this bench command, 2 x FETCH_SIZE + " \
+                              "WRITE_SIZE)" % os.path.basename(TRAFFIC_FILE)
         roofline = {
-            "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-            "traffic": (TRAFFIC_BYTES_PER_LAUNCH.get(dom)
-                        if (Hd, S, D) == (HIDDEN, STREAMS, DEPTH) else None),
-            "algorithmic_bytes": 4.0 * (I * H + 3 * S * I),  # W once, E in, X mask, E out
-            "avg_launch_us": avg_us, "launches": n, "flop_per_launch": flops[dom],
+            "bound": "mfma" if frac_mfma >= frac_hbm else "hbm", "kernel": dom, "achieved": achieved,
+            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": frac_mfma,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes": bytes_launch, "frac_of_hbm_peak": frac_hbm,
+            "avg_launch_us": avg_us, "launches": n, "launches_per_generation": launches_per_gen,
+            "flop_per_launch": flop_launch,
             "classes_ms_per_step": {k: v[0] / n_roof for k, v in cls.items()},
             "steps": n_roof,
         }
@@ -254,8 +438,10 @@ def main():
             "workload": "text-predict multi-tap generation: hidden %d, %d streams/GPU, BPTT depth "
                         "%d, 42 symbols, RELU, weighted momentum, lr 1e-5" % (Hd, S, D),
             "streams_per_gpu": S, "global_streams": S * world,
-            "parallelism": "streams sharded x%d, delta all-reduce (RCCL)" % world if world > 1
-                           else "single GPU",
+            "parallelism": ("streams sharded x%d, one RCCL all-reduce of the weight deltas per generation "
+                            "(in librecur_amd)" % world) if dist else "single GPU",
+            "rccl_ranks": amd.rnn_amd_dist_world() if dist else 0,
+            "untimed_prefill_generations": prefill,
             "mean_bptt_depth": mean_depth, "hidden_zero_fraction": zero_frac,
             "training_entropy_bits": t_entropy,
         },
@@ -263,10 +449,13 @@ def main():
     if roofline is not None:
         out["roofline"] = roofline
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(rc, sc, amd, gpu, text, i, args.cpu_seconds)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        base = cpu_one_core(rc, sc, gpu, text, i, args.cpu_seconds)
+        base["cores_available"] = all_cores.get("cores_available") if all_cores else None
+        base["all_cores"] = all_cores
+        out["cpu_baseline"] = base
+    if dist:
+        amd.rnn_amd_dist_barrier()
+        amd.rnn_amd_dist_finalize()
     if rank == 0:
         # RCCL writes a version banner through C stdio; push it out first so that the JSON
         # line is the last thing on stdout

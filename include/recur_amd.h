@@ -441,6 +441,37 @@ typedef struct RnnAmdStats {
 /* Reads (and optionally clears) the device accumulators; synchronises. */
 void rnn_amd_set_read_stats(RnnAmdSet *set, RnnAmdStats *stats, int clear);
 
+/* ---- multi-GPU: one process per GPU, streams sharded, one all-reduce per generation ----
+ * The reference sums the deltas of all streams in one process (recur-nn.c:724-739 over the
+ * sharing of recur-nn-init.c:232-241); these calls distribute that sum.  rank 0 obtains an
+ * id (128 bytes) and hands it to every rank by whatever means the launcher has (a file, a
+ * pipe, MPI, torchrun's store); every rank then joins with the device it selected with
+ * rnn_amd_use_device.  While a group is joined, rnn_amd_set_char_step (and
+ * rnn_amd_set_dist_all_reduce_deltas for callers that drive calc_deltas / apply_learning
+ * themselves) sum ih_delta||ho_delta over the ranks with ONE RCCL all-reduce on the
+ * library's stream between the deltas and the update; rnn_amd_set_open shards the text
+ * offsets as rnn_amd_set_shard(rank * n_nets, world * n_nets) unless told otherwise.
+ * All return 0 on success, -1 on failure (RCCL not loadable, bad arguments). */
+#define RNN_AMD_DIST_ID_BYTES 128
+int rnn_amd_dist_get_id(void *id);
+int rnn_amd_dist_init(int rank, int world, const void *id);
+void rnn_amd_dist_finalize(void);
+int rnn_amd_dist_rank(void);  /* 0 when no group is joined */
+int rnn_amd_dist_world(void); /* 1 when no group is joined */
+/* in-place sum over the ranks of a device buffer of floats, on the library's stream */
+void rnn_amd_dist_all_reduce(void *device_buffer, size_t n_floats);
+/* max over the ranks of a host value / a barrier (the timing bracket of a benchmark) */
+double rnn_amd_dist_max(double x);
+void rnn_amd_dist_barrier(void);
+/* rnn_new_training_set (recur-nn-init.c:221-243) for one shard of a set of global_count
+ * streams: the prototype's generator hands out the clone seeds of ALL global streams in
+ * order (recur-nn-init.c:300-305), this process keeps streams [global_first, global_first
+ * + n_local): nets[0] is the prototype (which, for global_first > 0, takes the generator of
+ * global stream global_first), nets[j] the clone of global stream global_first + j.  With
+ * global_first 0 and global_count == n_local it is rnn_new_training_set. */
+RecurNN **rnn_amd_new_training_set_shard(RecurNN *prototype, int n_local, int global_first,
+                                         int global_count);
+
 /* Multi-GPU: when set, ih_delta||ho_delta of the set live in the caller's
  * device buffer (ih_size + ho_size floats, ih first), so that the caller can
  * all-reduce it (RCCL) between calc_deltas and apply_learning.  Pass NULL to
@@ -455,6 +486,8 @@ void rnn_amd_set_shard(RnnAmdSet *set, int global_first, int global_count);
 /* Split rnn_amd_set_char_step for that use: everything up to and including
  * calc_deltas, then the update. */
 void rnn_amd_set_char_step_deltas(RnnAmdSet *set, int i);
+/* sums the set's ih_delta||ho_delta over the joined ranks (no-op without a group) */
+void rnn_amd_set_dist_all_reduce_deltas(RnnAmdSet *set);
 /* One net run over an encoded text without leaving the device: a one-hot opinion
  * (charmodel-helpers.h:16-33) of text[i] for every i < len - 1, and from i = skip on
  * the log2 of the softmax probability of text[i + 1] (capped at -100 like

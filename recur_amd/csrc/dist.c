@@ -1,0 +1,197 @@
+/* dist.c -- the multi-GPU exchange step of the RNN core (gnu11 C).
+ *
+ * The reference sums the weight deltas of all the streams of a training set in one
+ * process (recur-nn.c:724-739 over the sharing set up at recur-nn-init.c:232-241).  Here
+ * the streams are sharded over one process per GPU; every rank computes the deltas of its
+ * own streams into ih_delta||ho_delta and this file sums that ONE buffer over the ranks
+ * with ONE all-reduce per generation (RCCL over xGMI), after which every rank applies the
+ * identical update to its replica of the weights.
+ *
+ * RCCL is bound at rnn_amd_dist_init() time (dlopen of librccl.so.1 + dlsym), not at
+ * link time: the single-GPU user, the host-only half of the API and the CPU test suite do
+ * not map a 570 MB library they never call, and a process that already holds a copy of
+ * RCCL (PyTorch bundles one) keeps exactly one.  Everything after the bind is a direct
+ * call on the library's own stream.
+ */
+#include "rnn_host.h"
+#include <dlfcn.h>
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+/* the slice of rccl.h this file uses (ABI of RCCL 2.x: rccl/rccl.h:40-43, 187, 220, 260,
+ * 339, 591, 611) */
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+  char internal[128];
+} ncclUniqueId;
+typedef int ncclResult_t;
+enum { RAMD_NCCL_UINT8 = 1, RAMD_NCCL_FLOAT32 = 7, RAMD_NCCL_FLOAT64 = 8 };
+enum { RAMD_NCCL_SUM = 0, RAMD_NCCL_MAX = 2 };
+
+static struct {
+  void *dl;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  const char *(*GetErrorString)(ncclResult_t);
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
+} rccl;
+
+static ncclComm_t g_comm = NULL;
+static int g_rank = 0, g_world = 1;
+static void *g_scratch = NULL; /* 256 device bytes for the small exchanges */
+
+#define RCCL_OK(x)                                                                       \
+  do {                                                                                   \
+    ncclResult_t r_ = (x);                                                               \
+    if (r_ != 0) {                                                                       \
+      fprintf(stderr, "librecur_amd: RCCL error \"%s\" at %s:%d\n",                       \
+              rccl.GetErrorString ? rccl.GetErrorString(r_) : "?", __FILE__, __LINE__); \
+      abort();                                                                           \
+    }                                                                                    \
+  } while (0)
+#define HIP_OK(x)                                                                        \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess) {                                                              \
+      fprintf(stderr, "librecur_amd: HIP error \"%s\" at %s:%d\n", hipGetErrorString(e_), \
+              __FILE__, __LINE__);                                                       \
+      abort();                                                                           \
+    }                                                                                    \
+  } while (0)
+
+static int bind_rccl(void) {
+  if (rccl.dl) {
+    return 0;
+  }
+  const char *names[] = {getenv("RECUR_AMD_RCCL"), "librccl.so.1", "librccl.so",
+                         "/opt/rocm/lib/librccl.so.1"};
+  for (size_t i = 0; i < sizeof(names) / sizeof(names[0]) && !rccl.dl; i++) {
+    if (names[i] && *names[i]) {
+      rccl.dl = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    }
+  }
+  if (!rccl.dl) {
+    fprintf(stderr, "librecur_amd: cannot load librccl.so.1 (%s)\n", dlerror());
+    return -1;
+  }
+#define SYM(field, name)                                                       \
+  do {                                                                         \
+    *(void **)&rccl.field = dlsym(rccl.dl, name);                              \
+    if (!rccl.field) {                                                         \
+      fprintf(stderr, "librecur_amd: librccl has no symbol %s\n", name);       \
+      return -1;                                                               \
+    }                                                                          \
+  } while (0)
+  SYM(GetUniqueId, "ncclGetUniqueId");
+  SYM(CommInitRank, "ncclCommInitRank");
+  SYM(CommDestroy, "ncclCommDestroy");
+  SYM(GetErrorString, "ncclGetErrorString");
+  SYM(AllReduce, "ncclAllReduce");
+  SYM(Broadcast, "ncclBroadcast");
+#undef SYM
+  return 0;
+}
+
+int rnn_amd_dist_get_id(void *id) {
+  if (bind_rccl()) {
+    return -1;
+  }
+  ncclUniqueId u;
+  RCCL_OK(rccl.GetUniqueId(&u));
+  memcpy(id, &u, sizeof(u));
+  return 0;
+}
+
+int rnn_amd_dist_init(int rank, int world, const void *id) {
+  if (g_comm) {
+    fprintf(stderr, "librecur_amd: rnn_amd_dist_init called twice\n");
+    return -1;
+  }
+  if (world < 1 || rank < 0 || rank >= world || !id) {
+    fprintf(stderr, "librecur_amd: rnn_amd_dist_init(rank %d, world %d)\n", rank, world);
+    return -1;
+  }
+  ramd_require_device("rnn_amd_dist_init");
+  if (bind_rccl()) {
+    return -1;
+  }
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  RCCL_OK(rccl.CommInitRank(&g_comm, world, u, rank));
+  g_rank = rank;
+  g_world = world;
+  HIP_OK(hipMalloc(&g_scratch, 256));
+  return 0;
+}
+
+void rnn_amd_dist_finalize(void) {
+  if (g_comm) {
+    rnn_amd_synchronize();
+    RCCL_OK(rccl.CommDestroy(g_comm));
+    g_comm = NULL;
+    (void)hipFree(g_scratch);
+    g_scratch = NULL;
+  }
+  g_rank = 0;
+  g_world = 1;
+}
+
+int rnn_amd_dist_rank(void) { return g_rank; }
+int rnn_amd_dist_world(void) { return g_world; }
+int ramd_dist_active(void) { return g_comm != NULL; }
+
+void rnn_amd_dist_all_reduce(void *device_buffer, size_t n_floats) {
+  if (!g_comm) {
+    return; /* one process: the sum over ranks is the buffer itself */
+  }
+  RCCL_OK(rccl.AllReduce(device_buffer, device_buffer, n_floats, RAMD_NCCL_FLOAT32, RAMD_NCCL_SUM,
+                         g_comm, (hipStream_t)rnn_amd_current_stream()));
+}
+
+double rnn_amd_dist_max(double x) {
+  if (!g_comm) {
+    return x;
+  }
+  hipStream_t st = (hipStream_t)rnn_amd_current_stream();
+  HIP_OK(hipMemcpyAsync(g_scratch, &x, sizeof(x), hipMemcpyHostToDevice, st));
+  RCCL_OK(rccl.AllReduce(g_scratch, g_scratch, 1, RAMD_NCCL_FLOAT64, RAMD_NCCL_MAX, g_comm, st));
+  HIP_OK(hipMemcpyAsync(&x, g_scratch, sizeof(x), hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  return x;
+}
+
+void rnn_amd_dist_barrier(void) { (void)rnn_amd_dist_max(0.0); }
+
+/* a few host bytes from `root` to every rank (generator states: see ramd_shared_rng) */
+void ramd_dist_bcast(void *host, size_t bytes, int root) {
+  if (!g_comm || g_world < 2) {
+    return;
+  }
+  if (bytes > 256) {
+    fprintf(stderr, "librecur_amd: ramd_dist_bcast of %zu bytes\n", bytes);
+    abort();
+  }
+  hipStream_t st = (hipStream_t)rnn_amd_current_stream();
+  if (g_rank == root) {
+    HIP_OK(hipMemcpyAsync(g_scratch, host, bytes, hipMemcpyHostToDevice, st));
+  }
+  RCCL_OK(rccl.Broadcast(g_scratch, g_scratch, bytes, RAMD_NCCL_UINT8, root, g_comm, st));
+  HIP_OK(hipMemcpyAsync(host, g_scratch, bytes, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+}
+
+/* The prototype's generator is global stream 0's, so in a sharded set it lives on rank 0
+ * (on the others nets[0]->rng is the generator of THEIR first stream).  Draws that every
+ * replica has to make identically -- weight noise, perforation, the random damage of
+ * rnn_condition_net -- therefore take rank 0's state: rank 0 draws from its own generator
+ * (which advances, as in the reference), the others from a copy that is dropped. */
+rand_ctx *ramd_shared_rng(RecurNN *net, rand_ctx *tmp) {
+  if (!g_comm || g_world < 2) {
+    return &net->rng;
+  }
+  *tmp = net->rng;
+  ramd_dist_bcast(tmp, sizeof(*tmp), 0);
+  return g_rank == 0 ? &net->rng : tmp;
+}

@@ -30,6 +30,22 @@
     }                                                                             \
   } while (0)
 
+// Every launch is followed by hipGetLastError(): a bad launch configuration at an untested
+// shape is reported where it happens, not at the next synchronisation.
+static inline void ramd_check_launch(const char *file, int line) {
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) {
+    fprintf(stderr, "librecur_amd: kernel launch failed: %s at %s:%d\n", hipGetErrorString(e_), file,
+            line);
+    abort();
+  }
+}
+#define RAMD_LAUNCH(...)                       \
+  do {                                         \
+    hipLaunchKernelGGL(__VA_ARGS__);           \
+    ramd_check_launch(__FILE__, __LINE__);     \
+  } while (0)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // constants of the algorithm (recur-nn.h:28-47)
@@ -2815,9 +2831,22 @@ extern "C" double ramd_timing_ms(int which, long *launches, int reset) {
   return ms;
 }
 
+// Tuning knobs (RECUR_AMD_*) are read from the environment ONCE, the first time a launcher
+// asks for them, and frozen: the product path does not call getenv per launch.
 static int env_int(const char *name, int dflt) {
+  struct Knob {
+    const char *name;
+    int set, value;
+  };
+  static Knob knobs[48];
+  static int n_knobs = 0;
+  for (int i = 0; i < n_knobs; i++)
+    if (knobs[i].name == name || strcmp(knobs[i].name, name) == 0)
+      return knobs[i].set ? knobs[i].value : dflt;
   const char *e = getenv(name);
-  return (e && *e) ? atoi(e) : dflt;
+  Knob k = {name, (e && *e) ? 1 : 0, (e && *e) ? atoi(e) : 0};
+  if (n_knobs < 48) knobs[n_knobs++] = k;
+  return k.set ? k.value : dflt;
 }
 
 // Split-K factor: enough workgroups to give every CU two or three, without
@@ -2873,7 +2902,7 @@ static void launch_gemm(hipStream_t st, const Prob &p, float *slab, int M, int N
   int blocks;
   GemmOut o = make_gemm_out(slab, M, N, nkt, ks, col0, ldc, row0m, &blocks);
   int ev = timing_begin(st, cls);
-  hipLaunchKernelGGL((k_gemm<A_KM, B_KM, Prob>), dim3(blocks), dim3(256), 0, st, p, o);
+  RAMD_LAUNCH((k_gemm<A_KM, B_KM, Prob>), dim3(blocks), dim3(256), 0, st, p, o);
   timing_end(st, ev);
 }
 
@@ -2894,7 +2923,7 @@ static void launch_gemm2(hipStream_t st, const Prob &p, float *slab, int M, int 
   int panels = o.tn * ks;
   int blocks = ((panels + 7) / 8) * 8 * o.tm;
   int ev = timing_begin(st, cls);
-  hipLaunchKernelGGL((k_gemm2<Prob>), dim3(blocks), dim3(256), 0, st, p, o);
+  RAMD_LAUNCH((k_gemm2<Prob>), dim3(blocks), dim3(256), 0, st, p, o);
   timing_end(st, ev);
 }
 
@@ -2903,7 +2932,7 @@ extern "C" void ramd_launch_advance(ramd_stream_t st_, const RamdShape *sh, cons
                                     int row0, int nrows) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  hipLaunchKernelGGL(k_advance, dim3((nrows + 255) / 256), dim3(256), 0, st, v, row0, nrows);
+  RAMD_LAUNCH(k_advance, dim3((nrows + 255) / 256), dim3(256), 0, st, v, row0, nrows);
 }
 
 extern "C" void ramd_launch_assemble(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
@@ -2911,7 +2940,7 @@ extern "C" void ramd_launch_assemble(ramd_stream_t st_, const RamdShape *sh, con
                                      int text_i, int global_first, int n_set, int advance) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  hipLaunchKernelGGL(k_assemble, dim3(nrows), dim3(256), 0, st, v, row0, mode, dense, ld, text_i,
+  RAMD_LAUNCH(k_assemble, dim3(nrows), dim3(256), 0, st, v, row0, mode, dense, ld, text_i,
                      global_first, n_set, advance);
 }
 
@@ -2922,7 +2951,7 @@ extern "C" void ramd_launch_bottom_forward(ramd_stream_t st_, const RamdShape *s
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   size_t shm = (size_t)(sh->bI + sh->bO) * sizeof(float);
-  hipLaunchKernelGGL(k_bottom_forward, dim3(nrows), dim3(256), shm, st, v, row0, mode, dense, ld,
+  RAMD_LAUNCH(k_bottom_forward, dim3(nrows), dim3(256), shm, st, v, row0, mode, dense, ld,
                      text_i, global_first, n_set, noise);
 }
 
@@ -2932,11 +2961,11 @@ extern "C" void ramd_launch_bottom_deltas(ramd_stream_t st_, const RamdShape *sh
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   int nxp = (sh->I - sh->hidden_size + 3) & ~3;
-  hipLaunchKernelGGL(k_bottom_error, dim3(nrows), dim3(64), 0, st, v, row0, nxp, active);
+  RAMD_LAUNCH(k_bottom_error, dim3(nrows), dim3(64), 0, st, v, row0, nxp, active);
   int n = sh->bI * sh->bO;
   const float *cin = b->bcarry + (size_t)b->bcarry_cur * sh->bO;
   float *cout = b->bcarry + (size_t)(b->bcarry_cur ^ 1) * sh->bO;
-  hipLaunchKernelGGL(k_bottom_delta, dim3((n + 255) / 256), dim3(256), 0, st, v, row0, nrows,
+  RAMD_LAUNCH(k_bottom_delta, dim3((n + 255) / 256), dim3(256), 0, st, v, row0, nrows,
                      accumulate, active, cin, cout);
   b->bcarry_cur ^= 1;
 }
@@ -2955,7 +2984,7 @@ static const View *device_view(hipStream_t st, const View &v) {
   cur.b.uniform_idx = 0;
   if (!d_view) HIP_CHECK(hipMalloc(&d_view, sizeof(View)));
   if (!have || memcmp(&cur, &h_view, sizeof(View)) != 0) {
-    hipLaunchKernelGGL(k_store_view, dim3(1), dim3(1), 0, st, cur, d_view);
+    RAMD_LAUNCH(k_store_view, dim3(1), dim3(1), 0, st, cur, d_view);
     h_view = cur;
     have = true;
   }
@@ -2983,7 +3012,7 @@ extern "C" int ramd_launch_forward_fused(ramd_stream_t st_, const RamdShape *sh,
   int ev = timing_begin(st, T_FWD);
   const bool exact = sh->hidden_size % CK == 0 && !env_int("RECUR_AMD_FWD_NS0", 0);
 #define FWD_FUSED(NS)                                                                              \
-  hipLaunchKernelGGL((k_fwd_fused<NS>), dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx, row0, \
+  RAMD_LAUNCH((k_fwd_fused<NS>), dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx, row0, \
                      nrows, tm, tn, nstages, mode, text_i, global_first, n_set)
   if (exact && nstages == 8) FWD_FUSED(8);
   else if (exact && nstages == 4) FWD_FUSED(4);
@@ -3000,7 +3029,7 @@ extern "C" void ramd_launch_text_top(ramd_stream_t st_, const RamdShape *sh, con
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   size_t shm = (size_t)(sh->H + OUT_SEGS * 64 + 3 * sh->O) * sizeof(float);
-  hipLaunchKernelGGL(k_text_top, dim3(nrows), dim3(1024), shm, st, v, row0, nrows, fwd_ks);
+  RAMD_LAUNCH(k_text_top, dim3(nrows), dim3(1024), shm, st, v, row0, nrows, fwd_ks);
 }
 
 extern "C" int ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh,
@@ -3013,7 +3042,7 @@ extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, cons
   View v = make_view(sh, b);
   ramd_launch_forward_hidden(st_, sh, b, row0, nrows, noise, 0);
   if (sh->O <= 256 && !env_int("RECUR_AMD_OUT_GEMM", 0)) {
-    hipLaunchKernelGGL(k_out_layer, dim3(nrows), dim3(1024),
+    RAMD_LAUNCH(k_out_layer, dim3(nrows), dim3(1024),
                        (size_t)(sh->H + OUT_SEGS * 64) * sizeof(float), st, v, row0);
   } else { /* wide output layers (multi-head nets, O in the thousands): the MFMA GEMM */
     int tm = (nrows + BM - 1) / BM;
@@ -3022,7 +3051,7 @@ extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, cons
     ProbOut p = {v, row0, nrows};
     launch_gemm<false, true, ProbOut>(st, p, b->slab, nrows, sh->O, nkt, ks, T_OTHER);
     int n4 = nrows * (sh->O / 4);
-    hipLaunchKernelGGL(k_sum_slabs, dim3((n4 + 255) / 256), dim3(256), 0, st,
+    RAMD_LAUNCH(k_sum_slabs, dim3((n4 + 255) / 256), dim3(256), 0, st,
                        b->out + (size_t)row0 * sh->O, sh->O, b->slab, nrows, sh->O, ks, 0);
   }
 }
@@ -3047,11 +3076,11 @@ extern "C" int ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh
       launch_gemm<false, true, ProbFwd<false>>(st, p, b->slab, nrows, sh->H, nkt, ks, T_FWD);
     }
     if (noise != 0.0f)
-      hipLaunchKernelGGL(k_presynaptic_noise, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows,
+      RAMD_LAUNCH(k_presynaptic_noise, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows,
                          noise);
     if (leave_slabs) return ks;
     int n4 = nrows * (sh->H / 4);
-    hipLaunchKernelGGL(k_fwd_finalize, dim3((n4 + 255) / 256), dim3(256), 0, st, v, row0, nrows, ks);
+    RAMD_LAUNCH(k_fwd_finalize, dim3((n4 + 255) / 256), dim3(256), 0, st, v, row0, nrows, ks);
   }
   return 0;
 }
@@ -3060,7 +3089,7 @@ extern "C" void ramd_launch_softmax_error(ramd_stream_t st_, const RamdShape *sh
                                           const RamdBuffers *b, int row0, int nrows) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  hipLaunchKernelGGL(k_softmax_error, dim3(nrows), dim3(64), (size_t)sh->output_size * sizeof(float), st, v,
+  RAMD_LAUNCH(k_softmax_error, dim3(nrows), dim3(64), (size_t)sh->output_size * sizeof(float), st, v,
                      row0, nrows);
 }
 
@@ -3068,7 +3097,7 @@ extern "C" void ramd_launch_xent_accumulate(ramd_stream_t st_, const RamdShape *
                                             const RamdBuffers *b, int row, int count_it) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  hipLaunchKernelGGL(k_xent_accumulate, dim3(1), dim3(64), (size_t)sh->output_size * sizeof(float),
+  RAMD_LAUNCH(k_xent_accumulate, dim3(1), dim3(64), (size_t)sh->output_size * sizeof(float),
                      st, v, row, count_it);
 }
 
@@ -3079,7 +3108,7 @@ extern "C" void ramd_launch_multi_softmax_error(ramd_stream_t st_, const RamdSha
                                                 int *ranges, int range_stride) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  hipLaunchKernelGGL(k_multi_softmax_error, dim3(nrows), dim3(64), (size_t)alphabet_len * sizeof(float),
+  RAMD_LAUNCH(k_multi_softmax_error, dim3(nrows), dim3(64), (size_t)alphabet_len * sizeof(float),
                      st, v, row0, alphabet_len, n_classes, threshold, tclass, ranges, range_stride);
 }
 
@@ -3090,7 +3119,7 @@ extern "C" void ramd_launch_grouped_softmax_error(ramd_stream_t st_, const RamdS
                                                   const float *weight) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  hipLaunchKernelGGL(k_grouped_softmax_error, dim3(nrows), dim3(64), (size_t)largest * sizeof(float), st,
+  RAMD_LAUNCH(k_grouped_softmax_error, dim3(nrows), dim3(64), (size_t)largest * sizeof(float), st,
                      v, row0, ngroups, goff, gsize, gt, weight);
 }
 
@@ -3098,12 +3127,12 @@ extern "C" void ramd_launch_clear_deltas(ramd_stream_t st_, const RamdShape *sh,
                                          const RamdBuffers *b) {
   hipStream_t st = (hipStream_t)st_;
   size_t ih4 = (size_t)sh->I * sh->H / 4, ho4 = (size_t)sh->H * sh->O / 4;
-  hipLaunchKernelGGL(k_zero_f4, dim3((unsigned)((ih4 + 255) / 256)), dim3(256), 0, st, b->ih_delta, ih4);
-  hipLaunchKernelGGL(k_zero_f4, dim3((unsigned)((ho4 + 255) / 256)), dim3(256), 0, st, b->ho_delta, ho4);
+  RAMD_LAUNCH(k_zero_f4, dim3((unsigned)((ih4 + 255) / 256)), dim3(256), 0, st, b->ih_delta, ih4);
+  RAMD_LAUNCH(k_zero_f4, dim3((unsigned)((ho4 + 255) / 256)), dim3(256), 0, st, b->ho_delta, ho4);
   if (sh->bI) { /* recur-nn.c:687-692 */
     size_t b4 = (size_t)sh->bI * sh->bO / 4, c4 = (size_t)2 * sh->bO / 4;
-    hipLaunchKernelGGL(k_zero_f4, dim3((unsigned)((b4 + 255) / 256)), dim3(256), 0, st, b->bdelta, b4);
-    hipLaunchKernelGGL(k_zero_f4, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, st, b->bcarry, c4);
+    RAMD_LAUNCH(k_zero_f4, dim3((unsigned)((b4 + 255) / 256)), dim3(256), 0, st, b->bdelta, b4);
+    RAMD_LAUNCH(k_zero_f4, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, st, b->bcarry, c4);
   }
 }
 
@@ -3117,7 +3146,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   // top layer
   size_t shm = (size_t)(sh->O + sh->H) * sizeof(float);
   if (!(flags & 0x40000000u)) /* ramd_launch_text_top has already done the top backprop */
-    hipLaunchKernelGGL(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges,
+    RAMD_LAUNCH(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges,
                        range_stride, active);
   /* the weight-delta GEMM's path is decided here already: when it ends with the small GEMM
    * over the rows above the last whole 128-row tile, the top layer's equally small delta
@@ -3137,7 +3166,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
      * k_bptt_control rewrites it later in this call) */
     const float *live = b->ones + row0;
     if (active) {
-      hipLaunchKernelGGL(k_live_mask, dim3((nrows + 255) / 256), dim3(256), 0, st, b->coef + row0,
+      RAMD_LAUNCH(k_live_mask, dim3((nrows + 255) / 256), dim3(256), 0, st, b->coef + row0,
                          active, nrows);
       live = b->coef + row0;
     }
@@ -3171,7 +3200,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       launch_gemm<true, true, ProbHoDelta>(st, p, b->slab, sh->H, sh->O, nkt, ks, T_OTHER);
       /* with one range list per stream the set of touched columns differs per stream; the
        * error is zero outside a stream's own ranges, so every column may take its sum */
-      hipLaunchKernelGGL(k_ho_delta_finalize, dim3((ho + 255) / 256), dim3(256), 0, st, v, b->slab,
+      RAMD_LAUNCH(k_ho_delta_finalize, dim3((ho + 255) / 256), dim3(256), 0, st, v, b->slab,
                          ks, accumulate, range_stride ? nullptr : ranges);
     }
   }
@@ -3190,7 +3219,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int ev = timing_begin(st, T_CHAIN, sh->D);
     for (int t = 0; t < sh->D; t++) {
 #define CHAIN_NS(NS)                                                                               \
-  hipLaunchKernelGGL((k_chain_main<true, NS>), dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx, \
+  RAMD_LAUNCH((k_chain_main<true, NS>), dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx, \
                      row0, nrows, t, tm, tn, nstages)
       const bool exact = sh->hidden_size % CK == 0;
       if (b->uniform_idx >= 0 && exact && nstages == 8) CHAIN_NS(8);
@@ -3198,10 +3227,10 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       else if (b->uniform_idx >= 0 && exact && nstages == 2) CHAIN_NS(2);
       else if (b->uniform_idx >= 0 && exact && nstages == 16) CHAIN_NS(16);
       else if (b->uniform_idx >= 0)
-        hipLaunchKernelGGL(k_chain_main<true>, dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx, row0,
+        RAMD_LAUNCH(k_chain_main<true>, dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx, row0,
                            nrows, t, tm, tn, nstages);
       else
-        hipLaunchKernelGGL(k_chain_main<false>, dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx,
+        RAMD_LAUNCH(k_chain_main<false>, dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx,
                            row0, nrows, t, tm, tn, nstages);
 #undef CHAIN_NS
     }
@@ -3213,30 +3242,30 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       const int nq = (sh->H / 4 + 63) / 64;
       if (env_int("RECUR_AMD_EXTRAS_SPLIT", 0)) {
         if (nq <= 5)
-          hipLaunchKernelGGL(k_extras_gather<5>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
+          RAMD_LAUNCH(k_extras_gather<5>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
                              nxp, tn);
         else
-          hipLaunchKernelGGL(k_extras_gather<8>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
+          RAMD_LAUNCH(k_extras_gather<8>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
                              nxp, tn);
       } else {
         /* extras and control in one launch, one workgroup per stream */
         const size_t shm = (size_t)sh->D * sizeof(float);
         if (nq <= 5)
-          hipLaunchKernelGGL((k_extras_control<5, 1024>), dim3(nrows), dim3(1024), shm, st, v, row0, nrows,
+          RAMD_LAUNCH((k_extras_control<5, 1024>), dim3(nrows), dim3(1024), shm, st, v, row0, nrows,
                              nx, nxp, tn, active, flags);
         else
-          hipLaunchKernelGGL((k_extras_control<8, 512>), dim3(nrows), dim3(512), shm, st, v, row0, nrows,
+          RAMD_LAUNCH((k_extras_control<8, 512>), dim3(nrows), dim3(512), shm, st, v, row0, nrows,
                              nx, nxp, tn, active, flags);
         control_done = true;
       }
     } else { /* very wide nets: the dense GEMM over all extra columns */
       ProbExtras p = {v, row0, nrows, nx};
       launch_gemm<false, false, ProbExtras>(st, p, b->slab, M, nxp, nkt, ks, T_OTHER);
-      hipLaunchKernelGGL(k_extras_finalize, dim3(M), dim3(64), 0, st, v, row0, nrows, nx, nxp, ks, tn);
+      RAMD_LAUNCH(k_extras_finalize, dim3(M), dim3(64), 0, st, v, row0, nrows, nx, nxp, ks, tn);
     }
   }
   if (!control_done)
-    hipLaunchKernelGGL(k_bptt_control, dim3((nrows + 3) / 4), dim3(256), 0, st, v, row0, nrows,
+    RAMD_LAUNCH(k_bptt_control, dim3((nrows + 3) / 4), dim3(256), 0, st, v, row0, nrows,
                        active, flags, tn);
   // weight deltas: one GEMM over (step, stream)
   {
@@ -3287,7 +3316,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       const int per = 8 / kd;
       int blocks = ((tiles + per - 1) / per) * 8;
       int ev = timing_begin(st, T_DELTA);
-      hipLaunchKernelGGL(k_delta_dma, dim3(blocks), dim3(512), shm, st, v, row0, nrows, o);
+      RAMD_LAUNCH(k_delta_dma, dim3(blocks), dim3(512), shm, st, v, row0, nrows, o);
       timing_end(st, ev);
       ks_rest = 0;
       if (rows_core < sh->I) {
@@ -3299,14 +3328,14 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
           GemmOut oa = make_gemm_out(b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, 0, 0, 0, &blocks_a);
           GemmOut ob = make_gemm_out(b->slab, sh->I, ncol, nkt, ks_rest, 1, sh->H, rows_core, &blocks_b);
           int ev2 = timing_begin(st, T_DELTA);
-          hipLaunchKernelGGL((k_gemm_pair<ProbHoDelta, ProbDelta<true>>), dim3(blocks_a + blocks_b),
+          RAMD_LAUNCH((k_gemm_pair<ProbHoDelta, ProbDelta<true>>), dim3(blocks_a + blocks_b),
                              dim3(256), 0, st, ho_p, oa, blocks_a, p, ob);
           timing_end(st, ev2);
           ho_paired = false;
           if (ho_finalize_after && !ranges) {
             ho_in_final = true; /* summed by the k_delta_finalize launch below */
           } else if (ho_finalize_after) {
-            hipLaunchKernelGGL(k_ho_delta_finalize, dim3((sh->H * sh->O + 255) / 256), dim3(256), 0, st, v,
+            RAMD_LAUNCH(k_ho_delta_finalize, dim3((sh->H * sh->O + 255) / 256), dim3(256), 0, st, v,
                                b->ho_slab, ho_ks, accumulate, range_stride ? nullptr : ranges);
           }
         } else {
@@ -3344,7 +3373,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     if (defer) defer->slab = nullptr;
     const size_t ho_n = (size_t)sh->H * sh->O;
     const unsigned fin_blocks = (unsigned)((n4 + 255) / 256) + (ho_in_final ? (unsigned)((ho_n / 4 + 255) / 256) : 0u);
-    hipLaunchKernelGGL(k_delta_finalize, dim3(fin_blocks), dim3(256), 0, st, b->ih_delta, b->slab, n4, n, ks,
+    RAMD_LAUNCH(k_delta_finalize, dim3(fin_blocks), dim3(256), 0, st, b->ih_delta, b->slab, n4, n, ks,
                        accumulate, sh->H, sh->hidden_size, rows_core, ks_rest, b->ho_delta,
                        ho_in_final ? b->ho_slab : nullptr, ho_n, ho_ks);
   }
@@ -3355,7 +3384,7 @@ extern "C" void ramd_launch_err_writeback(ramd_stream_t st_, const RamdShape *sh
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   int nxp = (sh->I - sh->hidden_size + 3) & ~3;
-  hipLaunchKernelGGL(k_err_writeback, dim3(nrows), dim3(256), 0, st, v, row0, nxp);
+  RAMD_LAUNCH(k_err_writeback, dim3(nrows), dim3(256), 0, st, v, row0, nxp);
 }
 
 extern "C" void ramd_launch_apply_multi(ramd_stream_t st_, int method, int nseg, float *const *w,
@@ -3384,11 +3413,11 @@ extern "C" void ramd_launch_apply_multi(ramd_stream_t st_, int method, int nseg,
   dim3 gr(blocks), bl(256);
   int ev = timing_begin(st, T_APPLY);
   switch (method) {
-  case 1: hipLaunchKernelGGL(k_apply<1>, gr, bl, 0, st, sg, momentum, mw, rs); break;
-  case 4: hipLaunchKernelGGL(k_apply<4>, gr, bl, 0, st, sg, momentum, mw, rs); break;
-  case 5: hipLaunchKernelGGL(k_apply<5>, gr, bl, 0, st, sg, momentum, mw, rs); break;
-  case 6: hipLaunchKernelGGL(k_apply<6>, gr, bl, 0, st, sg, momentum, mw, rs); break;
-  default: hipLaunchKernelGGL(k_apply<0>, gr, bl, 0, st, sg, momentum, mw, rs); break;
+  case 1: RAMD_LAUNCH(k_apply<1>, gr, bl, 0, st, sg, momentum, mw, rs); break;
+  case 4: RAMD_LAUNCH(k_apply<4>, gr, bl, 0, st, sg, momentum, mw, rs); break;
+  case 5: RAMD_LAUNCH(k_apply<5>, gr, bl, 0, st, sg, momentum, mw, rs); break;
+  case 6: RAMD_LAUNCH(k_apply<6>, gr, bl, 0, st, sg, momentum, mw, rs); break;
+  default: RAMD_LAUNCH(k_apply<0>, gr, bl, 0, st, sg, momentum, mw, rs); break;
   }
   timing_end(st, ev);
 }
@@ -3405,26 +3434,26 @@ extern "C" void ramd_launch_top_apply_now(ramd_stream_t st_, const RamdShape *sh
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   int ho = sh->H * sh->O;
-  hipLaunchKernelGGL(k_top_apply_now, dim3((ho + 255) / 256), dim3(256), 0, st, v, row, rate,
+  RAMD_LAUNCH(k_top_apply_now, dim3((ho + 255) / 256), dim3(256), 0, st, v, row, rate,
                      momentum, mw);
 }
 
 extern "C" void ramd_launch_scale(ramd_stream_t st, float *a, size_t n, float scale) {
-  hipLaunchKernelGGL(k_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)st, a, n, scale);
+  RAMD_LAUNCH(k_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)st, a, n, scale);
 }
 extern "C" void ramd_launch_zero_small(ramd_stream_t st, float *a, size_t n) {
-  hipLaunchKernelGGL(k_zero_small, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)st, a, n);
+  RAMD_LAUNCH(k_zero_small, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)st, a, n);
 }
 extern "C" void ramd_launch_clamp(ramd_stream_t st, float *a, size_t n, float lo, float hi) {
-  hipLaunchKernelGGL(k_clamp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)st, a, n, lo, hi);
+  RAMD_LAUNCH(k_clamp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)st, a, n, lo, hi);
 }
 extern "C" void ramd_launch_add_at(ramd_stream_t st, float *a, size_t index, float v) {
-  hipLaunchKernelGGL(k_add_at, dim3(1), dim3(1), 0, (hipStream_t)st, a, index, v);
+  RAMD_LAUNCH(k_add_at, dim3(1), dim3(1), 0, (hipStream_t)st, a, index, v);
 }
 extern "C" void ramd_launch_tall_poppy(ramd_stream_t st, float *a, size_t n, float threshold,
                                        float scale, void *scratch) {
   const int parts = 256; /* scratch holds 256 BestAbs */
-  hipLaunchKernelGGL(k_absmax_part, dim3(parts), dim3(256), 0, (hipStream_t)st, a, n, (BestAbs *)scratch);
-  hipLaunchKernelGGL(k_tall_poppy, dim3(1), dim3(1), 0, (hipStream_t)st, a, (const BestAbs *)scratch, parts,
+  RAMD_LAUNCH(k_absmax_part, dim3(parts), dim3(256), 0, (hipStream_t)st, a, n, (BestAbs *)scratch);
+  RAMD_LAUNCH(k_tall_poppy, dim3(1), dim3(1), 0, (hipStream_t)st, a, (const BestAbs *)scratch, parts,
                      threshold, scale);
 }

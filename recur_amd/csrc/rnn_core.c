@@ -74,6 +74,7 @@ const char *rnn_amd_version(void) { return "recur_amd 0.1 (gfx950, fp32 MFMA)"; 
 void rnn_amd_synchronize(void) {
   if (g_device >= 0) {
     HIP_OK(hipStreamSynchronize(g_stream));
+    HIP_OK(hipDeviceSynchronize());
   }
 }
 void rnn_amd_kernel_time_enable(int enable) { ramd_timing_enable(enable); }
@@ -174,6 +175,23 @@ static void engine_delete(RamdEngine *e) {
     dsync();
   }
   engine_free_device(e);
+  /* clones may outlive the net that owns the weights (text-predict.c:654-656 deletes the
+   * training set, then its confab and validation clones): detach them so that their own
+   * rnn_delete_net finds no engine instead of a freed one */
+  for (int i = 0; i < e->n_streams; i++) {
+    if (e->streams[i] && e->streams[i] != e->owner) {
+      RamdPriv *q = ramd_priv(e->streams[i]);
+      q->eng = NULL;
+      q->stream = q->fwd = -1;
+    }
+  }
+  for (int i = 0; i < e->n_fwd; i++) {
+    if (e->fwd[i] && e->fwd[i] != e->owner) {
+      RamdPriv *q = ramd_priv(e->fwd[i]);
+      q->eng = NULL;
+      q->stream = q->fwd = -1;
+    }
+  }
   RamdEngine **pp = &g_engines;
   while (*pp && *pp != e) {
     pp = &(*pp)->next;
@@ -476,6 +494,9 @@ static void engine_ensure_device(RamdEngine *e) {
   if (e->dev_ready && e->sh.Scap >= e->n_streams && e->sh.Fcap >= e->n_fwd && same_bottom) {
     return;
   }
+  unsigned char *keep_text = NULL;
+  int keep_text_len = 0;
+  float *keep_ext = NULL;
   if (e->dev_ready) {
     engine_need_host(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
     for (int i = 0; i < e->n_streams; i++) {
@@ -491,6 +512,17 @@ static void engine_ensure_device(RamdEngine *e) {
       }
     }
     dsync();
+    /* what the caller registered with the engine survives the regrow: the text of the
+     * host-free epoch loop and the external delta buffer of the multi-GPU path */
+    if (e->b.text && e->b.text_len > 0) {
+      keep_text_len = e->b.text_len;
+      keep_text = malloc((size_t)keep_text_len);
+      d2h(keep_text, e->b.text, (size_t)keep_text_len);
+      dsync();
+    }
+    if (e->delta_external) {
+      keep_ext = e->b.ih_delta;
+    }
     engine_free_device(e);
   }
   RamdShape *s = &e->sh;
@@ -599,6 +631,18 @@ static void engine_ensure_device(RamdEngine *e) {
     b->bcarry_cur = 0;
   }
   e->lr_pushed = ramd_zalloc(S * sizeof(float));
+  if (keep_text) {
+    b->text = dev_alloc((size_t)keep_text_len);
+    h2d(b->text, keep_text, (size_t)keep_text_len);
+    b->text_len = keep_text_len;
+    dsync();
+    free(keep_text);
+  }
+  if (keep_ext) {
+    b->ih_delta = keep_ext;
+    b->ho_delta = keep_ext + e->ih_size;
+    e->delta_external = 1;
+  }
   e->dev_ready = 1;
   e->dev_valid = 0;
   e->err_pending = 0;
@@ -905,6 +949,51 @@ RecurNN **rnn_new_training_set(RecurNN *prototype, int n_nets) {
     nets[i]->bptt->ih_delta = prototype->bptt->ih_delta;
     nets[i]->bptt->ih_delta_tmp = prototype->bptt->ih_delta_tmp;
     nets[i]->bptt->ho_delta = prototype->bptt->ho_delta;
+  }
+  return nets;
+}
+
+/* One shard of a training set whose streams are spread over several processes (one per
+ * GPU).  The reference seeds clone g from the g-th draw of the prototype's generator
+ * (recur-nn-init.c:232-241, 300-305); every rank replays ALL the draws so that global
+ * stream g gets the reference's generator wherever it lives, and keeps its own range. */
+RecurNN **rnn_amd_new_training_set_shard(RecurNN *prototype, int n_local, int global_first,
+                                         int global_count) {
+  if (n_local < 1 || global_first < 0 || global_first + n_local > global_count) {
+    fprintf(stderr, "A training set shard of %d streams at %d of %d is not possible\n", n_local,
+            global_first, global_count);
+    return NULL;
+  }
+  RecurNN **nets = ramd_zalloc(n_local * sizeof(RecurNN *));
+  nets[0] = prototype;
+  u32 flags = prototype->flags;
+  flags &= ~RNN_NET_FLAG_OWN_WEIGHTS;
+  flags |= RNN_NET_FLAG_NO_MOMENTUMS;
+  flags |= RNN_NET_FLAG_NO_DELTAS;
+  if (ramd_priv(prototype)->eng && !ramd_priv(prototype)->host_valid) {
+    ramd_need_host(prototype, RNN_AMD_STREAM);
+  }
+  ramd_priv(prototype)->dev_valid = 0;
+  u64 first_seed = 0;
+  for (int g = 1; g < global_count; g++) {
+    u64 seed;
+    do {
+      seed = ramd_rand64(&prototype->rng);
+    } while (seed == RECUR_RNG_RANDOM_SEED);
+    int j = g - global_first;
+    if (j == 0) {
+      first_seed = seed;
+    } else if (j > 0 && j < n_local) {
+      nets[j] = rnn_clone(prototype, flags, seed, NULL);
+      nets[j]->bptt->ih_delta = prototype->bptt->ih_delta;
+      nets[j]->bptt->ih_delta_tmp = prototype->bptt->ih_delta_tmp;
+      nets[j]->bptt->ho_delta = prototype->bptt->ho_delta;
+    }
+  }
+  if (global_first > 0) {
+    /* this rank's first stream is global stream global_first: its generator, not the
+     * prototype's (which belongs to global stream 0 on rank 0; see ramd_shared_rng) */
+    ramd_init_rand64_maybe_randomly(&prototype->rng, first_seed);
   }
   return nets;
 }
@@ -1279,8 +1368,9 @@ void rnn_condition_net(RecurNN *net) {
     break;
   case RNN_COND_BIT_RAND: {
     stream_need_host(e, net); /* the generator may have advanced on the device (noise) */
-    int t = ramd_rand_small_int(&net->rng, net->ih_size + net->ho_size);
-    float damage = (ramd_cheap_gaussian_noise(&net->rng) * RANDOM_DAMAGE_FACTOR * net->h_size *
+    rand_ctx tmp, *rng = ramd_shared_rng(net, &tmp); /* every replica takes the same damage */
+    int t = ramd_rand_small_int(rng, net->ih_size + net->ho_size);
+    float damage = (ramd_cheap_gaussian_noise(rng) * RANDOM_DAMAGE_FACTOR * net->h_size *
                     net->bptt->learn_rate);
     ramd_priv(net)->dev_valid = 0; /* and now it advanced on the host */
     engine_need_dev(e, RNN_AMD_WEIGHTS);
@@ -1452,6 +1542,10 @@ RnnAmdSet *rnn_amd_set_open(RecurNN **nets, int n_nets) {
   set->fwd_only = fwd_only;
   set->global_first = 0;
   set->global_count = n_nets;
+  if (ramd_dist_active() && !fwd_only) { /* rank r holds global streams [r n, (r + 1) n) */
+    set->global_first = rnn_amd_dist_rank() * n_nets;
+    set->global_count = rnn_amd_dist_world() * n_nets;
+  }
   return set;
 }
 
@@ -1466,8 +1560,25 @@ void rnn_amd_set_close(RnnAmdSet *set) {
 int rnn_amd_set_size(const RnnAmdSet *set) { return set->n; }
 
 void rnn_amd_set_shard(RnnAmdSet *set, int global_first, int global_count) {
+  if (global_first < 0 || global_first + set->n > global_count) {
+    fprintf(stderr, "librecur_amd: rnn_amd_set_shard(%d, %d) for a set of %d streams\n", global_first,
+            global_count, set->n);
+    abort();
+  }
   set->global_first = global_first;
   set->global_count = global_count;
+  set->shard_set = 1;
+}
+
+void rnn_amd_set_dist_all_reduce_deltas(RnnAmdSet *set) {
+  RamdEngine *e = set->eng;
+  if (!ramd_dist_active()) {
+    return;
+  }
+  engine_need_dev(e, RNN_AMD_DELTAS);
+  /* ih_delta||ho_delta are one allocation (library-owned or the caller's external buffer) */
+  rnn_amd_dist_all_reduce(e->b.ih_delta, e->ih_size + e->ho_size);
+  engine_dev_wrote(e, RNN_AMD_DELTAS);
 }
 
 /* first state row of the set (forward-only rows sit after the Scap training rows) */
@@ -1768,6 +1879,10 @@ void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *ne
 
 void rnn_amd_set_load_text(RnnAmdSet *set, const u8 *text, int len) {
   RamdEngine *e = set->eng;
+  if (!text || len < 2) { /* a step reads text[o] and text[o + 1] */
+    fprintf(stderr, "librecur_amd: rnn_amd_set_load_text needs at least 2 symbols (got %d)\n", len);
+    abort();
+  }
   dsync();
   dev_free(e->b.text);
   e->b.text = dev_alloc(len);
@@ -1780,6 +1895,12 @@ static void char_step_deltas(RnnAmdSet *set, int i, RamdPendingDelta *defer) {
   RamdEngine *e = set->eng;
   if (!e->b.text) {
     fprintf(stderr, "librecur_amd: rnn_amd_set_char_step without rnn_amd_set_load_text\n");
+    abort();
+  }
+  /* the reference's loop runs i over [start, len - 1) (charmodel-predict.c:288); the
+   * kernels wrap the per-stream offset once, so i itself has to be in range */
+  if (i < 0 || i >= e->b.text_len - 1) {
+    fprintf(stderr, "librecur_amd: text position %d outside [0, %d)\n", i, e->b.text_len - 1);
     abort();
   }
   if (ramd_text_top_ok(&e->sh)) {
@@ -1803,8 +1924,14 @@ void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float mome
   /* the deltas go straight from the GEMM's K slabs into the update (and into ih_delta) when
    * nothing can look at them in between: library-owned storage, no log on the prototype */
   RamdPendingDelta pend = {0};
-  int fuse = !set->eng->delta_external && !set->nets[0]->log;
+  const int dist = ramd_dist_active();
+  int fuse = !set->eng->delta_external && !set->nets[0]->log && !dist;
   char_step_deltas(set, i, fuse ? &pend : NULL);
+  if (dist) {
+    /* the one exchange step of the path: this rank's deltas become the sum over all ranks'
+     * streams (recur-nn.c:724-739 distributed), then the identical update everywhere */
+    rnn_amd_dist_all_reduce(set->eng->b.ih_delta, set->eng->ih_size + set->eng->ho_size);
+  }
   apply_learning(set->nets[0], learning_style, momentum, (pend.slab || pend.ho_slab) ? &pend : NULL);
 }
 

@@ -69,6 +69,7 @@ struct RnnAmdSet {
   int row0;     /* first training-stream row, or first forward-only index when fwd_only */
   int fwd_only; /* the set is made of forward-only clones (no bptt): opinion calls only */
   int global_first, global_count;
+  int shard_set; /* rnn_amd_set_shard was called: do not derive the shard from the rank */
 };
 
 static inline RamdPriv *ramd_priv(const RecurNN *net) {
@@ -88,6 +89,11 @@ void ramd_host_wrote(RecurNN *net, int what);
 void ramd_require_device(const char *what);
 void ramd_rng_to_host(RecurNN *net);
 void ramd_rng_from_host(RecurNN *net);
+
+/* dist.c */
+int ramd_dist_active(void);
+void ramd_dist_bcast(void *host, size_t bytes, int root);
+rand_ctx *ramd_shared_rng(RecurNN *net, rand_ctx *tmp);
 
 /* rnn_init.c: Jenkins PRNG (recur-rng.h) */
 uint64_t ramd_rand64(rand_ctx *x);

@@ -309,6 +309,7 @@ static void runs_submethod(RecurNN *net, struct RecurInitialisationParameters *p
 /* recur-nn.h:287 / recur-nn-init.c:649-683 */
 void rnn_randomise_weights_clever(RecurNN *net, struct RecurInitialisationParameters *p) {
   ramd_need_host(net, RNN_AMD_WEIGHTS);
+  ramd_rng_to_host(net); /* the draws below continue the generator wherever it last advanced */
   switch (p->method) {
   case RNN_INIT_ZERO:
     memset(net->ih_weights, 0, (size_t)net->ih_size * sizeof(float));
@@ -329,6 +330,7 @@ void rnn_randomise_weights_clever(RecurNN *net, struct RecurInitialisationParame
   default:
     break;
   }
+  ramd_rng_from_host(net);
   ramd_host_wrote(net, RNN_AMD_WEIGHTS);
 }
 
@@ -384,25 +386,32 @@ static void perforate(float *array, int len, float dropout, rand_ctx *rng) {
 /* recur-nn.h:324 / recur-nn-init.c:739-742 */
 void rnn_perforate_weights(RecurNN *net, float p) {
   ramd_need_host(net, RNN_AMD_WEIGHTS);
-  perforate(net->ih_weights, net->ih_size, p, &net->rng);
-  perforate(net->ho_weights, net->ho_size, p, &net->rng);
+  ramd_rng_to_host(net);
+  rand_ctx tmp, *rng = ramd_shared_rng(net, &tmp);
+  perforate(net->ih_weights, net->ih_size, p, rng);
+  perforate(net->ho_weights, net->ho_size, p, rng);
+  ramd_rng_from_host(net);
   ramd_host_wrote(net, RNN_AMD_WEIGHTS);
 }
 
 /* recur-nn.h:328 / recur-nn.c:857-883 */
 void rnn_weight_noise(RecurNN *net, float deviation) {
   ramd_need_host(net, RNN_AMD_WEIGHTS);
+  /* on the batched path the device holds the stream's generator (presynaptic noise, the
+   * multi-head leakage draws): continue from there and hand the advanced state back */
+  ramd_rng_to_host(net);
+  rand_ctx tmp, *rng = ramd_shared_rng(net, &tmp); /* sharded sets: every replica adds the same noise */
   int rows = net->hidden_size + 1 + net->input_size;
   for (int y = 0; y < rows; y++) {
     float *row = net->ih_weights + 1 + (size_t)y * net->h_size;
     for (int i = 0; i < net->hidden_size; i++) {
-      row[i] += ramd_cheap_gaussian_noise(&net->rng) * deviation;
+      row[i] += ramd_cheap_gaussian_noise(rng) * deviation;
     }
   }
   for (int y = 0; y < net->hidden_size + 1; y++) {
     float *row = net->ho_weights + (size_t)y * net->o_size;
     for (int i = 0; i < net->output_size; i++) {
-      row[i] += ramd_cheap_gaussian_noise(&net->rng) * deviation;
+      row[i] += ramd_cheap_gaussian_noise(rng) * deviation;
     }
   }
   if (net->bottom_layer) {
@@ -412,10 +421,11 @@ void rnn_weight_noise(RecurNN *net, float deviation) {
     for (int y = 0; y < bl->output_size; y++) {
       float *row = bl->weights + 1 + (size_t)y * bl->i_size;
       for (int i = 0; i < bl->input_size; i++) {
-        row[i] += ramd_cheap_gaussian_noise(&net->rng) * deviation;
+        row[i] += ramd_cheap_gaussian_noise(rng) * deviation;
       }
     }
   }
+  ramd_rng_from_host(net);
   ramd_host_wrote(net, RNN_AMD_WEIGHTS);
 }
 
@@ -503,6 +513,7 @@ void rnn_clear_diagonal_only_section(RecurNN *net, uint len, uint friends) {
  * gain, driven by rectified gaussian probes through the hidden->hidden block */
 void rnn_scale_initial_weights(RecurNN *net, float target_gain) {
   ramd_need_host(net, RNN_AMD_WEIGHTS);
+  ramd_rng_to_host(net);
   int h_size = net->h_size;
   float *in = malloc(sizeof(float) * h_size), *out = malloc(sizeof(float) * h_size);
   double net_adjustment = 1.0, tail_in = 0, tail_out = 0;
@@ -552,6 +563,7 @@ void rnn_scale_initial_weights(RecurNN *net, float target_gain) {
   free(out);
   fprintf(stderr, "scaled toward target gain %.3f; hit roughly %.3f; adjusted by %.3f\n",
           target_gain, tail_out / tail_in, net_adjustment);
+  ramd_rng_from_host(net);
   ramd_host_wrote(net, RNN_AMD_WEIGHTS);
 }
 

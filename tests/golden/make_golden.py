@@ -128,7 +128,7 @@ def main():
 
     # G3/G4: training scenarios -----------------------------------------------------
     text = sc.synthetic_text(gc.TEXT_LEN)
-    assert np.array_equal(text, gc.synthetic_text_np())
+    assert np.array_equal(text, sc.synthetic_text_oracle(gc.TEXT_LEN))
     for name, c in gc.TRAIN_CASES.items():
         a = sc.ApiSet(ref, softmax_best_guess=ref.ref_softmax_best_guess, **gc.case_kwargs(c))
         gc.prepare(a, c, lambda x: ref.rnn_set_momentum_values(a.net, x),

@@ -240,6 +240,16 @@ AMD_API = {
                                                  c_u8_p]),
     "rnn_amd_set_multi_step_deltas": (None, [C.c_void_p, c_int_p, c_int_p, c_int_p, C.c_int, C.c_float, C.c_int]),
     "rnn_amd_synchronize": (None, []),
+    "rnn_amd_dist_get_id": (C.c_int, [C.c_void_p]),
+    "rnn_amd_dist_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
+    "rnn_amd_dist_finalize": (None, []),
+    "rnn_amd_dist_rank": (C.c_int, []),
+    "rnn_amd_dist_world": (C.c_int, []),
+    "rnn_amd_dist_all_reduce": (None, [C.c_void_p, C.c_size_t]),
+    "rnn_amd_dist_max": (C.c_double, [C.c_double]),
+    "rnn_amd_dist_barrier": (None, []),
+    "rnn_amd_new_training_set_shard": (C.POINTER(NetP), [NetP, C.c_int, C.c_int, C.c_int]),
+    "rnn_amd_set_dist_all_reduce_deltas": (None, [C.c_void_p]),
     "rnn_amd_kernel_time_enable": (None, [C.c_int]),
     "rnn_amd_kernel_time_ms": (C.c_double, [C.c_int, C.POINTER(C.c_long), C.c_int]),
 }
@@ -417,6 +427,17 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     d = np.linalg.norm(a - b)
     n = np.linalg.norm(b)
+    return d / n if n > 0 else d
+
+
+def max_err(a, b):
+    """max |a-b| / max |b|: the element-wise companion of rel_err."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    d = np.abs(a - b).max()
+    n = np.abs(b).max()
     return d / n if n > 0 else d
 
 

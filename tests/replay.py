@@ -225,13 +225,17 @@ def sparse_oracle():
 
 
 def check(got, want, rtol, keys=None, exact=("index", "generation")):
-    """Assert helper: relative 2-norm error per array."""
+    """Assert helper: per array, the relative 2-norm error AND the largest element error
+    against the largest reference magnitude (one bad row cannot hide in a large array)."""
     keys = keys or [k for k in want if k in got and want[k].dtype.kind == "f"]
     bad = []
     for k in keys:
         e = rc.rel_err(got[k], want[k])
         if not e <= rtol:
             bad.append("%s rel err %.3g" % (k, e))
+        m = rc.max_err(got[k], want[k])
+        if not m <= rtol:
+            bad.append("%s max element err %.3g of max|ref|" % (k, m))
     for k in exact:
         if k in got and k in want and not np.array_equal(got[k], want[k]):
             bad.append("%s differs" % k)

@@ -13,9 +13,22 @@ import numpy as np
 import recur_ctypes as rc
 
 
+_TEXT_CACHE = {}
+
+
 def synthetic_text(n, alphabet=42, seed=7):
-    """Seeded symbol stream: SURVEY.md section 8(d)'s data-free variant
-    (symbols from rand_small_int(seed 7, 42))."""
+    """Seeded symbol stream: SURVEY.md section 8(d)'s data-free variant (symbols from
+    rand_small_int(seed 7, 42)), from the numpy restatement of the generator: input data
+    does not come out of the checker's library."""
+    import golden_cases as gc
+    key = (alphabet, seed)
+    if key not in _TEXT_CACHE or len(_TEXT_CACHE[key]) < n:
+        _TEXT_CACHE[key] = gc.synthetic_text_np(max(n, 8000), alphabet, seed)
+    return _TEXT_CACHE[key][:n].copy()
+
+
+def synthetic_text_oracle(n, alphabet=42, seed=7):
+    """The same stream from the oracle's generator (cross-check of the two)."""
     orc = rc.load_oracle()
     rng = rc.OrcRng()
     orc.orc_init_rand64(C.byref(rng), seed)
@@ -31,9 +44,13 @@ class ApiSet:
     def __init__(self, lib, input_size, hidden_size, output_size, S, D, activation=rc.RELU,
                  flags=rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR, learn_rate=1e-3, seed=1,
                  momentum=0.95, variance=None, shape=rc.DIST_SEMICIRCLE, perforation=0.0,
-                 softmax_best_guess=None, noise=0.0, bottom_inputs=0, bottom_rate_scale=1.0):
+                 softmax_best_guess=None, noise=0.0, bottom_inputs=0, bottom_rate_scale=1.0,
+                 shard=None):
         self.lib = lib
         self.S, self.D = S, D
+        # shard = (global_first, global_count): this set holds S of the streams of a larger
+        # logical set (one shard per GPU / process)
+        self.global_first, self.global_count = shard if shard else (0, S)
         # with bottom_inputs the net sits on a bottom layer: `input_size` is that
         # layer's output size and bottom_inputs its input size
         # (rnn_new_with_bottom_layer, recur-nn-init.c:194-219)
@@ -58,7 +75,10 @@ class ApiSet:
         p.flat_shape = shape
         p.flat_perforation = perforation
         lib.rnn_randomise_weights_clever(net, C.byref(p))
-        self.nets = lib.rnn_new_training_set(net, S)
+        if shard and shard != (0, S):
+            self.nets = lib.rnn_amd_new_training_set_shard(net, S, shard[0], shard[1])
+        else:
+            self.nets = lib.rnn_new_training_set(net, S)
         # the caller-side loss (softmax_best_guess is a static inline of the
         # reference's badmaths.h, i.e. caller code, not library code)
         self._sbg = softmax_best_guess
@@ -90,10 +110,10 @@ class ApiSet:
 
     def char_step_deltas(self, text, i):
         L = len(text)
-        spacing = (L - 1) // self.S
+        spacing = (L - 1) // self.global_count
         stats = []
         for j in range(self.S):
-            off = i + j * spacing
+            off = i + (self.global_first + j) * spacing
             if off >= L - 1:
                 off -= L - 1
             self.lib.rnn_bptt_advance(self.nets[j])
@@ -242,6 +262,9 @@ def compare(got, want, rtol, keys=FLOAT_KEYS, exact=EXACT_KEYS):
             e = rc.rel_err(got[k], want[k])
             if not e <= rtol:
                 bad.append("%s: rel err %.3g > %.1g" % (k, e, rtol))
+            m = rc.max_err(got[k], want[k])
+            if not m <= rtol:
+                bad.append("%s: max element err %.3g of max|ref| > %.1g" % (k, m, rtol))
     for k in exact:
         if k in got and k in want and not np.array_equal(got[k], want[k]):
             bad.append("%s: not bit-exact" % k)

@@ -228,3 +228,150 @@ def test_compute_entry_points_fail_loudly_without_a_gpu():
             "a.rnn_opinion(n, None, 0.0)") % os.path.join(ROOT, "tests")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def test_cold_host_functions_bit_exact_with_reference():
+    """rnn_weight_noise, rnn_perforate_weights, rnn_zap_non_diagonals,
+    rnn_clear_diagonal_only_section, rnn_scale_initial_weights, the FAN_IN / RUNS / ZERO
+    initialisers, the optimiser ballast setters and rnn_log_net's lines
+    (recur-nn.c:857-904, 1027-1145; recur-nn-init.c:359-380, 382-861) against
+    tests/golden/ref_cold.npz, which tests/golden/make_golden_cold.py produced by running
+    the same script (tests/cold_cases.py) on the compiled reference.  Weights AND the
+    generator states must be bit-exact."""
+    import cold_cases
+    want = np.load(os.path.join(ROOT, "tests", "golden", "ref_cold.npz"))
+    got = cold_cases.run(AMD)
+    assert sorted(got) == sorted(want.files) and len(want.files) >= 60
+    bad = [k for k in want.files if not np.array_equal(got[k], want[k])]
+    assert bad == []
+    assert bytes(want["log_net.lines"]).decode().splitlines()[0] == "generation 77"
+
+
+def test_delete_order_of_text_predict_does_not_touch_freed_engine():
+    """text-predict.c:654-656 deletes the training set (prototype included) BEFORE its
+    confabulation and validation clones; gstrnnca's teardown has the same shape.  The
+    clones must survive their weight owner (a subprocess: a use-after-free may crash)."""
+    code = ("import sys; sys.path.insert(0, %r); import recur_ctypes as rc; a = rc.load_amd();"
+            "n = a.rnn_new(4, 7, 3, rc.FLAG_STANDARD, 1, None, 4, 0.01, 0.9, 0.0, rc.RELU);"
+            "nets = a.rnn_new_training_set(n, 3);"
+            "fl = n.contents.flags & ~(rc.FLAG_OWN_WEIGHTS | rc.FLAG_OWN_BPTT);"
+            "c1 = a.rnn_clone(n, fl, rc.SUBSEED, None); c2 = a.rnn_clone(n, fl, rc.SUBSEED, None);"
+            "a.rnn_delete_training_set(nets, 3, 0);"
+            "a.rnn_delete_net(c1); a.rnn_delete_net(c2); print('ok')") % os.path.join(ROOT, "tests")
+    for _ in range(3):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stderr
+
+
+REF = "/root/reference"
+needs_reference = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "recur-nn.h")),
+                                     reason="build container only: needs /root/reference")
+
+STRUCT_FIELDS = {
+    "RecurNN": ["i_size", "h_size", "o_size", "input_size", "hidden_size", "output_size", "ih_size",
+                "ho_size", "flags", "log", "mem", "input_layer", "hidden_layer", "output_layer",
+                "ih_weights", "ho_weights", "real_inputs", "rng", "bptt", "bottom_layer", "metadata",
+                "generation", "presynaptic_noise", "activation"],
+    "RecurNNBPTT": ["depth", "index", "i_error", "h_error", "o_error", "ih_momentum", "ho_momentum",
+                    "history", "ih_delta", "ho_delta", "ih_delta_tmp", "ih_aux", "ho_aux", "mem",
+                    "learn_rate", "ih_scale", "ho_scale", "momentum", "momentum_weight",
+                    "min_error_factor"],
+    "RecurExtraLayer": ["mem", "weights", "momentums", "aux", "delta", "inputs", "outputs", "i_error",
+                        "o_error", "learn_rate_scale", "input_size", "output_size", "i_size", "o_size",
+                        "overlap"],
+    "struct RecurInitialisationParameters": [
+        "method", "submethod", "bias_uses_submethod", "inputs_use_submethod", "fan_in_sum",
+        "fan_in_step", "fan_in_min", "fan_in_ratio", "flat_variance", "flat_shape", "flat_perforation",
+        "run_input_probability", "run_input_magnitude", "run_gain", "run_len_mean", "run_len_stddev",
+        "run_n", "run_loop", "run_crossing_paths", "run_inputs_miss", "run_input_at_start"],
+    "RecurErrorRange": ["start", "len"],
+}
+ENUMS = ["RNN_NET_FLAG_OWN_BPTT", "RNN_NET_FLAG_OWN_WEIGHTS", "RNN_NET_FLAG_LOG_APPEND",
+         "RNN_NET_FLAG_LOG_HIDDEN_SUM", "RNN_NET_FLAG_LOG_WEIGHT_SUM",
+         "RNN_NET_FLAG_BPTT_ADAPTIVE_MIN_ERROR", "RNN_NET_FLAG_NO_MOMENTUMS", "RNN_NET_FLAG_NO_DELTAS",
+         "RNN_NET_FLAG_BOTTOM_LAYER", "RNN_NET_FLAG_AUX_ARRAYS", "RNN_COND_USE_SCALE", "RNN_COND_USE_ZERO",
+         "RNN_COND_USE_LAWN_MOWER", "RNN_COND_USE_TALL_POPPY", "RNN_COND_USE_RAND",
+         "RNN_NET_FLAG_STANDARD", "RNN_MOMENTUM_WEIGHTED", "RNN_MOMENTUM_NESTEROV",
+         "RNN_MOMENTUM_SIMPLIFIED_NESTEROV", "RNN_MOMENTUM_CLASSICAL", "RNN_ADAGRAD", "RNN_ADADELTA",
+         "RNN_RPROP", "RNN_LAST_LEARNING_METHOD", "RNN_INIT_ZERO", "RNN_INIT_FLAT", "RNN_INIT_FAN_IN",
+         "RNN_INIT_RUNS", "RNN_RELU", "RNN_RESQRT", "RNN_RECLIP20", "RNN_INIT_DIST_UNIFORM",
+         "RNN_INIT_DIST_GAUSSIAN", "RNN_INIT_DIST_LOG_NORMAL", "RNN_INIT_DIST_SEMICIRCLE",
+         "RNN_CONDITIONING_INTERVAL", "RNN_COND_USE_OFFSET"]
+
+
+@needs_reference
+def test_offsetof_table_equals_the_reference_header(tmp_path):
+    """Every field of every public struct, every enum value: one C program compiled twice,
+    once against the reference's recur-nn.h and once against include/recur-nn.h."""
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "recur-nn.h"', 'int main(void){']
+    for st, fields in STRUCT_FIELDS.items():
+        lines.append('printf("sizeof %s %%zu\\n", sizeof(%s));' % (st, st))
+        for f in fields:
+            lines.append('printf("%s.%s %%zu %%zu\\n", offsetof(%s, %s), sizeof(((%s *)0)->%s));'
+                         % (st, f, st, f, st, f))
+    for e in ENUMS:
+        lines.append('printf("%s %%ld\\n", (long)%s);' % (e, e))
+    lines.append('printf("%g %g %g %g\\n", (double)MAX_TOP_ERROR_FACTOR, (double)BASE_MIN_ERROR_FACTOR, '
+                 '(double)WEIGHT_SCALE, (double)RNN_MOMENTUM_WEIGHT);')
+    lines.append("return 0;}")
+    src = tmp_path / "offsets.c"
+    src.write_text("\n".join(lines))
+    outs = []
+    for tag, inc in (("ref", ["-I", REF]), ("amd", ["-I", os.path.join(ROOT, "include")])):
+        exe = tmp_path / ("offsets_" + tag)
+        subprocess.run(["gcc", "-std=gnu11", "-D_GNU_SOURCE", "-fcommon", "-w"] + inc + [str(src), "-o", str(exe)],
+                       check=True)
+        outs.append(subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout)
+    assert outs[0] == outs[1]
+    assert outs[0].count("\n") > 120
+
+
+@needs_reference
+def test_reference_callers_compile_and_link_unchanged(tmp_path):
+    """The drop-in claim, mechanically: the reference's own callers of this path --
+    test/test_fb_backprop.c, text-predict.c with the reference's charmodel objects, and
+    text-predict.c against the library's own rnn_char_* -- compile UNCHANGED with
+    include/ in front of the reference's directory and link against librecur_amd.so
+    (Makefile:118 lists the objects this replaces).  Nothing is copied; outputs go to tmp."""
+    inc = os.path.join(ROOT, "include")
+    lib = os.path.join(ROOT, "recur_amd", "lib")
+    (tmp_path / "path.h").write_text('#define BASE_PATH "%s"\n#define TEST_DATA_DIR BASE_PATH "/test-images"\n'
+                                     '#define TEST_VIDEO_DIR BASE_PATH "/test-video"\n'
+                                     '#define DICKENS_SHUFFLED_TEXT BASE_PATH "/x.txt"\n'
+                                     '#define DICKENS_TEXT BASE_PATH "/y.txt"\n'
+                                     '#define EREWHON_TEXT BASE_PATH "/test-images/erewhon.txt"\n'
+                                     '#define LYSISTRATA_TEXT BASE_PATH "/z.txt"\n' % REF)
+    # ccan/opt wants a config.h (the reference generates it with ccan's configurator, Makefile:94-95)
+    (tmp_path / "config.h").write_text("#define HAVE_TYPEOF 1\n#define HAVE_BUILTIN_TYPES_COMPATIBLE_P 1\n"
+                                       "#define HAVE_STATEMENT_EXPR 1\n#define HAVE_ATTRIBUTE_UNUSED 1\n"
+                                       "#define HAVE_ATTRIBUTE_NORETURN 1\n#define HAVE_ATTRIBUTE_COLD 1\n"
+                                       "#define HAVE_ATTRIBUTE_PRINTF 1\n#define HAVE_ATTRIBUTE_CONST 1\n"
+                                       "#define HAVE_ATTRIBUTE_PURE 1\n#define HAVE_ATTRIBUTE_USED 1\n"
+                                       "#define HAVE_BUILTIN_CONSTANT_P 1\n#define HAVE_BUILTIN_EXPECT 1\n"
+                                       "#define HAVE_SYS_TERMIOS_H 1\n#define HAVE_ASPRINTF 1\n")
+    cflags = ["gcc", "-std=gnu11", "-O1", "-w", "-fcommon", "-D_GNU_SOURCE", "-DVECTOR", "-I", inc,
+              "-I", str(tmp_path), "-I", REF, "-I", os.path.join(REF, "ccan", "opt")]
+    link = ["-L", lib, "-lrecur_amd", "-Wl,-rpath," + lib, "-lm"]
+
+    def cc(src, obj):
+        subprocess.run(cflags + ["-c", src, "-o", str(tmp_path / obj)], check=True)
+        return str(tmp_path / obj)
+
+    # 1. the reference's backprop test program
+    exe = tmp_path / "test_fb_backprop"
+    subprocess.run(cflags + [os.path.join(REF, "test", "test_fb_backprop.c"), "-o", str(exe)] + link, check=True)
+    # 2. text-predict.c + the reference's charmodel layer on the library's rnn_* symbols
+    opt = [cc(os.path.join(REF, "ccan", "opt", f), "opt_" + f.replace(".c", ".o"))
+           for f in ("opt.c", "parse.c", "helpers.c", "usage.c")]
+    tp = cc(os.path.join(REF, "text-predict.c"), "text-predict.o")
+    cm = [cc(os.path.join(REF, f), f.replace(".c", ".o")) for f in ("charmodel-predict.c", "charmodel-init.c")]
+    subprocess.run(["gcc", tp] + cm + opt + ["-o", str(tmp_path / "text-predict-ref-charmodel")] + link, check=True)
+    # 3. text-predict.c on the library's own rnn_char_* as well
+    subprocess.run(["gcc", tp] + opt + ["-o", str(tmp_path / "text-predict-amd-charmodel")] + link, check=True)
+    for name in ("test_fb_backprop", "text-predict-ref-charmodel", "text-predict-amd-charmodel"):
+        r = subprocess.run(["nm", "-u", str(tmp_path / name)], capture_output=True, text=True, check=True)
+        undefined = {ln.split()[-1].split("@")[0] for ln in r.stdout.splitlines()}
+        assert sum(u.startswith("rnn_") for u in undefined) >= 5  # resolved by the shared library
+    # the reference's --help runs (host only, no device call)
+    r = subprocess.run([str(tmp_path / "text-predict-amd-charmodel"), "--help"], capture_output=True, text=True)
+    assert "usage" in (r.stdout + r.stderr).lower()

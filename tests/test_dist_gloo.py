@@ -2,6 +2,7 @@
 training set (computed by the oracle), one all-reduce of ih_delta||ho_delta per
 generation, replicated update -- must equal the single-process run over all the
 streams.  The same ShardedStep drives bench.py on the GPUs with RCCL."""
+import ctypes as C
 import os
 import socket
 import sys
@@ -15,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _worker(rank, world, port, S_local, steps, q):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
+    import ctypes as C
     import torch
     import torch.distributed as dist
     import recur_ctypes as rc
@@ -25,8 +27,22 @@ def _worker(rank, world, port, S_local, steps, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     text = sc.synthetic_text(4000)
     first, n, total = shard_range(rank, world, S_local)
-    o = sc.OracleSet(input_size=42, hidden_size=45, output_size=42, S=n, D=7, learn_rate=5e-3, seed=2)
+    o = sc.OracleSet(input_size=42, hidden_size=45, output_size=42, S=n, D=7, learn_rate=5e-3, seed=2,
+                     noise=0.03)
     o.z.contents.global_first, o.z.contents.global_count = first, total
+    # the shard's generators come from the PRODUCT's host logic (no GPU needed for it):
+    # rnn_amd_new_training_set_shard replays the reference's clone seeding for the global set
+    amd = rc.load_amd()
+    proto = amd.rnn_new(42, 45, 42, rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR, 2, None, 7, 5e-3, 0.9, 0.03,
+                        rc.RELU)
+    p = rc.InitParams()
+    amd.rnn_init_default_weight_parameters(proto, C.byref(p))
+    p.method, p.flat_shape, p.flat_perforation = rc.INIT_FLAT, rc.DIST_SEMICIRCLE, 0.0
+    amd.rnn_randomise_weights_clever(proto, C.byref(p))
+    nets = amd.rnn_amd_new_training_set_shard(proto, n, first, total)
+    for j in range(n):
+        r = nets[j].contents.rng
+        o.z.contents.rng[j].a, o.z.contents.rng[j].b, o.z.contents.rng[j].c, o.z.contents.rng[j].d = r.a, r.b, r.c, r.d
     a = o.arrays()
     ih, ho = a["ih_delta"], a["ho_delta"]
 
@@ -40,7 +56,7 @@ def _worker(rank, world, port, S_local, steps, q):
                        lambda: o.orc.orc_apply_learning(o.z, rc.WEIGHTED, 0.9))
     for i in range(steps):
         step(i)
-    q.put((rank, a["ih_w"].copy(), a["ho_w"].copy(), a["ih_m"].copy(), a["hidden"].copy()))
+    q.put((rank, a["ih_w"].copy(), a["ho_w"].copy(), a["ih_m"].copy(), a["hidden"].copy(), o.snapshot()["rng"]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -82,3 +98,5 @@ def test_two_rank_sharding_matches_single_process():
         assert err < 1e-5, err
     hidden = np.concatenate([r0[4], r1[4]])
     assert np.linalg.norm(hidden - single[4]) / np.linalg.norm(single[4]) < 1e-5
+    # every global stream drew its noise from the same generator wherever it lived
+    assert np.array_equal(np.concatenate([r0[5], r1[5]]), single[5])

@@ -1,0 +1,202 @@
+"""The sharded (multi-GPU) product path on ONE GPU.
+
+* Two ranks emulated one after the other in one process: two training-set shards
+  (rnn_amd_new_training_set_shard + rnn_amd_set_shard), each computing its deltas into its
+  own external device buffer (rnn_amd_set_external_delta), the two buffers summed by hand
+  (what the all-reduce does), rnn_apply_learning on each replica -- against the single set
+  of all the streams on the device AND against the oracle, generator states bit-exact
+  (so the clone seeding by global stream number, recur-nn-init.c:300-305, has to be right,
+  also with presynaptic noise).
+* The library's own exchange step through RCCL with one rank (a subprocess: a joined group
+  is process-wide state): rnn_amd_set_char_step with a group joined == without.
+
+The sum being distributed is recur-nn.c:724-739 over the sharing of recur-nn-init.c:232-241.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import recur_ctypes as rc
+import replay
+import scenarios as sc
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def amd():
+    lib = rc.load_amd()
+    assert lib.rnn_amd_device_count() >= 1, "no HIP device: the product has no CPU fallback"
+    return lib
+
+
+@pytest.fixture(scope="module")
+def hip():
+    lib = C.CDLL("libamdhip64.so")
+    lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.hipFree.argtypes = [C.c_void_p]
+    return lib
+
+
+D2H, H2D = 2, 1
+
+
+@pytest.mark.parametrize("label,kw,noise", [
+    # the LDS-DMA delta kernel + the fused forward / top kernels (32 streams per rank, hidden 128)
+    ("dma_path", dict(input_size=42, hidden_size=128, output_size=42, D=6, learn_rate=2e-3, seed=21), 0.0),
+    # presynaptic noise: every global stream must draw from the reference's generator for it
+    ("noisy", dict(input_size=42, hidden_size=64, output_size=42, D=5, learn_rate=2e-3, seed=22), 0.05),
+    # ragged: the generic GEMM kernels
+    ("ragged", dict(input_size=42, hidden_size=45, output_size=42, D=7, learn_rate=5e-3, seed=23), 0.0),
+])
+def test_two_emulated_ranks_equal_the_single_set_and_the_oracle(amd, hip, label, kw, noise):
+    S = 32 if label != "ragged" else 3
+    steps = 12
+    text = sc.synthetic_text(6000)
+    ranks = [sc.AmdBatchedSet(amd, S=S, noise=noise, shard=(r * S, 2 * S), **kw) for r in range(2)]
+    n_delta = ranks[0].I * ranks[0].H + ranks[0].H * ranks[0].O
+    bufs = []
+    for r, g in enumerate(ranks):
+        g.load_text(text)
+        amd.rnn_amd_set_shard(g.handle, r * S, 2 * S)
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), 4 * n_delta) == 0
+        amd.rnn_amd_set_external_delta(g.handle, p)
+        bufs.append(p)
+    single = sc.AmdBatchedSet(amd, S=2 * S, noise=noise, **kw)
+    single.load_text(text)
+    o = sc.OracleSet(S=2 * S, noise=noise, **kw)
+    h = [np.zeros(n_delta, np.float32) for _ in range(2)]
+    for i in range(steps):
+        for g in ranks:
+            amd.rnn_amd_set_char_step_deltas(g.handle, i)
+        amd.rnn_amd_synchronize()
+        for r in range(2):
+            assert hip.hipMemcpy(h[r].ctypes.data, bufs[r], 4 * n_delta, D2H) == 0
+        total = h[0] + h[1]  # what the all-reduce leaves on every rank
+        for r, g in enumerate(ranks):
+            assert hip.hipMemcpy(bufs[r], total.ctypes.data, 4 * n_delta, H2D) == 0
+            amd.rnn_apply_learning(g.net, rc.WEIGHTED, 0.9)
+        single.char_step(text, i, rc.WEIGHTED, 0.9)
+        o.char_step(text, i, rc.WEIGHTED, 0.9)
+    snaps = [g.snapshot() for g in ranks]
+    ss, so = single.snapshot(), o.snapshot()
+    # replicas are identical ...
+    for k in ("ih_w", "ho_w", "ih_m", "ho_m"):
+        assert np.array_equal(snaps[0][k], snaps[1][k]), k
+    # ... and equal the single device set and the oracle (the order of the sum over streams differs)
+    for want in (ss, so):
+        replay.check(snaps[0], want, RTOL, keys=["ih_w", "ho_w", "ih_m", "ho_m"], exact=())
+        # the external buffer holds the global sum; ih_delta of the snapshot comes from it
+        replay.check(snaps[1], want, RTOL, keys=["ih_delta", "ho_delta"], exact=())
+        both = {k: np.concatenate([snaps[0][k], snaps[1][k]], axis=1 if k == "hist" else 0)
+                for k in ("hist", "hidden", "output", "o_error", "min_error_factor", "ih_scale", "index",
+                          "generation", "rng")}
+        replay.check(both, want, RTOL, keys=["hist", "hidden", "output", "o_error", "min_error_factor",
+                                             "ih_scale"], exact=("index", "generation", "rng"))
+    for r, g in enumerate(ranks):
+        amd.rnn_amd_set_external_delta(g.handle, None)
+        g.close()
+        hip.hipFree(bufs[r])
+    single.close()
+    o.close()
+
+
+def test_regrow_keeps_the_text_and_the_external_delta_buffer(amd, hip):
+    """A clone made after rnn_amd_set_open (a validation net, say) regrows the device image;
+    the registered text and the external delta buffer must survive it."""
+    kw = dict(input_size=42, hidden_size=64, output_size=42, S=4, D=5, learn_rate=1e-3, seed=4)
+    text = sc.synthetic_text(3000)
+    g = sc.AmdBatchedSet(amd, **kw)
+    g.load_text(text)
+    n_delta = g.I * g.H + g.H * g.O
+    p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(p), 4 * n_delta) == 0
+    amd.rnn_amd_set_external_delta(g.handle, p)
+    o = sc.OracleSet(**kw)
+    for i in range(3):
+        amd.rnn_amd_set_char_step_deltas(g.handle, i)
+        amd.rnn_apply_learning(g.net, rc.WEIGHTED, 0.9)
+        o.char_step(text, i, rc.WEIGHTED, 0.9)
+    fl = g.net.contents.flags & ~(rc.FLAG_OWN_WEIGHTS | rc.FLAG_OWN_BPTT)
+    extra = [amd.rnn_clone(g.net, fl, rc.SUBSEED, None) for _ in range(3)]  # Fcap 1 -> 3: a regrow
+    rc.view(extra[2].contents.real_inputs, 42)[:] = 0
+    amd.rnn_opinion(extra[2], None, 0.0)
+    o.orc.orc_rand64(C.byref(o.z.contents.rng[0]))  # the three SUBSEED draws from the prototype
+    o.orc.orc_rand64(C.byref(o.z.contents.rng[0]))
+    o.orc.orc_rand64(C.byref(o.z.contents.rng[0]))
+    for i in range(3, 6):
+        amd.rnn_amd_set_char_step_deltas(g.handle, i)
+        amd.rnn_amd_synchronize()
+        amd.rnn_apply_learning(g.net, rc.WEIGHTED, 0.9)
+        o.char_step(text, i, rc.WEIGHTED, 0.9)
+    h = np.zeros(n_delta, np.float32)
+    assert hip.hipMemcpy(h.ctypes.data, p, 4 * n_delta, D2H) == 0
+    so = o.snapshot()
+    assert rc.rel_err(h[:g.I * g.H], so["ih_delta"].reshape(-1)) < RTOL  # still landing in the caller's buffer
+    replay.check(g.snapshot(), so, RTOL, keys=["ih_w", "ho_w", "ih_m", "hidden", "hist"],
+                 exact=("index", "generation", "rng"))
+    for e in extra:
+        amd.rnn_delete_net(e)
+    amd.rnn_amd_set_external_delta(g.handle, None)
+    g.close()
+    hip.hipFree(p)
+    o.close()
+
+
+RCCL_SCRIPT = r"""
+import ctypes as C, sys, json
+sys.path.insert(0, %(tests)r)
+import numpy as np, recur_ctypes as rc, scenarios as sc
+amd = rc.load_amd()
+amd.rnn_amd_use_device(0, None)
+text = sc.synthetic_text(6000)
+kw = dict(input_size=42, hidden_size=128, output_size=42, S=32, D=6, learn_rate=2e-3, seed=21)
+def run(n):
+    g = sc.AmdBatchedSet(amd, **kw)
+    g.load_text(text)
+    for i in range(n):
+        g.char_step(text, i, rc.WEIGHTED, 0.9)
+    s = g.snapshot()
+    g.close()
+    return s
+plain = run(10)
+buf = C.create_string_buffer(128)
+assert amd.rnn_amd_dist_get_id(buf) == 0
+assert amd.rnn_amd_dist_init(0, 1, buf) == 0
+assert amd.rnn_amd_dist_world() == 1 and amd.rnn_amd_dist_rank() == 0
+assert amd.rnn_amd_dist_max(3.5) == 3.5
+amd.rnn_amd_dist_barrier()
+joined = run(10)
+amd.rnn_amd_dist_finalize()
+after = run(10)
+out = {}
+for k in ("ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "hist"):
+    out[k] = [rc.rel_err(joined[k], plain[k]), rc.rel_err(after[k], plain[k])]
+out["rng"] = bool(np.array_equal(joined["rng"], plain["rng"]))
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_library_exchange_step_through_rccl_with_one_rank():
+    """rnn_amd_dist_init(0, 1, id) -> the generation goes deltas -> k_delta_finalize -> RCCL
+    all-reduce on the library's stream -> rnn_apply_learning; with one rank the sum is the
+    identity, so the weights must equal the plain path's (to the slab summation, i.e. exactly
+    or within rounding)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", RCCL_SCRIPT % {"tests": os.path.dirname(os.path.abspath(__file__))}],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    import json
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    res = json.loads(line[7:])
+    assert res.pop("rng")
+    for k, (joined, after) in res.items():
+        assert joined < 1e-6 and after == 0.0, (k, joined, after)

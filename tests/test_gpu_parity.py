@@ -63,25 +63,47 @@ def test_hot_case_stepwise(amd):
     kw = gc.case_kwargs(c)
     g = sc.AmdBatchedSet(amd, **kw)
     o = sc.OracleSet(**kw)
-    text = replay.text()
+    _stepwise(amd, gc.case_kwargs(c), replay.text(), c["steps"], c["method"], c["D"])
+
+
+def _stepwise(amd, kw, text, steps, method, depth):
+    g = sc.AmdBatchedSet(amd, **kw)
+    o = sc.OracleSet(**kw)
     seen_clamp = seen_exit = False
-    for i in range(c["steps"]):
-        g.char_step(text, i, c["method"], 0.9)
-        o.char_step(text, i, c["method"], 0.9)
+    compared = compared_clamped = 0
+    for i in range(steps):
+        g.char_step(text, i, method, 0.9)
+        o.char_step(text, i, method, 0.9)
         sg, so = g.snapshot(), o.snapshot()
         # break decisions can legitimately flip when an error sum sits on a threshold;
         # compare only if the oracle's executed depths match the device's
         same_depth = np.allclose(sg["ih_scale"] == 1.0, so["ih_scale"] == 1.0)
+        clamped = bool((so["ih_scale"] < 1.0).any())
         if same_depth:
             replay.check(sg, so, 2e-4, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "hidden", "ih_scale",
                                              "min_error_factor"])
-        seen_clamp |= bool((so["ih_scale"] < 1.0).any())
-        seen_exit |= bool((so["bptt_depth"] < c["D"]).any())
+            compared += 1
+            compared_clamped += clamped
+        seen_clamp |= clamped
+        seen_exit |= bool((so["bptt_depth"] < depth).any()) and i >= depth  # not the ring filling up
         # resynchronise the device to the oracle's state
         _load_state(amd, g, so)
-    assert seen_clamp
     g.close()
     o.close()
+    # the comparison cannot pass vacuously: both mechanisms fired, and most generations --
+    # clamped ones among them -- were actually compared
+    assert seen_clamp and seen_exit
+    assert compared >= steps // 2 and compared_clamped >= 1, (compared, compared_clamped)
+
+
+def test_hot_case_stepwise_on_the_dma_delta_path(amd):
+    """The same regime where k_delta_dma's coefficient path matters (recur-nn.c:387-413):
+    hidden 128 / 32 streams meets the LDS-DMA delta kernel's preconditions (streams % 32,
+    hidden % 128), learn rate 0.08 makes ih_scale < 1 on many streams and ends chains early,
+    so rows past a break (never multiplied, possibly inf) and coefficients below 1 both go
+    through the staged-coefficient select."""
+    kw = dict(input_size=42, hidden_size=128, output_size=42, S=32, D=8, learn_rate=0.08, seed=12)
+    _stepwise(amd, kw, sc.synthetic_text(6000), 40, rc.WEIGHTED, 8)
 
 
 def _load_state(amd, g, snap):
@@ -756,6 +778,7 @@ def test_random_shapes_match_oracle(amd, shape):
     g = sc.AmdBatchedSet(lib, **kw)
     o = sc.OracleSet(**kw)
     a = o.arrays()
+    compared = 0
     for step in range(shape["D"] + 3):
         x = (rs.standard_normal((shape["S"], shape["inputs"])) * (rs.random((shape["S"], shape["inputs"])) < 0.6)
              ).astype(np.float32)
@@ -781,5 +804,7 @@ def test_random_shapes_match_oracle(amd, shape):
         replay.check(sg, so, RTOL, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden",
                                          "output", "hist", "min_error_factor", "ih_scale"],
                      exact=("index", "generation"))
+        compared += 1
     g.close()
     o.close()
+    assert compared >= (shape["D"] + 3 + 1) // 2, "only %d generations were compared" % compared

@@ -37,7 +37,7 @@ def test_prng_derived_streams_bit_exact():
 
 def test_synthetic_text_matches_numpy_restatement():
     import scenarios as sc
-    assert np.array_equal(sc.synthetic_text(gc.TEXT_LEN), gc.synthetic_text_np())
+    assert np.array_equal(sc.synthetic_text_oracle(gc.TEXT_LEN), gc.synthetic_text_np())
 
 
 def test_fast_expf_softmax_softclip():

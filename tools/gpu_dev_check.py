@@ -3,6 +3,8 @@ few shapes through both the per-net drop-in calls and the batched calls."""
 import sys, time
 import ctypes as C
 import numpy as np
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import recur_ctypes as rc, scenarios as sc
 
 amd = rc.load_amd(); orc = rc.load_oracle()

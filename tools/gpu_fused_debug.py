@@ -1,7 +1,9 @@
 """Development probe: hidden rows after a few text steps, fused forward against the separate kernels."""
 import os, sys, subprocess, numpy as np
 if len(sys.argv) > 1:
-    import recur_ctypes as rc, scenarios as sc
+    import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import recur_ctypes as rc, scenarios as sc
     amd = rc.load_amd()
     H, S, D, steps = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
     g = sc.AmdBatchedSet(amd, input_size=42, hidden_size=H, output_size=42, S=S, D=D, learn_rate=1e-5, seed=3)

@@ -1,5 +1,7 @@
 """Development probe: host time to enqueue one generation vs device time per generation."""
 import time
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import recur_ctypes as rc, scenarios as sc
 amd = rc.load_amd()
 text = sc.synthetic_text(30000)

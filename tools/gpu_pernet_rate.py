@@ -1,6 +1,8 @@
 """Development probe: throughput of the per-net drop-in calls (the compatibility path)."""
 import time
 import numpy as np
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import recur_ctypes as rc, scenarios as sc
 amd = rc.load_amd()
 orc = rc.load_oracle()

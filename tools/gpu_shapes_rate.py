@@ -1,6 +1,8 @@
 """Development probe: generation rate of the batched text step at the BASELINE.json config shapes."""
 import sys
 import time
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import recur_ctypes as rc, scenarios as sc
 amd = rc.load_amd()
 text = sc.synthetic_text(30000)

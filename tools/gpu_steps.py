@@ -1,5 +1,6 @@
 """Development probe: run N generations of the north-star workload (for profilers)."""
 import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import recur_ctypes as rc, scenarios as sc
 amd = rc.load_amd()
 text = sc.synthetic_text(30000)

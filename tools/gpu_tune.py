@@ -1,6 +1,7 @@
 """Development probe: sweeps the split-K factors of the GEMMs (env overrides read
 at every launch) so that a rocprofv3 kernel trace can rank them by grid size."""
 import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import recur_ctypes as rc, scenarios as sc
 amd = rc.load_amd()
 text = sc.synthetic_text(30000)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Development aid (GPU box): per-kernel average durations of `tests/gpu_steps.py N` under rocprofv3.
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT/tests" || exit 1
+# Development aid (GPU box): per-kernel average durations of `tools/gpu_steps.py N` under rocprofv3.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT/tools" || exit 1
 rm -rf ../gpurun_out/ks
 rocprofv3 --kernel-trace --stats --output-format csv -d ../gpurun_out/ks -o s -- python3 gpu_steps.py "${1:-40}" > /dev/null 2>&1
 python3 - <<'PY'
