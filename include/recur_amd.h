@@ -420,6 +420,28 @@ void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *ne
                                    const int *target_class, int alphabet_len, float leakage,
                                    int accumulate);
 
+/* The two halves of rnn_amd_set_multi_step_deltas with the text on the device (stream j reads
+ * text[o], is scored against text[o + 1], o as in rnn_amd_set_char_step): the loss leaves
+ * o_error and one error-range list per stream on the device, the deltas call consumes them.
+ * In between a caller may apply the previous batch's deltas, as the reference's text_train
+ * does (charmodel-multi-predict.c:244-252).  target_class (host, n_nets) may be NULL to keep
+ * the classes of the previous call. */
+void rnn_amd_set_multi_text_loss(RnnAmdSet *set, int i, const int *target_class, int alphabet_len,
+                                 float leakage);
+void rnn_amd_set_multi_calc_deltas(RnnAmdSet *set, int accumulate);
+/* rnn_bptt_advance (if advance) + one_hot_opinion of each stream's text symbol and nothing
+ * else (rnn_char_multitext_spin's step, charmodel-multi-predict.c:293-297); 0 <= i < len */
+void rnn_amd_set_text_opinion(RnnAmdSet *set, int i, int advance);
+/* rnnca's loss on the device (gstrnnca.c:701-714, train_net) after an rnn_amd_set_opinion:
+ * for every stream the first n outputs become their fast_sigmoid IN PLACE (badmaths.h:33-44,
+ * as the reference's fast_sigmoid_array(answer, answer, 3) does to output_layer) and
+ * o_error[i] = a (1 - a) (targets[j * ld + i] - a); the error never visits the host. */
+void rnn_amd_set_sigmoid_mse_error(RnnAmdSet *set, const float *targets, int ld, int n);
+/* fill_frame's step after the opinion (gstrnnca.c:813-814): fast_sigmoid in place on the first
+ * n outputs of every net of the set (training or forward-only clones); outputs (host, n_nets x
+ * o_size, may be NULL) receives the answer rows, which synchronises. */
+void rnn_amd_set_sigmoid_outputs(RnnAmdSet *set, int n, float *outputs);
+
 /* Text on the device, for a host-free epoch loop (charmodel-predict.c:288-311). */
 void rnn_amd_set_load_text(RnnAmdSet *set, const u8 *text, int len);
 /* One generation of rnn_char_epoch's multi-tap branch for text position i:
@@ -495,6 +517,12 @@ void rnn_amd_set_dist_all_reduce_deltas(RnnAmdSet *set);
  * (charmodel-predict.c:62-76) without its final division; with skip >= len - 1 it is
  * rnn_char_prime's loop (407-416).  Works for nets with or without bptt. */
 double rnn_amd_run_text(RecurNN *net, const u8 *text, int len, int skip);
+/* The same for a net whose output row is output_size / alphabet_len heads: sums[c] (room for
+ * that many doubles) receives head c's sum of capped log2 softmax(head c)[text[i + 1]] over
+ * i in [skip, len - 1): rnn_char_multi_cross_entropy's loops (charmodel-multi-predict.c:388-403)
+ * without the final negation and division. */
+void rnn_amd_run_text_heads(RecurNN *net, const u8 *text, int len, int skip, int alphabet_len,
+                            double *sums);
 /* Block until all queued device work of the library has finished. */
 void rnn_amd_synchronize(void);
 

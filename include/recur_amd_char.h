@@ -143,6 +143,49 @@ double rnn_char_cross_entropy(RecurNN *net, RnnCharAlphabet *alphabet, const u8 
                               const int len, const int ignore_first, const u8 *prefix_text,
                               const int prefix_len);
 
+/* ---- the multi-head text trainer (charmodel.h:132-152, 242-265;
+ *      charmodel-multi-predict.c): py-recur-text.c's Net.train / Net.test backend ---- */
+typedef struct _RnnCharProgressReport { /* charmodel.h:132-138 */
+  float training_entropy;
+  float training_error;
+  float training_accuracy;
+  float per_second;
+} RnnCharProgressReport;
+
+typedef struct RnnCharMultiConfab { /* charmodel.h:140-152 */
+  RecurNN **nets;
+  int *last_char;
+  int caps_marker;
+  char **strings;
+  uint n_classes;
+  uint char_len;
+  uint byte_len;
+  float bias;
+  uint period;
+  RnnCharAlphabet *alphabet;
+} RnnCharMultiConfab;
+
+/* One pass over one class's text on ONE net whose outputs are output_size / alphabet_len
+ * heads: per symbol rnn_bptt_advance, the multi-head loss (own head always, the others
+ * with probability `leakage`), rnn_bptt_calc_deltas over the resulting error ranges,
+ * accumulating for batch_size symbols between rnn_apply_learning calls (which use the
+ * net's own bptt->momentum: the `momentum` argument is unused, as in the reference).
+ * The loop's work stays on the device. */
+void rnn_char_multitext_train(RecurNN *net, u8 *text, int len, int alphabet_len, int target_class,
+                              float leakage, RnnCharProgressReport *report,
+                              RnnCharMultiConfab *confab, int learning_style, float momentum,
+                              int batch_size, TemporalPPM *input_ppm, TemporalPPM *error_ppm,
+                              const char *periodic_pgm_string, int periodic_pgm_period);
+void rnn_char_multitext_spin(RecurNN *net, u8 *text, int len, TemporalPPM *input_ppm,
+                             TemporalPPM *error_ppm, const char *periodic_pgm_string,
+                             int periodic_pgm_period);
+/* entropy: n_classes doubles, the caller's running values (normally zeros) */
+void rnn_char_multi_cross_entropy(RecurNN *net, const u8 *text, int len, int alphabet_len,
+                                  double *entropy, int ignore_start);
+RnnCharMultiConfab *rnn_char_new_multi_confab(RecurNN *net, RnnCharAlphabet *alphabet, int n_classes,
+                                              int target_len, uint confab_period, int caps_marker);
+void rnn_char_free_multi_confab(RnnCharMultiConfab *mc);
+
 /* ---- metadata and names (charmodel.h:206-227; charmodel-init.c:440-800) ---- */
 char *rnn_char_uncollapse_text(RnnCharAlphabet *alphabet, const u8 *orig, int len, int *dest_len);
 void rnn_char_dump_collapsed_text(const u8 *text, int len, const char *name, const char *alphabet);

@@ -563,6 +563,49 @@ double orc_cross_entropy(OrcSet *z, int s, const uint8_t *text, int len, int ski
   return entropy / -(len - skip - 1);
 }
 
+/* rnn_char_multi_cross_entropy (charmodel-multi-predict.c:383-408): entropy[j] is the
+ * caller's running value (the reference subtracts into it and then divides) */
+void orc_multi_cross_entropy(OrcSet *z, int s, const uint8_t *text, int len, int alphabet_len,
+                             double *entropy, int ignore_start) {
+  float *error = malloc(sizeof(float) * alphabet_len);
+  int i, j;
+  int n_classes = z->output_size / alphabet_len;
+  for (i = 0; i < ignore_start; i++) {
+    orc_one_hot_opinion(z, s, text[i], 0);
+  }
+  for (; i < len - 1; i++) {
+    float *answer = orc_one_hot_opinion(z, s, text[i], 0);
+    for (j = 0; j < n_classes; j++) {
+      float *group = answer + alphabet_len * j;
+      orc_softmax(error, group, alphabet_len);
+      float e = error[text[i + 1]];
+      entropy[j] -= orc_capped_log2f(e);
+    }
+  }
+  for (j = 0; j < n_classes; j++) {
+    entropy[j] /= (len - ignore_start - 1);
+  }
+  free(error);
+}
+
+/* fast_sigmoid (badmaths.h:31-36) */
+float orc_fast_sigmoid(float x) { return 1.0f / (1.0f + orc_fast_expf(-x * 1.0f)); }
+
+/* rnnca's train_net after the opinion (gstrnnca.c:701-714): sigmoid of the first n answers
+ * in place (the answer IS output_layer), error = slope * (target - a) */
+void orc_sigmoid_mse_error(OrcSet *z, int s, const float *target, int n) {
+  float *answer = z->output + (size_t)s * z->O;
+  float *error = z->o_error + (size_t)s * z->O;
+  for (int i = 0; i < n; i++) {
+    answer[i] = orc_fast_sigmoid(answer[i]);
+  }
+  for (int i = 0; i < n; i++) {
+    float a = answer[i];
+    float slope = a * (1.0f - a);
+    error[i] = slope * (target[i] - a);
+  }
+}
+
 /* --------------------------------------------------------- backward pass -- */
 
 /* backprop_single_layer (recur-nn.c:199-228) */
@@ -1051,4 +1094,38 @@ void orc_set_char_step(OrcSet *z, const uint8_t *text, int len, int i, int metho
                        float momentum) {
   orc_set_char_step_deltas(z, text, len, i);
   orc_apply_learning(z, method, momentum);
+}
+
+/* text_train of the multi-head trainer (charmodel-multi-predict.c:234-281) for stream s of a
+ * set (the reference runs it on ONE net): per symbol advance, multi_softmax_error, then --
+ * when the batch countdown has run out -- rnn_apply_learning with the net's OWN momentum
+ * (line 247 passes bptt->momentum, not the caller's) before the non-accumulating calc_deltas.
+ * error_sum / entropy_sum receive what the progress report averages. */
+void orc_multitext_train(OrcSet *z, int s, const uint8_t *text, int len, int alphabet_len,
+                         int target_class, float leakage, int learning_style, float bptt_momentum,
+                         int batch_size, float *error_sum, float *entropy_sum) {
+  int n_classes = z->output_size / alphabet_len;
+  int *ranges = malloc(sizeof(int) * 2 * (n_classes + 1));
+  float error = 0.0f, entropy = 0.0f;
+  if (batch_size < 1) {
+    batch_size = 1;
+  }
+  int countdown = batch_size - z->generation[s] % batch_size;
+  for (int i = 0; i < len - 1; i++, countdown--) {
+    orc_advance(z, s);
+    float e = orc_multi_softmax_error(z, s, text[i], text[i + 1], target_class, alphabet_len, leakage,
+                                      ranges);
+    if (countdown == 0) {
+      orc_apply_learning(z, learning_style, bptt_momentum);
+      countdown = batch_size;
+      orc_calc_deltas(z, s, 0, ranges);
+    } else {
+      orc_calc_deltas(z, s, 1, ranges);
+    }
+    error += e;
+    entropy += orc_capped_log2f(1.0f - e);
+  }
+  free(ranges);
+  if (error_sum) *error_sum = error;
+  if (entropy_sum) *entropy_sum = entropy;
 }

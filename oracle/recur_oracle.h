@@ -11,11 +11,11 @@
  * tests/golden/make_golden.py) and, when oracle/_ref/librecur_ref.so is
  * present, against that library live (tests/test_oracle_vs_ref.py).
  *
- * Parity unpinned for two functions only: orc_multi_softmax_error and
- * orc_grouped_softmax_error restate static functions of charmodel-multi-predict.c
- * and gstclassify.c, files that cannot be compiled here (generated path.h, GStreamer);
- * everything they call (softmax, generator, calc_deltas with and without ranges) is
- * pinned.
+ * Parity unpinned for these caller-side restatements only: orc_multi_softmax_error,
+ * orc_multitext_train, orc_multi_cross_entropy (charmodel-multi-predict.c), orc_grouped_softmax_error
+ * (gstclassify.c) and orc_sigmoid_mse_error (gstrnnca.c) restate functions of files that cannot
+ * be compiled here (generated path.h, GStreamer); everything they call (softmax, fast_sigmoid,
+ * generator, calc_deltas with and without ranges, apply_learning) is pinned.
  */
 #ifndef RECUR_ORACLE_H
 #define RECUR_ORACLE_H 1
@@ -140,6 +140,14 @@ void orc_apply_learning(OrcSet *set, int method, float momentum);      /* recur-
 void orc_condition(OrcSet *set, uint32_t flags);                       /* recur-nn.c:782-855 */
 void orc_bptt_calculate(OrcSet *set, int s, unsigned batch_size, float momentum); /* recur-nn.c:999-1019 */
 double orc_cross_entropy(OrcSet *set, int s, const uint8_t *text, int len, int skip); /* charmodel-predict.c:62-80 */
+void orc_multi_cross_entropy(OrcSet *set, int s, const uint8_t *text, int len, int alphabet_len,
+                             double *entropy, int ignore_start); /* charmodel-multi-predict.c:383-408 */
+float orc_fast_sigmoid(float x);                                        /* badmaths.h:31-36 */
+void orc_sigmoid_mse_error(OrcSet *set, int s, const float *target, int n); /* gstrnnca.c:701-714 */
+/* charmodel-multi-predict.c:234-281 (text_train) for stream s */
+void orc_multitext_train(OrcSet *set, int s, const uint8_t *text, int len, int alphabet_len,
+                         int target_class, float leakage, int learning_style, float bptt_momentum,
+                         int batch_size, float *error_sum, float *entropy_sum);
 
 /* ---- whole-set generation of rnn_char_epoch's multi-tap branch
  *      (charmodel-predict.c:288-311) ---- */

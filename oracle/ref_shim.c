@@ -19,6 +19,7 @@ double ref_rand_double(rand_ctx *x) { return rand_double(x); }
 int ref_rand_small_int(rand_ctx *x, int cap) { return rand_small_int(x, cap); }
 float ref_cheap_gaussian_noise(rand_ctx *x) { return cheap_gaussian_noise(x); }
 float ref_fast_expf(float x) { return fast_expf(x); }
+float ref_fast_sigmoid(float x) { return fast_sigmoid(x); }
 void ref_softmax(float *dest, const float *src, int len) { softmax(dest, src, len); }
 int ref_softmax_best_guess(float *error, const float *src, int len) {
   return softmax_best_guess(error, src, len);

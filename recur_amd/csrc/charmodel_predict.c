@@ -559,3 +559,307 @@ int rnn_char_epoch(RnnCharModel *model, RecurNN *confab_net, RnnCharVentropy *v,
   }
   return result;
 }
+
+/* ============================================== the multi-head text trainer == */
+/* charmodel-multi-predict.c, the caller py-recur-text.c's Net.train / Net.test sit on
+ * (py-recur-text.c:759-871): ONE net whose output row is n_classes heads of alphabet_len
+ * symbols, trained on one class's text at a time with temporal batching.  The loops below
+ * keep the reference's order of operations; what runs per symbol is device work through
+ * the set calls (a set of this one net, the text resident in HBM), so no error vector,
+ * range list or statistic visits the host inside the loop. */
+
+/* charmodel-multi-predict.c:60-72: image rows and periodic dumps want host copies */
+static void multi_inner_cycle_dump(RecurNN *net, TemporalPPM *input_ppm, TemporalPPM *error_ppm,
+                                   const char *periodic_pgm_string, int periodic_pgm_period,
+                                   int *periodic_pgm_countdown) {
+  if (input_ppm || error_ppm) {
+    rnn_amd_sync_host(net, RNN_AMD_STREAM);
+  }
+  if (input_ppm) {
+    temporal_add_row(input_ppm, net->input_layer);
+  }
+  if (error_ppm) {
+    temporal_add_row(error_ppm, net->bptt->o_error);
+  }
+  if (periodic_pgm_period) {
+    if (!--*periodic_pgm_countdown) {
+      *periodic_pgm_countdown = periodic_pgm_period;
+      rnn_multi_pgm_dump(net, periodic_pgm_string, "multi-text");
+    }
+  }
+}
+
+/* charmodel-multi-predict.c:74-119 */
+RnnCharMultiConfab *rnn_char_new_multi_confab(RecurNN *net, RnnCharAlphabet *alphabet, int n_classes,
+                                              int target_len, uint confab_period, int caps_marker) {
+  int len = target_len / n_classes - 1;
+  if (len < 1) {
+    fprintf(stderr, "no room to confabulate %d sub-models in %d characters\n", n_classes, target_len);
+    return NULL;
+  }
+  RnnCharMultiConfab *mc = calloc(1, sizeof(*mc));
+  mc->char_len = len;
+  mc->byte_len = len * 6 + 1;
+  mc->alphabet = alphabet;
+  mc->period = confab_period;
+  mc->n_classes = n_classes;
+  mc->caps_marker = caps_marker;
+  mc->last_char = calloc(n_classes, sizeof(int));
+  mc->strings = calloc(n_classes, sizeof(char *));
+  mc->nets = calloc(n_classes, sizeof(RecurNN *));
+  for (int i = 0; i < n_classes; i++) {
+    mc->strings[i] = calloc(mc->byte_len, 1);
+    mc->nets[i] = rnn_clone(net, net->flags & ~(RNN_NET_FLAG_OWN_BPTT | RNN_NET_FLAG_OWN_WEIGHTS),
+                            RECUR_RNG_SUBSEED, NULL);
+  }
+  return mc;
+}
+
+void rnn_char_free_multi_confab(RnnCharMultiConfab *mc) {
+  for (uint i = 0; i < mc->n_classes; i++) {
+    free(mc->strings[i]);
+    rnn_delete_net(mc->nets[i]);
+  }
+  free(mc->strings);
+  free(mc->nets);
+  free(mc->last_char);
+  free(mc);
+}
+
+/* charmodel-multi-predict.c:122-142: sample the next symbol from head `offset` */
+static int offset_guess_next_character(RecurNN *net, float *error, int hot, float bias, uint offset,
+                                       int alphabet_len) {
+  float *answer = one_hot_opinion(net, hot, 0);
+  float *group = answer + alphabet_len * offset;
+  biased_softmax_host(error, group, alphabet_len, bias);
+  int result = -1;
+  while (result < 0) {
+    float r = ramd_rand_double(&net->rng);
+    float accum = 0.0f;
+    for (int i = 0; i < alphabet_len; i++) {
+      accum += error[i];
+      if (r < accum) {
+        result = i;
+        break;
+      }
+    }
+  }
+  ramd_rng_from_host(net);
+  return result;
+}
+
+/* charmodel-multi-predict.c:145-197 */
+static int multi_confab(RnnCharMultiConfab *mc) {
+  const int *alphabet = mc->alphabet->points;
+  int total = 0;
+  int utf8 = (mc->alphabet->flags & RNN_CHAR_FLAG_UTF8) != 0;
+  float *error = malloc(sizeof(float) * mc->alphabet->len);
+  int char_width = utf8 ? 5 : 1;
+  if ((int)mc->byte_len <= char_width) {
+    fprintf(stderr, "insufficient space to confabulate (%d bytes)\n", mc->byte_len);
+    free(error);
+    return 0;
+  }
+  for (uint m = 0; m < mc->n_classes; m++) {
+    RecurNN *net = mc->nets[m];
+    char *d = mc->strings[m];
+    int n = mc->last_char[m];
+    int bytes_left = mc->byte_len;
+    int pending_caps = 0;
+    for (int i = 0; i < (int)mc->char_len && bytes_left > char_width;) {
+      n = offset_guess_next_character(net, error, n, mc->bias, m, mc->alphabet->len);
+      int c = alphabet[n];
+      if (c == mc->caps_marker) {
+        pending_caps = 1;
+      } else {
+        if (pending_caps) { /* capitalisation is limited to ascii and greek */
+          if (c >= 'a' && c <= 'z') {
+            c -= ('a' - 'A');
+          } else if (c >= 945 && c <= 969) {
+            c -= 32;
+            if (c == 930) {
+              c++; /* word-final sigma capitalises to plain sigma */
+            }
+          }
+        }
+        int w = write_code_point(c, d, utf8);
+        d += w;
+        bytes_left -= w;
+        pending_caps = 0;
+        i++;
+      }
+    }
+    *d = '\0';
+    total += mc->byte_len - bytes_left;
+    mc->last_char[m] = n;
+  }
+  free(error);
+  return total;
+}
+
+/* charmodel-multi-predict.c:200-230: the heads' strings joined by `sep` */
+static int multi_confab_format_line(RnnCharMultiConfab *mc, char *dest, int len, char *sep) {
+  uint i = 0;
+  int in_sep = 0;
+  int total;
+  char *src = mc->strings[0];
+  for (total = 0; total < len - 1; total++, src++) {
+    char c = *src;
+    while (c == '\0') {
+      in_sep = !in_sep;
+      if (in_sep) {
+        src = sep;
+      } else {
+        i++;
+        if (i >= mc->n_classes) {
+          break;
+        }
+        src = mc->strings[i];
+      }
+      c = *src;
+    }
+    if (i >= mc->n_classes) {
+      break;
+    }
+    dest[total] = c;
+  }
+  dest[total] = '\0';
+  return total;
+}
+
+/* charmodel-multi-predict.c:234-281 (text_train) */
+static void multi_text_train(RecurNN *net, u8 *text, int len, int learning_style, int target_class,
+                             int batch_size, float leakage, int alphabet_len,
+                             RnnCharProgressReport *report, RnnCharMultiConfab *mc,
+                             TemporalPPM *input_ppm, TemporalPPM *error_ppm,
+                             const char *periodic_pgm_string, int periodic_pgm_period,
+                             int periodic_pgm_countdown) {
+  RecurNNBPTT *bptt = net->bptt;
+  int i = 0;
+  if (len >= 2) {
+    RecurNN *one[1] = {net};
+    RnnAmdSet *set = rnn_amd_set_open(one, 1);
+    if (!set) {
+      fprintf(stderr, "librecur_amd: rnn_char_multitext_train needs a net with its own bptt\n");
+      abort();
+    }
+    RnnAmdStats st;
+    rnn_amd_set_load_text(set, text, len);
+    rnn_amd_set_read_stats(set, &st, 1);
+    int countdown = batch_size - net->generation % batch_size;
+    const int dump = input_ppm || error_ppm || periodic_pgm_period;
+    for (i = 0; i < len - 1; i++, countdown--) {
+      /* rnn_bptt_advance + multi_softmax_error (its opinion, its leakage draws from the
+       * net's generator, the error ranges) */
+      rnn_amd_set_multi_text_loss(set, i, i == 0 ? &target_class : NULL, alphabet_len, leakage);
+      if (countdown == 0) {
+        /* line 247: the net's own momentum, not the caller's */
+        rnn_apply_learning(net, learning_style, bptt->momentum);
+        countdown = batch_size;
+        rnn_amd_set_multi_calc_deltas(set, 0);
+      } else {
+        rnn_amd_set_multi_calc_deltas(set, 1);
+      }
+      if (dump) {
+        multi_inner_cycle_dump(net, input_ppm, error_ppm, periodic_pgm_string, periodic_pgm_period,
+                               &periodic_pgm_countdown);
+      }
+    }
+    if (report) {
+      rnn_amd_set_read_stats(set, &st, 1);
+      float report_scale = 1.0f / (len - 1);
+      report->training_entropy = (float)(-st.entropy) * report_scale;
+      report->training_error = (float)st.error * report_scale;
+    }
+    rnn_amd_synchronize();
+    free(set); /* the net's state stays on the device; nothing to copy back here */
+  }
+  if (mc && mc->period && i % mc->period == 0) {
+    char *confab_line = malloc(mc->byte_len + 1);
+    multi_confab(mc);
+    multi_confab_format_line(mc, confab_line, mc->byte_len, C_CYAN "|" C_NORMAL);
+    printf("%8u" C_CYAN "|" C_NORMAL "%s\n", net->generation, confab_line);
+    free(confab_line);
+  }
+}
+
+/* charmodel.h:251-254; charmodel-multi-predict.c:283-301: run a text through the net without
+ * training (advance + opinion with the net's noise) */
+void rnn_char_multitext_spin(RecurNN *net, u8 *text, int len, TemporalPPM *input_ppm,
+                             TemporalPPM *error_ppm, const char *periodic_pgm_string,
+                             int periodic_pgm_period) {
+  int periodic_pgm_countdown = 0;
+  if (periodic_pgm_period) {
+    periodic_pgm_countdown = periodic_pgm_period - net->generation % periodic_pgm_period;
+  }
+  if (len < 1) {
+    return;
+  }
+  if (error_ppm) {
+    rnn_amd_sync_host(net, RNN_AMD_STREAM);
+    memset(net->bptt->o_error, 0, net->output_size * sizeof(float));
+    rnn_amd_host_written(net, RNN_AMD_STREAM);
+  }
+  RecurNN *one[1] = {net};
+  RnnAmdSet *set = rnn_amd_set_open(one, 1);
+  if (!set) {
+    fprintf(stderr, "librecur_amd: rnn_char_multitext_spin needs a net with its own bptt\n");
+    abort();
+  }
+  if (len == 1) { /* the device text wants two symbols: give the one a dummy successor */
+    u8 two[2] = {text[0], text[0]};
+    rnn_amd_set_load_text(set, two, 2);
+  } else {
+    rnn_amd_set_load_text(set, text, len);
+  }
+  const int dump = input_ppm || error_ppm || periodic_pgm_period;
+  for (int i = 0; i < len; i++) {
+    rnn_amd_set_text_opinion(set, i, 1);
+    if (dump) {
+      multi_inner_cycle_dump(net, input_ppm, error_ppm, periodic_pgm_string, periodic_pgm_period,
+                             &periodic_pgm_countdown);
+    }
+  }
+  rnn_amd_synchronize();
+  free(set);
+}
+
+/* charmodel.h:242-248; charmodel-multi-predict.c:307-347 */
+void rnn_char_multitext_train(RecurNN *net, u8 *text, int len, int alphabet_len, int target_class,
+                              float leakage, RnnCharProgressReport *report,
+                              RnnCharMultiConfab *confab, int learning_style, float momentum,
+                              int batch_size, TemporalPPM *input_ppm, TemporalPPM *error_ppm,
+                              const char *periodic_pgm_string, int periodic_pgm_period) {
+  struct timespec time_start, time_end;
+  int periodic_pgm_countdown = 0;
+  (void)momentum; /* unused by the reference too: text_train applies bptt->momentum */
+  if (periodic_pgm_period) {
+    periodic_pgm_countdown = periodic_pgm_period - net->generation % periodic_pgm_period;
+  }
+  batch_size = RAMD_MAX(batch_size, 1);
+  if (report) {
+    clock_gettime(CLOCK_MONOTONIC, &time_start);
+  }
+  multi_text_train(net, text, len, learning_style, target_class, batch_size, leakage, alphabet_len,
+                   report, confab, input_ppm, error_ppm, periodic_pgm_string, periodic_pgm_period,
+                   periodic_pgm_countdown);
+  if (report) {
+    clock_gettime(CLOCK_MONOTONIC, &time_end);
+    double elapsed = (time_end.tv_sec - time_start.tv_sec) + 1e-9 * (time_end.tv_nsec - time_start.tv_nsec);
+    report->per_second = (len - 1) / elapsed;
+  }
+}
+
+/* charmodel.h:255-257; charmodel-multi-predict.c:383-408: entropy[j] is subtracted into and
+ * then divided, exactly as the reference treats the caller's array */
+void rnn_char_multi_cross_entropy(RecurNN *net, const u8 *text, int len, int alphabet_len,
+                                  double *entropy, int ignore_start) {
+  int n_classes = net->output_size / alphabet_len;
+  double *sums = malloc(sizeof(double) * RAMD_MAX(n_classes, 1));
+  rnn_amd_run_text_heads(net, text, len, ignore_start, alphabet_len, sums);
+  for (int j = 0; j < n_classes; j++) {
+    entropy[j] -= sums[j];
+    entropy[j] /= (len - ignore_start - 1);
+  }
+  free(sums);
+}

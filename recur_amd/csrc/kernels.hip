@@ -1402,6 +1402,60 @@ __global__ __launch_bounds__(64) void k_xent_accumulate(View v, int r, int count
   v.b.xent[r] += (double)((e < 1e-30f) ? -100.0f : log2f(e));
 }
 
+// rnn_char_multi_cross_entropy's inner step (charmodel-multi-predict.c:395-403): block c
+// takes head c of the output row -- softmax over that head alone (badmaths.h:71-111), the
+// probability of the row's target symbol, capped log2 added to acc[c].
+__global__ __launch_bounds__(64) void k_multi_xent_accumulate(View v, int r, int alen, double *acc,
+                                                              int count_it) {
+  extern __shared__ float ex[];
+  const RamdShape &s = v.sh;
+  const int c = blockIdx.x;
+  const float *src = v.b.out + (size_t)r * s.O + (size_t)c * alen;
+  float lo = src[0], hi = src[0];
+  for (int i = threadIdx.x; i < alen; i += 64) {
+    hi = fmaxf(hi, src[i]);
+    lo = fminf(lo, src[i]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    lo = fminf(lo, __shfl_xor(lo, off, 64));
+  }
+  float adj = 0.0f;
+  if (hi > 50.0f) adj = 50.0f - hi;
+  else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+  for (int i = threadIdx.x; i < alen; i += 64) ex[i] = fast_expf_dev(src[i] + adj);
+  __syncthreads();
+  if (threadIdx.x != 0 || !count_it) return;
+  float sum = 0.0f;
+  for (int i = 0; i < alen; i++) sum += ex[i];
+  float e = ex[v.b.target[r]] / sum;
+  acc[c] += (double)((e < 1e-30f) ? -100.0f : log2f(e));
+}
+
+// rnnca's loss (gstrnnca.c:701-714, train_net): fast_sigmoid_array(answer, answer, n) IN
+// PLACE on the first n outputs (badmaths.h:33-44), then o_error[i] = a (1 - a) (target - a).
+// One thread per (stream, output); the rest of the error row stays as it was (zero).
+__global__ void k_sigmoid_mse_error(View v, int row0, int nrows, int n, const float *targets,
+                                    int ld) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nrows * n) return;
+  int j = q / n, i = q - j * n, r = row0 + j;
+  float *out = v.b.out + (size_t)r * v.sh.O;
+  float a = 1.0f / (1.0f + fast_expf_dev(-out[i] * 1.0f));
+  out[i] = a;
+  float slope = a * (1.0f - a);
+  v.b.o_error[(size_t)r * v.sh.O + i] = slope * (targets[(size_t)j * ld + i] - a);
+}
+
+// fill_frame's fast_sigmoid_array(answer, answer, 3) (gstrnnca.c:813-814) for state rows
+__global__ void k_sigmoid_outputs(View v, int r0, int nrows, int n) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nrows * n) return;
+  int j = q / n, i = q - j * n;
+  float *out = v.b.out + (size_t)(r0 + j) * v.sh.O;
+  out[i] = 1.0f / (1.0f + fast_expf_dev(-out[i] * 1.0f));
+}
+
 #pragma clang fp contract(fast)
 
 // ---------------------------------------------------- K5/K6: top backprop --
@@ -3099,6 +3153,31 @@ extern "C" void ramd_launch_xent_accumulate(ramd_stream_t st_, const RamdShape *
   View v = make_view(sh, b);
   RAMD_LAUNCH(k_xent_accumulate, dim3(1), dim3(64), (size_t)sh->output_size * sizeof(float),
                      st, v, row, count_it);
+}
+
+extern "C" void ramd_launch_multi_xent_accumulate(ramd_stream_t st_, const RamdShape *sh,
+                                                  const RamdBuffers *b, int row, int alphabet_len,
+                                                  int n_classes, double *acc, int count_it) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  RAMD_LAUNCH(k_multi_xent_accumulate, dim3(n_classes), dim3(64), (size_t)alphabet_len * sizeof(float), st,
+              v, row, alphabet_len, acc, count_it);
+}
+
+extern "C" void ramd_launch_sigmoid_mse_error(ramd_stream_t st_, const RamdShape *sh,
+                                              const RamdBuffers *b, int row0, int nrows, int n,
+                                              const float *targets, int ld) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  RAMD_LAUNCH(k_sigmoid_mse_error, dim3((nrows * n + 255) / 256), dim3(256), 0, st, v, row0, nrows, n,
+              targets, ld);
+}
+
+extern "C" void ramd_launch_sigmoid_outputs(ramd_stream_t st_, const RamdShape *sh,
+                                            const RamdBuffers *b, int r0, int nrows, int n) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  RAMD_LAUNCH(k_sigmoid_outputs, dim3((nrows * n + 255) / 256), dim3(256), 0, st, v, r0, nrows, n);
 }
 
 extern "C" void ramd_launch_multi_softmax_error(ramd_stream_t st_, const RamdShape *sh,

@@ -171,6 +171,18 @@ void ramd_launch_multi_softmax_error(ramd_stream_t st, const RamdShape *sh, cons
                                      int row0, int nrows, int alphabet_len, int n_classes,
                                      unsigned long long threshold, const int *tclass, int *ranges,
                                      int range_stride);
+/* one step of rnn_char_multi_cross_entropy (charmodel-multi-predict.c:395-403) for state row
+ * `row`: per head c, capped log2 of softmax(head c)[target] added to acc[c] (device doubles) */
+void ramd_launch_multi_xent_accumulate(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
+                                       int row, int alphabet_len, int n_classes, double *acc,
+                                       int count_it);
+/* rnnca's loss (gstrnnca.c:701-714): sigmoid in place on the first n outputs, slope * (target -
+ * a) into o_error; targets is a device array [nrows][ld] */
+void ramd_launch_sigmoid_mse_error(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
+                                   int row0, int nrows, int n, const float *targets, int ld);
+/* fast_sigmoid_array in place on the first n outputs of state rows r0 .. r0 + nrows */
+void ramd_launch_sigmoid_outputs(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int r0,
+                                 int nrows, int n);
 /* rebuilds err_a / err_b (bptt->h_error, i_error) from ehi after a calc_deltas */
 void ramd_launch_err_writeback(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                                int row0, int nrows);

@@ -632,7 +632,7 @@ static void engine_ensure_device(RamdEngine *e) {
   }
   e->lr_pushed = ramd_zalloc(S * sizeof(float));
   if (keep_text) {
-    b->text = dev_alloc((size_t)keep_text_len);
+    b->text = dev_alloc((size_t)keep_text_len + 1);
     h2d(b->text, keep_text, (size_t)keep_text_len);
     b->text_len = keep_text_len;
     dsync();
@@ -1466,21 +1466,29 @@ void rnn_log_net(RecurNN *net) {
 
 /* Runs one net over an encoded text without leaving the device: for every i < len - 1
  * a one_hot_opinion of text[i] (charmodel-helpers.h:16-33) and, from i = skip on, the
- * log2 probability the softmax gives text[i + 1].  Returns the sum of those logs
- * (get_cross_entropy's loop, charmodel-predict.c:62-76; with count == 0 it is
- * rnn_char_prime's loop, 407-416).  The net's state rows stay on the device. */
-double rnn_amd_run_text(RecurNN *net, const u8 *text, int len, int skip) {
+ * log2 probability the softmax gives text[i + 1].  With alphabet_len == 0 the softmax is
+ * over the whole output row and sums[0] gets the sum of the logs (get_cross_entropy's
+ * loop, charmodel-predict.c:62-76; with skip >= len - 1 it is rnn_char_prime's loop,
+ * 407-416); otherwise the row is output_size / alphabet_len heads and sums[c] gets head
+ * c's sum (rnn_char_multi_cross_entropy's loop, charmodel-multi-predict.c:388-403).
+ * The net's state rows stay on the device. */
+static void run_text(RecurNN *net, const u8 *text, int len, int skip, int alphabet_len,
+                     double *sums, int n_sums) {
   RamdEngine *e = ramd_engine_of(net);
   RamdPriv *p = ramd_priv(net);
   engine_ensure_device(e);
   engine_need_dev(e, RNN_AMD_WEIGHTS);
   stream_need_dev(e, net);
+  for (int c = 0; c < n_sums; c++) {
+    sums[c] = 0.0;
+  }
   if (len < 2) {
-    return 0.0;
+    return;
   }
   const RamdShape *s = &e->sh;
   int r = state_row(e, p);
   unsigned char *d_text = dev_alloc(len);
+  double *d_acc = alphabet_len ? dev_alloc((size_t)n_sums * sizeof(double)) : NULL;
   h2d(d_text, text, len);
   HIP_OK(hipMemsetAsync(e->b.xent + r, 0, sizeof(double), g_stream));
   if (p->stream >= 0) {
@@ -1500,17 +1508,43 @@ double rnn_amd_run_text(RecurNN *net, const u8 *text, int len, int skip) {
       ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_TEXT, NULL, 0, i, 0, 1, 0);
     }
     ramd_launch_forward(g_stream, s, &e->b, r, 1, 0.0f);
-    ramd_launch_xent_accumulate(g_stream, s, &e->b, r, i >= skip);
+    if (alphabet_len) {
+      if (i >= skip) {
+        ramd_launch_multi_xent_accumulate(g_stream, s, &e->b, r, alphabet_len, n_sums, d_acc, 1);
+      }
+    } else {
+      ramd_launch_xent_accumulate(g_stream, s, &e->b, r, i >= skip);
+    }
   }
-  double sum = 0.0;
-  d2h(&sum, e->b.xent + r, sizeof(double));
+  if (alphabet_len) {
+    d2h(sums, d_acc, (size_t)n_sums * sizeof(double));
+  } else {
+    d2h(sums, e->b.xent + r, sizeof(double));
+  }
   dsync();
   e->b.text = old_text;
   e->b.text_len = old_len;
   dev_free(d_text);
+  dev_free(d_acc);
   p->dev_valid = 1;
   p->host_valid = 0;
+}
+
+double rnn_amd_run_text(RecurNN *net, const u8 *text, int len, int skip) {
+  double sum = 0.0;
+  run_text(net, text, len, skip, 0, &sum, 1);
   return sum;
+}
+
+void rnn_amd_run_text_heads(RecurNN *net, const u8 *text, int len, int skip, int alphabet_len,
+                            double *sums) {
+  int n_classes = alphabet_len > 0 ? net->output_size / alphabet_len : 0;
+  if (n_classes < 1) {
+    fprintf(stderr, "librecur_amd: rnn_amd_run_text_heads: %d outputs as heads of %d\n",
+            net->output_size, alphabet_len);
+    abort();
+  }
+  run_text(net, text, len, skip, alphabet_len, sums, n_classes);
 }
 
 /* ================================================================ batched == */
@@ -1843,38 +1877,150 @@ void rnn_amd_set_grouped_softmax_error(RnnAmdSet *set, int n_groups, const int *
   }
 }
 
-/* One generation of the multi-head text model for the whole set: what
+/* The multi-head text model for the whole set, per generation: what
  * charmodel-multi-predict.c:244-256 does per net (rnn_bptt_advance, multi_softmax_error
  * with its one_hot_opinion, rnn_bptt_calc_deltas with the error ranges), stream j
- * accumulating on top of stream j - 1. */
-void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *next,
-                                   const int *target_class, int alphabet_len, float leakage,
-                                   int accumulate) {
-  RamdEngine *e = set->eng;
-  set_need_training(set, "rnn_amd_set_multi_step_deltas");
+ * accumulating on top of stream j - 1.  The loss half leaves o_error and one range list
+ * per stream on the device; the deltas half consumes them.  In between the caller may
+ * apply the previous batch's deltas, as text_train does (244-252). */
+static const int MULTI_RANGE_STRIDE = 2 * (64 + 1);
+
+static int multi_heads(RamdEngine *e, int alphabet_len) {
   const RamdShape *s = &e->sh;
-  int n_classes = s->output_size / alphabet_len;
+  int n_classes = alphabet_len > 0 ? s->output_size / alphabet_len : 0;
   if (alphabet_len < 1 || n_classes < 1 || n_classes > 64) {
     fprintf(stderr, "librecur_amd: %d outputs as heads of %d: 1 to 64 heads are supported\n",
             s->output_size, alphabet_len);
     abort();
   }
-  const int stride = 2 * (64 + 1);
   if (!e->d_mranges) {
-    e->d_mranges = dev_alloc((size_t)s->Scap * stride * sizeof(int));
+    e->d_mranges = dev_alloc((size_t)s->Scap * MULTI_RANGE_STRIDE * sizeof(int));
     e->d_mclass = dev_alloc((size_t)s->Scap * sizeof(int));
   }
-  h2d(e->b.hot + set->row0, hot, set->n * sizeof(int));
-  h2d(e->b.target + set->row0, next, set->n * sizeof(int));
-  h2d(e->d_mclass, target_class, set->n * sizeof(int));
-  dsync();
-  set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, NULL, 1, 0);
+  return n_classes;
+}
+
+/* the loss after the opinion: b.target holds each stream's next symbol */
+static void multi_loss(RnnAmdSet *set, const int *target_class, int alphabet_len, int n_classes,
+                       float leakage) {
+  RamdEngine *e = set->eng;
+  if (target_class) {
+    h2d(e->d_mclass + set->row0, target_class, set->n * sizeof(int));
+    dsync();
+  }
   /* u64 threshold = leakage * UINT64_MAX (charmodel-multi-predict.c:27): float arithmetic */
   float tf = leakage * (float)UINT64_MAX;
   unsigned long long threshold = tf >= 18446744073709551615.0f ? UINT64_MAX : (unsigned long long)tf;
-  ramd_launch_multi_softmax_error(g_stream, s, &e->b, set->row0, set->n, alphabet_len, n_classes,
-                                  threshold, e->d_mclass, e->d_mranges, stride);
-  set_calc_deltas(set, accumulate, NULL, NULL, 0, e->d_mranges, stride, NULL);
+  ramd_launch_multi_softmax_error(g_stream, &e->sh, &e->b, set->row0, set->n, alphabet_len, n_classes,
+                                  threshold, e->d_mclass + set->row0,
+                                  e->d_mranges + (size_t)set->row0 * MULTI_RANGE_STRIDE,
+                                  MULTI_RANGE_STRIDE);
+  set_streams_dev_wrote(set);
+}
+
+void rnn_amd_set_multi_calc_deltas(RnnAmdSet *set, int accumulate) {
+  RamdEngine *e = set->eng;
+  set_need_training(set, "rnn_amd_set_multi_calc_deltas");
+  if (!e->d_mranges) {
+    fprintf(stderr, "librecur_amd: rnn_amd_set_multi_calc_deltas before any multi-head loss\n");
+    abort();
+  }
+  set_calc_deltas(set, accumulate, NULL, NULL, 0,
+                  e->d_mranges + (size_t)set->row0 * MULTI_RANGE_STRIDE, MULTI_RANGE_STRIDE, NULL);
+}
+
+void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *next,
+                                   const int *target_class, int alphabet_len, float leakage,
+                                   int accumulate) {
+  RamdEngine *e = set->eng;
+  set_need_training(set, "rnn_amd_set_multi_step_deltas");
+  int n_classes = multi_heads(e, alphabet_len);
+  h2d(e->b.hot + set->row0, hot, set->n * sizeof(int));
+  h2d(e->b.target + set->row0, next, set->n * sizeof(int));
+  dsync();
+  set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, NULL, 1, 0);
+  multi_loss(set, target_class, alphabet_len, n_classes, leakage);
+  rnn_amd_set_multi_calc_deltas(set, accumulate);
+}
+
+static void check_text_pos(RamdEngine *e, int i, int last_ok, const char *what) {
+  if (!e->b.text) {
+    fprintf(stderr, "librecur_amd: %s without rnn_amd_set_load_text\n", what);
+    abort();
+  }
+  /* the reference's loops run i over [start, len - 1) (charmodel-predict.c:288,
+   * charmodel-multi-predict.c:244); the kernels wrap the per-stream offset once, so i
+   * itself has to be in range */
+  if (i < 0 || i >= e->b.text_len - 1 + last_ok) {
+    fprintf(stderr, "librecur_amd: %s: text position %d outside [0, %d)\n", what, i,
+            e->b.text_len - 1 + last_ok);
+    abort();
+  }
+}
+
+/* the same from the text on the device: stream j reads text[o] and is scored against
+ * text[o + 1], o as in rnn_amd_set_char_step */
+void rnn_amd_set_multi_text_loss(RnnAmdSet *set, int i, const int *target_class, int alphabet_len,
+                                 float leakage) {
+  RamdEngine *e = set->eng;
+  set_need_training(set, "rnn_amd_set_multi_text_loss");
+  check_text_pos(e, i, 0, "rnn_amd_set_multi_text_loss");
+  int n_classes = multi_heads(e, alphabet_len);
+  set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 0); /* advance + one-hot opinion + b.target */
+  multi_loss(set, target_class, alphabet_len, n_classes, leakage);
+}
+
+/* rnn_bptt_advance (optional) + one_hot_opinion of the stream's text symbol, nothing else:
+ * rnn_char_multitext_spin's step (charmodel-multi-predict.c:293-297); i may be len - 1 */
+void rnn_amd_set_text_opinion(RnnAmdSet *set, int i, int advance) {
+  RamdEngine *e = set->eng;
+  check_text_pos(e, i, 1, "rnn_amd_set_text_opinion");
+  set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, advance, 0);
+}
+
+/* rnnca's loss on the device (gstrnnca.c:701-714) after rnn_amd_set_opinion: sigmoid of the
+ * first n outputs in place, o_error = slope * (target - answer); targets: host [n_nets][ld] */
+void rnn_amd_set_sigmoid_mse_error(RnnAmdSet *set, const float *targets, int ld, int n) {
+  RamdEngine *e = set->eng;
+  set_need_training(set, "rnn_amd_set_sigmoid_mse_error");
+  if (n < 1 || n > e->sh.output_size || ld < n) {
+    fprintf(stderr, "librecur_amd: rnn_amd_set_sigmoid_mse_error over %d of %d outputs (ld %d)\n", n,
+            e->sh.output_size, ld);
+    abort();
+  }
+  set_streams_to_dev(set);
+  size_t bytes = (size_t)set->n * n * sizeof(float);
+  if (bytes > e->d_group_bytes) {
+    dsync();
+    dev_free(e->d_group);
+    e->d_group = dev_alloc(bytes);
+    e->d_group_bytes = bytes;
+  }
+  HIP_OK(hipMemcpy2DAsync(e->d_group, n * sizeof(float), targets, ld * sizeof(float), n * sizeof(float),
+                          set->n, hipMemcpyHostToDevice, g_stream));
+  dsync();
+  ramd_launch_sigmoid_mse_error(g_stream, &e->sh, &e->b, set->row0, set->n, n, (const float *)e->d_group,
+                                n);
+  set_streams_dev_wrote(set);
+}
+
+/* fill_frame's fast_sigmoid_array(answer, answer, n) (gstrnnca.c:813-814) for every net of the
+ * set (training or forward-only), then optionally the n_nets x o_size answers to the host */
+void rnn_amd_set_sigmoid_outputs(RnnAmdSet *set, int n, float *outputs) {
+  RamdEngine *e = set->eng;
+  if (n < 1 || n > e->sh.output_size) {
+    fprintf(stderr, "librecur_amd: rnn_amd_set_sigmoid_outputs over %d of %d outputs\n", n,
+            e->sh.output_size);
+    abort();
+  }
+  set_streams_to_dev(set);
+  const int r0 = set_state_row0(set);
+  ramd_launch_sigmoid_outputs(g_stream, &e->sh, &e->b, r0, set->n, n);
+  set_streams_dev_wrote(set);
+  if (outputs) {
+    d2h(outputs, e->b.out + (size_t)r0 * e->sh.O, (size_t)set->n * e->sh.O * sizeof(float));
+    dsync();
+  }
 }
 
 void rnn_amd_set_load_text(RnnAmdSet *set, const u8 *text, int len) {
@@ -1885,7 +2031,7 @@ void rnn_amd_set_load_text(RnnAmdSet *set, const u8 *text, int len) {
   }
   dsync();
   dev_free(e->b.text);
-  e->b.text = dev_alloc(len);
+  e->b.text = dev_alloc((size_t)len + 1); /* zeroed: the "next symbol" of the last one */
   h2d(e->b.text, text, len);
   e->b.text_len = len;
   dsync();
@@ -1893,16 +2039,7 @@ void rnn_amd_set_load_text(RnnAmdSet *set, const u8 *text, int len) {
 
 static void char_step_deltas(RnnAmdSet *set, int i, RamdPendingDelta *defer) {
   RamdEngine *e = set->eng;
-  if (!e->b.text) {
-    fprintf(stderr, "librecur_amd: rnn_amd_set_char_step without rnn_amd_set_load_text\n");
-    abort();
-  }
-  /* the reference's loop runs i over [start, len - 1) (charmodel-predict.c:288); the
-   * kernels wrap the per-stream offset once, so i itself has to be in range */
-  if (i < 0 || i >= e->b.text_len - 1) {
-    fprintf(stderr, "librecur_amd: text position %d outside [0, %d)\n", i, e->b.text_len - 1);
-    abort();
-  }
+  check_text_pos(e, i, 0, "rnn_amd_set_char_step");
   if (ramd_text_top_ok(&e->sh)) {
     /* advance + hidden layer, then output layer, loss and top backprop in one launch */
     int fwd_ks = set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 1);

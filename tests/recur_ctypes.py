@@ -239,6 +239,12 @@ AMD_API = {
     "rnn_amd_set_grouped_softmax_error": (None, [C.c_void_p, C.c_int, c_int_p, c_int_p, c_int_p, c_float_p,
                                                  c_u8_p]),
     "rnn_amd_set_multi_step_deltas": (None, [C.c_void_p, c_int_p, c_int_p, c_int_p, C.c_int, C.c_float, C.c_int]),
+    "rnn_amd_set_multi_text_loss": (None, [C.c_void_p, C.c_int, c_int_p, C.c_int, C.c_float]),
+    "rnn_amd_set_multi_calc_deltas": (None, [C.c_void_p, C.c_int]),
+    "rnn_amd_set_text_opinion": (None, [C.c_void_p, C.c_int, C.c_int]),
+    "rnn_amd_set_sigmoid_mse_error": (None, [C.c_void_p, c_float_p, C.c_int, C.c_int]),
+    "rnn_amd_set_sigmoid_outputs": (None, [C.c_void_p, C.c_int, c_float_p]),
+    "rnn_amd_run_text_heads": (None, [NetP, c_u8_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "rnn_amd_synchronize": (None, []),
     "rnn_amd_dist_get_id": (C.c_int, [C.c_void_p]),
     "rnn_amd_dist_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
@@ -263,6 +269,7 @@ REF_SHIM_API = {
     "ref_rand_small_int": (C.c_int, [C.POINTER(RandCtx), C.c_int]),
     "ref_cheap_gaussian_noise": (C.c_float, [C.POINTER(RandCtx)]),
     "ref_fast_expf": (C.c_float, [C.c_float]),
+    "ref_fast_sigmoid": (C.c_float, [C.c_float]),
     "ref_softmax": (None, [c_float_p, c_float_p, C.c_int]),
     "ref_softmax_best_guess": (C.c_int, [c_float_p, c_float_p, C.c_int]),
     "ref_soft_clip": (C.c_float, [C.c_float, C.c_float]),
@@ -378,6 +385,11 @@ ORACLE_API = {
     "orc_condition": (None, [OrcP, C.c_uint32]),
     "orc_bptt_calculate": (None, [OrcP, C.c_int, C.c_uint, C.c_float]),
     "orc_cross_entropy": (C.c_double, [OrcP, C.c_int, c_u8_p, C.c_int, C.c_int]),
+    "orc_multi_cross_entropy": (None, [OrcP, C.c_int, c_u8_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]),
+    "orc_fast_sigmoid": (C.c_float, [C.c_float]),
+    "orc_sigmoid_mse_error": (None, [OrcP, C.c_int, c_float_p, C.c_int]),
+    "orc_multitext_train": (None, [OrcP, C.c_int, c_u8_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                   C.c_float, C.c_int, c_float_p, c_float_p]),
     "orc_set_char_step": (None, [OrcP, c_u8_p, C.c_int, C.c_int, C.c_int, C.c_float]),
     "orc_set_char_step_deltas": (None, [OrcP, c_u8_p, C.c_int, C.c_int]),
 }
@@ -486,7 +498,25 @@ class CharMetadata(C.Structure):  # charmodel.h:75-81
 
 
 MetaP = C.POINTER(CharMetadata)
+class CharProgressReport(C.Structure):  # charmodel.h:132-138
+    _fields_ = [("training_entropy", C.c_float), ("training_error", C.c_float),
+                ("training_accuracy", C.c_float), ("per_second", C.c_float)]
+
+
+class CharMultiConfab(C.Structure):  # charmodel.h:140-152
+    _fields_ = [("nets", C.POINTER(NetP)), ("last_char", c_int_p), ("caps_marker", C.c_int),
+                ("strings", C.POINTER(C.c_char_p)), ("n_classes", C.c_uint), ("char_len", C.c_uint),
+                ("byte_len", C.c_uint), ("bias", C.c_float), ("period", C.c_uint), ("alphabet", AlphaP)]
+
+
 CHAR_API = {
+    "rnn_char_multitext_train": (None, [NetP, c_u8_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                        C.POINTER(CharProgressReport), C.POINTER(CharMultiConfab), C.c_int,
+                                        C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]),
+    "rnn_char_multitext_spin": (None, [NetP, c_u8_p, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]),
+    "rnn_char_multi_cross_entropy": (None, [NetP, c_u8_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]),
+    "rnn_char_new_multi_confab": (C.POINTER(CharMultiConfab), [NetP, AlphaP, C.c_int, C.c_int, C.c_uint, C.c_int]),
+    "rnn_char_free_multi_confab": (None, [C.POINTER(CharMultiConfab)]),
     "rnn_char_init_schedule": (None, [C.POINTER(CharSchedule), C.c_int, C.c_float, C.c_float, C.c_int]),
     "rnn_char_calc_ventropy": (C.c_float, [C.POINTER(CharModel), C.POINTER(CharVentropy), C.c_int]),
     "rnn_char_delete_ventropy": (None, [C.POINTER(CharVentropy)]),

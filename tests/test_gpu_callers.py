@@ -1,0 +1,307 @@
+"""The callers either side of the hot path, on their OWN workloads at BASELINE.json's sizes:
+
+* configs[3], the multi-head character model: the batched device generation at hidden 1024 /
+  256 streams (and 32 = the 8-GPU shard) with the fixture net's output shape (73 symbols x 50
+  heads = 3650 outputs), ADAGRAD, RESQRT, leakage > 0; and the reference's own trainer loop
+  (rnn_char_multitext_train / rnn_char_multi_cross_entropy, charmodel-multi-predict.c:234-408)
+  against an oracle restatement of that loop.
+* configs[4], rnnca: 35 dense inputs, 3 outputs, sigmoid-slope MSE loss ON THE DEVICE
+  (gstrnnca.c:701-714) at hidden 2048 / 512 streams / depth 10, and the frame fill
+  (gstrnnca.c:805-831): 13,824 forward-only cells per frame.
+
+Tolerance 1e-4 relative (2-norm and max element), generator states and counters bit-exact.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+import recur_ctypes as rc
+import replay
+import scenarios as sc
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def amd():
+    lib = rc.load_amd()
+    assert lib.rnn_amd_device_count() >= 1, "no HIP device: the product has no CPU fallback"
+    rc.bind_char(lib)
+    return lib
+
+
+def _sync_oracle_to(o, snap, keys=("ih_w", "ho_w", "ih_m", "ho_m", "hist", "hidden", "index", "min_error_factor")):
+    a = o.arrays()
+    for k in keys:
+        a[k][:] = snap[k]
+    a["generation"][:] = snap["generation"]
+    for j in range(o.S):
+        r = o.z.contents.rng[j]
+        r.a, r.b, r.c, r.d = (int(x) for x in snap["rng"][j])
+
+
+# ------------------------------------------------------------------ configs[3] --
+
+@pytest.mark.parametrize("S", [256, 32])
+def test_config3_multi_head_generation_at_size(amd, S):
+    """hidden 1024, alphabet 73 x 50 heads (o_size 3652: the wide-output GEMM path, ranged top
+    backprop with one range list per stream), ADAGRAD with ballast, RESQRT, leakage 0.1, noise
+    on: the ring is warmed on the device, then one generation on both sides from the same state."""
+    lib = amd
+    A, NC, D = 73, 50, 20
+    kw = dict(input_size=A, hidden_size=1024, output_size=A * NC, S=S, D=D, learn_rate=1e-4, seed=61,
+              activation=rc.RESQRT, noise=0.01, flags=rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR)
+    g = sc.AmdBatchedSet(lib, **kw)
+    lib.rnn_set_momentum_values(g.net, 200.0)  # the ADAGRAD ballast of py-recur-text.c:437-449
+    rs = np.random.default_rng(3)
+    leakage = 0.1
+
+    def draw():
+        return (rs.integers(0, A, S).astype(np.int32), rs.integers(0, A, S).astype(np.int32),
+                rs.integers(0, NC, S).astype(np.int32))
+
+    t0 = time.perf_counter()
+    n_warm = D + 3
+    for _ in range(n_warm):
+        hot, nxt, cls = draw()
+        lib.rnn_amd_set_multi_step_deltas(g.handle, rc.iptr(hot), rc.iptr(nxt), rc.iptr(cls), A, leakage, 0)
+        lib.rnn_apply_learning(g.net, rc.ADAGRAD, 0.9)
+    lib.rnn_amd_synchronize()
+    rate = n_warm * S / (time.perf_counter() - t0)
+    print("configs[3] multi-head step, %d streams: %.0f stream-timesteps/s (host uploads per step included)"
+          % (S, rate))
+    snap = g.snapshot()
+    o = sc.OracleSet(**kw)
+    _sync_oracle_to(o, snap)
+    hot, nxt, cls = draw()
+    g.stats(clear=True)
+    lib.rnn_amd_set_multi_step_deltas(g.handle, rc.iptr(hot), rc.iptr(nxt), rc.iptr(cls), A, leakage, 0)
+    lib.rnn_apply_learning(g.net, rc.ADAGRAD, 0.9)
+    ranges = (C.c_int * (2 * (NC + 1)))()
+    for j in range(S):
+        o.orc.orc_advance(o.z, j)
+        o.orc.orc_multi_softmax_error(o.z, j, int(hot[j]), int(nxt[j]), int(cls[j]), A, leakage, ranges)
+        o.orc.orc_calc_deltas(o.z, j, 1 if j else 0, ranges)
+    o.orc.orc_apply_learning(o.z, rc.ADAGRAD, 0.9)
+    sg, so = g.snapshot(), o.snapshot()
+    assert g.stats().bptt_depth_sum == float(so["bptt_depth"].sum()) and so["bptt_depth"].mean() > D / 2
+    assert np.array_equal(sg["hidden"] != 0, so["hidden"] != 0)
+    trained = (np.abs(so["o_error"])[:, :A * NC].reshape(S, NC, A).sum(axis=2) > 0).sum(axis=1)
+    assert trained.min() >= 1 and trained.max() > 1  # the leakage trained foreign heads too
+    replay.check(sg, so, RTOL, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "ih_m", "ho_m", "hidden", "output",
+                                     "o_error", "hist", "min_error_factor", "ih_scale"],
+                 exact=("index", "generation", "rng"))
+    g.close()
+    o.close()
+
+
+@pytest.mark.parametrize("method,batch,leakage,noise", [(rc.ADAGRAD, 5, 0.3, 0.0), (rc.WEIGHTED, 1, 0.0, 0.0),
+                                                        (rc.NESTEROV, 7, 0.8, 0.02)])
+def test_multitext_trainer_loop_matches_oracle(amd, method, batch, leakage, noise):
+    """rnn_char_multitext_train + rnn_char_multi_cross_entropy + rnn_char_multitext_spin with
+    the reference's signatures (charmodel.h:242-257) on one net of 3 heads, two texts of
+    different classes, against the oracle's restatement of text_train (temporal batching,
+    apply between loss and deltas, the net's own momentum)."""
+    lib = amd
+    A, NC, D = 12, 3, 6
+    kw = dict(input_size=A, hidden_size=40, output_size=A * NC, S=1, D=D, learn_rate=3e-3, seed=71,
+              activation=rc.RESQRT, noise=noise, momentum=0.9)
+    g = sc.ApiSet(lib, **kw)
+    o = sc.OracleSet(**kw)
+    if method == rc.ADAGRAD:
+        lib.rnn_set_momentum_values(g.net, 0.5)
+        a = o.arrays()
+        a["ih_m"][:] = 0.5
+        a["ho_m"][:] = 0.5
+    rs = np.random.default_rng(5)
+    report = rc.CharProgressReport()
+    for cls, n in ((1, 120), (2, 77), (0, 2)):
+        text = np.ascontiguousarray(rs.integers(0, A, n).astype(np.uint8))
+        lib.rnn_char_multitext_train(g.net, rc.u8ptr(text), n, A, cls, leakage, C.byref(report), None, method,
+                                     0.123, batch, None, None, None, 0)
+        e, h = C.c_float(0), C.c_float(0)
+        o.orc.orc_multitext_train(o.z, 0, rc.u8ptr(text), n, A, cls, leakage, method, 0.9, batch, C.byref(e),
+                                  C.byref(h))
+        assert abs(report.training_error - e.value / (n - 1)) <= 1e-4 * abs(e.value / (n - 1)) + 1e-7
+        assert abs(report.training_entropy + h.value / (n - 1)) <= 1e-4 * abs(h.value / (n - 1)) + 1e-7
+        assert report.per_second > 0
+    sg, so = g.snapshot(), o.snapshot()
+    replay.check(sg, so, RTOL, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "hist",
+                                     "min_error_factor"], exact=("index", "generation", "rng"))
+    # spin: advance + opinion only
+    text = np.ascontiguousarray(rs.integers(0, A, 9).astype(np.uint8))
+    lib.rnn_char_multitext_spin(g.net, rc.u8ptr(text), 9, None, None, None, 0)
+    for i in range(9):
+        o.orc.orc_advance(o.z, 0)
+        o.orc.orc_one_hot_opinion(o.z, 0, int(text[i]), noise)
+    # per-head cross entropy of a third text
+    text = np.ascontiguousarray(rs.integers(0, A, 60).astype(np.uint8))
+    ent_g = (C.c_double * NC)(*([0.0] * NC))
+    ent_o = (C.c_double * NC)(*([0.0] * NC))
+    lib.rnn_char_multi_cross_entropy(g.net, rc.u8ptr(text), 60, A, ent_g, 7)
+    o.orc.orc_multi_cross_entropy(o.z, 0, rc.u8ptr(text), 60, A, ent_o, 7)
+    for j in range(NC):
+        assert abs(ent_g[j] - ent_o[j]) <= 1e-4 * abs(ent_o[j]), (j, ent_g[j], ent_o[j])
+        assert 1.0 < ent_o[j] < 8.0
+    sg, so = g.snapshot(), o.snapshot()
+    replay.check(sg, so, RTOL, keys=["hidden", "output", "hist"], exact=("index", "generation", "rng"))
+    g.close()
+    o.close()
+
+
+def test_multi_confab_object_and_line(amd):
+    """rnn_char_new_multi_confab / the confabulation line text_train prints when the text
+    length hits the period (charmodel-multi-predict.c:74-119, 145-230, 268-280)."""
+    lib = amd
+    A, NC = 12, 3
+    g = sc.ApiSet(lib, input_size=A, hidden_size=24, output_size=A * NC, S=1, D=4, learn_rate=1e-3, seed=9)
+    alpha = lib.rnn_char_new_alphabet()
+    lib.rnn_char_alphabet_set_flags(alpha, False, False, False)
+    for i, ch in enumerate(b"abcdefghijk^"):
+        alpha.contents.points[i] = ch
+    alpha.contents.len = A
+    mc = lib.rnn_char_new_multi_confab(g.net, alpha, NC, 40, 10, ord("^"))
+    assert mc and mc.contents.n_classes == NC and mc.contents.char_len == 40 // NC - 1
+    assert mc.contents.byte_len == mc.contents.char_len * 6 + 1 and mc.contents.period == 10
+    assert not lib.rnn_char_new_multi_confab(g.net, alpha, NC, 3, 10, -1)  # no room
+    mc.contents.bias = 0.0
+    text = np.ascontiguousarray((np.arange(11) % A).astype(np.uint8))  # len - 1 == 10: the period
+    lib.rnn_char_multitext_train(g.net, rc.u8ptr(text), 11, A, 1, 0.0, None, mc, rc.WEIGHTED, 0.9, 4, None,
+                                 None, None, 0)
+    strings = [mc.contents.strings[i] for i in range(NC)]
+    assert all(len(s) == mc.contents.char_len for s in strings)  # one byte per char, caps markers dropped
+    assert all(set(s) <= set(b"abcdefghijkABCDEFGHIJK") for s in strings)
+    lib.rnn_char_free_multi_confab(mc)
+    lib.rnn_char_free_alphabet(alpha)
+    g.close()
+
+
+# ------------------------------------------------------------------ configs[4] --
+
+def _rnnca_inputs(rs, S):
+    """35 inputs per cell: 17 luma + 16 chroma neighbours as BYTE_TO_UNIT bytes, 2 position
+    values (gstrnnca.c:668-690)"""
+    x = (rs.integers(0, 256, (S, 35)) / np.float32(255.0)).astype(np.float32)
+    x[:, 33:] = rs.random((S, 2)).astype(np.float32)
+    return np.ascontiguousarray(x)
+
+
+@pytest.mark.parametrize("hidden,S,D", [(2048, 512, 10), (64, 20, 4)])
+def test_config4_rnnca_training_generation(amd, hidden, S, D):
+    """rnnca's maybe_learn (gstrnnca.c:693-740) for every trainer at once: clear deltas, dense
+    35-input opinion, sigmoid-slope MSE against the next frame's Y/Cb/Cr ON THE DEVICE,
+    accumulating calc_deltas, weighted-momentum update with the soft start.  The reference's
+    trainer never advances the ring (effective depth 1); the synthetic driver adds
+    rnn_bptt_advance so that depth 10 is exercised."""
+    lib = amd
+    kw = dict(input_size=35, hidden_size=hidden, output_size=3, S=S, D=D, learn_rate=1e-5 if hidden > 1000 else 1e-3,
+              seed=81, momentum=0.95)
+    g = sc.AmdBatchedSet(lib, **kw)
+    rs = np.random.default_rng(11)
+
+    def generation(gpu, orc_set, x, tgt, gen):
+        m = lib.rnn_calculate_momentum_soft_start(float(gen), 0.95, 2000.0)
+        if gpu is not None:
+            lib.rnn_bptt_clear_deltas(gpu.net)
+            lib.rnn_amd_set_advance(gpu.handle)
+            lib.rnn_amd_set_opinion(gpu.handle, rc.fptr(x), 35, None)
+            lib.rnn_amd_set_sigmoid_mse_error(gpu.handle, rc.fptr(tgt), 3, 3)
+            lib.rnn_amd_set_calc_deltas(gpu.handle, 1, None, None)
+            lib.rnn_apply_learning(gpu.net, rc.WEIGHTED, m)
+        if orc_set is not None:
+            oo = orc_set
+            oo.orc.orc_clear_deltas(oo.z)
+            for j in range(S):
+                oo.orc.orc_advance(oo.z, j)
+                oo.orc.orc_opinion(oo.z, j, rc.fptr(np.ascontiguousarray(x[j])), 0.0)
+                oo.orc.orc_sigmoid_mse_error(oo.z, j, rc.fptr(np.ascontiguousarray(tgt[j])), 3)
+                oo.orc.orc_calc_deltas(oo.z, j, 1, None)
+            oo.orc.orc_apply_learning(oo.z, rc.WEIGHTED, m)
+
+    n_warm = D + 2
+    t0 = time.perf_counter()
+    for gen in range(n_warm):
+        generation(g, None, _rnnca_inputs(rs, S), (rs.integers(0, 256, (S, 3)) / np.float32(255)).astype(np.float32),
+                   gen)
+    lib.rnn_amd_synchronize()
+    print("configs[4] rnnca training generation, hidden %d, %d cells: %.0f cell-timesteps/s"
+          % (hidden, S, n_warm * S / (time.perf_counter() - t0)))
+    snap = g.snapshot()
+    o = sc.OracleSet(**kw)
+    _sync_oracle_to(o, snap)
+    x = _rnnca_inputs(rs, S)
+    tgt = np.ascontiguousarray((rs.integers(0, 256, (S, 3)) / np.float32(255)).astype(np.float32))
+    generation(g, o, x, tgt, n_warm)
+    sg, so = g.snapshot(), o.snapshot()
+    assert np.array_equal(sg["hidden"] != 0, so["hidden"] != 0)
+    assert np.abs(so["o_error"][:, :3]).max() > 0 and (so["o_error"][:, 3:] == 0).all()
+    assert (so["output"][:, :3] > 0).all() and (so["output"][:, :3] < 1).all()  # the sigmoid landed in place
+    replay.check(sg, so, RTOL, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "ih_m", "ho_m", "hidden", "output",
+                                     "o_error", "hist", "min_error_factor", "ih_scale"],
+                 exact=("index", "generation"))
+    g.close()
+    o.close()
+
+
+def test_config4_rnnca_frame_fill_13824_cells(amd):
+    """fill_frame (gstrnnca.c:805-831): one forward-only clone per pixel of the 144 x 96 frame
+    (gstrnnca.h:14-15), 35 dense inputs each, fast_sigmoid on the three outputs -- as ONE
+    batched call per frame at hidden 2048; checked against the oracle on a sample of cells
+    and timed."""
+    lib = amd
+    W, Hh, hidden = 144, 96, 2048
+    F = W * Hh
+    net = lib.rnn_new(35, hidden, 3, rc.FLAG_OWN_WEIGHTS, 91, None, 0, 0.0, 0.0, 0.0, rc.RELU)
+    lib.rnn_randomise_weights_auto(net)
+    fl = net.contents.flags & ~(rc.FLAG_OWN_WEIGHTS | rc.FLAG_OWN_BPTT)
+    cells = (rc.NetP * F)()
+    for k in range(F):
+        cells[k] = lib.rnn_clone(net, fl, rc.SUBSEED, None)
+    handle = lib.rnn_amd_set_open(cells, F)
+    assert handle
+    O = net.contents.o_size
+    rs = np.random.default_rng(13)
+    out = np.zeros((F, O), np.float32)
+    frames = 4
+    xs = [_rnnca_inputs(rs, F) for _ in range(frames)]
+    lib.rnn_amd_set_opinion(handle, rc.fptr(xs[0]), 35, None)  # first touch: allocation, uploads
+    lib.rnn_amd_set_sigmoid_outputs(handle, 3, rc.fptr(out))
+    first = out.copy()
+    t0 = time.perf_counter()
+    for f in range(1, frames):
+        lib.rnn_amd_set_opinion(handle, rc.fptr(xs[f]), 35, None)
+        lib.rnn_amd_set_sigmoid_outputs(handle, 3, rc.fptr(out))
+    dt = (time.perf_counter() - t0) / (frames - 1)
+    print("configs[4] rnnca frame fill: %d cells at hidden %d in %.2f ms = %.0f frames/s (inputs uploaded and "
+          "answers downloaded every frame)" % (F, hidden, dt * 1e3, 1.0 / dt))
+    # the oracle on a sample of cells through all the frames (the state is recurrent)
+    sample = [0, 1, 143, 144, 7000, F - 1]
+    kw = dict(input_size=35, hidden_size=hidden, output_size=3, S=len(sample), D=1, learn_rate=0.0, seed=91)
+    o = sc.OracleSet(**kw)
+    a = o.arrays()
+    lib.rnn_amd_sync_host(net, rc.RNN_AMD_WEIGHTS)
+    a["ih_w"][:] = rc.view(net.contents.ih_weights, o.I, o.H)
+    a["ho_w"][:] = rc.view(net.contents.ho_weights, o.H, o.O)
+    for f in range(frames):
+        for q, k in enumerate(sample):
+            o.orc.orc_opinion(o.z, q, rc.fptr(np.ascontiguousarray(xs[f][k])), 0.0)
+            ans = a["output"][q]
+            for i in range(3):
+                ans[i] = o.orc.orc_fast_sigmoid(float(ans[i]))
+        if f == 0:
+            assert rc.rel_err(first[sample, :3], a["output"][:, :3]) < RTOL
+    assert rc.rel_err(out[sample, :3], a["output"][:, :3]) < RTOL
+    assert rc.max_err(out[sample, :3], a["output"][:, :3]) < RTOL
+    assert (out[:, :3] > 0).all() and (out[:, :3] < 1).all()
+    hid = np.zeros(o.H, np.float32)
+    lib.rnn_amd_sync_host(cells[7000], rc.RNN_AMD_STREAM)
+    hid[:] = rc.view(cells[7000].contents.hidden_layer, o.H)
+    assert rc.rel_err(hid, a["hidden"][4]) < RTOL
+    lib.rnn_amd_set_close(handle)
+    for k in range(F):
+        lib.rnn_delete_net(cells[k])
+    lib.rnn_delete_net(net)
+    o.close()

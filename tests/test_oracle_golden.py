@@ -109,3 +109,13 @@ def test_fused_single_net_path(name, batch):
 
 def test_sparse_error_ranges():
     replay.check(replay.sparse_oracle(), replay.golden_case("sparse"), RTOL)
+
+
+def test_fast_sigmoid_matches_reference():
+    """badmaths.h:31-36 through oracle/ref_shim.c (tests/golden/ref_cold.npz): what
+    orc_sigmoid_mse_error, the restatement of rnnca's loss (gstrnnca.c:701-714), is made of."""
+    import os
+    z = np.load(os.path.join(rc.ROOT, "tests", "golden", "ref_cold.npz"))
+    orc = rc.load_oracle()
+    got = np.array([orc.orc_fast_sigmoid(float(x)) for x in z["shim.fast_sigmoid_x"]], dtype=np.float32)
+    assert np.array_equal(got, z["shim.fast_sigmoid_y"])
