@@ -33,7 +33,8 @@ def amd():
     return lib
 
 
-def _sync_oracle_to(o, snap, keys=("ih_w", "ho_w", "ih_m", "ho_m", "hist", "hidden", "index", "min_error_factor")):
+def _sync_oracle_to(o, snap, g=None,
+                    keys=("ih_w", "ho_w", "ih_m", "ho_m", "hist", "hidden", "index", "min_error_factor")):
     a = o.arrays()
     for k in keys:
         a[k][:] = snap[k]
@@ -41,6 +42,22 @@ def _sync_oracle_to(o, snap, keys=("ih_w", "ho_w", "ih_m", "ho_m", "hist", "hidd
     for j in range(o.S):
         r = o.z.contents.rng[j]
         r.a, r.b, r.c, r.d = (int(x) for x in snap["rng"][j])
+        if g is not None:
+            # the sparse top path reads last generation's h_error where a hidden node is off
+            # (recur-nn.c:175-193): the error images are state too
+            b = g.nets[j].contents.bptt.contents
+            a["err_a"][j] = rc.view(b.h_error, o.I)
+            a["err_b"][j] = rc.view(b.i_error, o.I)
+
+
+def _same_mask(got, want, allowed=4):
+    """the zero pattern of the hidden rows (the reference's zero-row skip keys on it): equal,
+    except that a pre-activation within rounding of zero may land on either side in a
+    different summation order -- at most a handful among a million, each of them tiny"""
+    diff = (got != 0) != (want != 0)
+    assert diff.sum() <= allowed, "%d hidden values differ in being zero" % diff.sum()
+    if diff.any():
+        assert max(np.abs(got[diff]).max(), np.abs(want[diff]).max()) < 1e-5
 
 
 # ------------------------------------------------------------------ configs[3] --
@@ -75,7 +92,7 @@ def test_config3_multi_head_generation_at_size(amd, S):
           % (S, rate))
     snap = g.snapshot()
     o = sc.OracleSet(**kw)
-    _sync_oracle_to(o, snap)
+    _sync_oracle_to(o, snap, g)
     hot, nxt, cls = draw()
     g.stats(clear=True)
     lib.rnn_amd_set_multi_step_deltas(g.handle, rc.iptr(hot), rc.iptr(nxt), rc.iptr(cls), A, leakage, 0)
@@ -87,8 +104,9 @@ def test_config3_multi_head_generation_at_size(amd, S):
         o.orc.orc_calc_deltas(o.z, j, 1 if j else 0, ranges)
     o.orc.orc_apply_learning(o.z, rc.ADAGRAD, 0.9)
     sg, so = g.snapshot(), o.snapshot()
-    assert g.stats().bptt_depth_sum == float(so["bptt_depth"].sum()) and so["bptt_depth"].mean() > D / 2
-    assert np.array_equal(sg["hidden"] != 0, so["hidden"] != 0)
+    # (the adaptive min_error_factor steers the executed depth towards D / 2, recur-nn.c:399-413)
+    assert g.stats().bptt_depth_sum == float(so["bptt_depth"].sum()) and so["bptt_depth"].mean() >= D / 4
+    _same_mask(sg["hidden"], so["hidden"])
     trained = (np.abs(so["o_error"])[:, :A * NC].reshape(S, NC, A).sum(axis=2) > 0).sum(axis=1)
     assert trained.min() >= 1 and trained.max() > 1  # the leakage trained foreign heads too
     replay.check(sg, so, RTOL, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "ih_m", "ho_m", "hidden", "output",
@@ -236,7 +254,7 @@ def test_config4_rnnca_training_generation(amd, hidden, S, D):
     tgt = np.ascontiguousarray((rs.integers(0, 256, (S, 3)) / np.float32(255)).astype(np.float32))
     generation(g, o, x, tgt, n_warm)
     sg, so = g.snapshot(), o.snapshot()
-    assert np.array_equal(sg["hidden"] != 0, so["hidden"] != 0)
+    _same_mask(sg["hidden"], so["hidden"])
     assert np.abs(so["o_error"][:, :3]).max() > 0 and (so["o_error"][:, 3:] == 0).all()
     assert (so["output"][:, :3] > 0).all() and (so["output"][:, :3] < 1).all()  # the sigmoid landed in place
     replay.check(sg, so, RTOL, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "ih_m", "ho_m", "hidden", "output",
