@@ -1823,6 +1823,314 @@ __global__ __launch_bounds__(512) void k_chain_main(const View *__restrict__ vp,
     v.b.esum_part[((size_t)t * (tn + 1) + nt) * s.Scap + row0 + r] = sq;
 }
 
+// ------------------------------------------------ BPTT chain, one launch --
+//
+// All D steps of the chain in ONE launch (hidden 1024: 32 column tiles; up to 8 row tiles of
+// 32 streams).  What a kernel boundary costs the launch-per-step form -- 1.5 us of boundary,
+// 1.7 us until the first operand stage has landed from a cold L2, the W panel fetched again
+// every step -- is most of its 8.9 us; here the 32 workgroups that work on one row tile all
+// run on ONE XCD (each reads the XCD it runs on from HW_REG_XCC_ID and draws its column tile
+// by a ticket on that XCD: with one workgroup per CU and 32 CUs per XCD every XCD gets exactly
+// 32, whatever the dispatch order), so that a step's output rows travel producer -> consumer
+// through that XCD's L2 (plain stores, drained; a plain flag word per producer wave; L1-
+// bypassing `sc1` polls and LDS-DMA loads), and each row tile is split into two independent
+// sub-chains of 16 streams whose steps ALTERNATE on the matrix pipe: while the 32 workgroups
+// exchange sub-chain a's step t, they multiply sub-chain b's.  (A row tile's recurrences are
+// independent per stream: E[t+1][s] = mask[t][s] . (E[t][s] W^T), recur-nn.c:338-376.)
+//
+// Workgroup = 8 waves.  Waves 4-7 (one per SIMD) only multiply: the workgroup's W panel
+// (32 output columns x 1024 k) lives in their registers for the whole launch as MFMA B
+// fragments (v_mfma_f32_16x16x4_f32; each wave a quarter of K: 128 VGPRs), the A operand --
+// 16 error rows x 1024 k per sub-chain, 64 KB -- is read from LDS with conflict-free
+// ds_read_b128 (16-byte chunk c of row m sits at position c ^ m).  Waves 0-3 do everything
+// else for four of the 16 rows each: finish the previous half-step (sum the four K quarters
+// from LDS, zero-row mask, RESQRT derivative, sum of squares, store the rows), publish, poll
+// the 32 producers of their rows, and pull the next operand into LDS by LDS-DMA.  One
+// s_barrier per half-step couples the two groups.  Every poll is bounded; a time-out or a
+// surplus ticket raises the abort word (host-mapped), which the library checks at its next
+// synchronisation and aborts on -- results are never silently wrong.
+constexpr int PC_SUB = 16;                  /* streams per sub-chain                */
+constexpr int PC_K = 1024;                  /* hidden size this kernel is built for */
+constexpr int PC_BUF_FLOATS = PC_SUB * PC_K; /* one sub-chain's operand: 64 KB       */
+constexpr int PC_RED_FLOATS = 4 * PC_SUB * 32;
+constexpr int PC_LDS_BYTES = (2 * PC_BUF_FLOATS + 2 * PC_RED_FLOATS) * 4 + 64;
+#ifndef PC_SLEEP0
+#define PC_SLEEP0 56
+#define PC_SLEEP1 8
+#endif
+constexpr unsigned PC_EPOCH = 64;           /* flag values per launch (depth <= 60)  */
+
+// one LDS-DMA piece (64 lanes x 16 bytes, L1 bypassed) with a wave-uniform global base, a
+// per-lane byte offset and a wave-uniform LDS destination: no vector-ALU instruction at all
+// (the builtin form computes a 64-bit per-lane address first)
+__device__ __forceinline__ void lds_dma16_sc1(const void *sbase, unsigned voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+
+struct ChainSync {
+  unsigned tickets[8];       /* per XCD, monotonic over launches                     */
+  unsigned pad0[24];
+  unsigned flags[8][2][4][32]; /* [XCD][sub-chain][loader wave][column tile]           */
+  unsigned abort;            /* raised by any workgroup that gives up                */
+};
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+#ifdef PC_STAMPS /* development builds only (tools/mkabl.sh -DPC_STAMPS): where a half-step's time goes */
+__device__ unsigned long long g_pc_stamps[2][64][8];
+#define PC_STAMP(role, k, slot)                                                                    \
+  do {                                                                                             \
+    if (g == 0 && j == 0 && lane == 0 && (wave8 & 3) == 0 && (k) < 64)                             \
+      g_pc_stamps[role][k][slot] = __builtin_amdgcn_s_memrealtime();                               \
+  } while (0)
+#else
+#define PC_STAMP(role, k, slot) do { } while (0)
+#endif
+
+template <int ACT> /* rnn_activation */
+__global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ vp, int uniform_idx,
+                                                       int row0, int nrows, int depth, unsigned seq,
+                                                       ChainSync *sy, unsigned *host_abort) {
+  extern __shared__ __attribute__((aligned(16))) float psm[];
+  float *abuf = psm;                          /* [2][16][1024], swizzled chunks        */
+  float *red = psm + 2 * PC_BUF_FLOATS;       /* [2][4 waves][16 rows][32 cols]        */
+  unsigned *wg_info = reinterpret_cast<unsigned *>(red + 2 * PC_RED_FLOATS);
+  View v = *vp;
+  v.b.uniform_idx = uniform_idx;
+  const RamdShape &s = v.sh;
+  const int wave8 = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int mtiles = (nrows + 31) / 32;
+
+  // --- which XCD am I on, and which of its 32 seats do I get
+  if (threadIdx.x == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; /* HW_REG_XCC_ID */
+    const unsigned t = __hip_atomic_fetch_add(&sy->tickets[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                       (seq - 1u) * 32u;
+    wg_info[0] = xcc;
+    wg_info[1] = t;
+  }
+  __syncthreads();
+  const int g = (int)wg_info[0];
+  const unsigned seat = wg_info[1];
+  if (seat >= 32u) { /* cannot happen with one workgroup per CU on a 256-CU part */
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(host_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  if (g >= mtiles) return; /* fewer than 8 row tiles: this XCD has nothing to do */
+  const int j = (int)seat;
+  const int m0 = 32 * g, n0 = 1 + 32 * j;     /* output columns start at 1 */
+  const unsigned epoch0 = seq * PC_EPOCH;
+  const int halfsteps = 2 * depth;
+  const int tn = s.hidden_size / 32;
+  const size_t plane_stride = (size_t)s.Scap * s.I;
+
+  if (wave8 >= 4) {
+    // ============================================ multiply, finish, publish
+    // Waves 4-7, one per SIMD.  Wave wv multiplies the K quarter wv of BOTH 16 x 16 tiles of
+    // every half-step and, after the barrier, finishes rows 4 wv .. 4 wv + 3 of the tile
+    // pair: the four K quarters summed from LDS, the zero-row mask, the RESQRT derivative,
+    // the sum of squares, the store, and -- once the stores have drained, a few MFMAs into
+    // the next half-step -- the flag that the 32 consumers of those rows poll.  (The f32
+    // MFMA runs on the SIMD's vector ALU at the vector rate: a partner wave's VALU work does
+    // not overlap with it, so the epilogue belongs in the wave that owns the ALU.)
+    const int wv = __builtin_amdgcn_readfirstlane(wave8) - 4, m = lane & 15, kq = lane >> 4;
+    const int col = lane & 31, rh = lane >> 5;
+    float wreg[16][4][2];
+    {
+      const float *wb = v.b.ih_w + (size_t)(n0 + m) * s.H + 1 + 256 * wv + 4 * kq;
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) wreg[u][i][h] = wb[(size_t)16 * h * s.H + 16 * u + i];
+    }
+    // this thread's two outputs per half-step: rows 4 wv + rh and + 2 of the sub-chain, column
+    // n0 + col; per sub-chain x the global row, whether it exists, where its gate values and
+    // its outputs live (step 0 / plane 1; both move by a fixed stride per step)
+    int srow[2][2];
+    bool live[2][2];
+    const float *gate_p[2][2];
+    float *out_p[2][2];
+    float *esum_p[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int r = m0 + PC_SUB * x + 4 * wv + rh + 2 * q;
+        live[x][q] = r < nrows;
+        srow[x][q] = live[x][q] ? r : nrows - 1;
+        out_p[x][q] = v.b.ehi + plane_stride + (size_t)(row0 + srow[x][q]) * s.I + n0 + col;
+        esum_p[x][q] = v.b.esum_part + (size_t)j * s.Scap + row0 + srow[x][q];
+      }
+    auto gates = [&](int k, float (&xg)[2]) { /* X[t][row][n0 + col], t = k >> 1 */
+      const int x = k & 1, t = k >> 1;
+#pragma unroll
+      for (int q = 0; q < 2; q++) xg[q] = input_row<true>(v, row0 + srow[x][q], t)[n0 + col];
+    };
+    float xg[2] = {0.f, 0.f};
+    __syncthreads(); /* barrier 0: both operands of the first two half-steps have landed */
+    for (int k = 0; k <= halfsteps; k++) {
+      const int x = k & 1;
+      PC_STAMP(0, k, 0);
+      if (k >= 1) {
+        // ---- finish half-step k - 1 (sub-chain x ^ 1, step (k - 1) >> 1)
+        const int xf = x ^ 1, t = (k - 1) >> 1;
+        const float *rd = red + xf * PC_RED_FLOATS;
+        float sq[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int r = 4 * wv + rh + 2 * q;
+          const float p0 = rd[(0 * PC_SUB + r) * 32 + col], p1 = rd[(1 * PC_SUB + r) * 32 + col];
+          const float p2 = rd[(2 * PC_SUB + r) * 32 + col], p3 = rd[(3 * PC_SUB + r) * 32 + col];
+          float ev = (p0 + p1) + (p2 + p3);
+          const float xi = xg[q];
+          const bool on = xi != 0.0f && (ACT != 5 || xi < 20.0f);
+          ev = on ? ev : 0.0f;
+          if (on && ACT == 2) ev /= 2 * (xi + 1.0f);
+          if (live[xf][q]) out_p[xf][q][(size_t)t * plane_stride] = ev;
+          sq[q] = ev * ev;
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+          sq[0] += __shfl_xor(sq[0], off, 64);
+          sq[1] += __shfl_xor(sq[1], off, 64);
+        }
+        if (col == 0) {
+#pragma unroll
+          for (int q = 0; q < 2; q++)
+            if (live[xf][q]) esum_p[xf][q][(size_t)t * (tn + 1) * s.Scap] = sq[q];
+        }
+        PC_STAMP(0, k, 2);
+        /* drain and publish BEFORE the next MFMAs: stores issued under a back-to-back MFMA
+         * stream take microseconds to be acknowledged (measured: 1.2-3.8 us against 0.12 us
+         * with the vector ALU idle), and the 32 consumers of these rows are waiting */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) *(volatile unsigned *)&sy->flags[g][xf][wv][j] = epoch0 + (unsigned)t + 1u;
+        PC_STAMP(0, k, 3);
+      }
+      if (k == halfsteps) { /* nothing left to multiply: drain and publish (nobody polls it) */
+        break;
+      }
+      const float *arow = abuf + x * PC_BUF_FLOATS + m * PC_K;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int c = (64 * wv + 4 * u + kq) ^ m;
+        const float4 a = *reinterpret_cast<const float4 *>(arow + 4 * c);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wreg[u][0][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wreg[u][0][1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wreg[u][1][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wreg[u][1][1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wreg[u][2][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wreg[u][2][1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wreg[u][3][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wreg[u][3][1], acc1, 0, 0, 0);
+        if (u == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          gates(k, xg); /* for the finish of THIS half-step, one barrier from now */
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      /* this wave's K quarter of the 16 x 32 tile: register r of the accumulator is row
+       * 4 (lane >> 4) + r, column lane & 15 (+ 16 for the second accumulator) */
+      float *rdw = red + x * PC_RED_FLOATS + wv * (PC_SUB * 32);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        rdw[(4 * kq + r) * 32 + m] = acc0[r];
+        rdw[(4 * kq + r) * 32 + 16 + m] = acc1[r];
+      }
+      PC_STAMP(0, k, 1);
+      __syncthreads(); /* barrier k + 1 */
+    }
+    return;
+  }
+
+  // ======================================================= poll and fetch
+  // Waves 0-3: rows 4 lw .. 4 lw + 3 of each sub-chain's operand.  Almost no vector-ALU
+  // work (one compare per poll), so the multiplying waves keep the ALU.
+  const int lw = __builtin_amdgcn_readfirstlane(wave8); /* scalar: LDS addresses stay off the vector ALU */
+  const int col = lane & 31, rh = lane >> 5;
+  gu32 *aborted = (gu32 *)&sy->abort;
+  bool dead = false;                  /* gave up: keep the barriers going, nothing else */
+
+  // fetch rows 4 lw .. + 3 of sub-chain x, error plane `plane`, into its LDS image: 16 pieces
+  // of 1 KB (lane l of piece q lands at chunk position 64 (q & 3) + l of row q >> 2 and
+  // therefore brings chunk position ^ row)
+  // Per-lane BYTE offsets within a plane are fixed for the whole launch (the same for both
+  // sub-chains: b's rows are 16 rows further on); the plane / sub-chain base is wave-uniform.
+  // A fetch is then 16 x (s_mov m0, global_load_lds saddr + voffset): no vector-ALU
+  // instruction, which beside a multiplying wave would wait for a gap in its MFMAs.
+  unsigned voff[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int r = 4 * lw + (i >> 2);
+    const int c = (64 * (i & 3) + lane) ^ r;
+    voff[i] = (unsigned)(((size_t)r * s.I + 1 + 4 * c) * sizeof(float));
+  }
+  const float *sub_base = v.b.ehi + (size_t)(row0 + m0) * s.I; /* plane 0, sub-chain a, row 0 */
+  auto fetch = [&](int x, int plane) {
+    const char *base = reinterpret_cast<const char *>(sub_base + (size_t)plane * plane_stride +
+                                                      (size_t)x * PC_SUB * s.I);
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr(abuf + x * PC_BUF_FLOATS + 4 * lw * PC_K));
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      lds_dma16_sc1(base, voff[i], dst + (uint32_t)(((i >> 2) * PC_K + 256 * (i & 3)) * sizeof(float)));
+  };
+  // wait until all 32 column tiles have published step t of sub-chain x (rows of this wave)
+  auto wait_for = [&](int x, int t) {
+    const unsigned want = epoch0 + (unsigned)t + 1u;
+    gu32 *f = (gu32 *)&sy->flags[g][x][lw][col];
+    /* the producers are finishing these rows right now and publish ~1 us after the barrier.
+     * Polling earlier or harder is not free: L1-bypassing loads from this CU delay the
+     * acknowledgement of the multiplying waves' stores, which sits on the critical path
+     * (measured over the whole chain: first poll after 8 / 24 / 48 / 56 / 100 sleep units
+     * = 207 / 166 / 136 / 135 / 165 us) */
+    __builtin_amdgcn_s_sleep(PC_SLEEP0);
+    for (unsigned spins = 0;; spins++) {
+      unsigned got = 0u;
+      if (!rh) got = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if ((spins & 63u) == 63u) got = __hip_atomic_load(aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool ok = rh ? got == 0u : (int)(got - want) >= 0;
+      if (__all(ok)) return;
+      if (__any(rh && got != 0u) || spins > (1u << 15)) { /* ~tens of ms: the group is not all there */
+        if (lane == 0) {
+          __hip_atomic_store(aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        dead = true;
+        return;
+      }
+      __builtin_amdgcn_s_sleep(PC_SLEEP1);
+    }
+  };
+
+  fetch(0, 0);
+  if (halfsteps > 1) fetch(1, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads(); /* barrier 0 */
+  for (int k = 0; k < halfsteps; k++) {
+    PC_STAMP(1, k, 0);
+    if (k >= 1 && k + 1 < halfsteps && !dead) {
+      /* half-step k + 1 continues the sub-chain of half-step k - 1, which the multiplying
+       * waves of all 32 column tiles are finishing right now */
+      wait_for((k - 1) & 1, (k - 1) >> 1);
+      PC_STAMP(1, k, 2);
+      if (!dead) fetch((k + 1) & 1, (k + 1) >> 1);
+      PC_STAMP(1, k, 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PC_STAMP(1, k, 4);
+    __syncthreads(); /* barrier k + 1 */
+  }
+}
+
 // ------------------------------------- assemble + hidden layer in one launch --
 //
 // The text step's forward pass shaped like a chain step (recur-nn.c:104-148): output tile =
@@ -3045,6 +3353,64 @@ static const View *device_view(hipStream_t st, const View &v) {
   return d_view;
 }
 
+/* ---- the one-launch chain (k_chain_persist): its device state and the abort word ---- */
+static ChainSync *g_chain_sync = nullptr;
+static unsigned *g_chain_abort_host = nullptr, *g_chain_abort_dev = nullptr;
+static unsigned g_chain_seq = 0;
+static int g_chain_cus = -1;
+
+#ifdef PC_STAMPS
+extern "C" void ramd_chain_stamps(unsigned long long *out) {
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pc_stamps), sizeof(unsigned long long) * 2 * 64 * 8));
+}
+#endif
+
+extern "C" unsigned ramd_chain_abort_word(void) {
+  return g_chain_abort_host ? *(volatile unsigned *)g_chain_abort_host : 0u;
+}
+
+static bool chain_persist_ok(const RamdShape *sh, const RamdBuffers *b, int nrows) {
+  if (b->uniform_idx < 0 || sh->hidden_size != PC_K || nrows < 32 || nrows > 256 || nrows % 32 != 0 || sh->D > 60 ||
+      !env_int("RECUR_AMD_CHAIN_PERSIST", 1))
+    return false;
+  if (g_chain_cus < 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    g_chain_cus = prop.multiProcessorCount;
+  }
+  return g_chain_cus == 256; /* 8 XCDs x 32 CUs: one workgroup per CU, 32 seats per XCD */
+}
+
+static void launch_chain_persist(hipStream_t st, const View *d_view, const RamdShape *sh,
+                                 const RamdBuffers *b, int row0, int nrows) {
+  if (!g_chain_sync) {
+    HIP_CHECK(hipMalloc(&g_chain_sync, sizeof(ChainSync)));
+    HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
+    HIP_CHECK(hipHostMalloc((void **)&g_chain_abort_host, 64, hipHostMallocMapped));
+    *g_chain_abort_host = 0;
+    HIP_CHECK(hipHostGetDevicePointer((void **)&g_chain_abort_dev, g_chain_abort_host, 0));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  PC_LDS_BYTES));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  PC_LDS_BYTES));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<5>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  PC_LDS_BYTES));
+  }
+  const unsigned seq = ++g_chain_seq;
+  int ev = timing_begin(st, T_CHAIN, 1);
+#define CHAIN_PERSIST(ACT)                                                                         \
+  RAMD_LAUNCH((k_chain_persist<ACT>), dim3(256), dim3(512), PC_LDS_BYTES, st, d_view, b->uniform_idx, \
+              row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev)
+  if (sh->activation == 2) CHAIN_PERSIST(2);
+  else if (sh->activation == 5) CHAIN_PERSIST(5);
+  else CHAIN_PERSIST(1);
+#undef CHAIN_PERSIST
+  timing_end(st, ev);
+}
+
 /* assemble + hidden layer in one launch for the text step (k_fwd_fused); returns what
  * ramd_launch_text_top wants as fwd_ks (negative: one plane of sums + per-tile padding
  * partials), or 0 when the preconditions do not hold and nothing was launched */
@@ -3295,8 +3661,10 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     /* one event pair around the D launches: the per-launch average then carries
      * 1/D of the event overhead instead of all of it */
     const View *d_view = device_view(st, v);
-    int ev = timing_begin(st, T_CHAIN, sh->D);
-    for (int t = 0; t < sh->D; t++) {
+    const bool persist = chain_persist_ok(sh, b, nrows);
+    if (persist) launch_chain_persist(st, d_view, sh, b, row0, nrows);
+    int ev = persist ? -1 : timing_begin(st, T_CHAIN, sh->D);
+    for (int t = 0; t < (persist ? 0 : sh->D); t++) {
 #define CHAIN_NS(NS)                                                                               \
   RAMD_LAUNCH((k_chain_main<true, NS>), dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx, \
                      row0, nrows, t, tm, tn, nstages)

@@ -209,6 +209,10 @@ void ramd_launch_add_at(ramd_stream_t st, float *a, size_t index, float v);
 void ramd_launch_top_apply_now(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                                int row, float rate, float momentum, float momentum_weight);
 
+/* non-zero once the one-launch BPTT chain has given up (its workgroups were not all
+ * resident, or a poll timed out): the results of that launch are not valid */
+unsigned ramd_chain_abort_word(void);
+
 /* ---- timing hooks ---- */
 void ramd_timing_enable(int enable);
 double ramd_timing_ms(int which, long *launches, int reset);

@@ -23,6 +23,7 @@
     }                                                                              \
   } while (0)
 
+static void dsync(void);
 static int g_device = -1;      /* -1: not initialised */
 static int g_device_count = -1;
 static hipStream_t g_stream = NULL;
@@ -73,7 +74,7 @@ void *rnn_amd_current_stream(void) { return (void *)g_stream; }
 const char *rnn_amd_version(void) { return "recur_amd 0.1 (gfx950, fp32 MFMA)"; }
 void rnn_amd_synchronize(void) {
   if (g_device >= 0) {
-    HIP_OK(hipStreamSynchronize(g_stream));
+    dsync();
     HIP_OK(hipDeviceSynchronize());
   }
 }
@@ -106,7 +107,16 @@ static void d2h(void *h, const void *d, size_t bytes) {
     HIP_OK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, g_stream));
   }
 }
-static void dsync(void) { HIP_OK(hipStreamSynchronize(g_stream)); }
+static void dsync(void) {
+  HIP_OK(hipStreamSynchronize(g_stream));
+  if (ramd_chain_abort_word()) {
+    fprintf(stderr, "librecur_amd: the one-launch BPTT chain gave up (code %u: its 256 workgroups were "
+                    "not all resident, one per CU, or a hand-off timed out); its results are invalid.  "
+                    "Set RECUR_AMD_CHAIN_PERSIST=0 to use the launch-per-step chain.\n",
+            ramd_chain_abort_word());
+    abort();
+  }
+}
 
 void *ramd_zalloc(size_t bytes) {
   void *p = NULL;
