@@ -247,14 +247,23 @@ def test_config4_rnnca_training_generation(amd, hidden, S, D):
     lib.rnn_amd_synchronize()
     print("configs[4] rnnca training generation, hidden %d, %d cells: %.0f cell-timesteps/s"
           % (hidden, S, n_warm * S / (time.perf_counter() - t0)))
-    snap = g.snapshot()
     o = sc.OracleSet(**kw)
-    _sync_oracle_to(o, snap)
-    x = _rnnca_inputs(rs, S)
-    tgt = np.ascontiguousarray((rs.integers(0, 256, (S, 3)) / np.float32(255)).astype(np.float32))
-    generation(g, o, x, tgt, n_warm)
-    sg, so = g.snapshot(), o.snapshot()
-    _same_mask(sg["hidden"], so["hidden"])
+    for attempt in range(4):
+        # one generation on both sides from the device's state.  Among a million hidden values
+        # one may have a pre-activation within rounding of zero; its mask then depends on the
+        # summation order and decides whether that unit's top-layer error exists at all, which
+        # shows in one column of the deltas.  Such a generation is not a parity case: go on
+        # from where the device is and take the next one.
+        _sync_oracle_to(o, g.snapshot())
+        x = _rnnca_inputs(rs, S)
+        tgt = np.ascontiguousarray((rs.integers(0, 256, (S, 3)) / np.float32(255)).astype(np.float32))
+        generation(g, o, x, tgt, n_warm + attempt)
+        sg, so = g.snapshot(), o.snapshot()
+        if np.array_equal(sg["hidden"] != 0, so["hidden"] != 0):
+            break
+        _same_mask(sg["hidden"], so["hidden"])
+    else:
+        raise AssertionError("no generation without a rounding-level mask flip in 4 attempts")
     assert np.abs(so["o_error"][:, :3]).max() > 0 and (so["o_error"][:, 3:] == 0).all()
     assert (so["output"][:, :3] > 0).all() and (so["output"][:, :3] < 1).all()  # the sigmoid landed in place
     replay.check(sg, so, RTOL, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "ih_m", "ho_m", "hidden", "output",
