@@ -1954,18 +1954,14 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     // this thread's two outputs per half-step: rows 4 wv + rh and + 2 of the sub-chain, column
     // n0 + col; per sub-chain x the global row, whether it exists, where its gate values and
     // its outputs live (step 0 / plane 1; both move by a fixed stride per step)
-    int srow[2][2];
-    bool live[2][2];
-    const float *gate_p[2][2];
+    int srow[2][2]; /* (whole row tiles only: the launcher sees to it) */
     float *out_p[2][2];
     float *esum_p[2][2];
 #pragma unroll
     for (int x = 0; x < 2; x++)
 #pragma unroll
       for (int q = 0; q < 2; q++) {
-        const int r = m0 + PC_SUB * x + 4 * wv + rh + 2 * q;
-        live[x][q] = r < nrows;
-        srow[x][q] = live[x][q] ? r : nrows - 1;
+        srow[x][q] = m0 + PC_SUB * x + 4 * wv + rh + 2 * q;
         out_p[x][q] = v.b.ehi + plane_stride + (size_t)(row0 + srow[x][q]) * s.I + n0 + col;
         esum_p[x][q] = v.b.esum_part + (size_t)j * s.Scap + row0 + srow[x][q];
       }
@@ -1994,7 +1990,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
           const bool on = xi != 0.0f && (ACT != 5 || xi < 20.0f);
           ev = on ? ev : 0.0f;
           if (on && ACT == 2) ev /= 2 * (xi + 1.0f);
-          if (live[xf][q]) out_p[xf][q][(size_t)t * plane_stride] = ev;
+          out_p[xf][q][(size_t)t * plane_stride] = ev;
           sq[q] = ev * ev;
         }
 #pragma unroll
@@ -2005,12 +2001,18 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
         if (col == 0) {
 #pragma unroll
           for (int q = 0; q < 2; q++)
-            if (live[xf][q]) esum_p[xf][q][(size_t)t * (tn + 1) * s.Scap] = sq[q];
+            esum_p[xf][q][(size_t)t * (tn + 1) * s.Scap] = sq[q];
         }
         PC_STAMP(0, k, 2);
-        /* drain and publish BEFORE the next MFMAs: stores issued under a back-to-back MFMA
-         * stream take microseconds to be acknowledged (measured: 1.2-3.8 us against 0.12 us
-         * with the vector ALU idle), and the 32 consumers of these rows are waiting */
+        /* Drain and publish BEFORE the next MFMAs, with the vector ALU idle (0.45 us).  Every
+         * way of hiding this wait under the multiply was slower: stores of this wave issued
+         * ahead of its MFMAs and waited for 8 / 16 / 48 MFMAs later (135 / 136 / 147 us per
+         * chain against 135); the finished tile handed through LDS to the fetching waves,
+         * which store, drain and publish beside the MFMAs (150-155 us: their stores are
+         * acknowledged ~2 us late), also with the multiply held back until those stores were
+         * issued (141-150); the two sub-chains on wave groups of their own with LDS counters
+         * instead of barriers (195 us: a wave issuing f32 MFMAs back to back leaves its SIMD
+         * partners neither vector-ALU issue nor timely store completion, at any s_setprio). */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) *(volatile unsigned *)&sy->flags[g][xf][wv][j] = epoch0 + (unsigned)t + 1u;
         PC_STAMP(0, k, 3);
@@ -3398,6 +3400,7 @@ static void launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
                                   PC_LDS_BYTES));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<5>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   PC_LDS_BYTES));
+
   }
   const unsigned seq = ++g_chain_seq;
   int ev = timing_begin(st, T_CHAIN, 1);
