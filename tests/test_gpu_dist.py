@@ -200,3 +200,25 @@ def test_library_exchange_step_through_rccl_with_one_rank():
     assert res.pop("rng")
     for k, (joined, after) in res.items():
         assert joined < 1e-6 and after == 0.0, (k, joined, after)
+
+
+def test_c_driver_with_G_1_goes_through_the_library_exchange_step():
+    """tools/text_predict_amd -G 1: one forked-process-per-GPU launcher in plain C, the RCCL id
+    handed over in shared memory, rnn_amd_dist_init, the shard constructor, the all-reduce
+    inside rnn_amd_set_char_step.  With one rank the curve must be the plain run's."""
+    import re
+    exe = os.path.join(rc.ROOT, "build", "text_predict_amd")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.join(rc.ROOT, "recur_amd", "csrc")], check=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rows = {}
+    for tag, extra in (("plain", []), ("G1", ["-G", "1"])):
+        r = subprocess.run([exe, "-f", rc.EREWHON, "-H", "128", "-t", "32", "-d", "8", "-l", "1e-3", "-s", "150",
+                            "-r", "50", "-V", "1200"] + extra, capture_output=True, text=True, timeout=600,
+                           cwd=rc.ROOT, env=env)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+        rows[tag] = re.findall(r"generation\s+(\d+) t_entropy ([\d.]+) v_entropy ([\d.]+) accuracy ([\d.]+)", r.stdout)
+        assert [int(x[0]) for x in rows[tag]] == [50, 100, 150]
+    for a, b in zip(rows["plain"], rows["G1"]):
+        assert abs(float(a[1]) - float(b[1])) < 2e-4 and abs(float(a[2]) - float(b[2])) < 2e-3, (a, b)

@@ -11,13 +11,22 @@
  *
  *   text_predict_amd [-f text] [-H hidden] [-t streams] [-d depth] [-l learn_rate]
  *                    [-m momentum] [-s stop_generation] [-r report_interval]
- *                    [-V validate_chars] [-S seed] [-n net_file]
+ *                    [-V validate_chars] [-S seed] [-n net_file] [-G gpus]
+ *
+ * -G n shards the t streams over n GPUs, one PROCESS per GPU (forked here before anything
+ * touches a device): rank 0 makes the RCCL id and hands it over in shared memory, every
+ * rank joins with rnn_amd_dist_init, builds its shard of the training set with
+ * rnn_amd_new_training_set_shard, and rnn_amd_set_char_step then sums the weight deltas
+ * over the ranks inside the library (one all-reduce per generation).  -G 1 takes the same
+ * path with one rank.  Reports come from rank 0 (its own streams' statistics).
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
 #include <unistd.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
 #include "recur-nn.h"
 #include "recur_amd_char.h"
 
@@ -38,11 +47,11 @@ static double cross_entropy(RecurNN *net, RnnCharAlphabet *alphabet, const u8 *t
 
 int main(int argc, char **argv) {
   const char *file = "tests/golden/erewhon.txt", *save = NULL;
-  int hidden = 199, streams = 64, depth = 30, stop = 2000, report = 200, validate = 4000;
+  int hidden = 199, streams = 64, depth = 30, stop = 2000, report = 200, validate = 4000, gpus = 0;
   float lr = 1e-4f, momentum = 0.95f;
   unsigned long long seed = 1;
   int opt;
-  while ((opt = getopt(argc, argv, "f:H:t:d:l:m:s:r:V:S:n:")) != -1) {
+  while ((opt = getopt(argc, argv, "f:H:t:d:l:m:s:r:V:S:n:G:")) != -1) {
     switch (opt) {
     case 'f': file = optarg; break;
     case 'H': hidden = atoi(optarg); break;
@@ -55,6 +64,7 @@ int main(int argc, char **argv) {
     case 'V': validate = atoi(optarg); break;
     case 'S': seed = strtoull(optarg, NULL, 10); break;
     case 'n': save = optarg; break;
+    case 'G': gpus = atoi(optarg); break;
     default:
       fprintf(stderr, "see the comment at the top of %s\n", __FILE__);
       return 2;
@@ -86,8 +96,52 @@ int main(int argc, char **argv) {
   p.flat_shape = RNN_INIT_DIST_SEMICIRCLE;
   p.flat_perforation = 0;
   rnn_randomise_weights_clever(net, &p);
-  RecurNN **nets = rnn_new_training_set(net, streams);
-  RnnAmdSet *set = rnn_amd_set_open(nets, streams);
+  /* -G: one process per GPU, started before any device call */
+  int rank = 0, world = gpus > 0 ? gpus : 1;
+  pid_t kids[64];
+  if (gpus > 0) {
+    if (gpus > 64 || streams % gpus) {
+      fprintf(stderr, "-G %d: 1 to 64 GPUs, and the %d streams must divide evenly\n", gpus, streams);
+      return 2;
+    }
+    struct {
+      volatile int ready;
+      char id[RNN_AMD_DIST_ID_BYTES];
+    } *shared = mmap(NULL, 4096, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (shared == MAP_FAILED) {
+      perror("mmap");
+      return 1;
+    }
+    shared->ready = 0;
+    fflush(NULL);
+    for (int r = 1; r < world; r++) {
+      kids[r] = fork();
+      if (kids[r] == 0) {
+        rank = r;
+        break;
+      }
+    }
+    rnn_amd_use_device(rank, NULL);
+    if (rank == 0) {
+      if (rnn_amd_dist_get_id(shared->id)) {
+        return 1;
+      }
+      __sync_synchronize();
+      shared->ready = 1;
+    } else {
+      while (!shared->ready) {
+        usleep(1000);
+      }
+      __sync_synchronize();
+    }
+    if (rnn_amd_dist_init(rank, world, shared->id)) {
+      return 1;
+    }
+    streams /= world; /* per rank from here on */
+  }
+  RecurNN **nets = gpus > 0 ? rnn_amd_new_training_set_shard(net, streams, rank * streams, world * streams)
+                            : rnn_new_training_set(net, streams);
+  RnnAmdSet *set = rnn_amd_set_open(nets, streams); /* with a group joined: this rank's shard */
   rnn_amd_set_load_text(set, text, len);
 
   struct timespec t0, t1;
@@ -95,7 +149,7 @@ int main(int argc, char **argv) {
   for (int i = 0; i < len - 1 && (int)net->generation < stop; i++) {
     float m = rnn_calculate_momentum_soft_start(net->generation, momentum, 0);
     rnn_amd_set_char_step(set, i, RNN_MOMENTUM_WEIGHTED, m);
-    if (net->generation % report == 0) {
+    if (net->generation % report == 0 && rank == 0) {
       RnnAmdStats st;
       rnn_amd_set_read_stats(set, &st, 1);
       clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -103,12 +157,12 @@ int main(int argc, char **argv) {
       double v = cross_entropy(net, alphabet, vtext, validate, 5);
       printf("generation %6u t_entropy %.4f v_entropy %.4f accuracy %.3f depth %.1f  %.0f/s\n",
              net->generation, -st.entropy / st.count, v, (double)st.correct / st.count,
-             st.bptt_depth_sum / st.count, st.count / secs);
+             st.bptt_depth_sum / st.count, world * st.count / secs);
       fflush(stdout);
       clock_gettime(CLOCK_MONOTONIC, &t0);
     }
   }
-  if (save) {
+  if (save && rank == 0) {
     /* the alphabet travels in the net's metadata (text-predict.c:486-497), which is what
      * text_cross_entropy_amd and text_confabulate_amd rebuild it from */
     struct RnnCharMetadata m = {DEFAULT_CHARSET, DEFAULT_COLLAPSE_CHARS, 0, 1, 1};
@@ -120,8 +174,25 @@ int main(int argc, char **argv) {
     printf("saved %s\n", save);
   }
   rnn_amd_set_close(set);
+  int status = 0;
+  if (gpus > 0) {
+    rnn_amd_dist_barrier();
+    rnn_amd_dist_finalize();
+    if (rank != 0) {
+      fflush(NULL);
+      _exit(0);
+    }
+    for (int r = 1; r < world; r++) {
+      int st = 0;
+      waitpid(kids[r], &st, 0);
+      if (!WIFEXITED(st) || WEXITSTATUS(st)) {
+        fprintf(stderr, "rank %d failed (status %d)\n", r, st);
+        status = 1;
+      }
+    }
+  }
   rnn_delete_training_set(nets, streams, 0);
   rnn_char_free_alphabet(alphabet);
   free(text);
-  return 0;
+  return status;
 }
