@@ -1870,6 +1870,19 @@ __device__ __forceinline__ void lds_dma16_sc1(const void *sbase, unsigned voff, 
                : "memory");
 }
 
+__device__ __forceinline__ void lds_dma16(const void *sbase, unsigned voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void *sbase, unsigned voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+
 struct ChainSync {
   unsigned tickets[8];       /* per XCD, monotonic over launches                     */
   unsigned pad0[24];
@@ -2626,26 +2639,31 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
     // ---------------------------------------------------------------- loaders
     const int w = wave8 - 4;
     // instruction i (0..31): rows 2 (i & 15), +1 of A (i < 16) or B; wave w issues i = 8 w + j
-    const int rk = lane >> 5, c4 = (lane & 31) * 4;
+    /* Every DMA is (wave-uniform base, per-lane byte offset that never changes, wave-uniform
+     * LDS address): issued as saddr + voffset by inline asm, a fetch costs the loader wave no
+     * vector-ALU instruction -- beside a wave that issues f32 MFMAs back to back (they run on
+     * the SIMD's vector ALU) such instructions wait for a gap in the MFMA stream. */
+    const int ws = __builtin_amdgcn_readfirstlane(w);
+    const unsigned voff = (unsigned)(((size_t)(lane >> 5) * s.I + (lane & 31) * 4) * sizeof(float));
+    const unsigned voff_c = (unsigned)((lane & 31) * sizeof(float));
+    const uint32_t dsm_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(dsm));
     auto issue = [&](int st) {
       const int kt = kt0 + st;
       const int t = kt / rtiles, sb = (kt - t * rtiles) * BK;
       int slot = v.b.uniform_idx - t;
       if (slot < 0) slot += s.D;
-      const float *xa = v.b.arena + ((size_t)slot * s.Scap + row0 + sb) * s.I + m0 + c4;
-      const float *eb = v.b.ehi + ((size_t)t * s.Scap + row0 + sb) * s.I + n0 + c4;
-      float *dst = dsm + (st % DD_STAGES) * DD_STAGE_FLOATS;
+      /* waves 0, 1 fetch the history rows (A), waves 2, 3 the error rows (B): rows 2 (i & 15), + 1 */
+      const float *base = ws < 2 ? v.b.arena + ((size_t)slot * s.Scap + row0 + sb) * s.I + m0
+                                 : v.b.ehi + ((size_t)t * s.Scap + row0 + sb) * s.I + n0;
+      const uint32_t dst = dsm_lds + (uint32_t)(((st % DD_STAGES) * DD_STAGE_FLOATS + (ws < 2 ? 0 : BK * 128)) * sizeof(float));
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const int i = w * 8 + j;
-        const int row = 2 * (i & 15) + rk;
-        const float *g = (i < 16 ? xa : eb) + (size_t)row * s.I;
-        float *d = dst + (i < 16 ? 0 : BK * 128) + (i & 15) * 256;
-        __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)d, 16, 0, 0);
+        const int i15 = (ws & 1) * 8 + j; /* = (w * 8 + j) & 15 */
+        lds_dma16(base + (size_t)(2 * i15) * s.I, voff, dst + (uint32_t)(i15 * 256 * sizeof(float)));
       }
-      if (w == 0) { /* the 32 coefficients of the tile: lanes 32-63 repeat them */
-        const float *g = v.b.coef + (size_t)t * s.Scap + row0 + sb + (lane & 31);
-        __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(dst + 2 * BK * 128), 4, 0, 0);
+      if (ws == 0) { /* the 32 coefficients of the tile: lanes 32-63 repeat them */
+        lds_dma4(v.b.coef + (size_t)t * s.Scap + row0 + sb, voff_c,
+                 dsm_lds + (uint32_t)(((st % DD_STAGES) * DD_STAGE_FLOATS + 2 * BK * 128) * sizeof(float)));
       }
     };
 #pragma unroll
@@ -2706,7 +2724,10 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int jj = 0; jj < 4; jj++) b[i][jj] = (cfv[jj] == 0.0f) ? 0.0f : f.e[i][jj] * cfv[jj];
+      for (int jj = 0; jj < 4; jj++) /* v_mul_legacy_f32: 0 * x is 0 for ANY x (a step past the break
+                                       * may hold inf), otherwise the IEEE product: select and
+                                       * multiply in one instruction of the MFMAs' own ALU */
+        asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(b[i][jj]) : "v"(cfv[jj]), "v"(f.e[i][jj]));
 #pragma unroll
     for (int jj = 0; jj < 4; jj++)
 #pragma unroll
@@ -2719,8 +2740,14 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
     if (g < 3) {
       rd(st, g + 1, nxt);
     } else if (st + 1 < nst) {
+#ifdef PC_STAMPS
+      if (blockIdx.x == 0 && threadIdx.x == 0 && st < 63) g_pc_stamps[0][st + 1][4] = __builtin_amdgcn_s_memrealtime();
+#endif
       __builtin_amdgcn_s_barrier(); /* stage st + 1 has landed; stage st - 1's buffer is free */
       asm volatile("" ::: "memory");
+#ifdef PC_STAMPS
+      if (blockIdx.x == 0 && threadIdx.x == 0 && st < 63) g_pc_stamps[0][st + 1][5] = __builtin_amdgcn_s_memrealtime();
+#endif
       rd(st + 1, 0, nxt);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -2728,6 +2755,9 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
     __builtin_amdgcn_sched_barrier(0);
   };
   Frag f0, f1;
+#ifdef PC_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_pc_stamps[0][0][4] = __builtin_amdgcn_s_memrealtime();
+#endif
   if (nst > 0) {
     __builtin_amdgcn_s_barrier(); /* stage 0 has landed */
     asm volatile("" ::: "memory");
@@ -2739,6 +2769,9 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
     step(st, 2, f0, f1);
     step(st, 3, f1, f0);
   }
+#ifdef PC_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_pc_stamps[0][0][6] = __builtin_amdgcn_s_memrealtime();
+#endif
   float *c = o.slab + (size_t)z * o.M * o.ldc;
 #pragma unroll
   for (int i = 0; i < 2; i++)

@@ -1,0 +1,20 @@
+import ctypes as C, os, sys
+sys.path.insert(0, "tests")
+import numpy as np
+import recur_ctypes as rc, scenarios as sc
+amd = rc.load_amd()
+text = sc.synthetic_text(30000)
+g = sc.AmdBatchedSet(amd, input_size=42, hidden_size=1024, output_size=42, S=256, D=20, learn_rate=1e-5, seed=1)
+g.load_text(text)
+for i in range(30):
+    amd.rnn_amd_set_char_step(g.handle, i, rc.WEIGHTED, 0.95)
+buf = np.zeros((2, 64, 8), np.uint64)
+amd.ramd_chain_stamps(C.c_void_p(buf.ctypes.data))
+t0 = int(buf[0, 0, 4])
+us = lambda x: (int(x) - t0) / 100.0
+print("start->first barrier release: see stage 1; end of loop at %.2f us" % us(buf[0,0,6]))
+prev = None
+for st in range(1, 41):
+    a, b = us(buf[0, st, 4]), us(buf[0, st, 5])
+    print("stage %2d: arrive %7.2f release %7.2f wait %5.2f  since prev release %5.2f" % (st, a, b, b - a, (b - prev) if prev else 0))
+    prev = b
