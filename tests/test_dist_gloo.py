@@ -1,7 +1,9 @@
 """The N > 1 path on CPU: two gloo ranks, each holding half of the streams of one
 training set (computed by the oracle), one all-reduce of ih_delta||ho_delta per
 generation, replicated update -- must equal the single-process run over all the
-streams.  The same ShardedStep drives bench.py on the GPUs with RCCL."""
+streams.  On the GPUs the same three phases run inside librecur_amd (rnn_amd_set_char_step with
+a group joined: deltas, RCCL all-reduce, update); here the arithmetic is the oracle's, the
+sharding and the clone seeding are the product's host code."""
 import ctypes as C
 import os
 import socket
@@ -21,12 +23,11 @@ def _worker(rank, world, port, S_local, steps, q):
     import torch.distributed as dist
     import recur_ctypes as rc
     import scenarios as sc
-    from recur_amd.dist import ShardedStep, shard_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     text = sc.synthetic_text(4000)
-    first, n, total = shard_range(rank, world, S_local)
+    first, n, total = rank * S_local, S_local, world * S_local  # contiguous blocks of streams per rank
     o = sc.OracleSet(input_size=42, hidden_size=45, output_size=42, S=n, D=7, learn_rate=5e-3, seed=2,
                      noise=0.03)
     o.z.contents.global_first, o.z.contents.global_count = first, total
@@ -52,8 +53,12 @@ def _worker(rank, world, port, S_local, steps, q):
         ih.reshape(-1)[:] = flat[:ih.size].numpy()
         ho.reshape(-1)[:] = flat[ih.size:].numpy()
 
-    step = ShardedStep(lambda i: o.char_step_deltas(text, i), reduce if world > 1 else None,
-                       lambda: o.orc.orc_apply_learning(o.z, rc.WEIGHTED, 0.9))
+    def step(i):  # one generation = local deltas -> all-reduce(sum) -> replicated update
+        o.char_step_deltas(text, i)
+        if world > 1:
+            reduce()
+        o.orc.orc_apply_learning(o.z, rc.WEIGHTED, 0.9)
+
     for i in range(steps):
         step(i)
     q.put((rank, a["ih_w"].copy(), a["ho_w"].copy(), a["ih_m"].copy(), a["hidden"].copy(), o.snapshot()["rng"]))
