@@ -3406,7 +3406,7 @@ extern "C" unsigned ramd_chain_abort_word(void) {
 }
 
 static bool chain_persist_ok(const RamdShape *sh, const RamdBuffers *b, int nrows) {
-  if (b->uniform_idx < 0 || sh->hidden_size != PC_K || nrows < 32 || nrows > 256 || nrows % 32 != 0 || sh->D > 60 ||
+  if (b->uniform_idx < 0 || sh->hidden_size != PC_K || nrows < 32 || nrows % 32 != 0 || sh->D > 60 ||
       !env_int("RECUR_AMD_CHAIN_PERSIST", 1))
     return false;
   if (g_chain_cus < 0) {
@@ -3698,7 +3698,9 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
      * 1/D of the event overhead instead of all of it */
     const View *d_view = device_view(st, v);
     const bool persist = chain_persist_ok(sh, b, nrows);
-    if (persist) launch_chain_persist(st, d_view, sh, b, row0, nrows);
+    if (persist) /* 8 row tiles (one per XCD) per launch; more streams: one launch per 256 */
+      for (int r = 0; r < nrows; r += 256)
+        launch_chain_persist(st, d_view, sh, b, row0 + r, nrows - r < 256 ? nrows - r : 256);
     int ev = persist ? -1 : timing_begin(st, T_CHAIN, sh->D);
     for (int t = 0; t < (persist ? 0 : sh->D); t++) {
 #define CHAIN_NS(NS)                                                                               \

@@ -275,6 +275,10 @@ def test_full_size_generation_matches_oracle(amd, full_set):
     ("configs1_text_1024_64_20", dict(input_size=42, hidden_size=1024, output_size=42, S=64, D=20)),
     ("configs2_classify_like_512_128_30", dict(input_size=42, hidden_size=512, output_size=42, S=128, D=30)),
     ("configs4_rnnca_like_2048_512_10", dict(input_size=42, hidden_size=2048, output_size=42, S=512, D=10)),
+    # more than 8 row tiles: the one-launch chain once per 256 streams
+    ("two_chain_launches_1024_512_20", dict(input_size=42, hidden_size=1024, output_size=42, S=512, D=20)),
+    # fewer than 8 row tiles: XCDs without a row tile leave at once
+    ("three_row_tiles_1024_96_12", dict(input_size=42, hidden_size=1024, output_size=42, S=96, D=12)),
 ])
 def test_baseline_config_shapes_one_generation_matches_oracle(amd, label, kw):
     """BASELINE.json's other configurations at their full hidden / stream / depth sizes:
