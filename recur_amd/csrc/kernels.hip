@@ -1850,13 +1850,14 @@ __global__ __launch_bounds__(512) void k_chain_main(const View *__restrict__ vp,
 // surplus ticket raises the abort word (host-mapped), which the library checks at its next
 // synchronisation and aborts on -- results are never silently wrong.
 constexpr int PC_SUB = 16;                  /* streams per sub-chain                */
-constexpr int PC_K = 1024;                  /* hidden size this kernel is built for */
-constexpr int PC_BUF_FLOATS = PC_SUB * PC_K; /* one sub-chain's operand: 64 KB       */
 constexpr int PC_RED_FLOATS = 4 * PC_SUB * 32;
-constexpr int PC_LDS_BYTES = (2 * PC_BUF_FLOATS + 2 * PC_RED_FLOATS) * 4 + 64;
+constexpr int pc_lds_bytes(int K) { return (2 * PC_SUB * K + 2 * PC_RED_FLOATS) * 4 + 64; }
 #ifndef PC_SLEEP0
 #define PC_SLEEP0 56
 #define PC_SLEEP1 8
+#endif
+#ifndef PC_SLEEP0_SMALL
+#define PC_SLEEP0_SMALL 36 /* hidden 512 / 256: the half-step is shorter, the publish comes at the same ~1 us */
 #endif
 constexpr unsigned PC_EPOCH = 64;           /* flag values per launch (depth <= 60)  */
 
@@ -1886,7 +1887,7 @@ __device__ __forceinline__ void lds_dma4(const void *sbase, unsigned voff, uint3
 struct ChainSync {
   unsigned tickets[8];       /* per XCD, monotonic over launches                     */
   unsigned pad0[24];
-  unsigned flags[8][2][4][32]; /* [XCD][sub-chain][loader wave][column tile]           */
+  unsigned flags[32][2][4][32]; /* [row tile][sub-chain][fetching wave][column tile]   */
   unsigned abort;            /* raised by any workgroup that gives up                */
 };
 
@@ -1903,19 +1904,23 @@ __device__ unsigned long long g_pc_stamps[2][64][8];
 #define PC_STAMP(role, k, slot) do { } while (0)
 #endif
 
-template <int ACT> /* rnn_activation */
+template <int ACT, int K> /* rnn_activation; hidden size: 1024, 512 or 256 */
 __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ vp, int uniform_idx,
                                                        int row0, int nrows, int depth, unsigned seq,
                                                        ChainSync *sy, unsigned *host_abort) {
   extern __shared__ __attribute__((aligned(16))) float psm[];
-  float *abuf = psm;                          /* [2][16][1024], swizzled chunks        */
-  float *red = psm + 2 * PC_BUF_FLOATS;       /* [2][4 waves][16 rows][32 cols]        */
+  constexpr int BUF = PC_SUB * K;             /* one sub-chain's operand (64 KB at K = 1024) */
+  constexpr int NT = K / 32;                  /* column tiles of a row tile            */
+  constexpr int KB = K / 64;                  /* 16-k blocks of a wave's K quarter     */
+  constexpr int PPR = K / 256;                /* 1 KB LDS-DMA pieces per operand row   */
+  float *abuf = psm;                          /* [2][16][K], swizzled chunks           */
+  float *red = psm + 2 * BUF;                 /* [2][4 waves][16 rows][32 cols]        */
   unsigned *wg_info = reinterpret_cast<unsigned *>(red + 2 * PC_RED_FLOATS);
   View v = *vp;
   v.b.uniform_idx = uniform_idx;
   const RamdShape &s = v.sh;
   const int wave8 = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int mtiles = (nrows + 31) / 32;
+  const int mtiles = nrows / 32;
 
   // --- which XCD am I on, and which of its 32 seats do I get
   if (threadIdx.x == 0) {
@@ -1926,8 +1931,10 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     wg_info[1] = t;
   }
   __syncthreads();
-  const int g = (int)wg_info[0];
   const unsigned seat = wg_info[1];
+  /* row tile = XCD + 8 x (seat / column tiles): the first 8 row tiles spread over the 8 XCDs
+   * before any XCD takes a second one; column tile = seat % column tiles */
+  const int g = (int)wg_info[0] + 8 * (int)(seat / NT);
   if (seat >= 32u) { /* cannot happen with one workgroup per CU on a 256-CU part */
     if (threadIdx.x == 0) {
       __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1935,12 +1942,12 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     }
     return;
   }
-  if (g >= mtiles) return; /* fewer than 8 row tiles: this XCD has nothing to do */
-  const int j = (int)seat;
+  if (g >= mtiles) return; /* fewer row tiles than seats: nothing to do here */
+  const int j = (int)(seat % NT);
   const int m0 = 32 * g, n0 = 1 + 32 * j;     /* output columns start at 1 */
   const unsigned epoch0 = seq * PC_EPOCH;
   const int halfsteps = 2 * depth;
-  const int tn = s.hidden_size / 32;
+  const int tn = NT;
   const size_t plane_stride = (size_t)s.Scap * s.I;
 
   if (wave8 >= 4) {
@@ -1954,11 +1961,11 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     // not overlap with it, so the epilogue belongs in the wave that owns the ALU.)
     const int wv = __builtin_amdgcn_readfirstlane(wave8) - 4, m = lane & 15, kq = lane >> 4;
     const int col = lane & 31, rh = lane >> 5;
-    float wreg[16][4][2];
+    float wreg[KB][4][2];
     {
-      const float *wb = v.b.ih_w + (size_t)(n0 + m) * s.H + 1 + 256 * wv + 4 * kq;
+      const float *wb = v.b.ih_w + (size_t)(n0 + m) * s.H + 1 + (K / 4) * wv + 4 * kq;
 #pragma unroll
-      for (int u = 0; u < 16; u++)
+      for (int u = 0; u < KB; u++)
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -2033,11 +2040,11 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
       if (k == halfsteps) { /* nothing left to multiply: drain and publish (nobody polls it) */
         break;
       }
-      const float *arow = abuf + x * PC_BUF_FLOATS + m * PC_K;
+      const float *arow = abuf + x * BUF + m * K;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const int c = (64 * wv + 4 * u + kq) ^ m;
+      for (int u = 0; u < KB; u++) {
+        const int c = ((K / 16) * wv + 4 * u + kq) ^ m;
         const float4 a = *reinterpret_cast<const float4 *>(arow + 4 * c);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wreg[u][0][0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wreg[u][0][1], acc1, 0, 0, 0);
@@ -2082,21 +2089,21 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   // sub-chains: b's rows are 16 rows further on); the plane / sub-chain base is wave-uniform.
   // A fetch is then 16 x (s_mov m0, global_load_lds saddr + voffset): no vector-ALU
   // instruction, which beside a multiplying wave would wait for a gap in its MFMAs.
-  unsigned voff[16];
+  unsigned voff[4 * PPR]; /* this wave's four rows, PPR pieces of 64 chunks each */
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int r = 4 * lw + (i >> 2);
-    const int c = (64 * (i & 3) + lane) ^ r;
+  for (int i = 0; i < 4 * PPR; i++) {
+    const int r = 4 * lw + i / PPR;
+    const int c = (64 * (i % PPR) + lane) ^ r;
     voff[i] = (unsigned)(((size_t)r * s.I + 1 + 4 * c) * sizeof(float));
   }
   const float *sub_base = v.b.ehi + (size_t)(row0 + m0) * s.I; /* plane 0, sub-chain a, row 0 */
   auto fetch = [&](int x, int plane) {
     const char *base = reinterpret_cast<const char *>(sub_base + (size_t)plane * plane_stride +
                                                       (size_t)x * PC_SUB * s.I);
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr(abuf + x * PC_BUF_FLOATS + 4 * lw * PC_K));
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr(abuf + x * BUF + 4 * lw * K));
 #pragma unroll
-    for (int i = 0; i < 16; i++)
-      lds_dma16_sc1(base, voff[i], dst + (uint32_t)(((i >> 2) * PC_K + 256 * (i & 3)) * sizeof(float)));
+    for (int i = 0; i < 4 * PPR; i++)
+      lds_dma16_sc1(base, voff[i], dst + (uint32_t)(((i / PPR) * K + 256 * (i % PPR)) * sizeof(float)));
   };
   // wait until all 32 column tiles have published step t of sub-chain x (rows of this wave)
   auto wait_for = [&](int x, int t) {
@@ -2107,12 +2114,12 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
      * acknowledgement of the multiplying waves' stores, which sits on the critical path
      * (measured over the whole chain: first poll after 8 / 24 / 48 / 56 / 100 sleep units
      * = 207 / 166 / 136 / 135 / 165 us) */
-    __builtin_amdgcn_s_sleep(PC_SLEEP0);
+    __builtin_amdgcn_s_sleep(K == 1024 ? PC_SLEEP0 : PC_SLEEP0_SMALL);
     for (unsigned spins = 0;; spins++) {
       unsigned got = 0u;
-      if (!rh) got = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else if ((spins & 63u) == 63u) got = __hip_atomic_load(aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool ok = rh ? got == 0u : (int)(got - want) >= 0;
+      if (!rh && col < NT) got = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (rh && (spins & 63u) == 63u) got = __hip_atomic_load(aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool ok = rh ? got == 0u : (col >= NT || (int)(got - want) >= 0); /* NT producers */
       if (__all(ok)) return;
       if (__any(rh && got != 0u) || spins > (1u << 15)) { /* ~tens of ms: the group is not all there */
         if (lane == 0) {
@@ -3406,8 +3413,9 @@ extern "C" unsigned ramd_chain_abort_word(void) {
 }
 
 static bool chain_persist_ok(const RamdShape *sh, const RamdBuffers *b, int nrows) {
-  if (b->uniform_idx < 0 || sh->hidden_size != PC_K || nrows < 32 || nrows % 32 != 0 || sh->D > 60 ||
-      !env_int("RECUR_AMD_CHAIN_PERSIST", 1))
+  const int hs = sh->hidden_size;
+  if (b->uniform_idx < 0 || (hs != 1024 && hs != 512 && hs != 256) || nrows < 32 || nrows % 32 != 0 ||
+      sh->D > 60 || !env_int("RECUR_AMD_CHAIN_PERSIST", 1))
     return false;
   if (g_chain_cus < 0) {
     int dev = 0;
@@ -3419,6 +3427,22 @@ static bool chain_persist_ok(const RamdShape *sh, const RamdBuffers *b, int nrow
   return g_chain_cus == 256; /* 8 XCDs x 32 CUs: one workgroup per CU, 32 seats per XCD */
 }
 
+template <int ACT, int K>
+static void launch_chain_persist_k(hipStream_t st, const View *d_view, const RamdShape *sh,
+                                   const RamdBuffers *b, int row0, int nrows, unsigned seq) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<ACT, K>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, pc_lds_bytes(K)));
+    attr_set = true;
+  }
+  RAMD_LAUNCH((k_chain_persist<ACT, K>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view, b->uniform_idx,
+              row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev);
+}
+
+/* rows per launch: 8 XCDs x (32 seats / column tiles) row tiles of 32 streams */
+static int chain_persist_rows(const RamdShape *sh) { return 8 * (32 / (sh->hidden_size / 32)) * 32; }
+
 static void launch_chain_persist(hipStream_t st, const View *d_view, const RamdShape *sh,
                                  const RamdBuffers *b, int row0, int nrows) {
   if (!g_chain_sync) {
@@ -3427,19 +3451,15 @@ static void launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
     HIP_CHECK(hipHostMalloc((void **)&g_chain_abort_host, 64, hipHostMallocMapped));
     *g_chain_abort_host = 0;
     HIP_CHECK(hipHostGetDevicePointer((void **)&g_chain_abort_dev, g_chain_abort_host, 0));
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  PC_LDS_BYTES));
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  PC_LDS_BYTES));
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<5>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  PC_LDS_BYTES));
-
   }
   const unsigned seq = ++g_chain_seq;
   int ev = timing_begin(st, T_CHAIN, 1);
-#define CHAIN_PERSIST(ACT)                                                                         \
-  RAMD_LAUNCH((k_chain_persist<ACT>), dim3(256), dim3(512), PC_LDS_BYTES, st, d_view, b->uniform_idx, \
-              row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev)
+#define CHAIN_PERSIST(ACT)                                                                  \
+  do {                                                                                      \
+    if (sh->hidden_size == 1024) launch_chain_persist_k<ACT, 1024>(st, d_view, sh, b, row0, nrows, seq); \
+    else if (sh->hidden_size == 512) launch_chain_persist_k<ACT, 512>(st, d_view, sh, b, row0, nrows, seq); \
+    else launch_chain_persist_k<ACT, 256>(st, d_view, sh, b, row0, nrows, seq);             \
+  } while (0)
   if (sh->activation == 2) CHAIN_PERSIST(2);
   else if (sh->activation == 5) CHAIN_PERSIST(5);
   else CHAIN_PERSIST(1);
@@ -3698,9 +3718,11 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
      * 1/D of the event overhead instead of all of it */
     const View *d_view = device_view(st, v);
     const bool persist = chain_persist_ok(sh, b, nrows);
-    if (persist) /* 8 row tiles (one per XCD) per launch; more streams: one launch per 256 */
-      for (int r = 0; r < nrows; r += 256)
-        launch_chain_persist(st, d_view, sh, b, row0 + r, nrows - r < 256 ? nrows - r : 256);
+    if (persist) { /* as many row tiles per launch as there are seats; more streams: more launches */
+      const int per = chain_persist_rows(sh);
+      for (int r = 0; r < nrows; r += per)
+        launch_chain_persist(st, d_view, sh, b, row0 + r, nrows - r < per ? nrows - r : per);
+    }
     int ev = persist ? -1 : timing_begin(st, T_CHAIN, sh->D);
     for (int t = 0; t < (persist ? 0 : sh->D); t++) {
 #define CHAIN_NS(NS)                                                                               \
