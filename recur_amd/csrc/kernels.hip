@@ -2013,6 +2013,8 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
           out_p[xf][q][(size_t)t * plane_stride] = ev;
           sq[q] = ev * ev;
         }
+        /* (xor shuffles through the LDS crossbar: measured 3.7 us per chain faster than a DPP
+         * reduction, whose ten extra vector-ALU instructions come out of this wave's MFMA time) */
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) {
           sq[0] += __shfl_xor(sq[0], off, 64);
@@ -2024,7 +2026,9 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
             esum_p[xf][q][(size_t)t * (tn + 1) * s.Scap] = sq[q];
         }
         PC_STAMP(0, k, 2);
-        /* Drain and publish BEFORE the next MFMAs, with the vector ALU idle (0.45 us).  Every
+        /* (the two sum-of-squares stores above are the wave's youngest memory operations and
+         * nobody in this launch reads them: the wait below leaves them in flight)
+         * Drain and publish BEFORE the next MFMAs, with the vector ALU idle (0.45 us).  Every
          * way of hiding this wait under the multiply was slower: stores of this wave issued
          * ahead of its MFMAs and waited for 8 / 16 / 48 MFMAs later (135 / 136 / 147 us per
          * chain against 135); the finished tile handed through LDS to the fetching waves,
@@ -2033,7 +2037,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
          * issued (141-150); the two sub-chains on wave groups of their own with LDS counters
          * instead of barriers (195 us: a wave issuing f32 MFMAs back to back leaves its SIMD
          * partners neither vector-ALU issue nor timely store completion, at any s_setprio). */
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         if (lane == 0) *(volatile unsigned *)&sy->flags[g][xf][wv][j] = epoch0 + (unsigned)t + 1u;
         PC_STAMP(0, k, 3);
       }
