@@ -205,10 +205,12 @@ __global__ __launch_bounds__(256) void k_assemble(View v, int row0, int mode,
 // one XCD's L2 (MI355X_MICROARCH.md "Workgroup dispatch"; speed only).
 
 constexpr int BM = 64, BN = 64, BK = 32, LDK = BK + 4;
+constexpr int RAMD_MAX_REST_PLANES = 64;
 
 struct GemmOut {
   float *slab;   // [KS][M][ldc]
   int M, N, ldc;
+  size_t zs;     // floats between the planes of two K slices (M * ldc unless the planes are compact)
   int nkt;       // K tiles in total
   int tm, tn, ks;
   int col0;      // first output column (tiles start here; columns below are not produced)
@@ -353,7 +355,7 @@ __device__ __forceinline__ void gemm_body(const Prob &p, const GemmOut &o, const
       __syncthreads();
     }
   }
-  float *c = o.slab + (size_t)z * o.M * o.ldc;
+  float *c = o.slab + (size_t)z * o.zs;
   const int col = n0 + wn * 32 + lm;
   if (col < o.N) {
 #pragma unroll
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(256) void k_gemm2(Prob p, GemmOut o) {
       __syncthreads();
     }
   }
-  float *c = o.slab + (size_t)z * o.M * o.ldc;
+  float *c = o.slab + (size_t)z * o.zs;
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -2783,7 +2785,7 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
 #ifdef PC_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0) g_pc_stamps[0][0][6] = __builtin_amdgcn_s_memrealtime();
 #endif
-  float *c = o.slab + (size_t)z * o.M * o.ldc;
+  float *c = o.slab + (size_t)z * o.zs;
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -2906,12 +2908,27 @@ __global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, in
 
 // ------------------------------------------------------- finalize: delta --
 
+// the sum of ks planes in plane order, eight loads in flight at a time
+__device__ __forceinline__ float4 sum_planes(const float *src, size_t stride, int ks) {
+  float4 sum = zero4();
+  for (int z0 = 0; z0 < ks; z0 += 8) {
+    float4 t[8];
+#pragma unroll
+    for (int z = 0; z < 8; z++) t[z] = ld4(src + (size_t)(z0 + z < ks ? z0 + z : z0) * stride);
+#pragma unroll
+    for (int z = 0; z < 8; z++)
+      if (z0 + z < ks) { sum.x += t[z].x; sum.y += t[z].y; sum.z += t[z].z; sum.w += t[z].w; }
+  }
+  return sum;
+}
+
 // ih_delta (+)= sum of the K slabs (recur-nn.c:735-748 folded: the per-stream
 // ih_scale already multiplies the error rows that went into the GEMM)
 __global__ __launch_bounds__(256) void k_delta_finalize(float *delta, const float *slab,
                                                         size_t n4, size_t n, int ks,
                                                         int accumulate, int H, int hidden_size,
                                                         int rows_core, int ks_rest,
+                                                        const float *rest, size_t rest_stride,
                                                         float *ho_delta, const float *ho_slab,
                                                         size_t ho_n, int ho_ks) {
   size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -2931,14 +2948,16 @@ __global__ __launch_bounds__(256) void k_delta_finalize(float *delta, const floa
     return;
   }
   if (q >= n4) return;
-  /* rows below rows_core were produced with ks K slices, the others with ks_rest */
-  if ((int)((4 * q) / (size_t)H) >= rows_core) ks = ks_rest;
-  float4 a = accumulate ? ld4(delta + 4 * q) : zero4();
-  float4 sum = zero4();
-  for (int z = 0; z < ks; z++) {
-    float4 t = ld4(slab + (size_t)z * n + 4 * q);
-    sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+  /* rows below rows_core were produced with ks K slices, the others with ks_rest (their own planes) */
+  const float *src = slab + 4 * q;
+  size_t stride = n;
+  if ((int)((4 * q) / (size_t)H) >= rows_core) {
+    ks = ks_rest;
+    src = rest + (4 * q - (size_t)rows_core * H);
+    stride = rest_stride;
   }
+  float4 a = accumulate ? ld4(delta + 4 * q) : zero4();
+  float4 sum = sum_planes(src, stride, ks);
   /* the GEMM only produced columns 1..hidden_size; the others are exactly zero */
   int c = (int)((4 * q) % (size_t)H);
   a.x += (c + 0 >= 1 && c + 0 <= hidden_size) ? sum.x : 0.0f;
@@ -2991,6 +3010,7 @@ struct ApplySegs {
   size_t n4[3];
   float rate[3];
   unsigned first[4];
+  unsigned end1; /* one past the last block of segment 1 */
   /* when pend.slab is set, segment 1's deltas have not been summed yet: the kernel does what
    * k_delta_finalize would have (non-accumulating form) and stores them as well */
   RamdPendingDelta pend;
@@ -2999,7 +3019,10 @@ template <int METHOD>
 __global__ __launch_bounds__(256) void k_apply(ApplySegs sg, float momentum, float mw,
                                                const float *rs) {
   const int g = (blockIdx.x >= sg.first[2]) ? 2 : (blockIdx.x >= sg.first[1]) ? 1 : 0;
-  size_t q = (size_t)(blockIdx.x - sg.first[g]) * 256 + threadIdx.x;
+  /* the recurrent layer's blocks run from the bottom of the matrix up: the rows that sum many
+   * planes (the rest rows, last in memory) then start first instead of forming the tail */
+  const unsigned bl = (g == 1) ? sg.end1 - 1 - blockIdx.x : blockIdx.x - sg.first[g];
+  size_t q = (size_t)bl * 256 + threadIdx.x;
   if (q >= sg.n4[g]) return;
   float *w = sg.w[g], *m = sg.m[g], *aux = sg.aux[g];
   const float *delta = sg.delta[g];
@@ -3017,11 +3040,7 @@ __global__ __launch_bounds__(256) void k_apply(ApplySegs sg, float momentum, flo
       off -= (size_t)pd.rows_core * pd.H;
       stride = pd.rest_stride;
     }
-    float4 sum = zero4();
-    for (int z = 0; z < ks; z++) {
-      float4 t = ld4(src + (size_t)z * stride + off);
-      sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
-    }
+    float4 sum = sum_planes(src + off, stride, ks);
     int c = (int)((4 * q) % (size_t)pd.H);
     Dl.x = (c + 0 >= 1 && c + 0 <= pd.hidden_size) ? sum.x : 0.0f;
     Dl.y = (c + 1 >= 1 && c + 1 <= pd.hidden_size) ? sum.y : 0.0f;
@@ -3293,6 +3312,7 @@ static GemmOut make_gemm_out(float *slab, int M, int N, int nkt, int ks, int col
   o.M = M;
   o.N = N;
   o.ldc = ldc > 0 ? ldc : N;
+  o.zs = (size_t)M * o.ldc;
   o.nkt = nkt;
   o.row0m = row0m;
   o.tm = (M - row0m + BM - 1) / BM;
@@ -3306,9 +3326,10 @@ static GemmOut make_gemm_out(float *slab, int M, int N, int nkt, int ks, int col
 
 template <bool A_KM, bool B_KM, class Prob>
 static void launch_gemm(hipStream_t st, const Prob &p, float *slab, int M, int N, int nkt, int ks,
-                        int cls, int col0 = 0, int ldc = 0, int row0m = 0) {
+                        int cls, int col0 = 0, int ldc = 0, int row0m = 0, size_t zs = 0) {
   int blocks;
   GemmOut o = make_gemm_out(slab, M, N, nkt, ks, col0, ldc, row0m, &blocks);
+  if (zs) o.zs = zs;
   int ev = timing_begin(st, cls);
   RAMD_LAUNCH((k_gemm<A_KM, B_KM, Prob>), dim3(blocks), dim3(256), 0, st, p, o);
   timing_end(st, ev);
@@ -3322,6 +3343,7 @@ static void launch_gemm2(hipStream_t st, const Prob &p, float *slab, int M, int 
   o.M = M;
   o.N = N;
   o.ldc = ldc;
+  o.zs = (size_t)M * ldc;
   o.nkt = nkt;
   o.tm = (M + BM2 - 1) / BM2;
   o.tn = (N - col0 + BN2 - 1) / BN2;
@@ -3795,6 +3817,8 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       ks = pick_ks(tm2 * tn2, nkt, "RECUR_AMD_KS_DELTA", b->slab_floats, n);
     }
     int rows_core = sh->I, ks_rest = ks;
+    float *rest_base = b->slab; /* planes of the rows from rows_core on: rest_base + z * rest_stride */
+    size_t rest_stride = n;
     if (dma) {
       /* whole 128-row tiles by LDS-DMA, one workgroup per CU; the rows above them (the
        * input rows of a text net) by the generic kernel with its own K split */
@@ -3811,6 +3835,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       o.M = sh->I;
       o.N = ncol;
       o.ldc = sh->H;
+      o.zs = n;
       o.nkt = nkt;
       o.tm = rows_core / 128;
       o.tn = sh->hidden_size / 128;
@@ -3831,13 +3856,28 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       timing_end(st, ev);
       ks_rest = 0;
       if (rows_core < sh->I) {
-        int tmr = (sh->I - rows_core + BM - 1) / BM, tnr = (ncol - 1 + BN - 1) / BN;
-        ks_rest = pick_ks(tmr * tnr, nkt, "RECUR_AMD_KS_DELTA_REST", b->slab_floats, n);
+        /* The rest rows' planes are compact ([ks_rest][I - rows_core][H], behind the core planes).
+         * This GEMM is a few rows tall and K = S * D deep; measured at the north star its time does
+         * not fall below 17 us for any K split from 16 to 48 (one workgroup per CU and ten K tiles
+         * each, or three per CU and three tiles each: 0.87 us per 64 x 64 x 32 tile step and CU
+         * either way), while every further plane costs the optimiser's sum: 16 it is. */
+        const int rest_rows = sh->I - rows_core;
+        const size_t rest_plane = (size_t)rest_rows * sh->H;
+        int tmr = (rest_rows + BM - 1) / BM, tnr = (ncol - 1 + BN - 1) / BN;
+        ks_rest = pick_ks(tmr * tnr, nkt, "RECUR_AMD_KS_DELTA_REST", (size_t)RAMD_MAX_REST_PLANES, 1);
+        if (ks_rest > RAMD_MAX_REST_PLANES) ks_rest = RAMD_MAX_REST_PLANES;
+        if (ks_rest > nkt) ks_rest = nkt;
+        while (ks_rest > 1 && (size_t)ks * n + (size_t)ks_rest * rest_plane > b->slab_floats) ks_rest--;
+        if (ks_rest < 1) ks_rest = 1;
+        rest_base = b->slab + (size_t)ks * n;
+        rest_stride = rest_plane;
         ProbDelta<true> p = {v, row0, nrows, rtiles};
         if (ho_paired) {
           int blocks_a, blocks_b;
           GemmOut oa = make_gemm_out(b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, 0, 0, 0, &blocks_a);
-          GemmOut ob = make_gemm_out(b->slab, sh->I, ncol, nkt, ks_rest, 1, sh->H, rows_core, &blocks_b);
+          GemmOut ob = make_gemm_out(rest_base - (size_t)rows_core * sh->H, sh->I, ncol, nkt, ks_rest, 1,
+                                     sh->H, rows_core, &blocks_b);
+          ob.zs = rest_stride;
           int ev2 = timing_begin(st, T_DELTA);
           RAMD_LAUNCH((k_gemm_pair<ProbHoDelta, ProbDelta<true>>), dim3(blocks_a + blocks_b),
                              dim3(256), 0, st, ho_p, oa, blocks_a, p, ob);
@@ -3850,8 +3890,8 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
                                b->ho_slab, ho_ks, accumulate, range_stride ? nullptr : ranges);
           }
         } else {
-          launch_gemm<true, true, ProbDelta<true>>(st, p, b->slab, sh->I, ncol, nkt, ks_rest, T_DELTA, 1,
-                                                   sh->H, rows_core);
+          launch_gemm<true, true, ProbDelta<true>>(st, p, rest_base - (size_t)rows_core * sh->H, sh->I, ncol,
+                                                   nkt, ks_rest, T_DELTA, 1, sh->H, rows_core, rest_stride);
         }
       }
     } else if (big && b->uniform_idx >= 0) {
@@ -3876,8 +3916,8 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       defer->hidden_size = sh->hidden_size;
       defer->rows_core = rows_core;
       defer->ks_rest = ks_rest;
-      defer->rest = b->slab + (size_t)rows_core * sh->H;
-      defer->rest_stride = n;
+      defer->rest = rest_base == b->slab ? b->slab + (size_t)rows_core * sh->H : rest_base;
+      defer->rest_stride = rest_stride;
       defer->delta_out = b->ih_delta;
       return;
     }
@@ -3885,7 +3925,8 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     const size_t ho_n = (size_t)sh->H * sh->O;
     const unsigned fin_blocks = (unsigned)((n4 + 255) / 256) + (ho_in_final ? (unsigned)((ho_n / 4 + 255) / 256) : 0u);
     RAMD_LAUNCH(k_delta_finalize, dim3(fin_blocks), dim3(256), 0, st, b->ih_delta, b->slab, n4, n, ks,
-                       accumulate, sh->H, sh->hidden_size, rows_core, ks_rest, b->ho_delta,
+                       accumulate, sh->H, sh->hidden_size, rows_core, ks_rest,
+                       rest_base == b->slab ? b->slab + (size_t)rows_core * sh->H : rest_base, rest_stride, b->ho_delta,
                        ho_in_final ? b->ho_slab : nullptr, ho_n, ho_ks);
   }
 }
@@ -3917,6 +3958,7 @@ extern "C" void ramd_launch_apply_multi(ramd_stream_t st_, int method, int nseg,
       sg.n4[g] = n[g] / 4;
       sg.rate[g] = rate[g];
       blocks += (unsigned)((sg.n4[g] + 255) / 256);
+      if (g == 1) sg.end1 = blocks;
     }
   }
   sg.first[3] = blocks;
