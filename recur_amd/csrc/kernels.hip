@@ -2906,6 +2906,184 @@ __global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, in
   if (wave == 0) bptt_control_wave(v, r, j, lane, active, flags, es_sh, 1);
 }
 
+// ------------------------------------------ one stream, small net: one launch --
+//
+// bptt_and_accumulate_error (recur-nn.c:303-450) for ONE stream of a small net as one
+// workgroup -- what the per-net calls of an unchanged caller need (text-predict's default net
+// has 99 hidden units: D launches of a 100 x 142 matrix-vector product are all launch latency).
+// The workgroup walks the steps in the reference's own order.  Thread (y = tid / 8,
+// chunk = tid % 8) owns 16 columns of rows y and y + 128 of the recurrent matrix: their
+// weights AND their weight-delta sums live in its registers for the whole launch, so a step
+// costs it four float4 of the incoming error row and two input values from LDS, 32 + 32
+// multiply-adds, and three xor shuffles per row to close the dot products (LDS bandwidth is what
+// a single CU runs out of first: an earlier version that fetched the weights from LDS took
+// 2.1 us per step, all of it LDS reads).  The input rows of all D steps are brought into LDS
+// up front and the barriers inside the loop wait for LDS only: vmcnt counts stores too on this
+// architecture, so a global load inside the loop would make every step wait for the previous
+// step's plane stores.  The sum of squares closes the step and the loop ends where the
+// reference's would (recur-nn.c:387-389).  The planes the other kernels read afterwards
+// (error rows, extras, sums: k_err_writeback, k_bottom_error, the log) are written as the
+// chain kernels write them, the control logic is the shared bptt_control_wave, and
+// ih_delta (+)= ih_scale * the accumulated matrix at the end.
+// Preconditions (launcher): h_size <= 128, i_size <= 256, D * i_size floats fit in LDS.
+__global__ __launch_bounds__(1024) void k_bptt_small(View v, int r, int accumulate, unsigned flags,
+                                                     int nx, int nxp) {
+  extern __shared__ __attribute__((aligned(16))) float bsm[];
+  const RamdShape &s = v.sh;
+  const int I = s.I, H = s.H, hs = s.hidden_size, D = s.D;
+  float *h = bsm;             /* [128] error into the step, 0 at column 0 and past hidden_size */
+  float *xon = h + 128;       /* [256] the step's input row, 0 where the row is skipped or absent */
+  float *en = xon + 256;      /* [256] error out of the step, by row                           */
+  float *red = en + 256;      /* [16] + [1]                                                    */
+  float *es_sh = red + 20;    /* [D]  sums of squares by step                                  */
+  float *xall = es_sh + ((D + 3) & ~3); /* [D][I] the input rows of all the steps              */
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int y0 = tid >> 3, n0 = (tid & 7) * 16; /* rows y0, y0 + 128; columns n0 .. n0 + 15 */
+  const float *W = v.b.ih_w;
+  const int idx0 = v.b.idx[r];
+  /* weights: rows past I and columns past H are zero */
+  float w[2][16], acc[2][16];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int y = y0 + 128 * q;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      float4 t = (y < I && n0 + 4 * k < H) ? ld4(W + (size_t)y * H + n0 + 4 * k) : zero4();
+      w[q][4 * k] = t.x; w[q][4 * k + 1] = t.y; w[q][4 * k + 2] = t.z; w[q][4 * k + 3] = t.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc[q][k] = 0.0f;
+  }
+  {
+    const int I4 = I / 4;
+    for (int e = tid; e < D * I4; e += 1024) {
+      const int t = e / I4, i = e - t * I4;
+      int slot = idx0 - t;
+      if (slot < 0) slot += D;
+      *reinterpret_cast<float4 *>(xall + t * I + 4 * i) = ld4(v.b.arena + ((size_t)slot * s.Scap + r) * I + 4 * i);
+    }
+    const float *e0 = v.b.ehi + (size_t)r * I; /* plane 0: the top layer's error */
+    if (tid < 128) h[tid] = (tid == 0 || tid > hs || tid >= H) ? 0.0f : e0[tid];
+    if (tid < 256) xon[tid] = 0.0f;
+    for (int i = tid; i < D; i += 1024) es_sh[i] = 0.0f;
+  }
+  /* thresholds exactly as bptt_control_wave derives them */
+  const float top = v.b.top_scaled[r];
+  const float max_error_sum = MAX_ERROR_GAIN_F * top + 1;
+  const float min_error_gain = MIN_ERROR_GAIN_F * top;
+  const float mef_rate = v.b.mef[r] / v.b.lr[r];
+  const float min_error_sum = (mef_rate < min_error_gain) ? mef_rate : min_error_gain;
+  const size_t plane = (size_t)s.Scap * I;
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  /* sum over the eight lanes of a row without LDS: two quad permutes and a half-row mirror */
+#define DPP_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
+  const bool two_rows = (wave * 8 + 128) < I; /* this wave's second rows exist */
+  __syncthreads();
+  if (tid < I) { /* step 0's input row */
+    const float xi = xall[tid];
+    bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
+    xon[tid] = on ? xi : 0.0f;
+  }
+  LDS_BARRIER();
+  for (int t = 0; t < D; t++) {
+    float sq = 0.0f;
+    {
+      float hv[16];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float4 t4 = ld4(h + n0 + 4 * k);
+        hv[4 * k] = t4.x; hv[4 * k + 1] = t4.y; hv[4 * k + 2] = t4.z; hv[4 * k + 3] = t4.w;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        if (q == 1 && !two_rows) break; /* wave-uniform */
+        const float xi = xon[y0 + 128 * q];
+        /* weight deltas of the step (recur-nn.c:343-358) and the error that leaves it
+         * (359-376); a skipped row has xi == 0: nothing is added and its error is 0 */
+        float e = 0.0f, e1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+          acc[q][k] += xi * hv[k];
+          acc[q][k + 1] += xi * hv[k + 1];
+          e += w[q][k] * hv[k];
+          e1 += w[q][k + 1] * hv[k + 1];
+        }
+        e += e1;
+        DPP_ADD(e, 0xB1);  /* quad_perm [1,0,3,2] */
+        DPP_ADD(e, 0x4E);  /* quad_perm [2,3,0,1] */
+        DPP_ADD(e, 0x141); /* row_half_mirror: the other quad of the eight */
+        if (s.activation == 2) e /= 2 * (xi + 1.0f);
+        e = (xi != 0.0f) ? e : 0.0f;
+        if ((tid & 7) == 0) {
+          en[y0 + 128 * q] = e;
+          sq += e * e;
+        }
+      }
+    }
+    /* the wave's share of the sum of squares: its row leaders sit in lanes 0, 8, .., 56 */
+    DPP_ADD(sq, 0x128); /* row_ror 8: lanes 0 and 8 of every row of sixteen */
+    {
+      const int sqi = __builtin_bit_cast(int, sq);
+      float ws = __builtin_bit_cast(float, __builtin_amdgcn_readlane(sqi, 0)) +
+                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(sqi, 16));
+      ws += __builtin_bit_cast(float, __builtin_amdgcn_readlane(sqi, 32)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(sqi, 48));
+      if (lane == 0) red[wave] = ws;
+    }
+    LDS_BARRIER();
+    float es = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    es += ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
+    /* the planes, laid out as the chain and extras kernels leave them; the next step's rows */
+    {
+      float *eo = v.b.ehi + (size_t)(t + 1) * plane + (size_t)r * I;
+      if (tid >= 1 && tid <= hs) eo[tid] = en[tid];
+      float *xo = v.b.ex + ((size_t)(t + 1) * s.Scap + r) * nxp;
+      if (tid < nxp) xo[tid] = (tid == 0) ? en[0] : (tid < nx) ? en[hs + tid] : 0.0f;
+    }
+    if (tid < 128) h[tid] = (tid == 0 || tid > hs) ? 0.0f : en[tid];
+    if (tid < I && t + 1 < D) {
+      const float xi = xall[(t + 1) * I + tid];
+      bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
+      xon[tid] = on ? xi : 0.0f;
+    }
+    if (tid == 0) {
+      es_sh[t] = es;
+      v.b.esum[(size_t)t * s.Scap + r] = es;
+    }
+    LDS_BARRIER();
+    if (es <= min_error_sum || es > max_error_sum) break; /* the same for every thread */
+  }
+#undef DPP_ADD
+#undef LDS_BARRIER
+  if (wave == 0) {
+    /* the steps that did not run left zeros, which end the scan of bptt_control_wave too */
+    bptt_control_wave(v, r, 0, lane, nullptr, flags, es_sh, 1);
+    if (lane == 0) red[16] = v.b.ih_scale[r]; /* lane 0 wrote it */
+  }
+  __syncthreads();
+  const float scale = red[16];
+  float *d = v.b.ih_delta;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int y = y0 + 128 * q;
+    if (y < I) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (n0 + 4 * k < H) {
+          float4 *dp = reinterpret_cast<float4 *>(d + (size_t)y * H + n0 + 4 * k);
+          float4 a = make_float4(acc[q][4 * k] * scale, acc[q][4 * k + 1] * scale, acc[q][4 * k + 2] * scale,
+                                 acc[q][4 * k + 3] * scale);
+          if (accumulate) {
+            float4 o = *dp;
+            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+          }
+          *dp = a;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------- finalize: delta --
 
 // the sum of ks planes in plane order, eight loads in flight at a time
@@ -3736,6 +3914,26 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   const int tn = (sh->hidden_size + CN - 1) / CN;
   const int nx = sh->I - sh->hidden_size; /* column 0 + the input columns */
   const int nxp = (nx + 3) & ~3;
+  if (nrows == 1 && !active && !defer && row0 < sh->Scap && sh->H <= 256 &&
+      env_int("RECUR_AMD_BPTT_SMALL", 1)) {
+    /* one stream of a small net (the per-net calls): chain, extras, control and weight deltas
+     * in one workgroup */
+    /* h_size <= 128 and i_size <= 256 (text-predict's default 99 hidden units: 100 x 142):
+     * the matrix lives in the workgroup's registers; larger nets take the launch-per-step route */
+    const size_t shm = (size_t)(128 + 256 + 256 + 20 + ((sh->D + 3) & ~3) + (size_t)sh->D * sh->I) * sizeof(float);
+    if (sh->H <= 128 && sh->I <= 256 && shm <= 150 * 1024) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_bptt_small,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+      }
+      int ev = timing_begin(st, T_CHAIN, 1);
+      RAMD_LAUNCH(k_bptt_small, dim3(1), dim3(1024), shm, st, v, row0, accumulate, flags, nx, nxp);
+      timing_end(st, ev);
+      return;
+    }
+  }
   {
     int tm = (nrows + CM - 1) / CM;
     int nstages = (sh->hidden_size + CK - 1) / CK; /* K = the hidden columns 1..hidden_size */
@@ -3929,6 +4127,36 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
                        rest_base == b->slab ? b->slab + (size_t)rows_core * sh->H : rest_base, rest_stride, b->ho_delta,
                        ho_in_final ? b->ho_slab : nullptr, ho_n, ho_ks);
   }
+}
+
+// Up to 12 small word-wise copies in one launch: the per-net calls' traffic between a pinned
+// host mailbox and the device arrays (either side may be the host: the mailbox is mapped).
+struct SegCopy {
+  unsigned *dst[12];
+  const unsigned *src[12];
+  unsigned n[12];
+  int nseg;
+};
+__global__ __launch_bounds__(256) void k_segcopy(SegCopy sc) {
+  const int g = blockIdx.y;
+  if (g >= sc.nseg) return;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < sc.n[g]; i += gridDim.x * 256) sc.dst[g][i] = sc.src[g][i];
+}
+extern "C" void ramd_launch_segcopy(ramd_stream_t st_, int nseg, void *const *dst,
+                                    const void *const *src, const unsigned *nwords) {
+  hipStream_t st = (hipStream_t)st_;
+  SegCopy sc = {};
+  unsigned most = 1;
+  for (int g = 0; g < nseg; g++) {
+    sc.dst[g] = (unsigned *)dst[g];
+    sc.src[g] = (const unsigned *)src[g];
+    sc.n[g] = nwords[g];
+    if (nwords[g] > most) most = nwords[g];
+  }
+  sc.nseg = nseg;
+  unsigned bx = (most + 255) / 256;
+  if (bx > 16) bx = 16;
+  RAMD_LAUNCH(k_segcopy, dim3(bx, nseg), dim3(256), 0, st, sc);
 }
 
 extern "C" void ramd_launch_err_writeback(ramd_stream_t st_, const RamdShape *sh,

@@ -183,6 +183,9 @@ void ramd_launch_sigmoid_mse_error(ramd_stream_t st, const RamdShape *sh, const 
 /* fast_sigmoid_array in place on the first n outputs of state rows r0 .. r0 + nrows */
 void ramd_launch_sigmoid_outputs(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int r0,
                                  int nrows, int n);
+/* up to 12 word-wise copies (nwords[g] 32-bit words from src[g] to dst[g]) in one launch */
+void ramd_launch_segcopy(ramd_stream_t st, int nseg, void *const *dst, const void *const *src,
+                         const unsigned *nwords);
 /* rebuilds err_a / err_b (bptt->h_error, i_error) from ehi after a calc_deltas */
 void ramd_launch_err_writeback(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
                                int row0, int nrows);

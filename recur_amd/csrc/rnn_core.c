@@ -107,8 +107,10 @@ static void d2h(void *h, const void *d, size_t bytes) {
     HIP_OK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, g_stream));
   }
 }
+static unsigned long g_syncs = 0; /* completed stream synchronisations */
 static void dsync(void) {
   HIP_OK(hipStreamSynchronize(g_stream));
+  g_syncs++;
   if (ramd_chain_abort_word()) {
     fprintf(stderr, "librecur_amd: the one-launch BPTT chain gave up (code %u: its 256 workgroups were "
                     "not all resident, one per CU, or a hand-off timed out); its results are invalid.  "
@@ -116,6 +118,120 @@ static void dsync(void) {
             ramd_chain_abort_word());
     abort();
   }
+}
+
+/* ---------------------------------------------------------------- mailbox -- */
+
+/* The per-net calls move a handful of small vectors each way (the caller's inputs or output
+ * error in; the layers, the error images and two scalars out).  As separate hipMemcpyAsync
+ * calls on pageable memory each of them costs a staging copy and an implicit wait; here they
+ * are queued, carried by ONE kernel launch per direction through a pinned, device-mapped
+ * mailbox, and a call ends with one stream synchronisation.  mail_in snapshots the host
+ * data at once (the caller may change it as soon as we return), mail_out delivers after
+ * the synchronisation in mail_out_flush. */
+#define MAIL_SEGS 12
+#define MAIL_WORDS (1u << 18) /* per direction: 1 MB */
+static struct {
+  unsigned *buf; /* [2][MAIL_WORDS] pinned: inbound half, outbound half */
+  void *dst[MAIL_SEGS];
+  const void *src[MAIL_SEGS];
+  unsigned n[MAIL_SEGS];
+  int nseg;
+  unsigned cur;
+  unsigned long in_sync; /* g_syncs when the inbound half was last handed to the device */
+  int in_busy;
+} g_mail;
+
+static void mail_ready(void) {
+  if (!g_mail.buf) {
+    HIP_OK(hipHostMalloc((void **)&g_mail.buf, 2 * (size_t)MAIL_WORDS * sizeof(unsigned),
+                         hipHostMallocPortable | hipHostMallocMapped));
+  }
+}
+static void mail_in_flush(void) {
+  if (g_mail.nseg) {
+    ramd_launch_segcopy(g_stream, g_mail.nseg, g_mail.dst, g_mail.src, g_mail.n);
+    g_mail.nseg = 0;
+    g_mail.in_busy = 1;
+    g_mail.in_sync = g_syncs;
+  }
+}
+static void mail_in(void *dev, const void *host, size_t bytes) {
+  unsigned words = (unsigned)(bytes / 4);
+  if (!bytes) {
+    return;
+  }
+  mail_ready();
+  if ((bytes & 3) || words > MAIL_WORDS) { /* not this route's kind of copy */
+    mail_in_flush();
+    h2d(dev, host, bytes);
+    return;
+  }
+  if (g_mail.nseg == 0 && g_mail.in_busy) {
+    /* the inbound half may still be being read by the launch that carried the last batch */
+    if (g_mail.in_sync == g_syncs && g_mail.cur + words > MAIL_WORDS) {
+      dsync();
+    }
+    if (g_mail.in_sync != g_syncs) {
+      g_mail.in_busy = 0;
+      g_mail.cur = 0;
+    }
+  }
+  if (g_mail.nseg == MAIL_SEGS || g_mail.cur + words > MAIL_WORDS) {
+    mail_in_flush();
+    dsync();
+    g_mail.in_busy = 0;
+    g_mail.cur = 0;
+  }
+  unsigned *slot = g_mail.buf + g_mail.cur;
+  memcpy(slot, host, bytes);
+  g_mail.dst[g_mail.nseg] = dev;
+  g_mail.src[g_mail.nseg] = slot;
+  g_mail.n[g_mail.nseg] = words;
+  g_mail.nseg++;
+  g_mail.cur += words;
+}
+/* outbound: queue, then one launch + one synchronisation + the deliveries */
+static struct {
+  void *dst[MAIL_SEGS];
+  const void *src[MAIL_SEGS];
+  unsigned n[MAIL_SEGS];
+  void *host[MAIL_SEGS];
+  int nseg;
+  unsigned cur;
+} g_mail_out;
+static void mail_out_flush(void) {
+  mail_in_flush();
+  if (g_mail_out.nseg) {
+    ramd_launch_segcopy(g_stream, g_mail_out.nseg, g_mail_out.dst, g_mail_out.src, g_mail_out.n);
+  }
+  dsync();
+  for (int g = 0; g < g_mail_out.nseg; g++) {
+    memcpy(g_mail_out.host[g], g_mail_out.dst[g], (size_t)g_mail_out.n[g] * 4);
+  }
+  g_mail_out.nseg = 0;
+  g_mail_out.cur = 0;
+}
+static void mail_out(void *host, const void *dev, size_t bytes) {
+  unsigned words = (unsigned)(bytes / 4);
+  if (!bytes) {
+    return;
+  }
+  mail_ready();
+  if ((bytes & 3) || words > MAIL_WORDS) {
+    d2h(host, dev, bytes); /* completes with the synchronisation of the flush */
+    return;
+  }
+  if (g_mail_out.nseg == MAIL_SEGS || g_mail_out.cur + words > MAIL_WORDS) {
+    mail_out_flush();
+  }
+  unsigned *slot = g_mail.buf + MAIL_WORDS + g_mail_out.cur;
+  g_mail_out.dst[g_mail_out.nseg] = slot;
+  g_mail_out.src[g_mail_out.nseg] = dev;
+  g_mail_out.n[g_mail_out.nseg] = words;
+  g_mail_out.host[g_mail_out.nseg] = host;
+  g_mail_out.nseg++;
+  g_mail_out.cur += words;
 }
 
 void *ramd_zalloc(size_t bytes) {
@@ -174,6 +290,8 @@ static void engine_free_device(RamdEngine *e) {
   e->d_mclass = NULL;
   free(e->lr_pushed);
   e->lr_pushed = NULL;
+  free(e->idx_pushed);
+  e->idx_pushed = NULL;
   memset(b, 0, sizeof(*b));
   e->delta_own = NULL;
   e->delta_external = 0;
@@ -310,6 +428,7 @@ static void stream_copy(RamdEngine *e, RecurNN *net, int to_device) {
       h2d(b->idx + j, &bp->index, sizeof(int));
       h2d(b->lr + j, &bp->learn_rate, sizeof(float));
       e->lr_pushed[j] = bp->learn_rate;
+      e->idx_pushed[j] = bp->index;
     }
   } else {
     COPY(b->arena + ((size_t)s->D * s->Scap + p->fwd) * I, net->input_layer, I);
@@ -641,6 +760,7 @@ static void engine_ensure_device(RamdEngine *e) {
     b->bcarry_cur = 0;
   }
   e->lr_pushed = ramd_zalloc(S * sizeof(float));
+  e->idx_pushed = ramd_zalloc(S * sizeof(int));
   if (keep_text) {
     b->text = dev_alloc((size_t)keep_text_len + 1);
     h2d(b->text, keep_text, (size_t)keep_text_len);
@@ -1024,8 +1144,12 @@ void rnn_delete_training_set(RecurNN **nets, int n_nets, int leave_prototype) {
 
 /* The ring position every stream of [row0, row0 + nrows) shares, or -1.  The
  * host mirrors the indices exactly (they only ever change by rnn_bptt_advance). */
+static void push_indices(RamdEngine *e, int row0, int nrows);
 static void set_uniform_idx(RamdEngine *e, int row0, int nrows) {
   int u = -1;
+  if (e->dev_ready && row0 < e->n_streams && nrows > 0) {
+    push_indices(e, row0, nrows);
+  }
   if (row0 < e->n_streams && nrows > 0) {
     u = e->streams[row0]->bptt->index;
     for (int j = row0 + 1; j < row0 + nrows && j < e->n_streams; j++) {
@@ -1036,6 +1160,7 @@ static void set_uniform_idx(RamdEngine *e, int row0, int nrows) {
     }
   }
   e->b.uniform_idx = u;
+  mail_in_flush(); /* whatever the caller queued for the launches that follow */
 }
 
 /* ------------------------------------------------------------ scalars push -- */
@@ -1052,8 +1177,24 @@ static void push_learn_rates(RamdEngine *e, int row0, int nrows) {
     }
   }
   if (dirty) {
-    h2d(e->b.lr + row0, e->lr_pushed + row0, nrows * sizeof(float));
-    dsync();
+    mail_in(e->b.lr + row0, e->lr_pushed + row0, nrows * sizeof(float)); /* leaves with the next flush */
+  }
+}
+
+/* The ring indices are host-authoritative too: rnn_bptt_advance only steps the host's copy,
+ * and the device's is brought up to date here, before the next launch that reads it (the set
+ * calls that advance on the device record the new value in the mirror themselves). */
+static void push_indices(RamdEngine *e, int row0, int nrows) {
+  int dirty = 0;
+  for (int j = row0; j < row0 + nrows && j < e->n_streams; j++) {
+    int idx = e->streams[j]->bptt->index;
+    if (idx != e->idx_pushed[j]) {
+      e->idx_pushed[j] = idx;
+      dirty = 1;
+    }
+  }
+  if (dirty) {
+    mail_in(e->b.idx + row0, e->idx_pushed + row0, nrows * sizeof(int));
   }
 }
 
@@ -1138,12 +1279,7 @@ static void log_bptt(RamdEngine *e, RecurNN *net, float mef_before) {
 
 /* recur-nn.h:310 */
 void rnn_bptt_advance(RecurNN *net) {
-  host_advance(net);
-  RamdPriv *p = ramd_priv(net);
-  if (p->eng && p->eng->dev_ready && p->stream >= 0 && p->stream < p->eng->sh.Scap) {
-    h2d(p->eng->b.idx + p->stream, &net->bptt->index, sizeof(int));
-    dsync();
-  }
+  host_advance(net); /* the device's copy follows before the next launch that reads it: push_indices */
 }
 
 /* recur-nn.h:302 / recur-nn.c:83-154 for one stream */
@@ -1163,37 +1299,41 @@ float *rnn_opinion(RecurNN *net, const float *inputs, float presynaptic_noise) {
   free(keep);
   int r = state_row(e, p);
   float *d_slot;
+  /* everything that goes in travels in one mailbox launch, everything that comes back in
+   * another, and the call ends with one synchronisation */
   if (p->stream >= 0) {
     d_slot = e->b.arena + ((size_t)net->bptt->index * s->Scap + p->stream) * s->I;
-    h2d(e->b.idx + p->stream, &net->bptt->index, sizeof(int));
   } else {
     d_slot = e->b.arena + ((size_t)s->D * s->Scap + p->fwd) * s->I;
   }
   if (presynaptic_noise != 0.0f) { /* the host generator is the one the caller may have used */
-    h2d((char *)e->b.rng + (size_t)r * sizeof(rand_ctx), &net->rng, sizeof(rand_ctx));
+    mail_in((char *)e->b.rng + (size_t)r * sizeof(rand_ctx), &net->rng, sizeof(rand_ctx));
   }
   if (bl) { /* recur-nn.c:88-103: the layer's one input buffer is shared by every clone */
     bl->inputs[0] = 1.0f;
     if (inputs) {
       memcpy(bl->inputs + 1, inputs, sizeof(float) * bl->input_size);
     }
-    h2d(e->b.binp + (size_t)r * s->bI, bl->inputs, sizeof(float) * s->bI);
-    ramd_launch_bottom_forward(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1,
-                               presynaptic_noise);
-    d2h(bl->outputs, e->b.bout + (size_t)r * s->bO, sizeof(float) * s->bO);
+    mail_in(e->b.binp + (size_t)r * s->bI, bl->inputs, sizeof(float) * s->bI);
   } else {
-    h2d(d_slot + s->hidden_size + 1, net->real_inputs, sizeof(float) * s->input_size);
+    mail_in(d_slot + s->hidden_size + 1, net->real_inputs, sizeof(float) * s->input_size);
   }
   set_uniform_idx(e, p->stream >= 0 ? p->stream : e->n_streams, p->stream >= 0 ? 1 : 0);
+  mail_in_flush();
+  if (bl) {
+    ramd_launch_bottom_forward(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1,
+                               presynaptic_noise);
+    mail_out(bl->outputs, e->b.bout + (size_t)r * s->bO, sizeof(float) * s->bO);
+  }
   ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1, 0);
   ramd_launch_forward(g_stream, s, &e->b, r, 1, presynaptic_noise);
   if (presynaptic_noise != 0.0f) {
-    d2h(&net->rng, (char *)e->b.rng + (size_t)r * sizeof(rand_ctx), sizeof(rand_ctx));
+    mail_out(&net->rng, (char *)e->b.rng + (size_t)r * sizeof(rand_ctx), sizeof(rand_ctx));
   }
-  d2h(net->input_layer, d_slot, sizeof(float) * s->I);
-  d2h(net->hidden_layer, e->b.hidden + (size_t)r * s->H, sizeof(float) * s->H);
-  d2h(net->output_layer, e->b.out + (size_t)r * s->O, sizeof(float) * s->O);
-  dsync();
+  mail_out(net->input_layer, d_slot, sizeof(float) * s->I);
+  mail_out(net->hidden_layer, e->b.hidden + (size_t)r * s->H, sizeof(float) * s->H);
+  mail_out(net->output_layer, e->b.out + (size_t)r * s->O, sizeof(float) * s->O);
+  mail_out_flush();
   return net->output_layer;
 }
 
@@ -1209,8 +1349,7 @@ static const int *push_ranges(RamdEngine *e, RecurErrorRange *ranges) {
     fprintf(stderr, "librecur_amd: more than 64 error ranges\n");
     abort();
   }
-  h2d(e->d_ranges, ranges, (n + 1) * sizeof(RecurErrorRange));
-  dsync();
+  mail_in(e->d_ranges, ranges, (n + 1) * sizeof(RecurErrorRange));
   return e->d_ranges;
 }
 
@@ -1236,13 +1375,12 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
   free(keep);
   RecurNNBPTT *bp = net->bptt;
   float mef_before = bp->min_error_factor;
-  h2d(e->b.o_error + (size_t)j * s->O, bp->o_error, sizeof(float) * s->O);
-  h2d(e->b.idx + j, &bp->index, sizeof(int));
-  h2d(e->b.mef + j, &bp->min_error_factor, sizeof(float));
+  mail_in(e->b.o_error + (size_t)j * s->O, bp->o_error, sizeof(float) * s->O);
+  mail_in(e->b.mef + j, &bp->min_error_factor, sizeof(float));
   if (ranges) {
     /* the sparse top path reads last time's h_error */
     err_flush(e);
-    h2d(e->b.err_a + (size_t)j * s->I, bp->h_error, sizeof(float) * s->I);
+    mail_in(e->b.err_a + (size_t)j * s->I, bp->h_error, sizeof(float) * s->I);
   }
   push_learn_rates(e, j, 1);
   const int *d_ranges = push_ranges(e, ranges);
@@ -1250,6 +1388,7 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
     err_flush(e);
   }
   set_uniform_idx(e, j, 1);
+  mail_in_flush();
   ramd_launch_calc_deltas(g_stream, s, &e->b, j, 1, accumulate, d_ranges, 0, NULL,
                           net->flags | (fused ? 0x80000000u : 0), NULL);
   if (s->bI && !fused) { /* the fused path passes no bottom error (recur-nn.c:972, 986) */
@@ -1257,17 +1396,19 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
       engine_need_dev(e, RNN_AMD_DELTAS);
     }
     ramd_launch_bottom_deltas(g_stream, s, &e->b, j, 1, accumulate, NULL);
-    d2h(net->bottom_layer->o_error, e->b.bcarry + (size_t)e->b.bcarry_cur * s->bO,
-        sizeof(float) * s->bO);
+    mail_out(net->bottom_layer->o_error, e->b.bcarry + (size_t)e->b.bcarry_cur * s->bO,
+             sizeof(float) * s->bO);
   }
   engine_dev_wrote(e, RNN_AMD_DELTAS);
   e->err_pending = 1;
   e->err_row0 = j;
   e->err_nrows = 1;
   err_flush(e);
-  d2h(bp->h_error, e->b.err_a + (size_t)j * s->I, sizeof(float) * s->I);
-  d2h(bp->i_error, e->b.err_b + (size_t)j * s->I, sizeof(float) * s->I);
-  pull_scalars(e, j, 1);
+  mail_out(bp->h_error, e->b.err_a + (size_t)j * s->I, sizeof(float) * s->I);
+  mail_out(bp->i_error, e->b.err_b + (size_t)j * s->I, sizeof(float) * s->I);
+  mail_out(&bp->min_error_factor, e->b.mef + j, sizeof(float));
+  mail_out(&bp->ih_scale, e->b.ih_scale + j, sizeof(float));
+  mail_out_flush();
   net->generation++;
   log_bptt(e, net, mef_before);
 }
@@ -1651,6 +1792,10 @@ static void set_streams_to_dev(RnnAmdSet *set) {
   if (any) {
     dsync();
   }
+  if (!set->fwd_only) {
+    push_indices(e, set->row0, set->n);
+    mail_in_flush();
+  }
 }
 
 static void set_streams_dev_wrote(RnnAmdSet *set) {
@@ -1667,6 +1812,7 @@ void rnn_amd_set_advance(RnnAmdSet *set) {
   set_streams_to_dev(set);
   for (int j = 0; j < set->n; j++) {
     host_advance(set->nets[j]); /* the index is deterministic: both sides step */
+    e->idx_pushed[set->row0 + j] = set->nets[j]->bptt->index;
   }
   ramd_launch_advance(g_stream, &e->sh, &e->b, set->row0, set->n);
 }
@@ -1682,6 +1828,7 @@ static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, i
     set_need_training(set, "advancing");
     for (int j = 0; j < set->n; j++) {
       host_advance(set->nets[j]); /* the device steps its copy inside the assemble kernel */
+      e->idx_pushed[set->row0 + j] = set->nets[j]->bptt->index;
     }
   }
   const int r0 = set_state_row0(set);

@@ -59,6 +59,7 @@ typedef struct RamdEngine {
   int err_pending, err_row0, err_nrows;
   /* last per-stream scalars pushed to the device */
   float *lr_pushed;
+  int *idx_pushed;
   int scalars_dev_valid; /* device mef/ih_scale newer than the host structs */
 } RamdEngine;
 
