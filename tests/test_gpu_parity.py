@@ -106,6 +106,38 @@ def test_hot_case_stepwise_on_the_dma_delta_path(amd):
     _stepwise(amd, kw, sc.synthetic_text(6000), 40, rc.WEIGHTED, 8)
 
 
+@pytest.mark.parametrize("act,S,lr", [(rc.RELU, 1, 0.08), (rc.RESQRT, 3, 0.05), (rc.RECLIP20, 2, 0.08),
+                                      (rc.RELU, 2, 1e-3)])
+def test_per_net_calls_on_a_small_net_stepwise(amd, orc, act, S, lr):
+    """text-predict's default shape (99 hidden, depth 30) through the reference's per-net
+    calls: rnn_bptt_calc_deltas then runs the whole of bptt_and_accumulate_error
+    (recur-nn.c:303-450) as ONE workgroup (k_bptt_small).  Hot learn rates make the loop end
+    early and ih_scale drop below 1 (recur-nn.c:387-413); every generation is compared from the
+    oracle's own state, accumulating calls (j > 0) included."""
+    kw = dict(input_size=42, hidden_size=99, output_size=42, S=S, D=30, activation=act, learn_rate=lr, seed=5)
+    text = sc.synthetic_text(4000)
+    g = sc.ApiSet(amd, softmax_best_guess=orc.orc_softmax_best_guess, **kw)
+    o = sc.OracleSet(**kw)
+    steps, compared, seen_exit, seen_clamp = 60, 0, False, False
+    for i in range(steps):
+        g.char_step(text, i, rc.WEIGHTED, 0.9)
+        o.char_step(text, i, rc.WEIGHTED, 0.9)
+        sg, so = g.snapshot(), o.snapshot()
+        assert (sg["index"] == so["index"]).all() and (sg["generation"] == so["generation"]).all()
+        if np.array_equal(sg["ih_scale"] == 1.0, so["ih_scale"] == 1.0):
+            replay.check(sg, so, 2e-4, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "hidden", "ih_scale",
+                                             "min_error_factor", "o_error"])
+            compared += 1
+        seen_clamp |= bool((so["ih_scale"] < 1.0).any())
+        seen_exit |= bool((so["bptt_depth"] < 30).any()) and i >= 30
+        _load_state(amd, g, so)
+    g.close()
+    o.close()
+    assert compared >= steps // 2, compared
+    if lr > 0.01:
+        assert seen_exit and (seen_clamp or act == rc.RESQRT)
+
+
 def _load_state(amd, g, snap):
     """copy an oracle snapshot into the product's host structs and declare it written"""
     n0 = g.net.contents
