@@ -2631,7 +2631,23 @@ __global__ __launch_bounds__(64) void k_extras_finalize(View v, int row0, int nr
 constexpr int DD_STAGES = 4;
 constexpr int DD_STAGE_FLOATS = 2 * BK * 128 + 64; /* A, B, 32 coefficients (+ pad) */
 
-__global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, GemmOut o) {
+/* The rows above the last whole 128-row tile (the input rows of a text net: 44 at the north
+ * star) ride along: the tm workgroups that share a column tile and a K slice (mt = 0..tm-1;
+ * eight at hidden 1024) each take every tm-th K tile of the slice, fetch the 32 x 64 piece of the history rows'
+ * tail for it (columns rows_core .. rows_core + 63: past i_size they run into the next row,
+ * which only feeds output rows nobody stores), and multiply it with the error fragments they
+ * have in registers anyway: 8 more MFMAs per 16 in one K tile of tm, no second pass over
+ * the error planes.  Their partial sums are plane z * tm + mt of `planes`. */
+struct DeltaRest {
+  float *planes;  /* [ks * tm][rows][ldc] */
+  size_t stride;  /* floats between planes */
+  int rows;       /* i_size - rows_core, <= 64 */
+  int col;        /* rows_core */
+};
+constexpr int DD_REST_FLOATS = BK * 64; /* one rest tile: 32 k x 64 rows */
+
+template <bool REST>
+__global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, GemmOut o, DeltaRest dr) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const RamdShape &s = v.sh;
   const int L = blockIdx.x;
@@ -2647,6 +2663,11 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
   const int nst = kt1 - kt0;
   const int wave8 = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int rtiles = nrows / BK;
+  /* stage st carries rest work when st % tm == mt; its tile sits in slot (st / tm) % 2 behind the
+   * ring (tm >= 4, so a slot's previous tile was consumed long before the next one is fetched) */
+  auto is_rest = [&](int st) { return REST && st < nst && st % o.tm == mt; };
+  auto rest_slot = [&](int st) { return (st / o.tm) & 1; };
+  float *const rest_ring = dsm + DD_STAGES * DD_STAGE_FLOATS;
 
   if (wave8 >= 4) {
     // ---------------------------------------------------------------- loaders
@@ -2659,6 +2680,7 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
     const int ws = __builtin_amdgcn_readfirstlane(w);
     const unsigned voff = (unsigned)(((size_t)(lane >> 5) * s.I + (lane & 31) * 4) * sizeof(float));
     const unsigned voff_c = (unsigned)((lane & 31) * sizeof(float));
+    const unsigned voff_r = (unsigned)(((size_t)(lane >> 4) * s.I + (lane & 15) * 4) * sizeof(float));
     const uint32_t dsm_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(dsm));
     auto issue = [&](int st) {
       const int kt = kt0 + st;
@@ -2678,6 +2700,12 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
         lds_dma4(v.b.coef + (size_t)t * s.Scap + row0 + sb, voff_c,
                  dsm_lds + (uint32_t)(((st % DD_STAGES) * DD_STAGE_FLOATS + 2 * BK * 128) * sizeof(float)));
       }
+      if (REST && ws == 3 && is_rest(st)) { /* the tail of the 32 history rows: four rows per instruction */
+        const float *rb = v.b.arena + ((size_t)slot * s.Scap + row0 + sb) * s.I + dr.col;
+        const uint32_t rdst = dsm_lds + (uint32_t)((DD_STAGES * DD_STAGE_FLOATS + rest_slot(st) * DD_REST_FLOATS) * sizeof(float));
+#pragma unroll
+        for (int j = 0; j < 8; j++) lds_dma16(rb + (size_t)(4 * j) * s.I, voff_r, rdst + (uint32_t)(j * 256 * sizeof(float)));
+      }
     };
 #pragma unroll
     for (int p = 0; p < DD_STAGES - 1; p++)
@@ -2689,6 +2717,18 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
         if (ahead >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (REST && w == 3) {
+        /* eight more in flight for a rest stage among the ones ahead (at most one: they are eight apart) */
+        const bool more = (ahead >= 1 && is_rest(st + 1)) || (ahead >= 2 && is_rest(st + 2));
+        if (ahead >= 2) {
+          if (more) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else if (ahead == 1) {
+          if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
       } else {
         if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -2716,9 +2756,20 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
   struct Frag {
     float a[2][4], e[2][4];
     float4 cf;
+    float ar[4]; /* rest rows (REST stages only) */
   };
+  f32x16 racc[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int g = 0; g < 16; g++) racc[j][g] = 0.0f;
   const int lane_off = 4 * kh * 128 + lm;
-  auto rd = [&](int st, int g, Frag &f) {
+  auto rd = [&](int st, int g, Frag &f, bool rest) {
+    if (REST && rest) { /* wave-uniform */
+      const float *lr = rest_ring + rest_slot(st) * DD_REST_FLOATS + (8 * g + 4 * kh) * 64 + wm * 32 + lm;
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) f.ar[jj] = lr[jj * 64];
+    }
     const float *la = dsm + (st % DD_STAGES) * DD_STAGE_FLOATS + 8 * g * 128 + lane_off;
     const float *lb = la + BK * 128;
     f.cf = *reinterpret_cast<const float4 *>(dsm + (st % DD_STAGES) * DD_STAGE_FLOATS + 2 * BK * 128 +
@@ -2731,16 +2782,23 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
         f.e[i][jj] = lb[jj * 128 + wn * 64 + i * 32];
       }
   };
-  auto mm = [&](const Frag &f) {
+  auto mm = [&](const Frag &f, bool rest) {
     const float cfv[4] = {f.cf.x, f.cf.y, f.cf.z, f.cf.w};
     float b[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int jj = 0; jj < 4; jj++) /* v_mul_legacy_f32: 0 * x is 0 for ANY x (a step past the break
-                                       * may hold inf), otherwise the IEEE product: select and
-                                       * multiply in one instruction of the MFMAs' own ALU */
-        asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(b[i][jj]) : "v"(cfv[jj]), "v"(f.e[i][jj]));
+    /* v_mul_legacy_f32: 0 * x is 0 for ANY x (a step past the break may hold inf), otherwise the
+     * IEEE product: select and multiply in one instruction of the MFMAs' own ALU.  All eight in
+     * ONE statement with early-clobber outputs: eight distinct registers that nothing rewrites
+     * while the sixteen MFMAs that read them are being issued (as separate statements hipcc
+     * recycled two registers between the MFMAs, and results went wrong). */
+    asm volatile("v_mul_legacy_f32 %0, %8, %12\n\tv_mul_legacy_f32 %1, %9, %13\n\t"
+                 "v_mul_legacy_f32 %2, %10, %14\n\tv_mul_legacy_f32 %3, %11, %15\n\t"
+                 "v_mul_legacy_f32 %4, %8, %16\n\tv_mul_legacy_f32 %5, %9, %17\n\t"
+                 "v_mul_legacy_f32 %6, %10, %18\n\tv_mul_legacy_f32 %7, %11, %19\n\ts_nop 1"
+                 : "=&v"(b[0][0]), "=&v"(b[0][1]), "=&v"(b[0][2]), "=&v"(b[0][3]), "=&v"(b[1][0]),
+                   "=&v"(b[1][1]), "=&v"(b[1][2]), "=&v"(b[1][3])
+                 : "v"(cfv[0]), "v"(cfv[1]), "v"(cfv[2]), "v"(cfv[3]), "v"(f.e[0][0]), "v"(f.e[0][1]),
+                   "v"(f.e[0][2]), "v"(f.e[0][3]), "v"(f.e[1][0]), "v"(f.e[1][1]), "v"(f.e[1][2]),
+                   "v"(f.e[1][3]));
 #pragma unroll
     for (int jj = 0; jj < 4; jj++)
 #pragma unroll
@@ -2748,10 +2806,17 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
 #pragma unroll
         for (int jn = 0; jn < 2; jn++)
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][jj], b[jn][jj], acc[i][jn], 0, 0, 0);
+    if (REST && rest) { /* wave-uniform: this wave's 32 rest rows x its 64 columns */
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++)
+          racc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.ar[jj], b[jn][jj], racc[jn], 0, 0, 0);
+    }
   };
-  auto step = [&](int st, int g, Frag &cur, Frag &nxt) {
+  auto step = [&](int st, int g, Frag &cur, Frag &nxt, bool rest, bool rest_next) {
     if (g < 3) {
-      rd(st, g + 1, nxt);
+      rd(st, g + 1, nxt, rest);
     } else if (st + 1 < nst) {
 #ifdef PC_STAMPS
       if (blockIdx.x == 0 && threadIdx.x == 0 && st < 63) g_pc_stamps[0][st + 1][4] = __builtin_amdgcn_s_memrealtime();
@@ -2761,10 +2826,10 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
 #ifdef PC_STAMPS
       if (blockIdx.x == 0 && threadIdx.x == 0 && st < 63) g_pc_stamps[0][st + 1][5] = __builtin_amdgcn_s_memrealtime();
 #endif
-      rd(st + 1, 0, nxt);
+      rd(st + 1, 0, nxt, rest_next);
     }
     __builtin_amdgcn_sched_barrier(0);
-    mm(cur);
+    mm(cur, rest);
     __builtin_amdgcn_sched_barrier(0);
   };
   Frag f0, f1;
@@ -2774,13 +2839,14 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
   if (nst > 0) {
     __builtin_amdgcn_s_barrier(); /* stage 0 has landed */
     asm volatile("" ::: "memory");
-    rd(0, 0, f0);
+    rd(0, 0, f0, is_rest(0));
   }
   for (int st = 0; st < nst; st++) {
-    step(st, 0, f0, f1);
-    step(st, 1, f1, f0);
-    step(st, 2, f0, f1);
-    step(st, 3, f1, f0);
+    const bool r = is_rest(st), rn = is_rest(st + 1);
+    step(st, 0, f0, f1, r, rn);
+    step(st, 1, f1, f0, r, rn);
+    step(st, 2, f0, f1, r, rn);
+    step(st, 3, f1, f0, r, rn);
   }
 #ifdef PC_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0) g_pc_stamps[0][0][6] = __builtin_amdgcn_s_memrealtime();
@@ -2797,6 +2863,18 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
         c[(size_t)row * o.ldc + col] = acc[i][jn][g];
       }
     }
+  if (REST) {
+    float *rp = dr.planes + (size_t)(z * o.tm + mt) * dr.stride;
+#pragma unroll
+    for (int jn = 0; jn < 2; jn++) {
+      const int col = n0 + wn * 64 + jn * 32 + lm;
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+        int row = wm * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
+        if (row < dr.rows) rp[(size_t)row * o.ldc + col] = racc[jn][g];
+      }
+    }
+  }
 }
 
 // ----------------------------------------------------- K9: BPTT control --
@@ -4021,10 +4099,13 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       /* whole 128-row tiles by LDS-DMA, one workgroup per CU; the rows above them (the
        * input rows of a text net) by the generic kernel with its own K split */
       static bool attr_set = false;
-      const size_t shm = (size_t)DD_STAGES * DD_STAGE_FLOATS * sizeof(float);
+      size_t shm = (size_t)DD_STAGES * DD_STAGE_FLOATS * sizeof(float);
+      const size_t shm_rest = shm + 2 * (size_t)DD_REST_FLOATS * sizeof(float);
       if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_delta_dma,
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_delta_dma<false>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_delta_dma<true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_rest));
         attr_set = true;
       }
       rows_core = (sh->I / 128) * 128;
@@ -4049,18 +4130,47 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       o.ks = ks = kd;
       const int per = 8 / kd;
       int blocks = ((tiles + per - 1) / per) * 8;
+      /* the rows above the last whole tile inside the same launch (see DeltaRest) when there are at
+       * most 64 of them, at least four row tiles to share them out, and room for ks * tm planes */
+      const int rest_rows = sh->I - rows_core;
+      const size_t rest_plane = (size_t)rest_rows * sh->H;
+      const bool rest_in = rest_rows > 0 && rest_rows <= 64 && o.tm >= 4 && kd * o.tm <= RAMD_MAX_REST_PLANES &&
+                           (size_t)kd * n + (size_t)kd * o.tm * rest_plane <= b->slab_floats &&
+                           env_int("RECUR_AMD_DELTA_REST_IN", 1);
       int ev = timing_begin(st, T_DELTA);
-      RAMD_LAUNCH(k_delta_dma, dim3(blocks), dim3(512), shm, st, v, row0, nrows, o);
+      if (rest_in) {
+        DeltaRest dr;
+        dr.planes = b->slab + (size_t)kd * n;
+        dr.stride = rest_plane;
+        dr.rows = rest_rows;
+        dr.col = rows_core;
+        RAMD_LAUNCH(k_delta_dma<true>, dim3(blocks), dim3(512), shm_rest, st, v, row0, nrows, o, dr);
+      } else {
+        DeltaRest dr = {};
+        RAMD_LAUNCH(k_delta_dma<false>, dim3(blocks), dim3(512), shm, st, v, row0, nrows, o, dr);
+      }
       timing_end(st, ev);
       ks_rest = 0;
-      if (rows_core < sh->I) {
+      if (rest_in) {
+        ks_rest = kd * o.tm;
+        rest_base = b->slab + (size_t)kd * n;
+        rest_stride = rest_plane;
+        if (ho_paired) { /* the top layer's delta GEMM had been waiting for the pair launch */
+          launch_gemm<true, true, ProbHoDelta>(st, ho_p, b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, T_DELTA);
+          ho_paired = false;
+          if (ho_finalize_after && !ranges) {
+            ho_in_final = true; /* summed by the k_delta_finalize launch below */
+          } else if (ho_finalize_after) {
+            RAMD_LAUNCH(k_ho_delta_finalize, dim3((sh->H * sh->O + 255) / 256), dim3(256), 0, st, v,
+                               b->ho_slab, ho_ks, accumulate, range_stride ? nullptr : ranges);
+          }
+        }
+      } else if (rows_core < sh->I) {
         /* The rest rows' planes are compact ([ks_rest][I - rows_core][H], behind the core planes).
          * This GEMM is a few rows tall and K = S * D deep; measured at the north star its time does
          * not fall below 17 us for any K split from 16 to 48 (one workgroup per CU and ten K tiles
          * each, or three per CU and three tiles each: 0.87 us per 64 x 64 x 32 tile step and CU
          * either way), while every further plane costs the optimiser's sum: 16 it is. */
-        const int rest_rows = sh->I - rows_core;
-        const size_t rest_plane = (size_t)rest_rows * sh->H;
         int tmr = (rest_rows + BM - 1) / BM, tnr = (ncol - 1 + BN - 1) / BN;
         ks_rest = pick_ks(tmr * tnr, nkt, "RECUR_AMD_KS_DELTA_REST", (size_t)RAMD_MAX_REST_PLANES, 1);
         if (ks_rest > RAMD_MAX_REST_PLANES) ks_rest = RAMD_MAX_REST_PLANES;
