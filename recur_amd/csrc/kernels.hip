@@ -1858,6 +1858,9 @@ constexpr int pc_lds_bytes(int K) { return (2 * PC_SUB * K + 2 * PC_RED_FLOATS) 
 #define PC_SLEEP0 56
 #define PC_SLEEP1 8
 #endif
+#ifndef PC_SLEEP0_ONE
+#define PC_SLEEP0_ONE 32 /* 16-stream row tiles: the producers publish ~1 us after the barrier the poll starts at */
+#endif
 #ifndef PC_SLEEP0_SMALL
 #define PC_SLEEP0_SMALL 36 /* hidden 512 / 256: the half-step is shorter, the publish comes at the same ~1 us */
 #endif
@@ -1906,7 +1909,12 @@ __device__ unsigned long long g_pc_stamps[2][64][8];
 #define PC_STAMP(role, k, slot) do { } while (0)
 #endif
 
-template <int ACT, int K> /* rnn_activation; hidden size: 1024, 512 or 256 */
+/* ONE: row tiles of 16 streams, i.e. only sub-chain a exists and every other half-step is empty
+ * (the workgroup multiplies, then finishes and publishes, then waits for the 32 producers of its
+ * next operand): 4.5 instead of 6.4 us per step for HALF the streams per workgroup -- worse per
+ * stream, but a small set (64 streams at hidden 1024: a GPU's share of 512 on eight) then runs
+ * on twice as many CUs.  The launcher picks it when the 16-stream tiles still fit one launch. */
+template <int ACT, int K, bool ONE = false> /* rnn_activation; hidden size: 1024, 512 or 256 */
 __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ vp, int uniform_idx,
                                                        int row0, int nrows, int depth, unsigned seq,
                                                        ChainSync *sy, unsigned *host_abort) {
@@ -1922,7 +1930,8 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   v.b.uniform_idx = uniform_idx;
   const RamdShape &s = v.sh;
   const int wave8 = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int mtiles = nrows / 32;
+  constexpr int TR = ONE ? PC_SUB : 2 * PC_SUB; /* streams of a row tile */
+  const int mtiles = nrows / TR;
 
   // --- which XCD am I on, and which of its 32 seats do I get
   if (threadIdx.x == 0) {
@@ -1946,7 +1955,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   }
   if (g >= mtiles) return; /* fewer row tiles than seats: nothing to do here */
   const int j = (int)(seat % NT);
-  const int m0 = 32 * g, n0 = 1 + 32 * j;     /* output columns start at 1 */
+  const int m0 = TR * g, n0 = 1 + 32 * j;     /* output columns start at 1 */
   const unsigned epoch0 = seq * PC_EPOCH;
   const int halfsteps = 2 * depth;
   const int tn = NT;
@@ -1997,7 +2006,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     for (int k = 0; k <= halfsteps; k++) {
       const int x = k & 1;
       PC_STAMP(0, k, 0);
-      if (k >= 1) {
+      if (k >= 1 && !(ONE && x == 0)) {
         // ---- finish half-step k - 1 (sub-chain x ^ 1, step (k - 1) >> 1)
         const int xf = x ^ 1, t = (k - 1) >> 1;
         const float *rd = red + xf * PC_RED_FLOATS;
@@ -2045,6 +2054,10 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
       }
       if (k == halfsteps) { /* nothing left to multiply: drain and publish (nobody polls it) */
         break;
+      }
+      if (ONE && x == 1) { /* sub-chain b does not exist: an empty half-step */
+        __syncthreads();
+        continue;
       }
       const float *arow = abuf + x * BUF + m * K;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -2120,7 +2133,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
      * acknowledgement of the multiplying waves' stores, which sits on the critical path
      * (measured over the whole chain: first poll after 8 / 24 / 48 / 56 / 100 sleep units
      * = 207 / 166 / 136 / 135 / 165 us) */
-    __builtin_amdgcn_s_sleep(K == 1024 ? PC_SLEEP0 : PC_SLEEP0_SMALL);
+    __builtin_amdgcn_s_sleep(ONE ? PC_SLEEP0_ONE : K == 1024 ? PC_SLEEP0 : PC_SLEEP0_SMALL);
     for (unsigned spins = 0;; spins++) {
       unsigned got = 0u;
       if (!rh && col < NT) got = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2140,12 +2153,12 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   };
 
   fetch(0, 0);
-  if (halfsteps > 1) fetch(1, 0);
+  if (halfsteps > 1 && !ONE) fetch(1, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads(); /* barrier 0 */
   for (int k = 0; k < halfsteps; k++) {
     PC_STAMP(1, k, 0);
-    if (k >= 1 && k + 1 < halfsteps && !dead) {
+    if (k >= 1 && k + 1 < halfsteps && !dead && !(ONE && (k & 1) == 0)) {
       /* half-step k + 1 continues the sub-chain of half-step k - 1, which the multiplying
        * waves of all 32 column tiles are finishing right now */
       wait_for((k - 1) & 1, (k - 1) >> 1);
@@ -3696,7 +3709,7 @@ extern "C" unsigned ramd_chain_abort_word(void) {
 
 static bool chain_persist_ok(const RamdShape *sh, const RamdBuffers *b, int nrows) {
   const int hs = sh->hidden_size;
-  if (b->uniform_idx < 0 || (hs != 1024 && hs != 512 && hs != 256) || nrows < 32 || nrows % 32 != 0 ||
+  if (b->uniform_idx < 0 || (hs != 1024 && hs != 512 && hs != 256) || nrows < 16 || nrows % 16 != 0 ||
       sh->D > 60 || !env_int("RECUR_AMD_CHAIN_PERSIST", 1))
     return false;
   if (g_chain_cus < 0) {
@@ -3711,22 +3724,34 @@ static bool chain_persist_ok(const RamdShape *sh, const RamdBuffers *b, int nrow
 
 template <int ACT, int K>
 static void launch_chain_persist_k(hipStream_t st, const View *d_view, const RamdShape *sh,
-                                   const RamdBuffers *b, int row0, int nrows, unsigned seq) {
+                                   const RamdBuffers *b, int row0, int nrows, unsigned seq, bool one) {
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<ACT, K>,
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<ACT, K, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, pc_lds_bytes(K)));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<ACT, K, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, pc_lds_bytes(K)));
     attr_set = true;
   }
-  RAMD_LAUNCH((k_chain_persist<ACT, K>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view, b->uniform_idx,
-              row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev);
+  if (one)
+    RAMD_LAUNCH((k_chain_persist<ACT, K, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev);
+  else
+    RAMD_LAUNCH((k_chain_persist<ACT, K, false>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev);
 }
 
-/* rows per launch: 8 XCDs x (32 seats / column tiles) row tiles of 32 streams */
-static int chain_persist_rows(const RamdShape *sh) { return 8 * (32 / (sh->hidden_size / 32)) * 32; }
+/* row tiles per launch: 8 XCDs x (32 seats / column tiles) */
+static int chain_persist_seats(const RamdShape *sh) { return 8 * (32 / (sh->hidden_size / 32)); }
+/* 16-stream row tiles (one sub-chain per workgroup) when they all still fit one launch: twice the
+ * CUs for a small set; otherwise 32-stream tiles, which move more streams per microsecond */
+static bool chain_persist_one(const RamdShape *sh, int nrows) {
+  return nrows / 16 <= chain_persist_seats(sh) && (nrows % 32 != 0 || env_int("RECUR_AMD_CHAIN_ONE", 1));
+}
+static int chain_persist_rows(const RamdShape *sh, bool one) { return chain_persist_seats(sh) * (one ? 16 : 32); }
 
 static void launch_chain_persist(hipStream_t st, const View *d_view, const RamdShape *sh,
-                                 const RamdBuffers *b, int row0, int nrows) {
+                                 const RamdBuffers *b, int row0, int nrows, bool one) {
   if (!g_chain_sync) {
     HIP_CHECK(hipMalloc(&g_chain_sync, sizeof(ChainSync)));
     HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
@@ -3738,9 +3763,9 @@ static void launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
   int ev = timing_begin(st, T_CHAIN, 1);
 #define CHAIN_PERSIST(ACT)                                                                  \
   do {                                                                                      \
-    if (sh->hidden_size == 1024) launch_chain_persist_k<ACT, 1024>(st, d_view, sh, b, row0, nrows, seq); \
-    else if (sh->hidden_size == 512) launch_chain_persist_k<ACT, 512>(st, d_view, sh, b, row0, nrows, seq); \
-    else launch_chain_persist_k<ACT, 256>(st, d_view, sh, b, row0, nrows, seq);             \
+    if (sh->hidden_size == 1024) launch_chain_persist_k<ACT, 1024>(st, d_view, sh, b, row0, nrows, seq, one); \
+    else if (sh->hidden_size == 512) launch_chain_persist_k<ACT, 512>(st, d_view, sh, b, row0, nrows, seq, one); \
+    else launch_chain_persist_k<ACT, 256>(st, d_view, sh, b, row0, nrows, seq, one);             \
   } while (0)
   if (sh->activation == 2) CHAIN_PERSIST(2);
   else if (sh->activation == 5) CHAIN_PERSIST(5);
@@ -4021,9 +4046,16 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     const View *d_view = device_view(st, v);
     const bool persist = chain_persist_ok(sh, b, nrows);
     if (persist) { /* as many row tiles per launch as there are seats; more streams: more launches */
-      const int per = chain_persist_rows(sh);
-      for (int r = 0; r < nrows; r += per)
-        launch_chain_persist(st, d_view, sh, b, row0 + r, nrows - r < per ? nrows - r : per);
+      /* (an odd number of 16-stream tiles beyond one launch: 32-stream tiles, the last 16 streams alone) */
+      for (int r = 0; r < nrows;) {
+        const int left = nrows - r;
+        const bool one = chain_persist_one(sh, left);
+        const int per = chain_persist_rows(sh, one);
+        int n = left < per ? left : per;
+        if (!one) n &= ~31;
+        launch_chain_persist(st, d_view, sh, b, row0 + r, n, one);
+        r += n;
+      }
     }
     int ev = persist ? -1 : timing_begin(st, T_CHAIN, sh->D);
     for (int t = 0; t < (persist ? 0 : sh->D); t++) {

@@ -249,6 +249,13 @@ def test_empty_and_edge_inputs(amd):
     # and with a second generation accumulated on top (accumulate = 1 is the per-net path only,
     # so this one checks the non-accumulating batched form twice)
     ("dma_small", dict(input_size=42, hidden_size=128, output_size=42, S=32, D=6, learn_rate=1e-3, seed=34), 9),
+    # the one-launch chain with 16-stream row tiles (one sub-chain per workgroup): an odd number of
+    # them, a single one, and hidden 256 where four tiles share an XCD
+    ("chain_one_1024_48", dict(input_size=42, hidden_size=1024, output_size=42, S=48, D=6, learn_rate=1e-5, seed=35), 8),
+    ("chain_one_1024_16", dict(input_size=42, hidden_size=1024, output_size=42, S=16, D=4, learn_rate=1e-5, seed=36), 6),
+    ("chain_one_256_80", dict(input_size=42, hidden_size=256, output_size=42, S=80, D=7, learn_rate=1e-4, seed=37), 9),
+    # 17 tiles of 16 streams at hidden 1024: a launch of 32-stream tiles, then the last 16 streams alone
+    ("chain_mixed_1024_272", dict(input_size=42, hidden_size=1024, output_size=42, S=272, D=3, learn_rate=1e-5, seed=38), 4),
 ])
 def test_fallback_and_boundary_shapes_match_oracle(amd, label, kw, steps):
     text = sc.synthetic_text(4000)
