@@ -572,6 +572,36 @@ def test_c_driver_trains_on_erewhon():
     assert float(rows[-1][4]) > 10                              # BPTT runs deep
 
 
+def test_the_same_c_program_on_the_reference_and_on_the_product(tmp_path):
+    """tools/pernet_rate.c is the reference's per-net call sequence (rnn_bptt_advance, rnn_opinion,
+    the caller's softmax error, rnn_bptt_calculate / rnn_bptt_calc_deltas + rnn_apply_learning) as
+    one plain C program against include/recur-nn.h.  Linked against the compiled reference
+    (oracle/_ref) and against librecur_amd.so it must print the same mean error: the drop-in
+    boundary exercised by the same binary interface on both sides."""
+    import os
+    import re
+    import subprocess
+    ref = os.path.join(rc.ROOT, "oracle", "_ref")
+    if not os.path.exists(os.path.join(ref, "librecur_ref.so")):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    src = os.path.join(rc.ROOT, "tools", "pernet_rate.c")
+    inc = os.path.join(rc.ROOT, "include")
+    lib = os.path.join(rc.ROOT, "recur_amd", "lib")
+    exe_ref, exe_amd = str(tmp_path / "pn_ref"), str(tmp_path / "pn_amd")
+    subprocess.run(["gcc", "-O2", "-std=gnu11", "-D_GNU_SOURCE", "-I" + inc, src, "-o", exe_ref, "-L" + ref,
+                    "-lrecur_ref", "-Wl,-rpath," + ref, "-lm"], check=True)
+    subprocess.run(["gcc", "-O2", "-std=gnu11", "-D_GNU_SOURCE", "-I" + inc, src, "-o", exe_amd, "-L" + lib,
+                    "-lrecur_amd", "-Wl,-rpath," + lib, "-lm"], check=True)
+    for args in (["-H", "99", "-t", "1", "-d", "30", "-s", "400"], ["-H", "99", "-t", "3", "-d", "30", "-s", "150"],
+                 ["-H", "256", "-t", "2", "-d", "12", "-s", "60"]):
+        out = []
+        for exe in (exe_ref, exe_amd):
+            r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            out.append(float(re.search(r"mean error ([\d.]+)", r.stdout).group(1)))
+        assert abs(out[0] - out[1]) <= 1e-4 * abs(out[0]), (args, out)
+
+
 def test_text_tools_train_save_score_and_sample(tmp_path):
     """tools/text_predict_amd -> net file with the alphabet in its metadata ->
     tools/text_cross_entropy_amd and tools/text_confabulate_amd (the reference's

@@ -76,7 +76,7 @@ int main(int argc, char **argv) {
   }
   clock_gettime(CLOCK_MONOTONIC, &t1);
   double secs = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
-  printf("per-net calls: hidden %d, %d stream(s), depth %d: %.0f stream-timesteps/s (%.1f us per stream-step), mean error %.4f\n",
+  printf("per-net calls: hidden %d, %d stream(s), depth %d: %.0f stream-timesteps/s (%.1f us per stream-step), mean error %.6f\n",
          hidden, streams, depth, steps * (double)streams / secs, 1e6 * secs / (steps * (double)streams),
          err / ((steps + 50) * (double)streams));
   rnn_delete_training_set(nets, streams, 0);
