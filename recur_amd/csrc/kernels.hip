@@ -1825,6 +1825,161 @@ __global__ __launch_bounds__(512) void k_chain_main(const View *__restrict__ vp,
     v.b.esum_part[((size_t)t * (tn + 1) + nt) * s.Scap + row0 + r] = sq;
 }
 
+// ------------------------------------- BPTT chain step, 64 x 64 tiles (big sets) --
+//
+// The same step as k_chain_main for sets with many streams of a wide net (rnnca: 512 streams,
+// hidden 2048), where the one-launch chain does not apply (its W panel would not fit the
+// registers) and k_chain_main's 32 x 32 tiles are bound by the operand stream: a 32 x 32 tile
+// moves 32 KB into LDS per 1024 MFMA cycles of a wave, 1024 workgroups x 512 KB = 512 MB of
+// L2 -> LDS traffic per step.  Here the tile is 64 streams x 64 columns, the four multiplying
+// waves own a 32 x 32 quadrant each over the WHOLE K (no split-K, no cross-wave reduction), and a
+// K stage is 64 deep: 32 KB per 2048 MFMA cycles, half the bytes per MFMA, 256 workgroups = one
+// per CU for 512 x 2048.  Staging is k_chain_main's: both operands K-contiguous, 16-byte chunk c
+// of row r at position c ^ (r & 15) so that the b128 fragment reads are conflict free, four
+// loader waves with LDS-DMA into a four-deep ring, fragments of stage st + 1 read while stage
+// st multiplies (fully unrolled: NS stages).  Epilogue as in k_chain_main (zero-row mask, RESQRT
+// derivative, store, per-tile sum of squares), one partial per 64 columns.
+// Preconditions (launcher): every stream at one ring position, streams % 64 == 0,
+// hidden_size == 64 * NS.
+constexpr int WM = 64, WN = 64, WK = 64, W_STAGES = 4;
+constexpr int W_STAGE_FLOATS = (WM + WN) * WK; /* 32 KB */
+template <int NS>
+__global__ __launch_bounds__(512) void k_chain_wide(const View *__restrict__ vp, int uniform_idx, int row0,
+                                                    int nrows, int t, int tm, int tn) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  View v = *vp;
+  v.b.uniform_idx = uniform_idx;
+  const RamdShape &s = v.sh;
+  const int L = blockIdx.x;
+  const int xcd = L & 7, q = L >> 3;
+  const int mt = q % tm, nt = (q / tm) * 8 + xcd; /* the m tiles of one W panel share an XCD */
+  if (nt >= tn) return;
+  const int m0 = mt * WM, n0 = 1 + nt * WN; /* output columns start at 1 */
+  const int wave8 = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool loader = wave8 >= 4;
+  const int wave = wave8 & 3;
+  const int lm = lane & 31, kh = lane >> 5;
+  const float *ehi_t = v.b.ehi + ((size_t)t * s.Scap + row0) * s.I;
+  const uint32_t lds0 = lds_byte_addr(wsm);
+
+  if (loader) {
+    // instruction i (0..31 over the four loader waves) fills rows 4 (i & 15) .. + 3 of A (i < 16)
+    // or B: lane l brings chunk (l & 15) ^ (row & 15) of row 4 (i & 15) + (l >> 4)
+    const float *src[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = wave * 8 + j;
+      const int row = 4 * (i & 15) + (lane >> 4);
+      const int c = (lane & 15) ^ (row & 15);
+      const float *base = i < 16 ? ehi_t + (size_t)(m0 + row) * s.I : v.b.ih_w + (size_t)(n0 + row) * s.H;
+      src[j] = base + 1 + 4 * c; /* K runs over the hidden columns 1..hidden_size */
+    }
+    auto issue = [&](int stage) {
+      float *dst = wsm + (stage % W_STAGES) * W_STAGE_FLOATS + wave * 8 * 256;
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(src[j] + stage * WK), (lds_void_t *)(dst + j * 256), 16, 0, 0);
+    };
+#pragma unroll
+    for (int p = 0; p < W_STAGES - 1; p++)
+      if (p < NS) issue(p);
+#pragma unroll
+    for (int st = 0; st < NS; st++) {
+      const int ahead = (NS - 1 - st) < (W_STAGES - 2) ? (NS - 1 - st) : (W_STAGES - 2);
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); /* stage st has landed; stage st - 1's buffer is free */
+      if (st + W_STAGES - 1 < NS) issue(st + W_STAGES - 1);
+    }
+    __syncthreads();
+    return;
+  }
+
+  // ------------------------------------------------------------------ multiply
+  const int wm = wave >> 1, wn = wave & 1;
+  // the gate values of this thread's 4 x 4 outputs in the epilogue, requested now
+  const int etid = threadIdx.x; /* 0..255 */
+  const int rq = etid >> 4, c4 = (etid & 15) * 4;
+  float xin[4][4];
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++) {
+    const float *xrow = input_row<true>(v, row0 + m0 + 4 * rq + rr, t) + n0 + c4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) xin[rr][i] = xrow[i];
+  }
+  f32x16 acc; /* (a second accumulator taking turns with this one measured no difference) */
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+  const uint32_t arow = (uint32_t)(wm * 32 + lm) * (WK * 4u), brow = (uint32_t)(WM + wn * 32 + lm) * (WK * 4u);
+  auto rd = [&](int st, f32x4 (&a)[8], f32x4 (&b)[8]) {
+    const uint32_t base = lds0 + (uint32_t)((st % W_STAGES) * W_STAGE_FLOATS) * 4u;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t off = (uint32_t)(((2 * u + kh) ^ (lm & 15)) * 16);
+      a[u] = lds_read_b128(base + arow + off);
+      b[u] = lds_read_b128(base + brow + off);
+    }
+  };
+  auto step = [&](int st, f32x4 (&a)[8], f32x4 (&b)[8], f32x4 (&an)[8], f32x4 (&bn)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this stage's fragments have arrived */
+    if (st + 1 < NS) {
+      __builtin_amdgcn_s_barrier(); /* stage st + 1 has landed */
+      rd(st + 1, an, bn);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    f32x4 a0[8], b0[8], a1[8], b1[8];
+    __builtin_amdgcn_s_barrier(); /* stage 0 has landed */
+    rd(0, a0, b0);
+#pragma unroll
+    for (int st = 0; st < NS; st += 2) {
+      step(st, a0, b0, a1, b1);
+      if (st + 1 < NS) step(st + 1, a1, b1, a0, b0);
+    }
+  }
+  // the tile through LDS (the ring buffer stage NS would have used was read four barriers ago)
+  float *red = wsm + (NS % W_STAGES) * W_STAGE_FLOATS; /* [64][64] */
+#pragma unroll
+  for (int g = 0; g < 16; g++) {
+    const int row = wm * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
+    red[row * WN + wn * 32 + lm] = acc[g];
+  }
+  __syncthreads();
+  float *dst0 = v.b.ehi + ((size_t)(t + 1) * s.Scap + row0 + m0) * s.I + n0 + c4;
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++) {
+    const int row = 4 * rq + rr;
+    const float4 e4 = ld4(red + row * WN + c4);
+    const float e[4] = {e4.x, e4.y, e4.z, e4.w};
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float ev = e[i];
+      const float xi = xin[rr][i];
+      const bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
+      ev = on ? ev : 0.0f;
+      if (on && s.activation == 2) ev /= 2 * (xi + 1.0f);
+      dst0[(size_t)row * s.I + i] = ev;
+      sq += ev * ev;
+    }
+    sq += __shfl_xor(sq, 1, 64);
+    sq += __shfl_xor(sq, 2, 64);
+    sq += __shfl_xor(sq, 4, 64);
+    sq += __shfl_xor(sq, 8, 64);
+    if ((etid & 15) == 0) v.b.esum_part[((size_t)t * (tn + 1) + nt) * s.Scap + row0 + m0 + row] = sq;
+  }
+}
+
 // ------------------------------------------------ BPTT chain, one launch --
 //
 // All D steps of the chain in ONE launch (hidden 1024: 32 column tiles; up to 8 row tiles of
@@ -4015,6 +4170,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   // BPTT chain: D dependent steps, one launch each, then the extras of all steps
   bool control_done = false;
   const int tn = (sh->hidden_size + CN - 1) / CN;
+  int tn_parts = tn; /* partial sums of squares per (step, stream): one per column tile of the chain kernel used */
   const int nx = sh->I - sh->hidden_size; /* column 0 + the input columns */
   const int nxp = (nx + 3) & ~3;
   if (nrows == 1 && !active && !defer && row0 < sh->Scap && sh->H <= 256 &&
@@ -4057,8 +4213,36 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
         r += n;
       }
     }
-    int ev = persist ? -1 : timing_begin(st, T_CHAIN, sh->D);
-    for (int t = 0; t < (persist ? 0 : sh->D); t++) {
+    /* big sets of a wide net: 64 x 64 tiles (k_chain_wide), one partial sum per 64 columns */
+    const int wide_ns = sh->hidden_size / WK;
+    const bool wide = !persist && b->uniform_idx >= 0 && nrows % WM == 0 && sh->hidden_size % WN == 0 &&
+                      (wide_ns == 16 || wide_ns == 24 || wide_ns == 32) &&
+                      (nrows / WM) * (sh->hidden_size / WN) >= 128 && env_int("RECUR_AMD_CHAIN_WIDE", 1);
+    if (wide) {
+      static bool attr_set = false;
+      const size_t shm = (size_t)W_STAGES * W_STAGE_FLOATS * sizeof(float);
+      if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_wide<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_wide<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_wide<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        attr_set = true;
+      }
+      const int wtm = nrows / WM, wtn = sh->hidden_size / WN;
+      const int wblocks = ((wtn + 7) / 8) * 8 * wtm;
+      tn_parts = wtn;
+      int evw = timing_begin(st, T_CHAIN, sh->D);
+      for (int t = 0; t < sh->D; t++) {
+        if (wide_ns == 32)
+          RAMD_LAUNCH(k_chain_wide<32>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, t, wtm, wtn);
+        else if (wide_ns == 24)
+          RAMD_LAUNCH(k_chain_wide<24>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, t, wtm, wtn);
+        else
+          RAMD_LAUNCH(k_chain_wide<16>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, t, wtm, wtn);
+      }
+      timing_end(st, evw);
+    }
+    int ev = (persist || wide) ? -1 : timing_begin(st, T_CHAIN, sh->D);
+    for (int t = 0; t < ((persist || wide) ? 0 : sh->D); t++) {
 #define CHAIN_NS(NS)                                                                               \
   RAMD_LAUNCH((k_chain_main<true, NS>), dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx, \
                      row0, nrows, t, tm, tn, nstages)
@@ -4084,25 +4268,25 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       if (env_int("RECUR_AMD_EXTRAS_SPLIT", 0)) {
         if (nq <= 5)
           RAMD_LAUNCH(k_extras_gather<5>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
-                             nxp, tn);
+                             nxp, tn_parts);
         else
           RAMD_LAUNCH(k_extras_gather<8>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
-                             nxp, tn);
+                             nxp, tn_parts);
       } else {
         /* extras and control in one launch, one workgroup per stream */
         const size_t shm = (size_t)sh->D * sizeof(float);
         if (nq <= 5)
           RAMD_LAUNCH((k_extras_control<5, 1024>), dim3(nrows), dim3(1024), shm, st, v, row0, nrows,
-                             nx, nxp, tn, active, flags);
+                             nx, nxp, tn_parts, active, flags);
         else
           RAMD_LAUNCH((k_extras_control<8, 512>), dim3(nrows), dim3(512), shm, st, v, row0, nrows,
-                             nx, nxp, tn, active, flags);
+                             nx, nxp, tn_parts, active, flags);
         control_done = true;
       }
     } else { /* very wide nets: the dense GEMM over all extra columns */
       ProbExtras p = {v, row0, nrows, nx};
       launch_gemm<false, false, ProbExtras>(st, p, b->slab, M, nxp, nkt, ks, T_OTHER);
-      RAMD_LAUNCH(k_extras_finalize, dim3(M), dim3(64), 0, st, v, row0, nrows, nx, nxp, ks, tn);
+      RAMD_LAUNCH(k_extras_finalize, dim3(M), dim3(64), 0, st, v, row0, nrows, nx, nxp, ks, tn_parts);
     }
   }
   if (!control_done)
