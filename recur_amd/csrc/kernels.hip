@@ -681,8 +681,20 @@ __global__ __launch_bounds__(256) void k_sum_slabs(float *dst, int ld_dst, const
 struct DevRng {
   unsigned long long a, b, c, d;
 };
+/* k is a compile-time constant at every call site: two v_alignbit_b32 (full rate) instead of two
+ * 64-bit shifts and an or (the 64-bit shifts are quarter rate, and the generator's recurrence is
+ * a single lane's dependent instruction stream) */
 __device__ __forceinline__ unsigned long long rotl64(unsigned long long x, int k) {
-  return (x << k) | (x >> (64 - k));
+  unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+  if (k >= 32) {
+    unsigned t = lo;
+    lo = hi;
+    hi = t;
+    k -= 32;
+  }
+  if (k == 0) return ((unsigned long long)hi << 32) | lo;
+  const unsigned nh = __builtin_amdgcn_alignbit(hi, lo, 32 - k), nl = __builtin_amdgcn_alignbit(lo, hi, 32 - k);
+  return ((unsigned long long)nh << 32) | nl;
 }
 __device__ __forceinline__ unsigned long long dev_rand64(DevRng &x) {
   unsigned long long e = x.a - rotl64(x.b, 7);
@@ -692,26 +704,54 @@ __device__ __forceinline__ unsigned long long dev_rand64(DevRng &x) {
   x.d = e + x.a;
   return x.d;
 }
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+/* recur-rng.h:179-201: the sum of the twelve 16-bit fields of three draws.  The sum fits 20
+ * bits, so it is kept in 32 bits and each draw's four fields are two v_dot2_u32_u16 with (1, 1)
+ * -- this lane is alone on its SIMD's issue slot, every instruction saved is time saved */
 __device__ __forceinline__ float dev_cheap_gaussian(DevRng &x) {
-  long long a = 0;
+  unsigned a = 0;
+  const u16x2_t ones = {1, 1};
+#pragma unroll
   for (int w = 0; w < 3; w++) {
     unsigned long long bits = dev_rand64(x);
-    a += (long long)(bits & 0xffff) + (long long)((bits >> 16) & 0xffff) +
-         (long long)((bits >> 32) & 0xffff) + (long long)(bits >> 48);
+    a = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, (unsigned)bits), ones, a, false);
+    a = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, (unsigned)(bits >> 32)), ones, a, false);
   }
-  return (float)(a - 0xffff * 6) / (0xffff);
+  return (float)((int)a - 0xffff * 6) / (0xffff);
 }
 
 // MAYBE_ADD_ARRAY_NOISE on hidden[1..h_size) (recur-nn.c:120-121; the pad columns get
 // noise too).  The generator is sequential per stream, so one thread
 // walks each stream's row; the values are added to K slab 0 of the forward GEMM.
+/* One lane per stream: the stream's generator is a sequential recurrence (three rand64 per
+ * value).  The row is walked in pieces of 16 values whose old contents are requested BEFORE the
+ * piece's 48 generator steps and added and stored after them, so the memory round trips sit in
+ * the shadow of the recurrence (element by element, as a read-modify-write per value, this kernel
+ * took 360 us for 256 streams of 1028 values). */
 __global__ void k_presynaptic_noise(View v, int row0, int nrows, float deviation) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nrows) return;
   const RamdShape &s = v.sh;
   DevRng g = reinterpret_cast<DevRng *>(v.b.rng)[row0 + j];
   float *row = v.b.slab + (size_t)j * s.H;
-  for (int i = 1; i < s.H; i++) row[i] += dev_cheap_gaussian(g) * deviation;
+  /* column 0 gets no noise (recur-nn.c:120-121: i from 1); h_size is a multiple of 4 */
+  for (int i0 = 0; i0 < s.H; i0 += 16) {
+    const int n4 = min(4, (s.H - i0) / 4);
+    float4 old[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) old[k] = k < n4 ? ld4(row + i0 + 4 * k) : zero4();
+    float nz[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int i = i0 + k;
+      nz[k] = (i >= 1 && i < s.H) ? dev_cheap_gaussian(g) * deviation : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (k < n4)
+        *reinterpret_cast<float4 *>(row + i0 + 4 * k) =
+            make_float4(old[k].x + nz[4 * k], old[k].y + nz[4 * k + 1], old[k].z + nz[4 * k + 2], old[k].w + nz[4 * k + 3]);
+  }
   reinterpret_cast<DevRng *>(v.b.rng)[row0 + j] = g;
 }
 
@@ -1519,6 +1559,107 @@ __global__ __launch_bounds__(256) void k_top_backprop(View v, int row0, const in
   }
   float *dst = v.b.ehi + (size_t)r * s.I; /* step 0 plane */
   for (int y = threadIdx.x; y < s.H; y += 256) /* ehi keeps column 0 and the pad at zero */
+    dst[y] = (y == 0 || y > s.hidden_size) ? 0.0f : (sum > halfmax) ? herr[y] * scale : herr[y];
+  if (threadIdx.x == 0) {
+    v.b.top_raw[r] = sum;
+    v.b.top_scaled[r] = scaled;
+  }
+}
+
+// backprop_single_layer_sparse (recur-nn.c:156-196) with half a wave per hidden row: k_top_backprop
+// gives every thread a row of W_ho of its own and walks the ranges' columns one by one -- 64
+// lanes on 64 different cache lines per load -- which at o_size 3652 (the multi-head nets) took
+// 486 us for 256 streams.  Here 32 lanes read a row's range as float4 (a head of 73 symbols is 19
+// of them: one instruction per row and range), a wave works on eight rows at a time (four
+// instructions, each covering two rows) so that the loads and the shuffle chains of the rows
+// overlap, the products are reduced over the 32 lanes with xor shuffles (a fixed tree per range),
+// and the range's sum joins the row's running value and |running value| the error sum, range by
+// range as the reference does (recur-nn.c:178-191).  Rows whose hidden value is zero keep the
+// stale entry of the last BPTT run.  One workgroup of 16 waves per stream.
+__global__ __launch_bounds__(1024) void k_top_backprop_ranged(View v, int row0, const int *ranges,
+                                                              int range_stride, const unsigned char *active) {
+  extern __shared__ __attribute__((aligned(16))) float rsh[];
+  __shared__ float red[16];
+  __shared__ int rlist[2 * 65];
+  const RamdShape &s = v.sh;
+  const int j = blockIdx.x, r = row0 + j;
+  if (active && !active[j]) return;
+  ranges += (size_t)j * range_stride; /* 0: one list for every stream */
+  float *oerr = rsh;       /* [O] */
+  float *herr = rsh + s.O; /* [H] */
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int half = lane >> 5, l32 = lane & 31;
+  for (int i = threadIdx.x; i < s.O; i += 1024) oerr[i] = v.b.o_error[(size_t)r * s.O + i];
+  if (threadIdx.x == 0) {
+    int n = 0;
+    while (n < 64 && ranges[2 * n] >= 0) {
+      rlist[2 * n] = ranges[2 * n] & ~3;                 /* start, aligned as k_top_backprop does */
+      rlist[2 * n + 1] = (ranges[2 * n + 1] + 3) & ~3;   /* length */
+      n++;
+    }
+    rlist[2 * n] = -1;
+  }
+  __syncthreads();
+  const float *hid = v.b.hidden + (size_t)r * s.H;
+  const float *old = v.b.err_a + (size_t)r * s.I;
+  float sum = 0.0f; /* this half-wave's rows */
+  constexpr int PAIRS = 4; /* eight rows at a time */
+  for (int y0 = 2 * PAIRS * wave; y0 < s.H; y0 += 2 * PAIRS * 16) {
+    float e[PAIRS];
+    bool act[PAIRS];
+    const float *rowp[PAIRS];
+#pragma unroll
+    for (int q = 0; q < PAIRS; q++) {
+      const int y = y0 + 2 * q + half; /* this half-wave's row of pair q */
+      act[q] = y > 0 && y < s.H && hid[y < s.H ? y : 0] != 0.0f;
+      rowp[q] = v.b.ho_w + (size_t)(act[q] ? y : 0) * s.O;
+      e[q] = 0.0f;
+    }
+    for (int i = 0; rlist[2 * i] >= 0; i++) {
+      const int start = rlist[2 * i], len4 = rlist[2 * i + 1] >> 2;
+      float p[PAIRS];
+#pragma unroll
+      for (int q = 0; q < PAIRS; q++) p[q] = 0.0f;
+      for (int x4 = l32; x4 < len4; x4 += 32) {
+        const float4 o4 = ld4(oerr + start + 4 * x4);
+#pragma unroll
+        for (int q = 0; q < PAIRS; q++) {
+          const float4 w4 = ld4(rowp[q] + start + 4 * x4);
+          p[q] += (w4.x * o4.x + w4.y * o4.y) + (w4.z * o4.z + w4.w * o4.w);
+        }
+      }
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1)
+#pragma unroll
+        for (int q = 0; q < PAIRS; q++) p[q] += __shfl_xor(p[q], off, 64);
+#pragma unroll
+      for (int q = 0; q < PAIRS; q++)
+        if (act[q]) {
+          e[q] += p[q];
+          sum += fabsf(e[q]); /* once per range, e keeps running: recur-nn.c:178-191 */
+        }
+    }
+    if (l32 == 0) {
+#pragma unroll
+      for (int q = 0; q < PAIRS; q++) {
+        const int y = y0 + 2 * q + half;
+        if (y < s.H) herr[y] = (y == 0) ? 0.0f : act[q] ? e[q] : old[y]; /* stale value where the row is skipped */
+      }
+    }
+  }
+  sum += __shfl_xor(sum, 32, 64); /* the two half-waves' rows */
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+  sum += ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
+  float halfmax = s.H * MAX_TOP_ERROR_FACTOR_F;
+  float scaled = sum, scale = 1.0f;
+  if (sum > halfmax) {
+    scale = soft_clip_dev(sum, halfmax);
+    scaled = scale * sum;
+  }
+  float *dst = v.b.ehi + (size_t)r * s.I; /* step 0 plane */
+  for (int y = threadIdx.x; y < s.H; y += 1024) /* ehi keeps column 0 and the pad at zero */
     dst[y] = (y == 0 || y > s.hidden_size) ? 0.0f : (sum > halfmax) ? herr[y] * scale : herr[y];
   if (threadIdx.x == 0) {
     v.b.top_raw[r] = sum;
@@ -4108,9 +4249,12 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   View v = make_view(sh, b);
   // top layer
   size_t shm = (size_t)(sh->O + sh->H) * sizeof(float);
-  if (!(flags & 0x40000000u)) /* ramd_launch_text_top has already done the top backprop */
-    RAMD_LAUNCH(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges,
-                       range_stride, active);
+  if (!(flags & 0x40000000u)) { /* ramd_launch_text_top has already done the top backprop */
+    if (ranges && env_int("RECUR_AMD_TOP_RANGED", 1))
+      RAMD_LAUNCH(k_top_backprop_ranged, dim3(nrows), dim3(1024), shm, st, v, row0, ranges, range_stride, active);
+    else
+      RAMD_LAUNCH(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges, range_stride, active);
+  }
   /* the weight-delta GEMM's path is decided here already: when it ends with the small GEMM
    * over the rows above the last whole 128-row tile, the top layer's equally small delta
    * GEMM can share that launch (nothing before the optimiser needs its result) */

@@ -234,6 +234,55 @@ static void mail_out(void *host, const void *dev, size_t bytes) {
   g_mail_out.cur += words;
 }
 
+/* The set calls' small per-generation uploads (symbols, targets, dense input rows): snapshot into
+ * the pinned mailbox and carried by a launch on the stream -- the caller's buffer is free when we
+ * return and nobody waits for the device; what does not fit or is not word-sized goes the old way
+ * (copy, then wait).  rows of `width` bytes, `host_pitch` apart, land contiguously at `dev`. */
+static void upload_rows(void *dev, const void *host, size_t host_pitch, size_t width, size_t rows) {
+  size_t bytes = width * rows;
+  if (!bytes) {
+    return;
+  }
+  mail_ready();
+  if ((bytes & 3) || bytes / 4 > MAIL_WORDS) {
+    mail_in_flush();
+    if (host_pitch == width) {
+      h2d(dev, host, bytes);
+    } else {
+      HIP_OK(hipMemcpy2DAsync(dev, width, host, host_pitch, width, rows, hipMemcpyHostToDevice, g_stream));
+    }
+    dsync();
+    return;
+  }
+  if (host_pitch == width) {
+    mail_in(dev, host, bytes);
+  } else {
+    /* pack the rows behind one another in the mailbox: one segment */
+    unsigned words = (unsigned)(bytes / 4);
+    if (g_mail.nseg == 0 && g_mail.in_busy && g_mail.in_sync != g_syncs) {
+      g_mail.in_busy = 0;
+      g_mail.cur = 0;
+    }
+    if (g_mail.nseg == MAIL_SEGS || g_mail.cur + words > MAIL_WORDS) {
+      mail_in_flush();
+      dsync();
+      g_mail.in_busy = 0;
+      g_mail.cur = 0;
+    }
+    unsigned *slot = g_mail.buf + g_mail.cur;
+    for (size_t r = 0; r < rows; r++) {
+      memcpy((char *)slot + r * width, (const char *)host + r * host_pitch, width);
+    }
+    g_mail.dst[g_mail.nseg] = dev;
+    g_mail.src[g_mail.nseg] = slot;
+    g_mail.n[g_mail.nseg] = words;
+    g_mail.nseg++;
+    g_mail.cur += words;
+  }
+  mail_in_flush();
+}
+static void upload(void *dev, const void *host, size_t bytes) { upload_rows(dev, host, bytes, bytes, 1); }
+
 void *ramd_zalloc(size_t bytes) {
   void *p = NULL;
   if (posix_memalign(&p, 64, bytes ? bytes : 64)) {
@@ -1886,9 +1935,7 @@ void rnn_amd_set_opinion(RnnAmdSet *set, const float *inputs, int ld_inputs, flo
   RamdEngine *e = set->eng;
   if (inputs) {
     int w = e->sh.bI ? e->sh.b_in : e->sh.input_size;
-    HIP_OK(hipMemcpy2DAsync(e->d_dense, w * sizeof(float), inputs, ld_inputs * sizeof(float),
-                            w * sizeof(float), set->n, hipMemcpyHostToDevice, g_stream));
-    dsync();
+    upload_rows(e->d_dense, inputs, ld_inputs * sizeof(float), w * sizeof(float), set->n);
     set_forward(set, RAMD_IN_DENSE, e->d_dense, w, 0, outputs, 0, 0);
   } else {
     set_forward(set, RAMD_IN_KEEP, NULL, 0, 0, outputs, 0, 0);
@@ -1897,8 +1944,7 @@ void rnn_amd_set_opinion(RnnAmdSet *set, const float *inputs, int ld_inputs, flo
 
 void rnn_amd_set_one_hot_opinion(RnnAmdSet *set, const int *hot, float *outputs) {
   RamdEngine *e = set->eng;
-  h2d(e->b.hot + set_state_row0(set), hot, set->n * sizeof(int));
-  dsync();
+  upload(e->b.hot + set_state_row0(set), hot, set->n * sizeof(int));
   set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, outputs, 0, 0);
 }
 
@@ -1906,10 +1952,8 @@ void rnn_amd_set_put_o_error(RnnAmdSet *set, const float *o_error, int ld) {
   RamdEngine *e = set->eng;
   set_need_training(set, "rnn_amd_set_put_o_error");
   set_streams_to_dev(set);
-  HIP_OK(hipMemcpy2DAsync(e->b.o_error + (size_t)set->row0 * e->sh.O, e->sh.O * sizeof(float),
-                          o_error, ld * sizeof(float), e->sh.O * sizeof(float), set->n,
-                          hipMemcpyHostToDevice, g_stream));
-  dsync();
+  upload_rows(e->b.o_error + (size_t)set->row0 * e->sh.O, o_error, ld * sizeof(float), e->sh.O * sizeof(float),
+              set->n);
   set_streams_dev_wrote(set);
 }
 
@@ -1918,8 +1962,7 @@ void rnn_amd_set_softmax_error(RnnAmdSet *set, const int *target) {
   set_need_training(set, "rnn_amd_set_softmax_error");
   set_streams_to_dev(set);
   if (target) {
-    h2d(e->b.target + set->row0, target, set->n * sizeof(int));
-    dsync();
+    upload(e->b.target + set->row0, target, set->n * sizeof(int));
   }
   ramd_launch_softmax_error(g_stream, &e->sh, &e->b, set->row0, set->n);
   set_streams_dev_wrote(set);
@@ -2011,15 +2054,14 @@ void rnn_amd_set_grouped_softmax_error(RnnAmdSet *set, int n_groups, const int *
     e->d_group_bytes = bytes;
   }
   int *d = (int *)e->d_group;
-  h2d(d, group_offset, n_groups * sizeof(int));
-  h2d(d + n_groups, group_size, n_groups * sizeof(int));
-  h2d(d + 2 * n_groups, targets, (size_t)set->n * n_groups * sizeof(int));
+  upload(d, group_offset, n_groups * sizeof(int));
+  upload(d + n_groups, group_size, n_groups * sizeof(int));
+  upload(d + 2 * n_groups, targets, (size_t)set->n * n_groups * sizeof(int));
   float *dw = NULL;
   if (error_weight) {
     dw = (float *)(d + ints);
-    h2d(dw, error_weight, (size_t)s->output_size * sizeof(float));
+    upload(dw, error_weight, (size_t)s->output_size * sizeof(float));
   }
-  dsync();
   ramd_launch_grouped_softmax_error(g_stream, s, &e->b, set->row0, set->n, n_groups, largest, d,
                                     d + n_groups, d + 2 * n_groups, dw);
   set_streams_dev_wrote(set);
@@ -2062,8 +2104,7 @@ static void multi_loss(RnnAmdSet *set, const int *target_class, int alphabet_len
                        float leakage) {
   RamdEngine *e = set->eng;
   if (target_class) {
-    h2d(e->d_mclass + set->row0, target_class, set->n * sizeof(int));
-    dsync();
+    upload(e->d_mclass + set->row0, target_class, set->n * sizeof(int));
   }
   /* u64 threshold = leakage * UINT64_MAX (charmodel-multi-predict.c:27): float arithmetic */
   float tf = leakage * (float)UINT64_MAX;
@@ -2092,9 +2133,8 @@ void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *ne
   RamdEngine *e = set->eng;
   set_need_training(set, "rnn_amd_set_multi_step_deltas");
   int n_classes = multi_heads(e, alphabet_len);
-  h2d(e->b.hot + set->row0, hot, set->n * sizeof(int));
-  h2d(e->b.target + set->row0, next, set->n * sizeof(int));
-  dsync();
+  upload(e->b.hot + set->row0, hot, set->n * sizeof(int));
+  upload(e->b.target + set->row0, next, set->n * sizeof(int));
   set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, NULL, 1, 0);
   multi_loss(set, target_class, alphabet_len, n_classes, leakage);
   rnn_amd_set_multi_calc_deltas(set, accumulate);
@@ -2153,9 +2193,7 @@ void rnn_amd_set_sigmoid_mse_error(RnnAmdSet *set, const float *targets, int ld,
     e->d_group = dev_alloc(bytes);
     e->d_group_bytes = bytes;
   }
-  HIP_OK(hipMemcpy2DAsync(e->d_group, n * sizeof(float), targets, ld * sizeof(float), n * sizeof(float),
-                          set->n, hipMemcpyHostToDevice, g_stream));
-  dsync();
+  upload_rows(e->d_group, targets, ld * sizeof(float), n * sizeof(float), set->n);
   ramd_launch_sigmoid_mse_error(g_stream, &e->sh, &e->b, set->row0, set->n, n, (const float *)e->d_group,
                                 n);
   set_streams_dev_wrote(set);
