@@ -755,6 +755,42 @@ __global__ void k_presynaptic_noise(View v, int row0, int nrows, float deviation
   reinterpret_cast<DevRng *>(v.b.rng)[row0 + j] = g;
 }
 
+/* The same values without touching anything: out[j][1..H) and the generator state after them
+ * (see noise_speculate in rnn_core.c: runs on a second stream while the rest of the previous
+ * generation is still being computed) */
+__global__ void k_noise_speculate(View v, int row0, int nrows, float deviation, float *out, DevRng *state) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nrows) return;
+  const RamdShape &s = v.sh;
+  DevRng g = reinterpret_cast<DevRng *>(v.b.rng)[row0 + j];
+  float *row = out + (size_t)j * s.H;
+  for (int i0 = 0; i0 < s.H; i0 += 16) {
+    float nz[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int i = i0 + k;
+      nz[k] = (i >= 1 && i < s.H) ? dev_cheap_gaussian(g) * deviation : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (i0 + 4 * k < s.H)
+        *reinterpret_cast<float4 *>(row + i0 + 4 * k) = make_float4(nz[4 * k], nz[4 * k + 1], nz[4 * k + 2], nz[4 * k + 3]);
+  }
+  state[j] = g;
+}
+/* ... and their use by the forward pass: slab plane 0 += values, generators = the states after them */
+__global__ __launch_bounds__(256) void k_noise_apply(View v, int row0, int nrows) {
+  const RamdShape &s = v.sh;
+  const int q = blockIdx.x * 256 + threadIdx.x, per_row = s.H >> 2;
+  if (q >= nrows * per_row) return;
+  const int j = q / per_row, c = (q - j * per_row) * 4;
+  float4 a = ld4(v.b.slab + (size_t)j * s.H + c);
+  const float4 n4 = ld4(v.b.noise_spec + (size_t)j * s.H + c);
+  a.x += n4.x; a.y += n4.y; a.z += n4.z; a.w += n4.w;
+  *reinterpret_cast<float4 *>(v.b.slab + (size_t)j * s.H + c) = a;
+  if (c == 0) reinterpret_cast<DevRng *>(v.b.rng)[row0 + j] = reinterpret_cast<const DevRng *>(v.b.rng_spec)[j];
+}
+
 // ------------------------------------------------------- bottom layer --
 
 // The optional bottom layer of rnn_opinion (recur-nn.c:88-103): one workgroup per
@@ -4154,9 +4190,13 @@ extern "C" int ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh
       ProbFwd<false> p = {v, row0, nrows};
       launch_gemm<false, true, ProbFwd<false>>(st, p, b->slab, nrows, sh->H, nkt, ks, T_FWD);
     }
-    if (noise != 0.0f)
+    if (noise != 0.0f && b->noise_spec_use) {
+      int n4 = nrows * (sh->H / 4);
+      RAMD_LAUNCH(k_noise_apply, dim3((n4 + 255) / 256), dim3(256), 0, st, v, row0, nrows);
+    } else if (noise != 0.0f) {
       RAMD_LAUNCH(k_presynaptic_noise, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows,
                          noise);
+    }
     if (leave_slabs) return ks;
     int n4 = nrows * (sh->H / 4);
     RAMD_LAUNCH(k_fwd_finalize, dim3((n4 + 255) / 256), dim3(256), 0, st, v, row0, nrows, ks);
@@ -4612,6 +4652,14 @@ __global__ __launch_bounds__(256) void k_segcopy(SegCopy sc) {
   if (g >= sc.nseg) return;
   for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < sc.n[g]; i += gridDim.x * 256) sc.dst[g][i] = sc.src[g][i];
 }
+extern "C" void ramd_launch_noise_speculate(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
+                                            int row0, int nrows, float noise) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  RAMD_LAUNCH(k_noise_speculate, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows, noise, b->noise_spec,
+              (DevRng *)b->rng_spec);
+}
+
 extern "C" void ramd_launch_segcopy(ramd_stream_t st_, int nseg, void *const *dst,
                                     const void *const *src, const unsigned *nwords) {
   hipStream_t st = (hipStream_t)st_;

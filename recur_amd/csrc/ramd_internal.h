@@ -76,6 +76,12 @@ typedef struct RamdBuffers {
   /* ring position shared by every training stream of the current call, or -1
    * when they differ (set by the host before each launch) */
   int uniform_idx;
+  /* presynaptic noise generated ahead of its forward pass (see noise_speculate in rnn_core.c):
+   * [n][H] values and the generator states after them; noise_spec_use: the next forward adds
+   * these and adopts the states instead of running the generators */
+  float *noise_spec;
+  void *rng_spec;
+  int noise_spec_use;
 } RamdBuffers;
 
 /* ih_delta left as un-summed K slabs by ramd_launch_calc_deltas, for the optimiser launch
@@ -184,6 +190,10 @@ void ramd_launch_sigmoid_mse_error(ramd_stream_t st, const RamdShape *sh, const 
 void ramd_launch_sigmoid_outputs(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int r0,
                                  int nrows, int n);
 /* up to 12 word-wise copies (nwords[g] 32-bit words from src[g] to dst[g]) in one launch */
+/* the noise of the next forward pass of rows [row0, row0 + nrows), from the generators' current
+ * states, into b->noise_spec / b->rng_spec; the generators themselves are not touched */
+void ramd_launch_noise_speculate(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0,
+                                 int nrows, float noise);
 void ramd_launch_segcopy(ramd_stream_t st, int nseg, void *const *dst, const void *const *src,
                          const unsigned *nwords);
 /* rebuilds err_a / err_b (bptt->h_error, i_error) from ehi after a calc_deltas */

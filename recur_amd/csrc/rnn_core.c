@@ -313,11 +313,18 @@ static RamdEngine *engine_new(RecurNN *owner) {
   return e;
 }
 
+static hipStream_t g_side = NULL; /* noise_speculate's stream */
 static void engine_free_device(RamdEngine *e) {
   if (!e->dev_ready) {
     return;
   }
   RamdBuffers *b = &e->b;
+  if (e->spec_pending && g_side) {
+    HIP_OK(hipStreamSynchronize(g_side)); /* it writes into the buffers freed below */
+  }
+  e->spec_pending = 0;
+  dev_free(b->noise_spec);
+  dev_free(b->rng_spec);
   dev_free(b->ih_w); dev_free(b->ho_w); dev_free(b->ih_m); dev_free(b->ho_m);
   dev_free(b->ih_aux); dev_free(b->ho_aux); dev_free(e->delta_own);
   dev_free(b->arena); dev_free(b->hidden); dev_free(b->out); dev_free(b->o_error);
@@ -452,6 +459,7 @@ static void stream_copy(RamdEngine *e, RecurNN *net, int to_device) {
   COPY(b->out + (size_t)r * O, net->output_layer, O);
   if (to_device) {
     h2d((char *)b->rng + (size_t)r * sizeof(rand_ctx), &net->rng, sizeof(rand_ctx));
+    e->rng_version++;
   } else {
     d2h(&net->rng, (char *)b->rng + (size_t)r * sizeof(rand_ctx), sizeof(rand_ctx));
   }
@@ -648,6 +656,7 @@ void ramd_rng_from_host(RecurNN *net) {
   RamdEngine *e = p->eng;
   if (e && e->dev_ready && p->dev_valid) {
     h2d((char *)e->b.rng + (size_t)state_row(e, p) * sizeof(rand_ctx), &net->rng, sizeof(rand_ctx));
+    e->rng_version++;
     dsync();
   }
 }
@@ -1357,6 +1366,7 @@ float *rnn_opinion(RecurNN *net, const float *inputs, float presynaptic_noise) {
   }
   if (presynaptic_noise != 0.0f) { /* the host generator is the one the caller may have used */
     mail_in((char *)e->b.rng + (size_t)r * sizeof(rand_ctx), &net->rng, sizeof(rand_ctx));
+    e->rng_version++;
   }
   if (bl) { /* recur-nn.c:88-103: the layer's one input buffer is shared by every clone */
     bl->inputs[0] = 1.0f;
@@ -1887,6 +1897,16 @@ static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, i
     set_uniform_idx(e, set->row0, set->n);
   }
   float noise = set->nets[0]->presynaptic_noise;
+  if (noise != 0.0f) {
+    /* values generated ahead for exactly this pass, and nothing has touched the generators since? */
+    e->b.noise_spec_use = e->spec_pending && e->spec_version == e->rng_version && e->spec_row0 == r0 &&
+                          e->spec_n == set->n && e->spec_dev == noise && !e->sh.bI;
+    if (e->b.noise_spec_use) {
+      HIP_OK(hipStreamWaitEvent(g_stream, (hipEvent_t)e->spec_done, 0));
+    }
+    e->spec_pending = 0;
+    e->rng_version++; /* this pass moves the generators, either way */
+  }
   for (int j = 1; j < set->n; j++) {
     if (set->nets[j]->presynaptic_noise != noise) {
       fprintf(stderr, "librecur_amd: the nets of a set must share presynaptic_noise\n");
@@ -1923,6 +1943,7 @@ static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, i
   } else {
     ramd_launch_forward(g_stream, &e->sh, &e->b, r0, set->n, noise);
   }
+  e->b.noise_spec_use = 0;
   set_streams_dev_wrote(set);
   if (outputs) {
     d2h(outputs, e->b.out + (size_t)r0 * e->sh.O, (size_t)set->n * e->sh.O * sizeof(float));
@@ -2100,9 +2121,53 @@ static int multi_heads(RamdEngine *e, int alphabet_len) {
 }
 
 /* the loss after the opinion: b.target holds each stream's next symbol */
+/* The presynaptic noise of the NEXT forward pass of this set, generated now on a second stream.
+ * A stream's generator is a sequential recurrence -- 3 x (h_size - 1) dependent steps per pass,
+ * one lane per stream, 0.2 ms for 1028 values whatever the number of streams -- so the only
+ * way to take it off the generation's critical path is to run it beside something else: it is
+ * launched as soon as the last draw before the next pass has been made (the multi-head loss's
+ * leak decisions, or the pass itself in the text step) and runs beside the whole backward
+ * pass.  It reads the generators and leaves them alone; the forward pass adds the values and
+ * adopts the generator states that go with them (k_noise_apply) provided nothing has moved the
+ * generators in between (rng_version: uploads of a generator, other passes, other losses),
+ * otherwise it generates as before and the speculated values are dropped. */
+static void noise_speculate(RnnAmdSet *set) {
+  RamdEngine *e = set->eng;
+  const float noise = set->nets[0]->presynaptic_noise;
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char *env = getenv("RECUR_AMD_NOISE_AHEAD");
+    enabled = !(env && atoi(env) == 0);
+  }
+  if (noise == 0.0f || e->sh.bI || set->fwd_only || !enabled) {
+    return;
+  }
+  if (!g_side) {
+    HIP_OK(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+  }
+  if (!e->spec_go) {
+    HIP_OK(hipEventCreateWithFlags((hipEvent_t *)&e->spec_go, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags((hipEvent_t *)&e->spec_done, hipEventDisableTiming));
+  }
+  if (!e->b.noise_spec) {
+    e->b.noise_spec = dev_alloc((size_t)e->sh.Scap * e->sh.H * sizeof(float));
+    e->b.rng_spec = dev_alloc((size_t)e->sh.Scap * sizeof(rand_ctx));
+  }
+  HIP_OK(hipEventRecord((hipEvent_t)e->spec_go, g_stream)); /* the draws made so far */
+  HIP_OK(hipStreamWaitEvent(g_side, (hipEvent_t)e->spec_go, 0));
+  ramd_launch_noise_speculate(g_side, &e->sh, &e->b, set->row0, set->n, noise);
+  HIP_OK(hipEventRecord((hipEvent_t)e->spec_done, g_side));
+  e->spec_pending = 1;
+  e->spec_version = e->rng_version;
+  e->spec_row0 = set->row0;
+  e->spec_n = set->n;
+  e->spec_dev = noise;
+}
+
 static void multi_loss(RnnAmdSet *set, const int *target_class, int alphabet_len, int n_classes,
                        float leakage) {
   RamdEngine *e = set->eng;
+  e->rng_version++; /* the leak decisions are draws from the streams' generators */
   if (target_class) {
     upload(e->d_mclass + set->row0, target_class, set->n * sizeof(int));
   }
@@ -2114,6 +2179,7 @@ static void multi_loss(RnnAmdSet *set, const int *target_class, int alphabet_len
                                   e->d_mranges + (size_t)set->row0 * MULTI_RANGE_STRIDE,
                                   MULTI_RANGE_STRIDE);
   set_streams_dev_wrote(set);
+  noise_speculate(set); /* the next draws are the next forward pass's noise */
 }
 
 void rnn_amd_set_multi_calc_deltas(RnnAmdSet *set, int accumulate) {
@@ -2238,10 +2304,12 @@ static void char_step_deltas(RnnAmdSet *set, int i, RamdPendingDelta *defer) {
   if (ramd_text_top_ok(&e->sh)) {
     /* advance + hidden layer, then output layer, loss and top backprop in one launch */
     int fwd_ks = set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 1);
+    noise_speculate(set); /* no draws between this pass's noise and the next one's */
     ramd_launch_text_top(g_stream, &e->sh, &e->b, set->row0, set->n, fwd_ks);
     set_calc_deltas(set, 0, NULL, NULL, RAMD_TOP_DONE, NULL, 0, defer);
   } else {
     set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 0); /* advance + one-hot opinion */
+    noise_speculate(set);
     ramd_launch_softmax_error(g_stream, &e->sh, &e->b, set->row0, set->n);
     set_calc_deltas(set, 0, NULL, NULL, 0, NULL, 0, defer);
   }

@@ -60,6 +60,12 @@ typedef struct RamdEngine {
   /* last per-stream scalars pushed to the device */
   float *lr_pushed;
   int *idx_pushed;
+  /* noise generated ahead (noise_speculate): valid while nothing else has moved the device's
+   * generators since (rng_version) */
+  unsigned long rng_version, spec_version;
+  int spec_pending, spec_row0, spec_n;
+  float spec_dev;
+  void *spec_go, *spec_done; /* hipEvent_t */
   int scalars_dev_valid; /* device mef/ih_scale newer than the host structs */
 } RamdEngine;
 
