@@ -4447,7 +4447,9 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int M = sh->D * nrows;
     int etm = (M + BM - 1) / BM, etn = (nx + BN - 1) / BN, nkt = (sh->H + BK - 1) / BK;
     int ks = pick_ks(etm * etn, nkt, "RECUR_AMD_KS_EXTRAS", b->slab_floats, (size_t)M * nxp);
-    if (sh->H <= 2048 && !env_int("RECUR_AMD_EXTRAS_GEMM", 0)) {
+    /* the gather over the non-zero input rows (one-hot symbols: two rows per step and stream) or,
+     * for dense inputs with more than a handful of columns, the GEMM over all of them */
+    if (sh->H <= 2048 && !env_int("RECUR_AMD_EXTRAS_GEMM", 0) && !(b->dense_inputs && nx > 8)) {
       const int nq = (sh->H / 4 + 63) / 64;
       if (env_int("RECUR_AMD_EXTRAS_SPLIT", 0)) {
         if (nq <= 5)

@@ -82,6 +82,10 @@ typedef struct RamdBuffers {
   float *noise_spec;
   void *rng_spec;
   int noise_spec_use;
+  /* hint: the set's last forward pass took dense input rows (audio features, pixels) rather than
+   * one-hot symbols -- the extras of the BPTT chain are then a GEMM, not a gather over the few
+   * non-zero input rows (either is correct for any input) */
+  int dense_inputs;
 } RamdBuffers;
 
 /* ih_delta left as un-summed K slabs by ramd_launch_calc_deltas, for the optimiser launch

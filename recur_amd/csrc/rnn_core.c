@@ -238,7 +238,7 @@ static void mail_out(void *host, const void *dev, size_t bytes) {
  * the pinned mailbox and carried by a launch on the stream -- the caller's buffer is free when we
  * return and nobody waits for the device; what does not fit or is not word-sized goes the old way
  * (copy, then wait).  rows of `width` bytes, `host_pitch` apart, land contiguously at `dev`. */
-static void upload_rows(void *dev, const void *host, size_t host_pitch, size_t width, size_t rows) {
+static void upload_rows_q(void *dev, const void *host, size_t host_pitch, size_t width, size_t rows, int flush) {
   size_t bytes = width * rows;
   if (!bytes) {
     return;
@@ -279,9 +279,16 @@ static void upload_rows(void *dev, const void *host, size_t host_pitch, size_t w
     g_mail.nseg++;
     g_mail.cur += words;
   }
-  mail_in_flush();
+  if (flush) {
+    mail_in_flush();
+  }
 }
-static void upload(void *dev, const void *host, size_t bytes) { upload_rows(dev, host, bytes, bytes, 1); }
+static void upload_rows(void *dev, const void *host, size_t host_pitch, size_t width, size_t rows) {
+  upload_rows_q(dev, host, host_pitch, width, rows, 1);
+}
+static void upload(void *dev, const void *host, size_t bytes) { upload_rows_q(dev, host, bytes, bytes, 1, 1); }
+/* queued: leaves with the next upload() / mail_in_flush() */
+static void upload_q(void *dev, const void *host, size_t bytes) { upload_rows_q(dev, host, bytes, bytes, 1, 0); }
 
 void *ramd_zalloc(size_t bytes) {
   void *p = NULL;
@@ -1896,6 +1903,11 @@ static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, i
   } else {
     set_uniform_idx(e, set->row0, set->n);
   }
+  if (mode == RAMD_IN_DENSE) {
+    e->b.dense_inputs = 1;
+  } else if (mode == RAMD_IN_ONE_HOT || mode == RAMD_IN_TEXT) {
+    e->b.dense_inputs = 0;
+  }
   float noise = set->nets[0]->presynaptic_noise;
   if (noise != 0.0f) {
     /* values generated ahead for exactly this pass, and nothing has touched the generators since? */
@@ -2075,14 +2087,15 @@ void rnn_amd_set_grouped_softmax_error(RnnAmdSet *set, int n_groups, const int *
     e->d_group_bytes = bytes;
   }
   int *d = (int *)e->d_group;
-  upload(d, group_offset, n_groups * sizeof(int));
-  upload(d + n_groups, group_size, n_groups * sizeof(int));
-  upload(d + 2 * n_groups, targets, (size_t)set->n * n_groups * sizeof(int));
+  upload_q(d, group_offset, n_groups * sizeof(int));
+  upload_q(d + n_groups, group_size, n_groups * sizeof(int));
+  upload_q(d + 2 * n_groups, targets, (size_t)set->n * n_groups * sizeof(int));
   float *dw = NULL;
   if (error_weight) {
     dw = (float *)(d + ints);
-    upload(dw, error_weight, (size_t)s->output_size * sizeof(float));
+    upload_q(dw, error_weight, (size_t)s->output_size * sizeof(float));
   }
+  mail_in_flush();
   ramd_launch_grouped_softmax_error(g_stream, s, &e->b, set->row0, set->n, n_groups, largest, d,
                                     d + n_groups, d + 2 * n_groups, dw);
   set_streams_dev_wrote(set);
@@ -2199,7 +2212,7 @@ void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *ne
   RamdEngine *e = set->eng;
   set_need_training(set, "rnn_amd_set_multi_step_deltas");
   int n_classes = multi_heads(e, alphabet_len);
-  upload(e->b.hot + set->row0, hot, set->n * sizeof(int));
+  upload_q(e->b.hot + set->row0, hot, set->n * sizeof(int));
   upload(e->b.target + set->row0, next, set->n * sizeof(int));
   set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, NULL, 1, 0);
   multi_loss(set, target_class, alphabet_len, n_classes, leakage);

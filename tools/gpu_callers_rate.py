@@ -1,6 +1,6 @@
 """Development probe: steady-state rates of the callers' own workloads at BASELINE.json's sizes
-(configs[3] multi-head step, configs[4] rnnca training generation).  Under tools/kstats-style
-profiling: rocprofv3 --kernel-trace --stats -- python3 gpu_callers_rate.py multi|rnnca"""
+(configs[2] gstclassify training generation, configs[3] multi-head step, configs[4] rnnca training generation).  Under tools/kstats-style
+profiling: rocprofv3 --kernel-trace --stats -- python3 gpu_callers_rate.py classify|multi|rnnca"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
@@ -54,5 +54,34 @@ if which in ("rnnca", "both"):
     amd.rnn_amd_synchronize()
     dt = time.perf_counter() - t0
     print("configs[4] rnnca training generation 2048 / %d cells / depth %d: %.0f cell-timesteps/s, %.1f us per generation"
+          % (S, D, n * S / dt, 1e6 * dt / n))
+    g.close()
+if which in ("classify", "both"):
+    # gstclassify's train_channel order (gstclassify.c:2070-2130): opinion, class-group loss on the
+    # device, calc_deltas over the channels that trained, advance; Nesterov update per generation
+    H, S, D, NIN = 512, 128, 30, 32
+    g = sc.AmdBatchedSet(amd, input_size=NIN, hidden_size=H, output_size=2, S=S, D=D, learn_rate=3e-4, seed=6)
+    rs = np.random.default_rng(12)
+    goff, gsize = np.array([0], np.int32), np.array([2], np.int32)
+    xs = [np.ascontiguousarray((rs.standard_normal((S, NIN)) * 0.5).astype(np.float32)) for _ in range(4)]
+    tg = [np.ascontiguousarray(rs.integers(-1, 2, (S, 1)).astype(np.int32)) for _ in range(4)]
+    trained = np.zeros(S, np.uint8)
+    def gen(i):
+        amd.rnn_bptt_clear_deltas(g.net)
+        amd.rnn_amd_set_opinion(g.handle, rc.fptr(xs[i % 4]), NIN, None)
+        amd.rnn_amd_set_grouped_softmax_error(g.handle, 1, rc.iptr(goff), rc.iptr(gsize), rc.iptr(tg[i % 4]), None,
+                                              rc.u8ptr(trained))
+        amd.rnn_amd_set_calc_deltas(g.handle, 1, None, rc.u8ptr(trained))
+        amd.rnn_amd_set_advance(g.handle)
+        amd.rnn_apply_learning(g.net, rc.NESTEROV, 0.9)
+    for i in range(D + 5):
+        gen(i)
+    amd.rnn_amd_synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        gen(i)
+    amd.rnn_amd_synchronize()
+    dt = time.perf_counter() - t0
+    print("configs[2] gstclassify training generation 512 / %d channels / depth %d: %.0f channel-timesteps/s, %.1f us per generation"
           % (S, D, n * S / dt, 1e6 * dt / n))
     g.close()
