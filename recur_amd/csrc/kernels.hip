@@ -995,6 +995,33 @@ __global__ __launch_bounds__(1024) void k_out_layer(View v, int row0) {
   }
 }
 
+// The same for o_size == 4 (rnnca: Y, Cb, Cr + padding): a row of W_ho is ONE float4, so a wave
+// per state row walks the hidden units 64 at a time (coalesced hidden values, coalesced float4
+// weights) and reduces with xor shuffles.  k_out_layer gives every column a lane and every
+// sixteenth of the rows a wave, which with 4 columns leaves 60 of 64 lanes idle: 252 us for
+// the 13,824 rows of an rnnca frame at hidden 2048.
+__global__ __launch_bounds__(256) void k_out_layer_o4(View v, int row0, int nrows) {
+  const RamdShape &s = v.sh;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= nrows) return;
+  const int r = row0 + j;
+  const float *hid = v.b.hidden + (size_t)r * s.H;
+  float4 acc = zero4();
+  for (int y = lane; y < s.H; y += 64) {
+    const float h = hid[y];
+    const float4 w = ld4(v.b.ho_w + (size_t)y * 4);
+    acc.x += h * w.x; acc.y += h * w.y; acc.z += h * w.z; acc.w += h * w.w;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    acc.x += __shfl_xor(acc.x, off, 64);
+    acc.y += __shfl_xor(acc.y, off, 64);
+    acc.z += __shfl_xor(acc.z, off, 64);
+    acc.w += __shfl_xor(acc.w, off, 64);
+  }
+  if (lane == 0) *reinterpret_cast<float4 *>(v.b.out + (size_t)r * 4) = acc;
+}
+
 // net_error_bptt's loss (charmodel-predict.c:18-27): softmax (badmaths.h:71-111),
 // best guess and negation (badmaths.h:113-141), +1 on the target; plus the
 // running statistics of the epoch loop (charmodel-predict.c:302-304).  One
@@ -1774,6 +1801,19 @@ __device__ __forceinline__ f32x4 lds_read_b128(uint32_t addr) {
   return v;
 }
 
+/* [k][col] and [k + 1][col] of a 64-column K-major stage; _hi: k + 2, k + 3 (offsets in dwords) */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 lds_read2_b32_w64(uint32_t addr) {
+  f32x2 v;
+  asm volatile("ds_read2_b32 %0, %1 offset1:64" : "=v"(v) : "v"(addr));
+  return v;
+}
+__device__ __forceinline__ f32x2 lds_read2_b32_w64_hi(uint32_t addr) {
+  f32x2 v;
+  asm volatile("ds_read2_b32 %0, %1 offset0:128 offset1:192" : "=v"(v) : "v"(addr));
+  return v;
+}
+
 // stores the launch-invariant part of the kernel arguments in device memory (see below)
 __global__ void k_store_view(View v, View *dst) { *dst = v; }
 
@@ -2157,6 +2197,157 @@ __global__ __launch_bounds__(512) void k_chain_wide(const View *__restrict__ vp,
   }
 }
 
+// ------------------------------------ forward GEMM, 64 x 64 tiles (big sets) --
+//
+// hidden sums = X . W_ih (recur-nn.c:117-119) for big sets of dense-input nets -- rnnca's frame
+// fill is 13,824 forward-only cells of a 2048-hidden net per frame, 118 GFLOP -- on k_chain_wide's
+// plan: 64 rows x 64 columns per workgroup, four multiplying waves with a 32 x 32 quadrant each
+// over the whole K, four loader waves with LDS-DMA into a four-deep ring of 64-deep stages.
+// A (the input rows, K-contiguous) is staged as in the chain: chunk c of row r at position
+// c ^ (r & 15), one b128 read = four k.  B is W_ih itself, K-major: a stage is [64 k][64 columns]
+// as it lies in memory (one DMA instruction = four k rows of 256 bytes), and a lane fetches its
+// four k of a chunk with two ds_read2_b32 (as k_fwd_fused does).  K = i_size is padded to whole
+// stages with zeros (chunks and rows past i_size come from a zero line); the column tiles start
+// at column 0 and the last one runs past h_size, where nothing is stored.  The sums go to slab
+// plane 0 for k_fwd_finalize (noise, activation, bias node).
+// Preconditions (launcher): rows % 64 == 0, NS == ceil(i_size / 64).
+template <int NS>
+__global__ __launch_bounds__(512) void k_fwd_wide(const View *__restrict__ vp, int uniform_idx, int row0,
+                                                  int nrows, int tm, int tn) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  View v = *vp;
+  v.b.uniform_idx = uniform_idx;
+  const RamdShape &s = v.sh;
+  /* Blocks are dealt round-robin over the 8 XCDs and an XCD runs 32 workgroups at a time: those 32
+   * are a supertile of 4 row tiles x 8 column tiles, so that while they walk K together every
+   * stage of the input rows is fetched into that XCD's L2 once per 8 workgroups and every stage of
+   * W once per 4 (one column tile after another for all the row tiles, as the chain's mapping
+   * does, re-reads the whole input set once per column tile: 3.8 GB for a 13,824-cell frame). */
+  const int L = blockIdx.x;
+  const int xcd = L & 7, q = L >> 3;
+  const int st_i = (q >> 5) * 8 + xcd, in_i = q & 31;
+  const int stm = (tm + 3) >> 2;
+  const int mt = (st_i % stm) * 4 + (in_i & 3), nt = (st_i / stm) * 8 + (in_i >> 2);
+  if (mt >= tm || nt >= tn) return;
+  const int m0 = mt * WM, n0 = nt * WN;
+  const int wave8 = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool loader = wave8 >= 4;
+  const int wave = wave8 & 3;
+  const int lm = lane & 31, kh = lane >> 5;
+  const uint32_t lds0 = lds_byte_addr(wsm);
+
+  if (loader) {
+    // instruction i (0..31): i < 16: rows 4 i .. + 3 of A (lane l: chunk (l & 15) ^ (row & 15) of
+    // row 4 i + (l >> 4)); i >= 16: k rows 4 (i - 16) .. + 3 of B (lane l: 16-byte piece l & 15 of
+    // k row 4 (i - 16) + (l >> 4), i.e. columns n0 + 4 (l & 15) ..)
+    const float *src[8];
+    int kofs[8]; /* A: first k of this lane's chunk within a stage; B: this lane's k row within a stage */
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = wave * 8 + j;
+      if (i < 16) {
+        const int row = 4 * i + (lane >> 4);
+        const int c = (lane & 15) ^ (row & 15);
+        src[j] = input_row<false>(v, row0 + m0 + row, 0) + 4 * c;
+        kofs[j] = 4 * c;
+      } else {
+        const int k = 4 * (i - 16) + (lane >> 4);
+        src[j] = v.b.ih_w + (size_t)k * s.H + n0 + 4 * (lane & 15);
+        kofs[j] = k;
+      }
+    }
+    auto issue = [&](int stage) {
+      float *dst = wsm + (stage % W_STAGES) * W_STAGE_FLOATS + wave * 8 * 256;
+      const int k0 = stage * WK;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const bool a_side = wave * 8 + j < 16;
+        const float *g = a_side ? src[j] + k0 : src[j] + (size_t)k0 * s.H;
+        if ((k0 + WK > s.I && k0 + kofs[j] >= s.I) || (!a_side && n0 + 4 * (lane & 15) >= s.H))
+          g = v.b.zeros + 4 * (lane & 15); /* past K, or past the last column of W: zeros */
+        __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(dst + j * 256), 16, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int p = 0; p < W_STAGES - 1; p++)
+      if (p < NS) issue(p);
+#pragma unroll
+    for (int st = 0; st < NS; st++) {
+      const int ahead = (NS - 1 - st) < (W_STAGES - 2) ? (NS - 1 - st) : (W_STAGES - 2);
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); /* stage st has landed; stage st - 1's buffer is free */
+      if (st + W_STAGES - 1 < NS) issue(st + W_STAGES - 1);
+    }
+    __syncthreads();
+    return;
+  }
+
+  // ------------------------------------------------------------------ multiply
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+  const uint32_t arow = (uint32_t)(wm * 32 + lm) * (WK * 4u);
+  const uint32_t bcol = (uint32_t)(WM * WK + wn * 32 + lm) * 4u; /* B: [k][64 columns] behind A */
+  auto rd = [&](int st, f32x4 (&a)[8], f32x2 (&b0)[8], f32x2 (&b1)[8]) {
+    const uint32_t base = lds0 + (uint32_t)((st % W_STAGES) * W_STAGE_FLOATS) * 4u;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int c = 2 * u + kh; /* chunk = k 4 c .. 4 c + 3 of the stage, on both operands */
+      a[u] = lds_read_b128(base + arow + (uint32_t)((c ^ (lm & 15)) * 16));
+      const uint32_t baddr = base + bcol + (uint32_t)(4 * c) * (WN * 4u);
+      b0[u] = lds_read2_b32_w64(baddr);     /* k, k + 1 */
+      b1[u] = lds_read2_b32_w64_hi(baddr);  /* k + 2, k + 3 */
+    }
+  };
+  auto step = [&](int st, f32x4 (&a)[8], f32x2 (&b0)[8], f32x2 (&b1)[8], f32x4 (&an)[8], f32x2 (&b0n)[8],
+                  f32x2 (&b1n)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this stage's fragments have arrived */
+    if (st + 1 < NS) {
+      __builtin_amdgcn_s_barrier(); /* stage st + 1 has landed */
+      rd(st + 1, an, b0n, b1n);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b0[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b0[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b1[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b1[u].y, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    f32x4 a0[8], a1[8];
+    f32x2 p0[8], q0[8], p1[8], q1[8];
+    __builtin_amdgcn_s_barrier(); /* stage 0 has landed */
+    rd(0, a0, p0, q0);
+#pragma unroll
+    for (int st = 0; st < NS; st += 2) {
+      step(st, a0, p0, q0, a1, p1, q1);
+      if (st + 1 < NS) step(st + 1, a1, p1, q1, a0, p0, q0);
+    }
+  }
+  // the tile through LDS (the ring buffer stage NS would have used was read four barriers ago)
+  float *red = wsm + (NS % W_STAGES) * W_STAGE_FLOATS; /* [64][64] */
+#pragma unroll
+  for (int g = 0; g < 16; g++) {
+    const int row = wm * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
+    red[row * WN + wn * 32 + lm] = acc[g];
+  }
+  __syncthreads();
+  const int etid = threadIdx.x, rq = etid >> 4, c4 = (etid & 15) * 4;
+  if (n0 + c4 < s.H) { /* h_size % 4 == 0: whole float4s */
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int row = 4 * rq + rr;
+      *reinterpret_cast<float4 *>(v.b.slab + (size_t)(m0 + row) * s.H + n0 + c4) = ld4(red + row * WN + c4);
+    }
+  }
+}
+
 // ------------------------------------------------ BPTT chain, one launch --
 //
 // All D steps of the chain in ONE launch (hidden 1024: 32 column tiles; up to 8 row tiles of
@@ -2525,7 +2716,6 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
 //     partial sums in plane 1 ([tn][nrows][4]) that k_text_top adds up.
 // Launcher preconditions: every stream at the same ring position, one-hot or text input, no
 // presynaptic noise, no bottom layer, hidden_size a multiple of 32.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 /* [k][col] and [k + 1][col] of a 32-column K-major stage; _hi: k + 2, k + 3.  The results are
  * used as they come (sub-registers of the asm output): a copy the compiler is free to place
  * before the s_waitcnt would read them too early */
@@ -4156,7 +4346,9 @@ extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, cons
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   ramd_launch_forward_hidden(st_, sh, b, row0, nrows, noise, 0);
-  if (sh->O <= 256 && !env_int("RECUR_AMD_OUT_GEMM", 0)) {
+  if (sh->O == 4 && nrows >= 64) {
+    RAMD_LAUNCH(k_out_layer_o4, dim3((nrows + 3) / 4), dim3(256), 0, st, v, row0, nrows);
+  } else if (sh->O <= 256 && !env_int("RECUR_AMD_OUT_GEMM", 0)) {
     RAMD_LAUNCH(k_out_layer, dim3(nrows), dim3(1024),
                        (size_t)(sh->H + OUT_SEGS * 64) * sizeof(float), st, v, row0);
   } else { /* wide output layers (multi-head nets, O in the thousands): the MFMA GEMM */
@@ -4183,7 +4375,35 @@ extern "C" int ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh
   {
     int tn = (sh->H + BN - 1) / BN, nkt = (sh->I + BK - 1) / BK;
     int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_FWD", b->slab_floats, (size_t)nrows * sh->H);
-    if (b->uniform_idx >= 0) {
+    const int wide_ns = (sh->I + WK - 1) / WK;
+    /* (from 2048 rows: h_size = hidden_size + 4 makes 33 column tiles of 64, and with a few hundred
+     * rows that 33rd tile is a second round of workgroups: 97 us against the generic kernel's 60
+     * at 512 x 2048; at 13,824 rows it is 1406 us against 1515) */
+    if (nrows % WM == 0 && nrows >= 2048 && (wide_ns == 9 || wide_ns == 17 || wide_ns == 33) &&
+        (size_t)nrows * sh->H <= b->slab_floats && env_int("RECUR_AMD_FWD_WIDE", 1)) {
+      /* big sets: 64 x 64 tiles, operands by LDS-DMA (k_fwd_wide); one plane of sums */
+      static bool attr_set = false;
+      const size_t shm = (size_t)W_STAGES * W_STAGE_FLOATS * sizeof(float);
+      if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_wide<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_wide<17>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_wide<33>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        attr_set = true;
+      }
+      const View *d_view = device_view(st, v);
+      const int wtm = nrows / WM, wtn = (sh->H + WN - 1) / WN;
+      const int supertiles = ((wtm + 3) / 4) * ((wtn + 7) / 8); /* of 4 x 8 tiles, 32 blocks each */
+      const int wblocks = ((supertiles + 7) / 8) * 8 * 32;
+      int ev = timing_begin(st, T_FWD);
+      if (wide_ns == 33)
+        RAMD_LAUNCH(k_fwd_wide<33>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, wtm, wtn);
+      else if (wide_ns == 17)
+        RAMD_LAUNCH(k_fwd_wide<17>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, wtm, wtn);
+      else
+        RAMD_LAUNCH(k_fwd_wide<9>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, wtm, wtn);
+      timing_end(st, ev);
+      ks = 1;
+    } else if (b->uniform_idx >= 0) {
       ProbFwd<true> p = {v, row0, nrows};
       launch_gemm<false, true, ProbFwd<true>>(st, p, b->slab, nrows, sh->H, nkt, ks, T_FWD);
     } else {
