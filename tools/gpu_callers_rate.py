@@ -11,7 +11,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 if which in ("multi", "both"):
     A, NC, D, S = 73, 50, 20, int(os.environ.get("TUNE_S", "256"))
     g = sc.AmdBatchedSet(amd, input_size=A, hidden_size=1024, output_size=A * NC, S=S, D=D, learn_rate=1e-4, seed=61,
-                         activation=rc.RESQRT, noise=0.01, flags=rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR)
+                         activation=rc.RESQRT, noise=float(os.environ.get("TUNE_NOISE", "0.01")), flags=rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR)
     amd.rnn_set_momentum_values(g.net, 200.0)
     rs = np.random.default_rng(3)
     draws = [(rs.integers(0, A, S).astype(np.int32), rs.integers(0, A, S).astype(np.int32),
