@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
   __syncthreads();
   // ---- top-layer backprop + soft clip (recur-nn.c:199-228, 719-721)
   float sum = 0.0f;
-  float ev[2] = {0.0f, 0.0f}; /* h_size <= 2048 per launch condition */
+  float ev[3] = {0.0f, 0.0f, 0.0f}; /* h_size <= 3072 per launch condition */
   for (int q = 0, y = threadIdx.x; y < s.H; y += 1024, q++) {
     float e = 0.0f;
     if (y != 0 && shid[y] != 0.0f) {
@@ -3010,7 +3010,7 @@ template <int MAXQ> struct ExtrasIn {
   float4 ev[MAXQ];
   float xi, pv;
 };
-template <int MAXQ> /* float4 per lane: 5 covers h_size <= 1280, 8 h_size <= 2048 */
+template <int MAXQ> /* float4 per lane: 5 covers h_size <= 1280, 8 h_size <= 2048, 9 h_size <= 2304 */
 __device__ __forceinline__ void extras_load(const View &v, int t, int r, int nx, int tn, int lane,
                                             ExtrasIn<MAXQ> &in) {
   const RamdShape &s = v.sh;
@@ -4192,7 +4192,7 @@ extern "C" void ramd_launch_bottom_deltas(ramd_stream_t st_, const RamdShape *sh
 }
 
 extern "C" int ramd_text_top_ok(const RamdShape *sh) {
-  return sh->O <= 256 && sh->H <= 2048 && !env_int("RECUR_AMD_NO_TEXT_TOP", 0);
+  return sh->O <= 256 && sh->H <= 3072 && !env_int("RECUR_AMD_NO_TEXT_TOP", 0);
 }
 
 /* the device copy of the View for the kernels that take it by pointer, rewritten only when
@@ -4669,14 +4669,17 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int ks = pick_ks(etm * etn, nkt, "RECUR_AMD_KS_EXTRAS", b->slab_floats, (size_t)M * nxp);
     /* the gather over the non-zero input rows (one-hot symbols: two rows per step and stream) or,
      * for dense inputs with more than a handful of columns, the GEMM over all of them */
-    if (sh->H <= 2048 && !env_int("RECUR_AMD_EXTRAS_GEMM", 0) && !(b->dense_inputs && nx > 8)) {
+    if (sh->H <= 2304 && !env_int("RECUR_AMD_EXTRAS_GEMM", 0) && !(b->dense_inputs && nx > 8)) {
       const int nq = (sh->H / 4 + 63) / 64;
       if (env_int("RECUR_AMD_EXTRAS_SPLIT", 0)) {
         if (nq <= 5)
           RAMD_LAUNCH(k_extras_gather<5>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
                              nxp, tn_parts);
-        else
+        else if (nq <= 8)
           RAMD_LAUNCH(k_extras_gather<8>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
+                             nxp, tn_parts);
+        else /* h_size 2052: hidden 2048 */
+          RAMD_LAUNCH(k_extras_gather<9>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
                              nxp, tn_parts);
       } else {
         /* extras and control in one launch, one workgroup per stream */
@@ -4684,8 +4687,11 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
         if (nq <= 5)
           RAMD_LAUNCH((k_extras_control<5, 1024>), dim3(nrows), dim3(1024), shm, st, v, row0, nrows,
                              nx, nxp, tn_parts, active, flags);
-        else
+        else if (nq <= 8)
           RAMD_LAUNCH((k_extras_control<8, 512>), dim3(nrows), dim3(512), shm, st, v, row0, nrows,
+                             nx, nxp, tn_parts, active, flags);
+        else /* h_size 2052: hidden 2048 */
+          RAMD_LAUNCH((k_extras_control<9, 512>), dim3(nrows), dim3(512), shm, st, v, row0, nrows,
                              nx, nxp, tn_parts, active, flags);
         control_done = true;
       }
