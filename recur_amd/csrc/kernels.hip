@@ -2379,6 +2379,8 @@ constexpr int PC_RED_FLOATS = 4 * PC_SUB * 32;
 constexpr int pc_lds_bytes(int K) { return (2 * PC_SUB * K + 2 * PC_RED_FLOATS) * 4 + 64; }
 #ifndef PC_SLEEP0
 #define PC_SLEEP0 56
+#endif
+#ifndef PC_SLEEP1
 #define PC_SLEEP1 8
 #endif
 #ifndef PC_SLEEP0_ONE

@@ -318,6 +318,18 @@ def test_full_size_generation_matches_oracle(amd, full_set):
     ("two_chain_launches_1024_512_20", dict(input_size=42, hidden_size=1024, output_size=42, S=512, D=20)),
     # fewer than 8 row tiles: XCDs without a row tile leave at once
     ("three_row_tiles_1024_96_12", dict(input_size=42, hidden_size=1024, output_size=42, S=96, D=12)),
+    # the other activations' instances of the chain kernels: one sub-chain per workgroup with the
+    # RESQRT derivative (hidden 512) and the RECLIP20 row rule (hidden 256), two sub-chains with
+    # RESQRT (hidden 256, 160 streams), and the 64 x 64-tile step with RESQRT (hidden 1536: a
+    # net the one-launch chain does not take)
+    ("one_sub_chain_resqrt_512_64_8", dict(input_size=42, hidden_size=512, output_size=42, S=64, D=8,
+                                           activation=rc.RESQRT)),
+    ("one_sub_chain_reclip20_256_48_8", dict(input_size=42, hidden_size=256, output_size=42, S=48, D=8,
+                                             activation=rc.RECLIP20)),
+    ("two_sub_chains_resqrt_256_640_6", dict(input_size=42, hidden_size=256, output_size=42, S=640, D=6,
+                                             activation=rc.RESQRT)),
+    ("wide_step_resqrt_1536_512_4", dict(input_size=42, hidden_size=1536, output_size=42, S=512, D=4,
+                                         activation=rc.RESQRT)),
 ])
 def test_baseline_config_shapes_one_generation_matches_oracle(amd, label, kw):
     """BASELINE.json's other configurations at their full hidden / stream / depth sizes:
@@ -344,6 +356,36 @@ def test_baseline_config_shapes_one_generation_matches_oracle(amd, label, kw):
     assert g.stats().bptt_depth_sum == float(so["bptt_depth"].sum())
     replay.check(sg, so, RTOL, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "ih_m", "ho_m", "hidden",
                                      "output", "o_error", "hist", "min_error_factor", "ih_scale"])
+    g.close()
+    o.close()
+
+
+def test_noise_generated_ahead_is_dropped_when_a_generator_moves(amd):
+    """The set calls generate the presynaptic noise of the NEXT forward pass on a second stream
+    right after the current one (noise_speculate).  If the caller reseeds a stream's generator
+    in between (net->rng is public: recur-nn.h:158-186), the values generated ahead came from
+    the old state and must not be used: every generation is compared with the oracle, generator
+    states bit for bit, across such a reseeding and across a host round trip without one."""
+    kw = dict(input_size=42, hidden_size=64, output_size=42, S=8, D=5, learn_rate=1e-3, seed=9, noise=0.05)
+    g = sc.AmdBatchedSet(amd, **kw)
+    o = sc.OracleSet(**kw)
+    text = sc.synthetic_text(4000)
+    for i in range(12):
+        g.char_step(text, i, rc.WEIGHTED, 0.9)
+        o.char_step(text, i, rc.WEIGHTED, 0.9)
+        sg, so = g.snapshot(), o.snapshot()          # a host round trip: reads, changes nothing
+        assert np.array_equal(sg["rng"], so["rng"]), i
+        replay.check(sg, so, RTOL, keys=["hidden", "ih_w", "ho_w", "hist"], exact=("index", "generation", "rng"))
+        if i in (3, 7):                               # reseed stream 2 (and 5) on both sides
+            for j in ((2,) if i == 3 else (2, 5)):
+                seed = 1000 + 17 * i + j
+                r = g.nets[j].contents.rng
+                tmp = rc.OrcRng()
+                o.orc.orc_init_rand64(C.byref(tmp), seed)
+                r.a, r.b, r.c, r.d = tmp.a, tmp.b, tmp.c, tmp.d
+                zr = o.z.contents.rng[j]
+                zr.a, zr.b, zr.c, zr.d = tmp.a, tmp.b, tmp.c, tmp.d
+                amd.rnn_amd_host_written(g.nets[j], rc.RNN_AMD_STREAM)
     g.close()
     o.close()
 
