@@ -528,7 +528,22 @@ static void stream_need_dev(RamdEngine *e, RecurNN *net) {
 
 /* ------------------------------------------- host <-> device: the big arrays -- */
 
+/* rnn_bptt_clear_deltas is lazy: the callers that clear per generation (gstclassify, rnnca) go on
+ * with an accumulating rnn_bptt_calc_deltas, which can just as well not accumulate -- two memset
+ * launches less.  Whoever else needs the delta arrays gets the zeros first. */
+static void deltas_materialize(RamdEngine *e) {
+  if (e->deltas_zero_pending) {
+    e->deltas_zero_pending = 0;
+    if (e->dev_ready) {
+      ramd_launch_clear_deltas(g_stream, &e->sh, &e->b);
+    }
+  }
+}
+
 static void engine_need_host(RamdEngine *e, int what) {
+  if (what & RNN_AMD_DELTAS) {
+    deltas_materialize(e);
+  }
   RecurNN *o = e->owner;
   RecurExtraLayer *bl = e->sh.bI ? o->bottom_layer : NULL;
   size_t bn = (size_t)e->sh.bI * e->sh.bO;
@@ -567,6 +582,9 @@ static void engine_need_host(RamdEngine *e, int what) {
 }
 
 static void engine_need_dev(RamdEngine *e, int what) {
+  if (what & RNN_AMD_DELTAS) {
+    deltas_materialize(e);
+  }
   RecurNN *o = e->owner;
   RecurExtraLayer *bl = e->sh.bI ? o->bottom_layer : NULL;
   size_t bn = (size_t)e->sh.bI * e->sh.bO;
@@ -1429,6 +1447,10 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
   engine_ensure_device(e);
   const RamdShape *s = &e->sh;
   int j = p->stream;
+  if (e->deltas_zero_pending) { /* the sum into zeros is the sum */
+    accumulate = 0;
+    e->deltas_zero_pending = 0;
+  }
   engine_need_dev(e, RNN_AMD_WEIGHTS | (accumulate ? RNN_AMD_DELTAS : 0));
   if (fused) {
     engine_need_dev(e, RNN_AMD_MOMENTUMS);
@@ -1489,7 +1511,12 @@ void rnn_bptt_calc_deltas(RecurNN *net, int accumulate_delta, RecurErrorRange *t
 void rnn_bptt_clear_deltas(RecurNN *net) {
   RamdEngine *e = ramd_engine_of(net);
   engine_ensure_device(e);
-  ramd_launch_clear_deltas(g_stream, &e->sh, &e->b);
+  if (e->sh.bI) { /* the bottom layer's error accumulator is cleared with them: at once */
+    e->deltas_zero_pending = 0;
+    ramd_launch_clear_deltas(g_stream, &e->sh, &e->b);
+  } else {
+    e->deltas_zero_pending = 1; /* see deltas_materialize */
+  }
   engine_dev_wrote(e, RNN_AMD_DELTAS);
 }
 
@@ -2017,6 +2044,10 @@ static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ran
                             int range_stride, RamdPendingDelta *defer) {
   RamdEngine *e = set->eng;
   set_need_training(set, "rnn_amd_set_calc_deltas");
+  if (e->deltas_zero_pending) { /* the sum into zeros is the sum */
+    accumulate = 0;
+    e->deltas_zero_pending = 0;
+  }
   engine_need_dev(e, RNN_AMD_WEIGHTS | (accumulate ? RNN_AMD_DELTAS : 0));
   set_streams_to_dev(set);
   push_learn_rates(e, set->row0, set->n);
@@ -2385,6 +2416,7 @@ void rnn_amd_set_read_stats(RnnAmdSet *set, RnnAmdStats *stats, int clear) {
 void rnn_amd_set_external_delta(RnnAmdSet *set, void *device_buffer) {
   RamdEngine *e = set->eng;
   float *dst = device_buffer ? (float *)device_buffer : e->delta_own;
+  deltas_materialize(e);
   if (dst != e->b.ih_delta) {
     HIP_OK(hipMemcpyAsync(dst, e->b.ih_delta, (e->ih_size + e->ho_size) * sizeof(float),
                           hipMemcpyDeviceToDevice, g_stream));

@@ -60,6 +60,9 @@ typedef struct RamdEngine {
   /* last per-stream scalars pushed to the device */
   float *lr_pushed;
   int *idx_pushed;
+  /* rnn_bptt_clear_deltas was called and nothing has needed the zeros yet: an accumulating
+   * calc_deltas that follows simply does not accumulate (deltas_materialize otherwise) */
+  int deltas_zero_pending;
   /* noise generated ahead (noise_speculate): valid while nothing else has moved the device's
    * generators since (rng_version) */
   unsigned long rng_version, spec_version;
