@@ -1902,12 +1902,12 @@ static void set_streams_dev_wrote(RnnAmdSet *set) {
 void rnn_amd_set_advance(RnnAmdSet *set) {
   RamdEngine *e = set->eng;
   set_need_training(set, "rnn_amd_set_advance");
-  set_streams_to_dev(set);
+  (void)e;
   for (int j = 0; j < set->n; j++) {
-    host_advance(set->nets[j]); /* the index is deterministic: both sides step */
-    e->idx_pushed[set->row0 + j] = set->nets[j]->bptt->index;
+    host_advance(set->nets[j]);
   }
-  ramd_launch_advance(g_stream, &e->sh, &e->b, set->row0, set->n);
+  /* the device's copy of the indices follows with the next call's uploads (push_indices): no
+   * launch of its own for rnn_bptt_advance's three integer operations per stream */
 }
 
 /* hidden_only: stop after the hidden layer's GEMM and leave its K slabs for
@@ -1995,7 +1995,8 @@ void rnn_amd_set_opinion(RnnAmdSet *set, const float *inputs, int ld_inputs, flo
   RamdEngine *e = set->eng;
   if (inputs) {
     int w = e->sh.bI ? e->sh.b_in : e->sh.input_size;
-    upload_rows(e->d_dense, inputs, ld_inputs * sizeof(float), w * sizeof(float), set->n);
+    /* (queued: leaves with the ring indices in set_forward's flush) */
+    upload_rows_q(e->d_dense, inputs, ld_inputs * sizeof(float), w * sizeof(float), set->n, set->fwd_only);
     set_forward(set, RAMD_IN_DENSE, e->d_dense, w, 0, outputs, 0, 0);
   } else {
     set_forward(set, RAMD_IN_KEEP, NULL, 0, 0, outputs, 0, 0);
