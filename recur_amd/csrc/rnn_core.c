@@ -165,6 +165,7 @@ static void mail_in(void *dev, const void *host, size_t bytes) {
   if ((bytes & 3) || words > MAIL_WORDS) { /* not this route's kind of copy */
     mail_in_flush();
     h2d(dev, host, bytes);
+    dsync(); /* the caller's buffer is its own again when we return */
     return;
   }
   if (g_mail.nseg == 0 && g_mail.in_busy) {
