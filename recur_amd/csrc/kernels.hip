@@ -1638,9 +1638,14 @@ __global__ __launch_bounds__(256) void k_top_backprop(View v, int row0, const in
 // overlap, the products are reduced over the 32 lanes with xor shuffles (a fixed tree per range),
 // and the range's sum joins the row's running value and |running value| the error sum, range by
 // range as the reference does (recur-nn.c:178-191).  Rows whose hidden value is zero keep the
-// stale entry of the last BPTT run.  One workgroup of 16 waves per stream.
+// stale entry of the last BPTT run.  One workgroup of 16 waves per stream; with
+// few streams (a GPU's share of a sharded set, the one-net trainer) the rows of a stream are
+// shared out over gridDim.y workgroups -- a row is a chain of memory round trips per range, and
+// 32 busy CUs of 256 leave most of the latency exposed -- which leave the unscaled values and
+// their partial sums of |e| (part) for k_top_backprop_scale.
 __global__ __launch_bounds__(1024) void k_top_backprop_ranged(View v, int row0, const int *ranges,
-                                                              int range_stride, const unsigned char *active) {
+                                                              int range_stride, const unsigned char *active,
+                                                              float *part) {
   extern __shared__ __attribute__((aligned(16))) float rsh[];
   __shared__ float red[16];
   __shared__ int rlist[2 * 65];
@@ -1666,15 +1671,19 @@ __global__ __launch_bounds__(1024) void k_top_backprop_ranged(View v, int row0, 
   const float *hid = v.b.hidden + (size_t)r * s.H;
   const float *old = v.b.err_a + (size_t)r * s.I;
   float sum = 0.0f; /* this half-wave's rows */
-  constexpr int PAIRS = 4; /* eight rows at a time */
-  for (int y0 = 2 * PAIRS * wave; y0 < s.H; y0 += 2 * PAIRS * 16) {
+  constexpr int PAIRS = 8; /* sixteen rows at a time */
+  /* this workgroup's rows: [ylo, yhi), whole groups of sixteen */
+  const int nb = gridDim.y, groups = (s.H + 2 * PAIRS - 1) / (2 * PAIRS);
+  const int ylo = (int)(((long)groups * blockIdx.y) / nb) * 2 * PAIRS;
+  const int yhi = min(s.H, (int)(((long)groups * (blockIdx.y + 1)) / nb) * 2 * PAIRS);
+  for (int y0 = ylo + 2 * PAIRS * wave; y0 < yhi; y0 += 2 * PAIRS * 16) {
     float e[PAIRS];
     bool act[PAIRS];
     const float *rowp[PAIRS];
 #pragma unroll
     for (int q = 0; q < PAIRS; q++) {
       const int y = y0 + 2 * q + half; /* this half-wave's row of pair q */
-      act[q] = y > 0 && y < s.H && hid[y < s.H ? y : 0] != 0.0f;
+      act[q] = y > 0 && y < yhi && hid[y < s.H ? y : 0] != 0.0f;
       rowp[q] = v.b.ho_w + (size_t)(act[q] ? y : 0) * s.O;
       e[q] = 0.0f;
     }
@@ -1706,7 +1715,7 @@ __global__ __launch_bounds__(1024) void k_top_backprop_ranged(View v, int row0, 
 #pragma unroll
       for (int q = 0; q < PAIRS; q++) {
         const int y = y0 + 2 * q + half;
-        if (y < s.H) herr[y] = (y == 0) ? 0.0f : act[q] ? e[q] : old[y]; /* stale value where the row is skipped */
+        if (y < yhi) herr[y] = (y == 0) ? 0.0f : act[q] ? e[q] : old[y]; /* stale value where the row is skipped */
       }
     }
   }
@@ -1715,6 +1724,12 @@ __global__ __launch_bounds__(1024) void k_top_backprop_ranged(View v, int row0, 
   __syncthreads();
   sum = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
   sum += ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
+  if (nb > 1) { /* unscaled values and this workgroup's share of the sum: k_top_backprop_scale goes on */
+    float *dst = v.b.ehi + (size_t)r * s.I;
+    for (int y = ylo + threadIdx.x; y < yhi; y += 1024) dst[y] = (y == 0 || y > s.hidden_size) ? 0.0f : herr[y];
+    if (threadIdx.x == 0) part[(size_t)j * nb + blockIdx.y] = sum;
+    return;
+  }
   float halfmax = s.H * MAX_TOP_ERROR_FACTOR_F;
   float scaled = sum, scale = 1.0f;
   if (sum > halfmax) {
@@ -1724,6 +1739,29 @@ __global__ __launch_bounds__(1024) void k_top_backprop_ranged(View v, int row0, 
   float *dst = v.b.ehi + (size_t)r * s.I; /* step 0 plane */
   for (int y = threadIdx.x; y < s.H; y += 1024) /* ehi keeps column 0 and the pad at zero */
     dst[y] = (y == 0 || y > s.hidden_size) ? 0.0f : (sum > halfmax) ? herr[y] * scale : herr[y];
+  if (threadIdx.x == 0) {
+    v.b.top_raw[r] = sum;
+    v.b.top_scaled[r] = scaled;
+  }
+}
+
+/* the end of backprop_single_layer_sparse + the soft clip (recur-nn.c:719-721) for streams whose
+ * rows were shared out over nb workgroups: the partial sums in order, the scale, the row */
+__global__ __launch_bounds__(256) void k_top_backprop_scale(View v, int row0, const unsigned char *active,
+                                                            const float *part, int nb) {
+  const RamdShape &s = v.sh;
+  const int j = blockIdx.x, r = row0 + j;
+  if (active && !active[j]) return;
+  float sum = 0.0f;
+  for (int k = 0; k < nb; k++) sum += part[(size_t)j * nb + k];
+  const float halfmax = s.H * MAX_TOP_ERROR_FACTOR_F;
+  float scaled = sum;
+  if (sum > halfmax) {
+    const float scale = soft_clip_dev(sum, halfmax);
+    scaled = scale * sum;
+    float *dst = v.b.ehi + (size_t)r * s.I;
+    for (int y = threadIdx.x; y < s.H; y += 256) dst[y] *= scale; /* (0 stays 0) */
+  }
   if (threadIdx.x == 0) {
     v.b.top_raw[r] = sum;
     v.b.top_scaled[r] = scaled;
@@ -4512,9 +4550,17 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   // top layer
   size_t shm = (size_t)(sh->O + sh->H) * sizeof(float);
   if (!(flags & 0x40000000u)) { /* ramd_launch_text_top has already done the top backprop */
-    if (ranges && env_int("RECUR_AMD_TOP_RANGED", 1))
-      RAMD_LAUNCH(k_top_backprop_ranged, dim3(nrows), dim3(1024), shm, st, v, row0, ranges, range_stride, active);
-    else
+    if (ranges && env_int("RECUR_AMD_TOP_RANGED", 1)) {
+      /* few streams: up to 16 workgroups per stream (their partial sums sit in the split-K
+       * workspace, which nothing uses at this point) */
+      int nb = nrows >= 128 ? 1 : 256 / nrows;
+      if (nb > 16) nb = 16;
+      if ((size_t)nrows * nb > b->slab_floats) nb = 1;
+      RAMD_LAUNCH(k_top_backprop_ranged, dim3(nrows, nb), dim3(1024), shm, st, v, row0, ranges, range_stride,
+                  active, b->slab);
+      if (nb > 1)
+        RAMD_LAUNCH(k_top_backprop_scale, dim3(nrows), dim3(256), 0, st, v, row0, active, b->slab, nb);
+    } else
       RAMD_LAUNCH(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges, range_stride, active);
   }
   /* the weight-delta GEMM's path is decided here already: when it ends with the small GEMM
