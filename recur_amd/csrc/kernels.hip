@@ -4271,7 +4271,7 @@ extern "C" unsigned ramd_chain_abort_word(void) {
 
 static bool chain_persist_ok(const RamdShape *sh, const RamdBuffers *b, int nrows) {
   const int hs = sh->hidden_size;
-  if (b->uniform_idx < 0 || (hs != 1024 && hs != 512 && hs != 256) || nrows < 16 || nrows % 16 != 0 ||
+  if (b->uniform_idx < 0 || (hs != 1024 && hs != 512 && hs != 256) || nrows < 1 || nrows % 16 != 0 ||
       sh->D > 60 || !env_int("RECUR_AMD_CHAIN_PERSIST", 1))
     return false;
   if (g_chain_cus < 0) {
@@ -4652,11 +4652,17 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     /* one event pair around the D launches: the per-launch average then carries
      * 1/D of the event overhead instead of all of it */
     const View *d_view = device_view(st, v);
-    const bool persist = chain_persist_ok(sh, b, nrows);
+    /* a set that is not whole 16-row tiles may run over the unused rows above it (zeros that
+     * belong to nobody: RamdBuffers.n_rows_used) -- a one-net trainer then takes the one-launch
+     * chain with a single tile instead of D launches */
+    int chain_rows = nrows;
+    if (nrows % 16 != 0 && row0 + nrows == b->n_rows_used && row0 + ((nrows + 15) & ~15) <= sh->Scap)
+      chain_rows = (nrows + 15) & ~15;
+    const bool persist = chain_persist_ok(sh, b, chain_rows);
     if (persist) { /* as many row tiles per launch as there are seats; more streams: more launches */
       /* (an odd number of 16-stream tiles beyond one launch: 32-stream tiles, the last 16 streams alone) */
-      for (int r = 0; r < nrows;) {
-        const int left = nrows - r;
+      for (int r = 0; r < chain_rows;) {
+        const int left = chain_rows - r;
         const bool one = chain_persist_one(sh, left);
         const int per = chain_persist_rows(sh, one);
         int n = left < per ? left : per;
