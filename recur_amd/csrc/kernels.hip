@@ -2477,10 +2477,13 @@ __device__ unsigned long long g_pc_stamps[2][64][8];
  * next operand): 4.5 instead of 6.4 us per step for HALF the streams per workgroup -- worse per
  * stream, but a small set (64 streams at hidden 1024: a GPU's share of 512 on eight) then runs
  * on twice as many CUs.  The launcher picks it when the 16-stream tiles still fit one launch. */
-template <int ACT, int K, bool ONE = false> /* rnn_activation; hidden size: 1024, 512 or 256 */
+/* PAD (with ONE): the set is not whole row tiles -- only rows [vlo, nvalid) of the launch are its
+ * own; the others belong to other streams or to nobody: they are multiplied like the rest (rows
+ * do not mix) and never stored. */
+template <int ACT, int K, bool ONE = false, bool PAD = false> /* rnn_activation; hidden size: 1024, 512 or 256 */
 __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ vp, int uniform_idx,
                                                        int row0, int nrows, int depth, unsigned seq,
-                                                       ChainSync *sy, unsigned *host_abort) {
+                                                       ChainSync *sy, unsigned *host_abort, int nvalid, int vlo) {
   extern __shared__ __attribute__((aligned(16))) float psm[];
   constexpr int BUF = PC_SUB * K;             /* one sub-chain's operand (64 KB at K = 1024) */
   constexpr int NT = K / 32;                  /* column tiles of a row tile            */
@@ -2584,7 +2587,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
           const bool on = xi != 0.0f && (ACT != 5 || xi < 20.0f);
           ev = on ? ev : 0.0f;
           if (on && ACT == 2) ev /= 2 * (xi + 1.0f);
-          out_p[xf][q][(size_t)t * plane_stride] = ev;
+          if (!PAD || (srow[xf][q] >= vlo && srow[xf][q] < nvalid)) out_p[xf][q][(size_t)t * plane_stride] = ev;
           sq[q] = ev * ev;
         }
         /* (xor shuffles through the LDS crossbar: measured 3.7 us per chain faster than a DPP
@@ -2597,7 +2600,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
         if (col == 0) {
 #pragma unroll
           for (int q = 0; q < 2; q++)
-            esum_p[xf][q][(size_t)t * (tn + 1) * s.Scap] = sq[q];
+            if (!PAD || (srow[xf][q] >= vlo && srow[xf][q] < nvalid)) esum_p[xf][q][(size_t)t * (tn + 1) * s.Scap] = sq[q];
         }
         PC_STAMP(0, k, 2);
         /* (the two sum-of-squares stores above are the wave's youngest memory operations and
@@ -4286,21 +4289,27 @@ static bool chain_persist_ok(const RamdShape *sh, const RamdBuffers *b, int nrow
 
 template <int ACT, int K>
 static void launch_chain_persist_k(hipStream_t st, const View *d_view, const RamdShape *sh,
-                                   const RamdBuffers *b, int row0, int nrows, unsigned seq, bool one) {
+                                   const RamdBuffers *b, int row0, int nrows, unsigned seq, bool one, int nvalid,
+                                   int vlo) {
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<ACT, K, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, pc_lds_bytes(K)));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<ACT, K, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, pc_lds_bytes(K)));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<ACT, K, true, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, pc_lds_bytes(K)));
     attr_set = true;
   }
-  if (one)
+  if (one && (nvalid < nrows || vlo > 0))
+    RAMD_LAUNCH((k_chain_persist<ACT, K, true, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nvalid, vlo);
+  else if (one)
     RAMD_LAUNCH((k_chain_persist<ACT, K, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
-                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev);
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0);
   else
     RAMD_LAUNCH((k_chain_persist<ACT, K, false>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
-                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev);
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0);
 }
 
 /* row tiles per launch: 8 XCDs x (32 seats / column tiles) */
@@ -4313,7 +4322,7 @@ static bool chain_persist_one(const RamdShape *sh, int nrows) {
 static int chain_persist_rows(const RamdShape *sh, bool one) { return chain_persist_seats(sh) * (one ? 16 : 32); }
 
 static void launch_chain_persist(hipStream_t st, const View *d_view, const RamdShape *sh,
-                                 const RamdBuffers *b, int row0, int nrows, bool one) {
+                                 const RamdBuffers *b, int row0, int nrows, bool one, int nvalid, int vlo = 0) {
   if (!g_chain_sync) {
     HIP_CHECK(hipMalloc(&g_chain_sync, sizeof(ChainSync)));
     HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
@@ -4325,9 +4334,9 @@ static void launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
   int ev = timing_begin(st, T_CHAIN, 1);
 #define CHAIN_PERSIST(ACT)                                                                  \
   do {                                                                                      \
-    if (sh->hidden_size == 1024) launch_chain_persist_k<ACT, 1024>(st, d_view, sh, b, row0, nrows, seq, one); \
-    else if (sh->hidden_size == 512) launch_chain_persist_k<ACT, 512>(st, d_view, sh, b, row0, nrows, seq, one); \
-    else launch_chain_persist_k<ACT, 256>(st, d_view, sh, b, row0, nrows, seq, one);             \
+    if (sh->hidden_size == 1024) launch_chain_persist_k<ACT, 1024>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo); \
+    else if (sh->hidden_size == 512) launch_chain_persist_k<ACT, 512>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo); \
+    else launch_chain_persist_k<ACT, 256>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo);             \
   } while (0)
   if (sh->activation == 2) CHAIN_PERSIST(2);
   else if (sh->activation == 5) CHAIN_PERSIST(5);
@@ -4652,22 +4661,36 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     /* one event pair around the D launches: the per-launch average then carries
      * 1/D of the event overhead instead of all of it */
     const View *d_view = device_view(st, v);
-    /* a set that is not whole 16-row tiles may run over the unused rows above it (zeros that
-     * belong to nobody: RamdBuffers.n_rows_used) -- a one-net trainer then takes the one-launch
-     * chain with a single tile instead of D launches */
+    /* a set that is not whole 16-row tiles runs over the rows above it (Scap is a multiple of 16:
+     * they exist), which are multiplied along and never stored (PAD) -- a one-net trainer or a
+     * per-net call then takes the one-launch chain with a single tile instead of D launches */
     int chain_rows = nrows;
-    if (nrows % 16 != 0 && row0 + nrows == b->n_rows_used && row0 + ((nrows + 15) & ~15) <= sh->Scap)
-      chain_rows = (nrows + 15) & ~15;
-    const bool persist = chain_persist_ok(sh, b, chain_rows);
-    if (persist) { /* as many row tiles per launch as there are seats; more streams: more launches */
+    if (nrows % 16 != 0 && row0 + ((nrows + 15) & ~15) <= sh->Scap) chain_rows = (nrows + 15) & ~15;
+    /* ... and a small set that does not start on a tile boundary (a per-net call on stream j):
+     * the tiles from the boundary below it, one launch */
+    const int span_base = row0 & ~15, span = ((row0 + nrows + 15) & ~15) - span_base;
+    const bool windowed = span_base != row0 && span / 16 <= chain_persist_seats(sh) && span_base + span <= sh->Scap &&
+                          chain_persist_ok(sh, b, span);
+    if (windowed) {
+      launch_chain_persist(st, d_view, sh, b, span_base, span, true, row0 - span_base + nrows, row0 - span_base);
+    }
+    const bool persist = windowed || chain_persist_ok(sh, b, chain_rows);
+    if (persist && !windowed) { /* as many row tiles per launch as there are seats; more streams: more launches */
       /* (an odd number of 16-stream tiles beyond one launch: 32-stream tiles, the last 16 streams alone) */
       for (int r = 0; r < chain_rows;) {
-        const int left = chain_rows - r;
-        const bool one = chain_persist_one(sh, left);
-        const int per = chain_persist_rows(sh, one);
-        int n = left < per ? left : per;
-        if (!one) n &= ~31;
-        launch_chain_persist(st, d_view, sh, b, row0 + r, n, one);
+        const int left = chain_rows - r, real_left = nrows - r;
+        bool one = chain_persist_one(sh, left);
+        int n = 0;
+        if (!one) { /* 32-stream tiles over whole, real tiles only */
+          n = real_left & ~31;
+          if (n > chain_persist_rows(sh, false)) n = chain_persist_rows(sh, false);
+          if (n == 0) one = true;
+        }
+        if (one) {
+          n = chain_persist_rows(sh, true);
+          if (n > left) n = left;
+        }
+        launch_chain_persist(st, d_view, sh, b, row0 + r, n, one, real_left < n ? real_left : n);
         r += n;
       }
     }

@@ -258,6 +258,8 @@ def test_empty_and_edge_inputs(amd):
     ("chain_padded_256_5", dict(input_size=42, hidden_size=256, output_size=42, S=5, D=6, learn_rate=1e-4, seed=39), 9),
     ("chain_padded_1024_1", dict(input_size=42, hidden_size=1024, output_size=42, S=1, D=5, learn_rate=1e-5, seed=40), 7),
     ("chain_padded_512_21", dict(input_size=42, hidden_size=512, output_size=42, S=21, D=4, learn_rate=1e-4, seed=41), 6),
+    # 250 streams at hidden 1024: seven 32-stream tiles, then two 16-stream tiles of which 26 rows are real
+    ("chain_padded_1024_250", dict(input_size=42, hidden_size=1024, output_size=42, S=250, D=3, learn_rate=1e-5, seed=42), 4),
     # 17 tiles of 16 streams at hidden 1024: a launch of 32-stream tiles, then the last 16 streams alone
     ("chain_mixed_1024_272", dict(input_size=42, hidden_size=1024, output_size=42, S=272, D=3, learn_rate=1e-5, seed=38), 4),
 ])
