@@ -86,10 +86,6 @@ typedef struct RamdBuffers {
    * one-hot symbols -- the extras of the BPTT chain are then a GEMM, not a gather over the few
    * non-zero input rows (either is correct for any input) */
   int dense_inputs;
-  /* training rows in use (n_streams <= Scap, which is a multiple of 16): the rows above them
-   * exist, hold zeros and belong to nobody, so a kernel that wants whole 16-row tiles may run
-   * over them when its set ends at n_rows_used */
-  int n_rows_used;
 } RamdBuffers;
 
 /* ih_delta left as un-summed K slabs by ramd_launch_calc_deltas, for the optimiser launch

@@ -745,7 +745,7 @@ static void engine_ensure_device(RamdEngine *e) {
   s->bO = bO;
   s->b_in = obl ? obl->input_size : 0;
   s->b_out = obl ? obl->output_size : 0;
-  s->Scap = (RAMD_MAX(e->n_streams, 1) + 15) / 16 * 16; /* whole 16-row tiles: see n_rows_used */
+  s->Scap = (RAMD_MAX(e->n_streams, 1) + 15) / 16 * 16; /* whole 16-row tiles (k_chain_persist's PAD launches run over the rows above a set) */
   s->Fcap = RAMD_MAX(e->n_fwd, 1);
   if (s->D < 1) {
     s->D = 1;
@@ -1244,7 +1244,6 @@ static void set_uniform_idx(RamdEngine *e, int row0, int nrows) {
     }
   }
   e->b.uniform_idx = u;
-  e->b.n_rows_used = e->n_streams;
   mail_in_flush(); /* whatever the caller queued for the launches that follow */
 }
 
