@@ -82,6 +82,11 @@ __device__ __forceinline__ float *input_row(const View &v, int r, int back) {
   return v.b.arena + (s.D * s.Scap + (r - s.Scap)) * s.I;
 }
 
+/* the same with the choice made at run time (b.uniform_idx >= 0: no index load in front of the row's) */
+__device__ __forceinline__ float *input_row_auto(const View &v, int r, int back) {
+  return v.b.uniform_idx >= 0 ? input_row<true>(v, r, back) : input_row<false>(v, r, back);
+}
+
 // recur-nn-helpers.h:104-113
 __device__ __forceinline__ float soft_clip_dev(float sum, float halfmax) {
   if (halfmax == 0) return sum;
@@ -3058,7 +3063,7 @@ __device__ __forceinline__ void extras_load(const View &v, int t, int r, int nx,
                                             ExtrasIn<MAXQ> &in) {
   const RamdShape &s = v.sh;
   const float *erow = v.b.ehi + (t * s.Scap + r) * s.I;
-  const float *x = input_row<false>(v, r, t);
+  const float *x = input_row_auto(v, r, t);
   const int nq = (s.H / 4 + 63) / 64;
 #pragma unroll
   for (int i = 0; i < MAXQ; i++) {
@@ -3072,7 +3077,7 @@ template <int MAXQ>
 __device__ __forceinline__ float extras_compute(const View &v, int t, int r, int nx, int nxp, int tn,
                                                 int lane, const ExtrasIn<MAXQ> &in) {
   const RamdShape &s = v.sh;
-  const float *x = input_row<false>(v, r, t);
+  const float *x = input_row_auto(v, r, t);
   float *dst = v.b.ex + ((size_t)(t + 1) * s.Scap + r) * nxp;
   const int nq = (s.H / 4 + 63) / 64;
   float sq = 0.0f;
