@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of EACH cpu leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--prefill", type=int, default=300, help="untimed generations before the warm-up")
     ap.add_argument("--dist", action="store_true",
                     help="join an RCCL group even with one rank (exercises the exchange step)")
     return ap.parse_args()
@@ -330,7 +331,7 @@ def main():
     # untimed, before the warm-up: the history ring is full whatever --warmup is (D + 5), and the
     # device has ramped to the clocks it holds under this load (measured: a 20-step timed region
     # right after 30 generations runs 2.4 % slower than after 300; sustained rate is the metric)
-    prefill = max(D + 5, 300)
+    prefill = max(D + 5, args.prefill)
     total_steps = prefill + args.warmup + args.steps + 260
     text = gc.synthetic_text_np(max(20000, S * world * 40 + total_steps + 16), ALPHABET, 7)
 
