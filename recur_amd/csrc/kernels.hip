@@ -1342,26 +1342,63 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
 // the reference builds for rnn_bptt_calc_deltas -- aligned, merged when they touch -- are
 // left in ranges[j].  One wave per stream; every lane runs the generator redundantly so
 // that the decisions are uniform.
-__global__ __launch_bounds__(64) void k_multi_softmax_error(View v, int row0, int alen, int ncls,
-                                                            unsigned long long threshold,
-                                                            const int *tclass, int *ranges,
-                                                            int range_stride) {
-  extern __shared__ float ex[]; /* [alen] */
+// Four waves per stream: wave 0 makes the leak decisions (the generator is sequential) and the
+// range list while all four clear the error row; then the trained heads are shared out over the
+// waves, each head's softmax exactly as before (the sum of the exponentials in index order).
+// (As one wave per stream this was 35 us for 256 streams of 50 heads.)
+constexpr int MS_WAVES = 4, MS_MAXCLS = 256;
+__global__ __launch_bounds__(64 * MS_WAVES) void k_multi_softmax_error(View v, int row0, int alen, int ncls,
+                                                                       unsigned long long threshold,
+                                                                       const int *tclass, int *ranges,
+                                                                       int range_stride) {
+  extern __shared__ float exs[]; /* [MS_WAVES][alen] */
+  __shared__ short trained[MS_MAXCLS];
+  __shared__ int ntrained;
+  __shared__ float own_err_sh;
   const RamdShape &s = v.sh;
-  const int j = blockIdx.x, r = row0 + j, lane = threadIdx.x;
+  const int j = blockIdx.x, r = row0 + j, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float *src = v.b.out + (size_t)r * s.O;
   float *err = v.b.o_error + (size_t)r * s.O;
-  for (int i = lane; i < s.output_size; i += 64) err[i] = 0.0f;
   const int next = v.b.target[r], own = tclass[j];
-  int *rg = ranges + (size_t)j * range_stride;
-  DevRng g = reinterpret_cast<DevRng *>(v.b.rng)[r];
-  int nr = 0, prev_start = 0, prev_len = 0;
-  float own_err = 0.0f;
-  for (int c = 0; c < ncls; c++) {
-    const int offset = c * alen;
-    bool train = (c == own);
-    if (!train) train = dev_rand64(g) < threshold;
-    if (!train) continue;
+  for (int i = threadIdx.x; i < s.output_size; i += 64 * MS_WAVES) err[i] = 0.0f;
+  if (wave == 0) {
+    /* every lane runs the generator redundantly, so that the decisions are wave-uniform */
+    int *rg = ranges + (size_t)j * range_stride;
+    DevRng g = reinterpret_cast<DevRng *>(v.b.rng)[r];
+    int nt = 0, nr = 0, prev_start = 0, prev_len = 0;
+    for (int c = 0; c < ncls; c++) {
+      bool train = (c == own);
+      if (!train) train = dev_rand64(g) < threshold;
+      if (!train) continue;
+      if (lane == 0) trained[nt] = (short)c;
+      nt++;
+      const int offset = c * alen;
+      int start = offset & ~3, end = (offset + alen + 3) & ~3;
+      if (nr && prev_start + prev_len >= start) {
+        prev_len = end - prev_start;
+        if (lane == 0) rg[2 * (nr - 1) + 1] = prev_len;
+      } else {
+        prev_start = start;
+        prev_len = end - start;
+        if (lane == 0) {
+          rg[2 * nr] = prev_start;
+          rg[2 * nr + 1] = prev_len;
+        }
+        nr++;
+      }
+    }
+    if (lane == 0) {
+      rg[2 * nr] = -1;
+      rg[2 * nr + 1] = 0;
+      reinterpret_cast<DevRng *>(v.b.rng)[r] = g;
+      ntrained = nt;
+    }
+  }
+  __syncthreads(); /* the row is clear, the list is there */
+  float *ex = exs + wave * alen;
+  const int nt = ntrained;
+  for (int k = wave; k < nt; k += MS_WAVES) {
+    const int c = trained[k], offset = c * alen;
     const float *gs = src + offset;
     float lo = gs[0], hi = gs[0];
     for (int i = lane; i < alen; i += 64) {
@@ -1375,34 +1412,20 @@ __global__ __launch_bounds__(64) void k_multi_softmax_error(View v, int row0, in
     float adj = 0.0f;
     if (hi > 50.0f) adj = 50.0f - hi;
     else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
-    __syncthreads();
     for (int i = lane; i < alen; i += 64) ex[i] = fast_expf_dev(gs[i] + adj);
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* one wave: its LDS writes are ordered */
     float sum = 0.0f;
     for (int i = 0; i < alen; i++) sum += ex[i];
     for (int i = lane; i < alen; i += 64) {
       float e = ex[i] / sum;
       err[offset + i] = (i == next) ? -e + 1.0f : -e;
     }
-    if (c == own) own_err = -(ex[next] / sum) + 1.0f;
-    int start = offset & ~3, end = (offset + alen + 3) & ~3;
-    if (nr && prev_start + prev_len >= start) {
-      prev_len = end - prev_start;
-      if (lane == 0) rg[2 * (nr - 1) + 1] = prev_len;
-    } else {
-      prev_start = start;
-      prev_len = end - start;
-      if (lane == 0) {
-        rg[2 * nr] = prev_start;
-        rg[2 * nr + 1] = prev_len;
-      }
-      nr++;
-    }
+    if (c == own && lane == 0) own_err_sh = -(ex[next] / sum) + 1.0f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* before this wave's next head rewrites ex */
   }
-  if (lane == 0) {
-    rg[2 * nr] = -1;
-    rg[2 * nr + 1] = 0;
-    reinterpret_cast<DevRng *>(v.b.rng)[r] = g;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float own_err = own_err_sh;
     float l = 1.0f - own_err;
     v.b.stat_err[r] += own_err;
     v.b.stat_ent[r] += (l < 1e-30f) ? -100.0f : log2f(l);
@@ -4526,8 +4549,13 @@ extern "C" void ramd_launch_multi_softmax_error(ramd_stream_t st_, const RamdSha
                                                 int *ranges, int range_stride) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  RAMD_LAUNCH(k_multi_softmax_error, dim3(nrows), dim3(64), (size_t)alphabet_len * sizeof(float),
-                     st, v, row0, alphabet_len, n_classes, threshold, tclass, ranges, range_stride);
+  if (n_classes > MS_MAXCLS) {
+    fprintf(stderr, "librecur_amd: more than %d class heads\n", MS_MAXCLS);
+    abort();
+  }
+  RAMD_LAUNCH(k_multi_softmax_error, dim3(nrows), dim3(64 * MS_WAVES),
+                     (size_t)MS_WAVES * alphabet_len * sizeof(float), st, v, row0, alphabet_len, n_classes,
+                     threshold, tclass, ranges, range_stride);
 }
 
 extern "C" void ramd_launch_grouped_softmax_error(ramd_stream_t st_, const RamdShape *sh,
