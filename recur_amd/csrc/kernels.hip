@@ -3247,12 +3247,13 @@ constexpr int DD_STAGE_FLOATS = 2 * BK * 128 + 64; /* A, B, 32 coefficients (+ p
 struct DeltaRest {
   float *planes;  /* [ks * tm][rows][ldc] */
   size_t stride;  /* floats between planes */
-  int rows;       /* i_size - rows_core, <= 64 */
+  int rows;       /* i_size - rows_core, <= RR */
   int col;        /* rows_core */
 };
-constexpr int DD_REST_FLOATS = BK * 64; /* one rest tile: 32 k x 64 rows */
+constexpr int DD_REST_FLOATS = BK * 128; /* the rest ring: two tiles of 32 k x 64 rows or one of 32 k x 128 */
 
-template <bool REST>
+/* RR: rows of the rest tile: 0 (none), 64 or 128 (a wave then has 32 or 64 rest rows x its 64 columns) */
+template <int RR>
 __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, GemmOut o, DeltaRest dr) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const RamdShape &s = v.sh;
@@ -3271,8 +3272,11 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
   const int rtiles = nrows / BK;
   /* stage st carries rest work when st % tm == mt; its tile sits in slot (st / tm) % 2 behind the
    * ring (tm >= 4, so a slot's previous tile was consumed long before the next one is fetched) */
+  constexpr bool REST = RR > 0;
+  constexpr int RI = RR / 64; /* 32-row groups of rest rows per wave */
   auto is_rest = [&](int st) { return REST && st < nst && st % o.tm == mt; };
-  auto rest_slot = [&](int st) { return (st / o.tm) & 1; };
+  /* byte-free float offset of a stage's rest tile in the rest ring: two slots of 64 rows, one of 128 */
+  auto rest_slot = [&](int st) { return RR == 64 ? ((st / o.tm) & 1) * (BK * 64) : 0; };
   float *const rest_ring = dsm + DD_STAGES * DD_STAGE_FLOATS;
 
   if (wave8 >= 4) {
@@ -3286,7 +3290,7 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
     const int ws = __builtin_amdgcn_readfirstlane(w);
     const unsigned voff = (unsigned)(((size_t)(lane >> 5) * s.I + (lane & 31) * 4) * sizeof(float));
     const unsigned voff_c = (unsigned)((lane & 31) * sizeof(float));
-    const unsigned voff_r = (unsigned)(((size_t)(lane >> 4) * s.I + (lane & 15) * 4) * sizeof(float));
+    const unsigned voff_r = RR == 128 ? voff : (unsigned)(((size_t)(lane >> 4) * s.I + (lane & 15) * 4) * sizeof(float));
     const uint32_t dsm_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(dsm));
     auto issue = [&](int st) {
       const int kt = kt0 + st;
@@ -3308,9 +3312,11 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
       }
       if (REST && ws == 3 && is_rest(st)) { /* the tail of the 32 history rows: four rows per instruction */
         const float *rb = v.b.arena + ((size_t)slot * s.Scap + row0 + sb) * s.I + dr.col;
-        const uint32_t rdst = dsm_lds + (uint32_t)((DD_STAGES * DD_STAGE_FLOATS + rest_slot(st) * DD_REST_FLOATS) * sizeof(float));
+        const uint32_t rdst = dsm_lds + (uint32_t)((DD_STAGES * DD_STAGE_FLOATS + rest_slot(st)) * sizeof(float));
+        /* an instruction moves 1 KB: four rows of 64 floats or two of 128 */
 #pragma unroll
-        for (int j = 0; j < 8; j++) lds_dma16(rb + (size_t)(4 * j) * s.I, voff_r, rdst + (uint32_t)(j * 256 * sizeof(float)));
+        for (int j = 0; j < 8 * (RI ? RI : 1); j++)
+          lds_dma16(rb + (size_t)((RR == 128 ? 2 : 4) * j) * s.I, voff_r, rdst + (uint32_t)(j * 256 * sizeof(float)));
       }
     };
 #pragma unroll
@@ -3324,13 +3330,16 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else if (REST && w == 3) {
-        /* eight more in flight for a rest stage among the ones ahead (at most one: they are eight apart) */
+        /* 8 (RR 64) or 16 (RR 128) more in flight for a rest stage among the ones ahead (at most one:
+         * they are tm >= 4 apart) */
         const bool more = (ahead >= 1 && is_rest(st + 1)) || (ahead >= 2 && is_rest(st + 2));
         if (ahead >= 2) {
-          if (more) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+          if (more && RR == 128) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+          else if (more) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         } else if (ahead == 1) {
-          if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          if (more && RR == 128) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+          else if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3362,19 +3371,23 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
   struct Frag {
     float a[2][4], e[2][4];
     float4 cf;
-    float ar[4]; /* rest rows (REST stages only) */
+    float ar[RI ? RI : 1][4]; /* rest rows (REST stages only) */
   };
-  f32x16 racc[2];
+  f32x16 racc[RI ? RI : 1][2];
 #pragma unroll
-  for (int j = 0; j < 2; j++)
+  for (int i = 0; i < (RI ? RI : 1); i++)
 #pragma unroll
-    for (int g = 0; g < 16; g++) racc[j][g] = 0.0f;
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) racc[i][j][g] = 0.0f;
   const int lane_off = 4 * kh * 128 + lm;
   auto rd = [&](int st, int g, Frag &f, bool rest) {
     if (REST && rest) { /* wave-uniform */
-      const float *lr = rest_ring + rest_slot(st) * DD_REST_FLOATS + (8 * g + 4 * kh) * 64 + wm * 32 + lm;
+      const float *lr = rest_ring + rest_slot(st) + (8 * g + 4 * kh) * RR + wm * (RR / 2) + lm;
 #pragma unroll
-      for (int jj = 0; jj < 4; jj++) f.ar[jj] = lr[jj * 64];
+      for (int i = 0; i < RI; i++)
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) f.ar[i][jj] = lr[jj * RR + i * 32];
     }
     const float *la = dsm + (st % DD_STAGES) * DD_STAGE_FLOATS + 8 * g * 128 + lane_off;
     const float *lb = la + BK * 128;
@@ -3412,12 +3425,14 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
 #pragma unroll
         for (int jn = 0; jn < 2; jn++)
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][jj], b[jn][jj], acc[i][jn], 0, 0, 0);
-    if (REST && rest) { /* wave-uniform: this wave's 32 rest rows x its 64 columns */
+    if (REST && rest) { /* wave-uniform: this wave's 32 or 64 rest rows x its 64 columns */
 #pragma unroll
       for (int jj = 0; jj < 4; jj++)
 #pragma unroll
-        for (int jn = 0; jn < 2; jn++)
-          racc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.ar[jj], b[jn][jj], racc[jn], 0, 0, 0);
+        for (int i = 0; i < RI; i++)
+#pragma unroll
+          for (int jn = 0; jn < 2; jn++)
+            racc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.ar[i][jj], b[jn][jj], racc[i][jn], 0, 0, 0);
     }
   };
   auto step = [&](int st, int g, Frag &cur, Frag &nxt, bool rest, bool rest_next) {
@@ -3472,14 +3487,16 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
   if (REST) {
     float *rp = dr.planes + (size_t)(z * o.tm + mt) * dr.stride;
 #pragma unroll
-    for (int jn = 0; jn < 2; jn++) {
-      const int col = n0 + wn * 64 + jn * 32 + lm;
+    for (int i = 0; i < RI; i++)
 #pragma unroll
-      for (int g = 0; g < 16; g++) {
-        int row = wm * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
-        if (row < dr.rows) rp[(size_t)row * o.ldc + col] = racc[jn][g];
+      for (int jn = 0; jn < 2; jn++) {
+        const int col = n0 + wn * 64 + jn * 32 + lm;
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+          int row = wm * (RR / 2) + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
+          if (row < dr.rows) rp[(size_t)row * o.ldc + col] = racc[i][jn][g];
+        }
       }
-    }
   }
 }
 
@@ -4838,11 +4855,13 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
        * input rows of a text net) by the generic kernel with its own K split */
       static bool attr_set = false;
       size_t shm = (size_t)DD_STAGES * DD_STAGE_FLOATS * sizeof(float);
-      const size_t shm_rest = shm + 2 * (size_t)DD_REST_FLOATS * sizeof(float);
+      const size_t shm_rest = shm + (size_t)DD_REST_FLOATS * sizeof(float);
       if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_delta_dma<false>,
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_delta_dma<0>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_delta_dma<true>,
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_delta_dma<64>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_rest));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_delta_dma<128>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_rest));
         attr_set = true;
       }
@@ -4869,10 +4888,10 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       const int per = 8 / kd;
       int blocks = ((tiles + per - 1) / per) * 8;
       /* the rows above the last whole tile inside the same launch (see DeltaRest) when there are at
-       * most 64 of them, at least four row tiles to share them out, and room for ks * tm planes */
+       * most 128 of them, at least four row tiles to share them out, and room for ks * tm planes */
       const int rest_rows = sh->I - rows_core;
       const size_t rest_plane = (size_t)rest_rows * sh->H;
-      const bool rest_in = rest_rows > 0 && rest_rows <= 64 && o.tm >= 4 && kd * o.tm <= RAMD_MAX_REST_PLANES &&
+      const bool rest_in = rest_rows > 0 && rest_rows <= 128 && o.tm >= 4 && kd * o.tm <= RAMD_MAX_REST_PLANES &&
                            (size_t)kd * n + (size_t)kd * o.tm * rest_plane <= b->slab_floats &&
                            env_int("RECUR_AMD_DELTA_REST_IN", 1);
       int ev = timing_begin(st, T_DELTA);
@@ -4882,10 +4901,13 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
         dr.stride = rest_plane;
         dr.rows = rest_rows;
         dr.col = rows_core;
-        RAMD_LAUNCH(k_delta_dma<true>, dim3(blocks), dim3(512), shm_rest, st, v, row0, nrows, o, dr);
+        if (rest_rows <= 64)
+          RAMD_LAUNCH(k_delta_dma<64>, dim3(blocks), dim3(512), shm_rest, st, v, row0, nrows, o, dr);
+        else
+          RAMD_LAUNCH(k_delta_dma<128>, dim3(blocks), dim3(512), shm_rest, st, v, row0, nrows, o, dr);
       } else {
         DeltaRest dr = {};
-        RAMD_LAUNCH(k_delta_dma<false>, dim3(blocks), dim3(512), shm, st, v, row0, nrows, o, dr);
+        RAMD_LAUNCH(k_delta_dma<0>, dim3(blocks), dim3(512), shm, st, v, row0, nrows, o, dr);
       }
       timing_end(st, ev);
       ks_rest = 0;

@@ -771,7 +771,7 @@ static void engine_ensure_device(RamdEngine *e) {
   e->delta_own = dev_alloc((e->ih_size + e->ho_size) * fl);
   b->ih_delta = e->delta_own;
   b->ho_delta = e->delta_own + e->ih_size;
-  b->arena = dev_alloc(((D * S + F) * I + 128) * fl); /* + slack: k_delta_dma's rest tile reads 64 floats from column rows_core of the last row */
+  b->arena = dev_alloc(((D * S + F) * I + 128) * fl); /* + slack: k_delta_dma's rest tile reads up to 128 floats from column rows_core of the last row */
   b->hidden = dev_alloc((S + F) * H * fl);
   b->out = dev_alloc((S + F) * O * fl);
   b->o_error = dev_alloc(S * O * fl);
