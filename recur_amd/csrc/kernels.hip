@@ -4610,9 +4610,12 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   size_t shm = (size_t)(sh->O + sh->H) * sizeof(float);
   if (!(flags & 0x40000000u)) { /* ramd_launch_text_top has already done the top backprop */
     if (ranges && env_int("RECUR_AMD_TOP_RANGED", 1)) {
-      /* few streams: up to 16 workgroups per stream (their partial sums sit in the split-K
-       * workspace, which nothing uses at this point) */
-      int nb = nrows >= 128 ? 1 : 256 / nrows;
+      /* up to 16 workgroups per stream (their partial sums sit in the split-K workspace, which
+       * nothing uses at this point) */
+      /* (measured: 256 streams with 1 / 2 / 4 / 8 / 16 workgroups per stream = 552 / 548 / 538 /
+       * 550 / 629 us per generation; 64 streams with 4 / 16: 347 / 358; 32 streams with 8 / 16: 306 / 312) */
+      int nb = 256 / nrows;
+      if (nb < 4) nb = nrows > 1024 ? 1 : 4;
       if (nb > 16) nb = 16;
       if ((size_t)nrows * nb > b->slab_floats) nb = 1;
       RAMD_LAUNCH(k_top_backprop_ranged, dim3(nrows, nb), dim3(1024), shm, st, v, row0, ranges, range_stride,
