@@ -3607,6 +3607,89 @@ __global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, in
   if (wave == 0) bptt_control_wave(v, r, j, lane, active, flags, es_sh, 1);
 }
 
+// ------------------------------------ one stream, small net: forward in one launch --
+//
+// rnn_opinion for ONE stream of a small net (recur-nn.c:83-154 without noise and bottom layer):
+// the input row (bias, previous hidden values, the inputs the caller put there, the emergency
+// soft clip of maybe_scale_inputs), hidden = act(x . W_ih) with the zero-row skip, bias node,
+// out = hidden . W_ho -- k_assemble + k_gemm + k_fwd_finalize + k_out_layer as one workgroup.
+// Thread (g = tid / HC, n = tid % HC) walks the input rows y = g, g + G, .. of column n (a wave
+// reads whole contiguous rows of W_ih), the G partial sums per column are added in order.
+// Preconditions (launcher): h_size <= 256, i_size <= 512, o_size <= 64.
+__global__ __launch_bounds__(1024) void k_fwd_small(View v, int r) {
+  __shared__ float xs[512], hsh[256], part[1024], red[16];
+  const RamdShape &s = v.sh;
+  const int I = s.I, H = s.H, O = s.O, hs = s.hidden_size;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float *slot = input_row<false>(v, r, 0);
+  float *hid = v.b.hidden + (size_t)r * H;
+  // the input row (k_assemble, mode KEEP) and its sum
+  float sum = 0.0f;
+  if (tid < I) {
+    float x = (tid == 0) ? 1.0f : (tid <= hs) ? hid[tid] : slot[tid];
+    xs[tid] = x;
+    sum = x;
+  }
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+  {
+    const float softclip = I * INPUT_MEAN_SOFT_TOP_F;
+    float scale = 1.0f;
+    if (sum > softclip) scale = soft_clip_dev(sum, softclip);
+    if (tid < I) {
+      const float x = xs[tid] * scale;
+      if (sum > softclip) xs[tid] = x;
+      slot[tid] = (sum > softclip) ? x : xs[tid];
+    }
+  }
+  __syncthreads();
+  // hidden sums: column n, rows y = g, g + G, ...
+  const int HC = H <= 128 ? 128 : 256, G = 1024 / HC;
+  const int n = tid & (HC - 1), g = tid / HC;
+  float acc = 0.0f;
+  if (n < H) {
+    const float *w = v.b.ih_w + n;
+    for (int y = g; y < I; y += G) {
+      const float x = xs[y]; /* the same for the whole group: whole waves skip a zero row */
+      if (x != 0.0f) acc += x * w[(size_t)y * H];
+    }
+  }
+  part[tid] = acc;
+  __syncthreads();
+  if (tid < H) {
+    float x = part[tid];
+    for (int k = 1; k < G; k++) x += part[k * HC + tid];
+    if (s.activation == 2) {
+      x = (x > 0.0f) ? sqrtf(x + 1.0f) - 1.0f : 0.0f;
+    } else if (s.activation == 5) {
+      x = x < 20.0f ? x : 20.0f;
+      x = (x > 0.0f) ? x : 0.0f;
+    } else {
+      x = (x > 0.0f) ? x : 0.0f;
+    }
+    if (tid == 0) x = 1.0f; /* the bias node, recur-nn.c:148 */
+    hid[tid] = x;
+    hsh[tid] = x;
+  }
+  __syncthreads();
+  // output layer: column o, rows y = g2, g2 + 16, ...
+  {
+    const int o = tid & 63, g2 = tid >> 6;
+    float a = 0.0f;
+    if (o < O)
+      for (int y = g2; y < H; y += 16) a += hsh[y] * v.b.ho_w[(size_t)y * O + o];
+    part[tid] = a;
+    __syncthreads();
+    if (tid < O) {
+      float x = part[tid];
+      for (int k = 1; k < 16; k++) x += part[k * 64 + tid];
+      v.b.out[(size_t)r * O + tid] = x;
+    }
+  }
+}
+
 // ------------------------------------------ one stream, small net: one launch --
 //
 // bptt_and_accumulate_error (recur-nn.c:303-450) for ONE stream of a small net as one
@@ -4434,6 +4517,18 @@ extern "C" void ramd_launch_text_top(ramd_stream_t st_, const RamdShape *sh, con
 extern "C" int ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh,
                                           const RamdBuffers *b, int row0, int nrows, float noise,
                                           int leave_slabs);
+
+/* rnn_opinion's device work for one stream of a small net in one launch (k_fwd_small); returns 0
+ * when the shape is not its kind and nothing was launched */
+extern "C" int ramd_launch_forward_small(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b, int r) {
+  if (sh->H > 256 || sh->I > 512 || sh->O > 64 || sh->bI || !env_int("RECUR_AMD_FWD_SMALL", 1)) return 0;
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  int ev = timing_begin(st, T_FWD);
+  RAMD_LAUNCH(k_fwd_small, dim3(1), dim3(1024), 0, st, v, r);
+  timing_end(st, ev);
+  return 1;
+}
 
 extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
                                     int row0, int nrows, float noise) {

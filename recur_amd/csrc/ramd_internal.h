@@ -193,6 +193,8 @@ void ramd_launch_sigmoid_mse_error(ramd_stream_t st, const RamdShape *sh, const 
 /* fast_sigmoid_array in place on the first n outputs of state rows r0 .. r0 + nrows */
 void ramd_launch_sigmoid_outputs(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int r0,
                                  int nrows, int n);
+/* rnn_opinion's device work for one stream of a small net in one launch; 0: not its kind of shape */
+int ramd_launch_forward_small(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int r);
 /* up to 12 word-wise copies (nwords[g] 32-bit words from src[g] to dst[g]) in one launch */
 /* the noise of the next forward pass of rows [row0, row0 + nrows), from the generators' current
  * states, into b->noise_spec / b->rng_spec; the generators themselves are not touched */

@@ -1410,8 +1410,10 @@ float *rnn_opinion(RecurNN *net, const float *inputs, float presynaptic_noise) {
                                presynaptic_noise);
     mail_out(bl->outputs, e->b.bout + (size_t)r * s->bO, sizeof(float) * s->bO);
   }
-  ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1, 0);
-  ramd_launch_forward(g_stream, s, &e->b, r, 1, presynaptic_noise);
+  if (bl || presynaptic_noise != 0.0f || !ramd_launch_forward_small(g_stream, s, &e->b, r)) {
+    ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1, 0);
+    ramd_launch_forward(g_stream, s, &e->b, r, 1, presynaptic_noise);
+  }
   if (presynaptic_noise != 0.0f) {
     mail_out(&net->rng, (char *)e->b.rng + (size_t)r * sizeof(rand_ctx), sizeof(rand_ctx));
   }
