@@ -3842,10 +3842,33 @@ __global__ __launch_bounds__(1024) void k_bptt_small(View v, int r, int accumula
   if (wave == 0) {
     /* the steps that did not run left zeros, which end the scan of bptt_control_wave too */
     bptt_control_wave(v, r, 0, lane, nullptr, flags, es_sh, 1);
-    if (lane == 0) red[16] = v.b.ih_scale[r]; /* lane 0 wrote it */
+    if (lane == 0) {
+      red[16] = v.b.ih_scale[r]; /* lane 0 wrote it */
+      red[17] = __int_as_float(v.b.n_exec[r]);
+    }
   }
-  __syncthreads();
+  __syncthreads(); /* (also: every plane store of this workgroup has been performed) */
   const float scale = red[16];
+  {
+    /* bptt->h_error / i_error as the reference leaves them: k_err_writeback's job, from the planes
+     * this workgroup has just written (nothing of them was read before: no stale lines) */
+    const int nex = __float_as_int(red[17]);
+    if (nex > 0 && tid < I) {
+      float *A = v.b.err_a + (size_t)r * I, *B = v.b.err_b + (size_t)r * I;
+      float *last_written = (nex & 1) ? B : A, *last_read = (nex & 1) ? A : B;
+      const float *enp = v.b.ehi + (size_t)nex * plane + (size_t)r * I;
+      const float *epp = v.b.ehi + (size_t)(nex - 1) * plane + (size_t)r * I;
+      const float *xn = v.b.ex + ((size_t)nex * s.Scap + r) * nxp;
+      const float *xp = v.b.ex + ((size_t)(nex - 1) * s.Scap + r) * nxp;
+      const int i = tid;
+      last_written[i] = (i == 0) ? xn[0] : (i <= hs) ? enp[i] : xn[i - hs];
+      if (i < H) {
+        last_read[i] = (i == 0 || i > hs) ? 0.0f : epp[i];
+      } else if (nex > 1) { /* the top error (nex == 1) only covers h_size entries */
+        last_read[i] = xp[i - hs];
+      }
+    }
+  }
   float *d = v.b.ih_delta;
 #pragma unroll
   for (int q = 0; q < 2; q++) {
@@ -4694,11 +4717,20 @@ extern "C" void ramd_launch_clear_deltas(ramd_stream_t st_, const RamdShape *sh,
   }
 }
 
+static int g_calc_wrote_images = 0;
+/* whether the last ramd_launch_calc_deltas also rebuilt bptt->h_error / i_error (reads and clears) */
+extern "C" int ramd_calc_wrote_images(void) {
+  int w = g_calc_wrote_images;
+  g_calc_wrote_images = 0;
+  return w;
+}
+
 extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
                                         const RamdBuffers *b, int row0, int nrows, int accumulate,
                                         const int *ranges, int range_stride,
                                         const unsigned char *active, unsigned flags,
                                         RamdPendingDelta *defer) {
+  g_calc_wrote_images = 0;
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   // top layer
@@ -4799,6 +4831,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       int ev = timing_begin(st, T_CHAIN, 1);
       RAMD_LAUNCH(k_bptt_small, dim3(1), dim3(1024), shm, st, v, row0, accumulate, flags, nx, nxp);
       timing_end(st, ev);
+      g_calc_wrote_images = 1; /* the error images are done: no k_err_writeback for this call */
       return;
     }
   }

@@ -195,6 +195,8 @@ void ramd_launch_sigmoid_outputs(ramd_stream_t st, const RamdShape *sh, const Ra
                                  int nrows, int n);
 /* rnn_opinion's device work for one stream of a small net in one launch; 0: not its kind of shape */
 int ramd_launch_forward_small(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int r);
+/* whether the last ramd_launch_calc_deltas also rebuilt the h_error / i_error images (reads and clears) */
+int ramd_calc_wrote_images(void);
 /* up to 12 word-wise copies (nwords[g] 32-bit words from src[g] to dst[g]) in one launch */
 /* the noise of the next forward pass of rows [row0, row0 + nrows), from the generators' current
  * states, into b->noise_spec / b->rng_spec; the generators themselves are not touched */

@@ -1491,10 +1491,14 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
              sizeof(float) * s->bO);
   }
   engine_dev_wrote(e, RNN_AMD_DELTAS);
-  e->err_pending = 1;
-  e->err_row0 = j;
-  e->err_nrows = 1;
-  err_flush(e);
+  if (ramd_calc_wrote_images()) { /* the one-workgroup BPTT of a small net leaves them itself */
+    e->err_pending = 0;
+  } else {
+    e->err_pending = 1;
+    e->err_row0 = j;
+    e->err_nrows = 1;
+    err_flush(e);
+  }
   mail_out(bp->h_error, e->b.err_a + (size_t)j * s->I, sizeof(float) * s->I);
   mail_out(bp->i_error, e->b.err_b + (size_t)j * s->I, sizeof(float) * s->I);
   mail_out(&bp->min_error_factor, e->b.mef + j, sizeof(float));
