@@ -396,6 +396,48 @@ def test_noise_generated_ahead_is_dropped_when_a_generator_moves(amd):
     o.close()
 
 
+def test_weight_noise_continues_the_generator_the_device_holds(amd, orc):
+    """rnn_weight_noise (recur-nn.c:857-883) draws from net->rng.  After batched generations with
+    presynaptic noise the device holds that generator (and has moved it): the noise must continue
+    from THERE, twice in a row (text-predict's --periodic-weight-noise), and the next generation's
+    presynaptic noise from where the weight noise stopped.  Expected values: the oracle's
+    generator primitives from the state read back before the call."""
+    kw = dict(input_size=12, hidden_size=24, output_size=12, S=3, D=4, learn_rate=1e-3, seed=17, noise=0.03)
+    g = sc.AmdBatchedSet(amd, **kw)
+    o = sc.OracleSet(**kw)
+    text = sc.synthetic_text(2000) % 12
+    for i in range(5):
+        g.char_step(text, i, rc.WEIGHTED, 0.9)
+        o.char_step(text, i, rc.WEIGHTED, 0.9)
+    for rep in range(2):
+        sg = g.snapshot()
+        st = rc.OrcRng()
+        st.a, st.b, st.c, st.d = (int(x) for x in sg["rng"][0])
+        I, H, O, hs, isz, osz = g.I, g.H, g.O, 24, 12, 12
+        want_ih, want_ho = sg["ih_w"].copy(), sg["ho_w"].copy()
+        for y in range(hs + 1 + isz):
+            for i in range(hs):
+                want_ih[y, 1 + i] += np.float32(orc.orc_cheap_gaussian_noise(C.byref(st))) * np.float32(0.01)
+        for y in range(hs + 1):
+            for i in range(osz):
+                want_ho[y, i] += np.float32(orc.orc_cheap_gaussian_noise(C.byref(st))) * np.float32(0.01)
+        amd.rnn_weight_noise(g.net, 0.01)
+        after = g.snapshot()
+        assert np.array_equal(after["ih_w"], want_ih) and np.array_equal(after["ho_w"], want_ho), rep
+        assert tuple(int(x) for x in after["rng"][0]) == (st.a, st.b, st.c, st.d)
+        # the oracle follows: same weights, same generator for stream 0
+        a = o.arrays()
+        a["ih_w"][:] = after["ih_w"]
+        a["ho_w"][:] = after["ho_w"]
+        zr = o.z.contents.rng[0]
+        zr.a, zr.b, zr.c, zr.d = st.a, st.b, st.c, st.d
+        g.char_step(text, 5 + rep, rc.WEIGHTED, 0.9)
+        o.char_step(text, 5 + rep, rc.WEIGHTED, 0.9)
+        replay.check(g.snapshot(), o.snapshot(), RTOL, keys=["hidden", "ih_w", "ho_w"], exact=("index", "generation", "rng"))
+    g.close()
+    o.close()
+
+
 @pytest.mark.parametrize("hidden,act", [(64, rc.RELU), (128, rc.RESQRT), (96, rc.RELU)])
 def test_text_step_emergency_soft_clip_of_the_input_row(amd, hidden, act):
     """maybe_scale_inputs (recur-nn.c:68-81): a hidden state large enough that the input row's
