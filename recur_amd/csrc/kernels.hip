@@ -4287,6 +4287,11 @@ static int pick_ks(int tiles, int nkt, const char *env, size_t slab_floats, size
   if (ks > nkt) ks = nkt;
   if (ks < 1) ks = 1;
   while (ks > 1 && (size_t)ks * out_floats > slab_floats) ks--;
+  if (out_floats > slab_floats) { /* the workspace is sized for every output at engine creation */
+    fprintf(stderr, "librecur_amd: a GEMM output of %zu floats does not fit the split-K workspace (%zu)\n",
+            out_floats, slab_floats);
+    abort();
+  }
   return ks;
 }
 

@@ -806,6 +806,10 @@ static void engine_ensure_device(RamdEngine *e) {
       slabs = (size_t)atoi(env);
     }
     b->slab_floats = per * slabs;
+    /* ... and at least ONE slab of the two outputs that scale with o_size (the top layer's delta
+     * GEMM, the output layer of all rows): a narrow net with a very wide output layer (40 hidden
+     * units under 56 heads of 35 symbols) has them larger than 16 of everything else */
+    b->slab_floats = RAMD_MAX(b->slab_floats, RAMD_MAX(e->ho_size, (S + F) * O));
     b->slab = dev_alloc(b->slab_floats * fl);
     b->ho_slab = e->ho_size <= ((size_t)1 << 20) ? dev_alloc(8 * e->ho_size * fl) : NULL;
   }
