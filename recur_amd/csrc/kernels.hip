@@ -3565,7 +3565,10 @@ __device__ __forceinline__ void bptt_control_wave(const View &v, int r, int j, i
     v.b.depth_log[r] = D - t;
     v.b.stat_depth[r] += (double)(D - t);
   }
-  for (int k = lane; k < D; k += 64) v.b.coef[(size_t)k * s.Scap + r] = (k < n_exec) ? scale : 0.0f;
+  /* 0x20000000: rnn_bptt_calculate without batching leaves the UNSCALED sum in ih_delta and puts
+   * ih_scale into the rate (recur-nn.c:966-975) */
+  const float cf = (flags & 0x20000000u) ? 1.0f : scale;
+  for (int k = lane; k < D; k += 64) v.b.coef[(size_t)k * s.Scap + r] = (k < n_exec) ? cf : 0.0f;
 }
 
 __global__ __launch_bounds__(256) void k_bptt_control(View v, int row0, int nrows,
@@ -3848,7 +3851,7 @@ __global__ __launch_bounds__(1024) void k_bptt_small(View v, int r, int accumula
     }
   }
   __syncthreads(); /* (also: every plane store of this workgroup has been performed) */
-  const float scale = red[16];
+  const float scale = (flags & 0x20000000u) ? 1.0f : red[16]; /* see bptt_control_wave */
   {
     /* bptt->h_error / i_error as the reference leaves them: k_err_writeback's job, from the planes
      * this workgroup has just written (nothing of them was read before: no stale lines) */

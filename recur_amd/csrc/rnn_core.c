@@ -1485,7 +1485,7 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
   set_uniform_idx(e, j, 1);
   mail_in_flush();
   ramd_launch_calc_deltas(g_stream, s, &e->b, j, 1, accumulate, d_ranges, 0, NULL,
-                          net->flags | (fused ? 0x80000000u : 0), NULL);
+                          net->flags | (fused ? 0x80000000u : 0) | (fused == 2 ? 0x20000000u : 0), NULL);
   if (s->bI && !fused) { /* the fused path passes no bottom error (recur-nn.c:972, 986) */
     if (accumulate) {
       engine_need_dev(e, RNN_AMD_DELTAS);
@@ -1667,16 +1667,19 @@ void rnn_bptt_calculate(RecurNN *net, uint batch_size) {
   RamdPriv *p = ramd_priv(net);
   RecurNNBPTT *bptt = net->bptt;
   int batched = batch_size > 1;
-  calc_deltas_one(net, batched, NULL, 1); /* also does generation++ */
+  /* without batching the reference leaves the unscaled sum in ih_delta and multiplies the rate by
+   * ih_scale (recur-nn.c:966-975); batched, ih_scale goes into the sum (977-994) */
+  calc_deltas_one(net, batched, NULL, batched ? 1 : 2); /* also does generation++ */
   ramd_launch_top_apply_now(g_stream, &e->sh, &e->b, p->stream, bptt->learn_rate, bptt->momentum,
                             bptt->momentum_weight);
   /* generation was already incremented; the reference tests the value before
    * its increment (recur-nn.c:991, 1010) */
   if (!batched || ((net->generation - 1) % batch_size) == 0) {
     ramd_launch_apply(g_stream, RNN_MOMENTUM_WEIGHTED, e->b.ih_w, e->b.ih_delta, e->b.ih_m, NULL,
-                      e->ih_size, bptt->learn_rate, bptt->momentum, bptt->momentum_weight, NULL);
-    if (batched) {
-      ramd_launch_clear_deltas(g_stream, &e->sh, &e->b);
+                      e->ih_size, bptt->learn_rate, bptt->momentum, bptt->momentum_weight,
+                      batched ? NULL : e->b.ih_scale + p->stream);
+    if (batched) { /* ih_delta only (recur-nn.c:991): ho_delta is not this path's */
+      HIP_OK(hipMemsetAsync(e->b.ih_delta, 0, e->ih_size * sizeof(float), g_stream));
     }
   }
   engine_dev_wrote(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);

@@ -179,6 +179,43 @@ def test_fused_single_net_path(amd, orc, name, batch):
     replay.check(got, replay.golden_case(name), RTOL)
 
 
+@pytest.mark.parametrize("hidden,batch", [(39, 1), (39, 3), (130, 1), (130, 3)])
+def test_fused_path_leaves_the_delta_arrays_as_the_reference_does(amd, orc, hidden, batch):
+    """What rnn_bptt_calculate leaves in the arrays a caller can see, in a regime where ih_scale < 1: without
+    batching ih_delta holds the UNSCALED sum and ih_scale goes into the rate (recur-nn.c:966-975); with batching the
+    scaled sums add up and ih_delta alone is cleared after the update (977-994) -- ho_delta, left by an earlier
+    rnn_bptt_calc_deltas, is not this path's to touch.  Both were found by tools/gpu_fuzz_api.py (random call
+    sequences against the compiled reference); hidden 39 takes the one-workgroup BPTT, 130 the general route."""
+    lib = amd
+    kw = dict(input_size=30, hidden_size=hidden, output_size=30, S=4, D=6, learn_rate=0.2, seed=77)
+    g = sc.AmdBatchedSet(lib, softmax_best_guess=orc.orc_softmax_best_guess, **kw)
+    o = sc.OracleSet(**kw)
+    t = sc.synthetic_text(2000, alphabet=30)
+    for i in range(8):                                   # ordinary generations: ho_delta is now non-zero
+        g.char_step(t, i, rc.WEIGHTED, 0.9)
+        o.char_step(t, i, rc.WEIGHTED, 0.9)
+    seen_clip = False
+    c = C.c_int(0)
+    for i in range(8, 8 + 7):
+        lib.rnn_bptt_advance(g.net)
+        g.net_error_bptt(0, int(t[i]), int(t[i + 1]))
+        g.net.contents.bptt.contents.momentum = 0.9
+        lib.rnn_bptt_calculate(g.net, batch)
+        o.orc.orc_advance(o.z, 0)
+        o.orc.orc_net_error_bptt(o.z, 0, int(t[i]), int(t[i + 1]), C.byref(c))
+        o.orc.orc_bptt_calculate(o.z, 0, batch, 0.9)
+        sg, so = g.snapshot(), o.snapshot()
+        if not np.array_equal(sg["hidden"] != 0, so["hidden"] != 0):
+            break                                        # a rounding-level mask flip ends the comparison
+        seen_clip |= bool(so["ih_scale"][0] < 0.999)
+        assert np.abs(so["ho_delta"]).max() > 0
+        replay.check(sg, so, RTOL, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "hist",
+                                         "min_error_factor", "ih_scale"], exact=("index", "generation"))
+    assert seen_clip, "the regime never clipped: the test would not see a scaled ih_delta"
+    g.close()
+    o.close()
+
+
 @pytest.mark.parametrize("batched", [False, True])
 def test_sparse_error_ranges(amd, batched):
     got = replay.sparse_api(amd, batched=batched)

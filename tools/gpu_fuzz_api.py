@@ -1,0 +1,163 @@
+"""Development probe: RANDOM SEQUENCES of the reference's own API calls, the same Python driver on two libraries --
+the compiled reference (oracle/_ref/librecur_ref.so, CPU) and librecur_amd.so -- compared after every operation
+(weights, momentums, deltas, history, layers, error vectors at 1e-4; ring indices, generation counters and generator
+states exactly).  What it is after is the coherence between the host structs a caller sees and the device image:
+per-net calls, batched set calls, host-side edits, forgotten histories, clones made and deleted in between, weight
+noise, the fused single-net call, accumulation patterns, error ranges.
+    gpu_fuzz_api.py <seed> <trials> [ops per trial]
+A trial ends at the first zero-mask difference (a pre-activation within rounding of zero; counted as a flip)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np
+import recur_ctypes as rc
+import scenarios as sc
+
+amd = rc.bind_char(rc.load_amd())
+ref = rc.load_ref()
+orc = rc.load_oracle()  # only for softmax_best_guess, the callers' inline loss helper
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+trials = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+n_ops = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+rs = np.random.default_rng(seed)
+KEYS = ["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "output", "hist", "o_error",
+        "min_error_factor", "ih_scale"]
+EXACT = ["index", "generation", "rng"]
+bad = flipped = 0
+
+
+def both(fn):
+    fn(G, amd)
+    fn(R, ref)
+
+
+for trial in range(trials):
+    hidden = int(rs.choice([12, 20, 48, 99, 128, 130]))
+    A = int(rs.integers(3, 50))
+    S = int(rs.integers(1, 10))
+    if os.environ.get("FUZZ_SHAPE"):
+        hidden, S = (int(x) for x in os.environ["FUZZ_SHAPE"].split(","))
+    D = int(rs.integers(2, 9))
+    act = int(rs.choice([rc.RELU, rc.RESQRT, rc.RECLIP20]))
+    noise = float(rs.choice([0.0, 0.0, 0.02]))
+    kw = dict(input_size=A, hidden_size=hidden, output_size=A, S=S, D=D, learn_rate=float(os.environ.get("FUZZ_LR") or rs.choice([3e-4, 1e-3])),
+              seed=int(rs.integers(1, 10000)), activation=act, noise=noise)
+    print("trial %d: %s" % (trial, kw), flush=True)
+    text = sc.synthetic_text(3000, alphabet=A)
+    G = sc.AmdBatchedSet(amd, softmax_best_guess=orc.orc_softmax_best_guess, **kw)
+    R = sc.ApiSet(ref, softmax_best_guess=orc.orc_softmax_best_guess, **kw)
+    i = 0
+    log = []
+    ok = True
+    forced = [x for x in os.environ.get("FUZZ_OPS", "").split(",") if x]
+    for step in range(len(forced) if forced else n_ops):
+        op = forced[step] if forced else str(rs.choice(["pernet", "pernet", "batched", "batched", "batched", "noise", "forget", "edit", "fused",
+                            "ranges", "clone", "accumulate", "read", "momentum"]))
+        if forced:
+            rs.choice(3)  # keep drawing
+        if op == "pernet":  # the reference's per-stream loop on both
+            m = int(rs.choice([rc.WEIGHTED, rc.NESTEROV, rc.CLASSICAL]))
+            sc.ApiSet.char_step(G, text, i, m, 0.9)
+            R.char_step(text, i, m, 0.9)
+            i += 1
+        elif op == "batched":  # one device generation against the per-stream loop
+            m = int(rs.choice([rc.WEIGHTED, rc.NESTEROV]))
+            G.char_step(text, i, m, 0.9)
+            R.char_step(text, i, m, 0.9)
+            i += 1
+        elif op == "noise":  # recur-nn.c:1027-1041: draws from the prototype's generator
+            dev = float(rs.choice([1e-3, 1e-2]))
+            both(lambda s, lib: lib.rnn_weight_noise(s.net, dev))
+        elif op == "forget":  # recur-nn.c:8-16
+            j, too = int(rs.integers(0, S)), int(rs.integers(0, 2))
+            both(lambda s, lib: lib.rnn_forget_history(s.nets[j], too))
+        elif op == "edit":  # a caller writing into the big arrays (text-predict.c:467)
+            y, x, x2 = int(rs.integers(0, hidden)), int(rs.integers(1, hidden)), int(rs.integers(0, A))
+            dv = float(rs.normal()) * 0.05
+            amd.rnn_amd_sync_host(G.net, rc.RNN_AMD_WEIGHTS)
+            for s in (G, R):
+                n0 = s.net.contents
+                rc.view(n0.ih_weights, s.I, s.H)[y, x] += dv
+                rc.view(n0.ho_weights, s.H, s.O)[y, x2] -= dv
+            amd.rnn_amd_host_written(G.net, rc.RNN_AMD_WEIGHTS)
+        elif op == "fused":  # rnn_bptt_calculate on the prototype (recur-nn.c:919-1019)
+            c, nx, batch = int(text[i]), int(text[i + 1]), int(rs.choice([1, 1, 3]))
+
+            def fused(s, lib):
+                lib.rnn_bptt_advance(s.net)
+                s.net_error_bptt(0, c, nx)
+                s.net.contents.bptt.contents.momentum = 0.9
+                lib.rnn_bptt_calculate(s.net, batch)
+            both(fused)
+            op = "fused/%d" % batch
+        elif op == "ranges":  # the sparse top layer (recur-nn.c:156-196, 275-301) on every stream
+            a0 = int(rs.integers(0, max(1, A - 2)))
+            ln = int(rs.integers(1, A - a0 + 1))
+            ranges = (rc.ErrorRange * 2)((a0, ln), (-1, 0))
+
+            def sparse(s, lib):
+                for j in range(S):
+                    lib.rnn_bptt_advance(s.nets[j])
+                    s.net_error_bptt(j, int(text[i + 7 * j]), int(text[i + 7 * j + 1]))
+                    e = rc.view(s.nets[j].contents.bptt.contents.o_error, s.O)
+                    e[:a0] = 0
+                    e[a0 + ln:] = 0
+                    lib.rnn_bptt_calc_deltas(s.nets[j], 1 if j else 0, ranges)
+                lib.rnn_apply_learning(s.net, rc.WEIGHTED, 0.9)
+            both(sparse)
+            i += 1
+        elif op == "clone":  # a forward-only clone made now (the device image regrows), used, deleted
+            hot = int(rs.integers(0, A))
+            outs = []
+
+            def clone(s, lib):
+                n0 = s.net.contents
+                c = lib.rnn_clone(s.net, n0.flags & ~(rc.FLAG_OWN_BPTT | rc.FLAG_OWN_WEIGHTS), rc.SUBSEED, None)
+                real = rc.view(c.contents.real_inputs, s.input_size)
+                real[:] = 0
+                real[hot] = 1.0
+                for _ in range(3):
+                    out = lib.rnn_opinion(c, None, 0.0)
+                outs.append(np.ctypeslib.as_array(out, (s.output_size,)).copy())
+                lib.rnn_delete_net(c)
+            both(clone)
+            err = np.abs(outs[0] - outs[1]).max() / max(np.abs(outs[1]).max(), 1e-30)
+            if err > 1e-4:
+                print("   clone opinion differs: %.3g" % err)
+                ok = False
+        elif op == "accumulate":  # gstclassify's order: clear, accumulate over the streams, one update
+            def acc(s, lib):
+                lib.rnn_bptt_clear_deltas(s.net)
+                for j in range(S):
+                    lib.rnn_bptt_advance(s.nets[j])
+                    s.net_error_bptt(j, int(text[i + 5 * j]), int(text[i + 5 * j + 1]))
+                    lib.rnn_bptt_calc_deltas(s.nets[j], 1, None)
+                lib.rnn_apply_learning(s.net, rc.NESTEROV, 0.9)
+            both(acc)
+            i += 1
+        elif op == "read":  # nothing: the comparison below reads everything back
+            pass
+        elif op == "momentum":  # recur-nn-init.c:359-380
+            v = float(rs.choice([0.0, 1e-3]))  # (large ballast makes WEIGHTED momentum explode: chaos, not parity)
+            both(lambda s, lib: lib.rnn_set_momentum_values(s.net, v))
+        log.append(op)
+        sg, sr = G.snapshot(), R.snapshot()
+        if not np.array_equal(sg["hidden"] != 0, sr["hidden"] != 0) or not np.array_equal(sg["hist"] != 0, sr["hist"] != 0):
+            flipped += 1
+            print("   zero-mask flip after %d operations: trial ends" % len(log))
+            break
+        wrong = sc.compare(sg, sr, 2e-4, keys=KEYS, exact=EXACT)
+        if wrong or not ok:
+            bad += 1
+            print("   MISMATCH after %s: %s" % (log, str(wrong)[:400]), flush=True)
+            for k in ("ih_delta", "ho_delta"):
+                print("      %s: product norm %.6g, reference norm %.6g, difference %.6g" % (
+                    k, np.linalg.norm(sg[k]), np.linalg.norm(sr[k]), np.linalg.norm(sg[k] - sr[k])))
+            break
+    else:
+        print("   %d operations ok: %s" % (len(log), " ".join(log)), flush=True)
+    G.close()
+    R.close()
+print("bad: %d, trials ended by a mask flip: %d" % (bad, flipped))
