@@ -639,7 +639,17 @@ template <bool UNI> struct ProbDelta {
   }
   __device__ float4 a_fix(int kt, int k, int m, const Raw &r) const {
     int t = kt / rtiles, s = (kt - t * rtiles) * BK + k;
-    return (s < nrows && m < v.sh.I) ? r.v : zero4();
+    if (!(s < nrows && m < v.sh.I)) return zero4();
+    float4 x = r.v;
+    if (v.sh.activation == 5) {
+      /* RNN_RECLIP20: an input row at the ceiling is skipped like a zero one, its delta row too
+       * (recur-nn.c:340-341) */
+      x.x = x.x < 20.0f ? x.x : 0.0f;
+      x.y = x.y < 20.0f ? x.y : 0.0f;
+      x.z = x.z < 20.0f ? x.z : 0.0f;
+      x.w = x.w < 20.0f ? x.w : 0.0f;
+    }
+    return x;
   }
   __device__ const float *b_ptr(int kt, int k, int n) const {
     int t = kt / rtiles, s = (kt - t * rtiles) * BK + k;

@@ -216,6 +216,45 @@ def test_fused_path_leaves_the_delta_arrays_as_the_reference_does(amd, orc, hidd
     o.close()
 
 
+@pytest.mark.parametrize("hidden,S,variance,batched", [(40, 8, 0.3, True), (130, 8, 0.1, True), (256, 32, 0.1, True),
+                                                       (40, 3, 0.3, False), (130, 3, 0.1, False)])
+def test_reclip20_units_at_the_ceiling_are_skipped_like_zeros(amd, orc, hidden, S, variance, batched):
+    """RNN_RECLIP20 with units AT the ceiling (large initial weights): bptt_and_accumulate_error skips an input row
+    whose value is 20 exactly like a zero one -- no error through it and NO weight-delta row (recur-nn.c:340-341).
+    The delta GEMM's history operand did not mask such rows until tools/gpu_fuzz_api.py ran into a saturated net
+    (ih_delta off by several hundred per cent there).  Stepwise against the oracle, batched and per-net calls."""
+    lib = amd
+    # (variances at which units reach 20 within eight generations while the oracle's two builds, plain and -Ofast,
+    # still agree to 1e-5: larger ones make the net chaotic)
+    kw = dict(input_size=19, hidden_size=hidden, output_size=19, S=S, D=5, learn_rate=1e-5, seed=3, activation=rc.RECLIP20,
+              variance=variance)
+    g = sc.AmdBatchedSet(lib, softmax_best_guess=orc.orc_softmax_best_guess, **kw)
+    o = sc.OracleSet(**kw)
+    t = sc.synthetic_text(3000, alphabet=19)
+    at_ceiling = compared = 0
+    for i in range(8):
+        if batched:
+            g.char_step(t, i, rc.WEIGHTED, 0.9)
+        else:
+            sc.ApiSet.char_step(g, t, i, rc.WEIGHTED, 0.9)
+        o.char_step(t, i, rc.WEIGHTED, 0.9)
+        sg, so = g.snapshot(), o.snapshot()
+        if any(not np.array_equal(f(sg[k]), f(so[k])) for k in ("hidden", "hist") for f in (lambda a: a != 0,
+                                                                                            lambda a: a >= 20.0)):
+            break                                        # a value within rounding of 0 or of 20: not a parity case
+        at_ceiling += int((so["hist"] >= 20.0).sum())
+        compared += 1
+        replay.check(sg, so, RTOL, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "ih_m", "hidden", "hist",
+                                         "min_error_factor"], exact=("index", "generation"))
+        # ih_scale is the soft clip of a stream's summed error norms, all of which have passed through the saturated
+        # net: the one value here that carries the regime's amplification (1.3e-4 at 256 / 32; the oracle's own two
+        # builds differ by 2e-5 in this regime)
+        replay.check(sg, so, 3 * RTOL, keys=["ih_scale"], exact=())
+    assert compared >= 6 and at_ceiling > 20
+    g.close()
+    o.close()
+
+
 @pytest.mark.parametrize("batched", [False, True])
 def test_sparse_error_ranges(amd, batched):
     got = replay.sparse_api(amd, batched=batched)

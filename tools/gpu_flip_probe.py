@@ -15,6 +15,8 @@ noise, lr, seed = float(a[6]), float(a[7]), int(a[8])
 steps = int(a[9]) if len(a) > 9 else D + 4
 amd = rc.load_amd()
 kw = dict(input_size=A, hidden_size=hidden, output_size=A, S=S, D=D, learn_rate=lr, seed=seed, activation=act, noise=noise)
+if os.environ.get("VARIANCE"):  # large initial weights: RECLIP20 units reach 20
+    kw["variance"] = float(os.environ["VARIANCE"])
 text = sc.synthetic_text(int(os.environ.get("TEXT_LEN", "8000")), alphabet=A)
 g, o = sc.AmdBatchedSet(amd, **kw), sc.OracleSet(**kw)
 for i in range(steps):
@@ -28,6 +30,7 @@ for i in range(steps):
     print("   history flips %d, ih_delta rel %.2e (max element %.2e of max)" % (
         nh, np.linalg.norm(dd) / max(np.linalg.norm(so["ih_delta"]), 1e-30), dd.max() / max(np.abs(so["ih_delta"]).max(), 1e-30)))
     rel = np.abs(hg - ho).max() / max(np.abs(ho).max(), 1e-30)
+    print("   units at RECLIP20's ceiling: %d / %d, ceiling flips %d" % (int((ho >= 20).sum()), int((hg >= 20).sum()), int(((hg >= 20) != (ho >= 20)).sum())))
     print("generation %d: %d flips, hidden max|diff|/max %.2e, max|hidden| %.3g, ih_w diff %.2e" % (
         i, len(d), rel, np.abs(ho).max(), np.abs(sg["ih_w"] - so["ih_w"]).max() / np.abs(so["ih_w"]).max()), flush=True)
     if len(d):
