@@ -735,6 +735,13 @@ static float bptt_accumulate(OrcSet *z, int s, float *ih_delta, float *cumulativ
   }
   if (error_sum > error_sum_ceiling) {
     z->ih_scale[s] = orc_soft_clip(error_sum, max_error_sum);
+    if (cumulative_input_error) {
+      /* recur-nn.c:391-399: the accumulator -- ALL of it, earlier streams and generations included,
+       * it is the bottom layer's one o_error -- shrinks by ih_scale twice */
+      for (int y = 0; y < z->input_size; y++) {
+        cumulative_input_error[y] *= z->ih_scale[s] * z->ih_scale[s];
+      }
+    }
   } else {
     z->ih_scale[s] = 1.0f;
     if (z->flags & ORC_FLAG_ADAPTIVE_MIN_ERROR) {

@@ -842,10 +842,12 @@ __global__ __launch_bounds__(256) void k_bottom_forward(View v, int row0, int mo
     /* one_hot_opinion's bottom-layer branch clears and indexes the layer's inputs from
      * the bias slot (charmodel-helpers.h:20-23, 30-31): symbol k lights entry k, the
      * last entry is never cleared */
-    else if (i == s.b_in) x = inp[i];
+    else if (i == s.b_in) x = v.b.blast[0]; /* ONE buffer for all clones: what the last dense pass of ANY stream left */
     else x = (i == hot) ? 1.0f : 0.0f;
     inp[i] = x;
     sin[i] = x;
+    if (i == s.b_in && (mode == RAMD_IN_DENSE || mode == RAMD_IN_KEEP) && j == (int)gridDim.x - 1)
+      v.b.blast[0] = x; /* the last stream of the pass is the one whose inputs stay in the buffer */
   }
   __syncthreads();
   for (int x = threadIdx.x; x < s.bO; x += 256) {
@@ -905,6 +907,10 @@ __global__ __launch_bounds__(256) void k_bottom_delta(View v, int row0, int nrow
     if (active && !active[j]) continue;
     int r = row0 + j;
     cum += v.b.berr[(size_t)r * s.bO + x];
+    /* a stream whose error gain was clipped shrinks the accumulator -- all of it, it is the layer's
+     * one o_error -- by ih_scale twice (recur-nn.c:391-399); an unclipped stream has ih_scale 1 */
+    const float sc = v.b.ih_scale[r];
+    if (sc != 1.0f && x < s.input_size) cum *= sc * sc;
     float xi = v.b.binp[(size_t)r * s.bI + yi];
     if (xi != 0.0f) acc += xi * cum;
   }

@@ -72,6 +72,9 @@ typedef struct RamdBuffers {
    * reference's never-cleared bottom->o_error accumulator (ping-pong, bcarry_cur = the
    * current one) */
   float *bw, *bm, *baux, *bdelta, *binp, *bout, *berr, *bcarry;
+  /* the layer has ONE input buffer for all clones and one_hot_opinion never clears its last entry
+   * (charmodel-helpers.h:20-31): that entry, as the last dense / kept forward pass left it */
+  float *blast;
   int bcarry_cur;
   /* ring position shared by every training stream of the current call, or -1
    * when they differ (set by the host before each launch) */

@@ -345,7 +345,7 @@ static void engine_free_device(RamdEngine *e) {
   dev_free(b->stat_depth); dev_free(b->stat_correct); dev_free(b->stat_count);
   dev_free(b->text);
   dev_free(b->bw); dev_free(b->bm); dev_free(b->baux); dev_free(b->bdelta);
-  dev_free(b->binp); dev_free(b->bout); dev_free(b->berr); dev_free(b->bcarry);
+  dev_free(b->binp); dev_free(b->bout); dev_free(b->berr); dev_free(b->bcarry); dev_free(b->blast);
   dev_free(e->d_scratch); dev_free(e->d_ranges); dev_free(e->d_dense);
   dev_free(e->d_mranges); dev_free(e->d_mclass); dev_free(e->d_group);
   e->d_group = NULL;
@@ -846,6 +846,9 @@ static void engine_ensure_device(RamdEngine *e) {
     b->berr = dev_alloc(S * bO * fl);
     b->bcarry = dev_alloc(2 * (size_t)bO * fl);
     b->bcarry_cur = 0;
+    b->blast = dev_alloc(16);
+    h2d(b->blast, obl->inputs + obl->input_size, fl); /* the host's buffer is kept current (set_opinion) */
+    dsync();
   }
   e->lr_pushed = ramd_zalloc(S * sizeof(float));
   e->idx_pushed = ramd_zalloc(S * sizeof(int));
@@ -2012,6 +2015,13 @@ void rnn_amd_set_opinion(RnnAmdSet *set, const float *inputs, int ld_inputs, flo
     /* (queued: leaves with the ring indices in set_forward's flush) */
     upload_rows_q(e->d_dense, inputs, ld_inputs * sizeof(float), w * sizeof(float), set->n, set->fwd_only);
     set_forward(set, RAMD_IN_DENSE, e->d_dense, w, 0, outputs, 0, 0);
+    if (e->sh.bI) {
+      /* the layer's one input buffer, shared by every clone, as the per-net loop would leave it:
+       * the last stream's inputs (recur-nn.c:88-94) */
+      RecurExtraLayer *bl = set->nets[0]->bottom_layer;
+      bl->inputs[0] = 1.0f;
+      memcpy(bl->inputs + 1, inputs + (size_t)(set->n - 1) * ld_inputs, sizeof(float) * bl->input_size);
+    }
   } else {
     set_forward(set, RAMD_IN_KEEP, NULL, 0, 0, outputs, 0, 0);
   }

@@ -44,6 +44,10 @@ TRAIN_CASES = {
                             seed=16, bottom=16, bottom_rate_scale=0.5),
     "bottom_adagrad_noisy": dict(hidden=39, S=3, D=6, act=rc.RESQRT, method=rc.ADAGRAD, lr=1e-2, steps=12,
                                  seed=17, bottom=12, ballast=0.1, noise=0.03),
+    # ... and a bottom layer in the hot regime: a stream whose error gain is clipped shrinks the layer's
+    # (shared, never cleared) error accumulator by ih_scale twice (recur-nn.c:391-399)
+    "bottom_hot_clamps": dict(hidden=39, S=4, D=8, act=rc.RELU, method=rc.WEIGHTED, lr=0.05, steps=30,
+                              seed=18, bottom=16, bottom_rate_scale=0.5),
     "depth1": dict(hidden=23, S=2, D=1, act=rc.RELU, method=rc.WEIGHTED, lr=1e-2, steps=6, seed=12),
 }
 

@@ -39,7 +39,7 @@ def orc():
 
 # cases whose dynamics amplify rounding differences beyond 1e-4 over their length
 # are compared over a prefix on the oracle instead (see test_hot_case_stepwise)
-LONG_OK = [n for n in sorted(gc.TRAIN_CASES) if n != "hot_clamps"]
+LONG_OK = [n for n in sorted(gc.TRAIN_CASES) if n not in ("hot_clamps", "bottom_hot_clamps")]
 
 
 @pytest.mark.parametrize("name", LONG_OK)
@@ -94,6 +94,40 @@ def _stepwise(amd, kw, text, steps, method, depth):
     # clamped ones among them -- were actually compared
     assert seen_clamp and seen_exit
     assert compared >= steps // 2 and compared_clamped >= 1, (compared, compared_clamped)
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_bottom_layer_in_the_hot_regime(amd, orc, batched):
+    """A bottom layer under a net whose error gain gets clipped: such a stream shrinks the layer's error
+    accumulator -- the ONE bottom->o_error all clones share, earlier streams and generations included -- by
+    ih_scale twice (recur-nn.c:391-399) before its own bottom deltas are formed.  Neither the product nor
+    the oracle did that until tools/gpu_fuzz_api.py met a clipped stream on a bottom-layer net; the oracle is
+    now pinned to the reference's vectors for this regime (golden case bottom_hot_clamps, bit-exact).
+    Generation by generation from a cold start, up to the first rounding-level flip of a mask or of a clip
+    decision."""
+    c = gc.TRAIN_CASES["bottom_hot_clamps"]
+    kw = gc.case_kwargs(c)
+    g = sc.AmdBatchedSet(amd, softmax_best_guess=orc.orc_softmax_best_guess, **kw)
+    o = sc.OracleSet(**kw)
+    t = replay.text()
+    compared = clipped = 0
+    for i in range(c["steps"]):
+        if batched:
+            g.char_step(t, i, c["method"], 0.95)
+        else:
+            sc.ApiSet.char_step(g, t, i, c["method"], 0.95)
+        o.char_step(t, i, c["method"], 0.95)
+        sg, so = g.snapshot(), o.snapshot()
+        if (not np.array_equal(sg["hidden"] != 0, so["hidden"] != 0) or not np.array_equal(sg["hist"] != 0, so["hist"] != 0)
+                or not np.array_equal(sg["ih_scale"] == 1.0, so["ih_scale"] == 1.0)):
+            break
+        replay.check(sg, so, 2e-4, keys=["b_delta", "b_o_error", "b_w", "b_m", "ih_delta", "ho_delta", "ih_w", "ho_w",
+                                         "hidden", "ih_scale"], exact=("index", "generation"))
+        compared += 1
+        clipped += int((so["ih_scale"] < 1.0).sum())
+    assert compared >= 10 and clipped >= 3, (compared, clipped)
+    g.close()
+    o.close()
 
 
 def test_hot_case_stepwise_on_the_dma_delta_path(amd):

@@ -44,10 +44,40 @@ for trial in range(trials):
     noise = float(rs.choice([0.0, 0.0, 0.02]))
     kw = dict(input_size=A, hidden_size=hidden, output_size=A, S=S, D=D, learn_rate=float(os.environ.get("FUZZ_LR") or rs.choice([3e-4, 1e-3])),
               seed=int(rs.integers(1, 10000)), activation=act, noise=noise)
-    print("trial %d: %s" % (trial, kw), flush=True)
+    # the optimiser family of the trial (the momentum arrays mean different things to them) and a bottom layer
+    # (RPROP steps by the SIGN of a delta, so a delta within rounding of zero is a flip of its own kind: its parity
+    # is the golden case's business, not this tool's)
+    family = str(rs.choice(["momentum", "momentum", "momentum", "adagrad", "adadelta", "adadelta"]))
+    bottom = int(rs.choice([0, 0, 0, int(rs.integers(4, 24))]))
+    family = os.environ.get("FUZZ_FAMILY", family)
+    bottom = int(os.environ.get("FUZZ_BOTTOM", bottom))
+    if family in ("adadelta", "rprop"):
+        kw["flags"] = rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR | rc.FLAG_AUX_ARRAYS
+    if bottom:  # text-predict --bottom-layer: A symbols -> `bottom` rectified nodes -> the net
+        kw.update(input_size=bottom, bottom_inputs=A, bottom_rate_scale=float(rs.choice([1.0, 0.5])))
+    if os.environ.get("FUZZ_KW"):  # a whole trial given: the dict a failing run printed
+        import ast
+        kw = ast.literal_eval(os.environ["FUZZ_KW"])
+        bottom = kw["input_size"] if kw.get("bottom_inputs") else 0
+        A = kw.get("bottom_inputs") or kw["input_size"]
+        hidden, S, D, act, noise = kw["hidden_size"], kw["S"], kw["D"], kw["activation"], kw["noise"]
+    methods = {"momentum": [rc.WEIGHTED, rc.NESTEROV, rc.SIMPLIFIED_NESTEROV, rc.CLASSICAL], "adagrad": [rc.ADAGRAD],
+               "adadelta": [rc.ADADELTA], "rprop": [rc.RPROP]}[family]
+    print("trial %d: %s %s" % (trial, family, kw), flush=True)
     text = sc.synthetic_text(3000, alphabet=A)
     G = sc.AmdBatchedSet(amd, softmax_best_guess=orc.orc_softmax_best_guess, **kw)
     R = sc.ApiSet(ref, softmax_best_guess=orc.orc_softmax_best_guess, **kw)
+    if family == "adagrad":
+        both(lambda s, lib: lib.rnn_set_momentum_values(s.net, 0.1))  # the accumulators' ballast
+    if family == "rprop":
+        both(lambda s, lib: lib.rnn_set_aux_values(s.net, 1e-4))
+    keys = KEYS + (["b_w", "b_m", "b_delta", "b_o_error"] if bottom else [])
+    allowed = None
+    if family != "momentum":  # (the fused call and the ballast operation treat the momentum arrays as momentums)
+        allowed = ["pernet", "batched", "noise", "forget", "edit", "ranges", "clone", "accumulate", "read", "set_dense",
+                   "set_onehot"]
+    if bottom:
+        allowed = ["pernet", "batched", "noise", "forget", "accumulate", "read", "set_dense"]
     i = 0
     log = []
     ok = True
@@ -58,13 +88,15 @@ for trial in range(trials):
                             "set_onehot"]))
         if forced:
             rs.choice(3)  # keep drawing
+        elif allowed is not None and op not in allowed:
+            op = "read"
         if op == "pernet":  # the reference's per-stream loop on both
-            m = int(rs.choice([rc.WEIGHTED, rc.NESTEROV, rc.CLASSICAL]))
+            m = int(rs.choice(methods))
             sc.ApiSet.char_step(G, text, i, m, 0.9)
             R.char_step(text, i, m, 0.9)
             i += 1
         elif op == "batched":  # one device generation against the per-stream loop
-            m = int(rs.choice([rc.WEIGHTED, rc.NESTEROV]))
+            m = int(rs.choice(methods))
             G.char_step(text, i, m, 0.9)
             R.char_step(text, i, m, 0.9)
             i += 1
@@ -106,7 +138,7 @@ for trial in range(trials):
                     e[:a0] = 0
                     e[a0 + ln:] = 0
                     lib.rnn_bptt_calc_deltas(s.nets[j], 1 if j else 0, ranges)
-                lib.rnn_apply_learning(s.net, rc.WEIGHTED, 0.9)
+                lib.rnn_apply_learning(s.net, methods[0], 0.9)
             both(sparse)
             i += 1
         elif op == "clone":  # a forward-only clone made now (the device image regrows), used, deleted
@@ -135,7 +167,7 @@ for trial in range(trials):
                     lib.rnn_bptt_advance(s.nets[j])
                     s.net_error_bptt(j, int(text[i + 5 * j]), int(text[i + 5 * j + 1]))
                     lib.rnn_bptt_calc_deltas(s.nets[j], 1, None)
-                lib.rnn_apply_learning(s.net, rc.NESTEROV, 0.9)
+                lib.rnn_apply_learning(s.net, methods[-1], 0.9)
             both(acc)
             i += 1
         elif op == "set_dense":  # gstclassify / rnnca order on the set calls: dense inputs, the caller's own error
@@ -144,6 +176,11 @@ for trial in range(trials):
             tgt = np.ascontiguousarray(rs.random((S, A)).astype(np.float32))
             active = (rs.random(S) < 0.8).astype(np.uint8)
             active[int(rs.integers(0, S))] = 1
+            if os.environ.get("FUZZ_INACTIVE"):
+                active[:] = 1
+                active[int(os.environ["FUZZ_INACTIVE"])] = 0
+            if os.environ.get("FUZZ_DEBUG"):
+                print("   set_dense active", list(active), flush=True)
             outs = np.zeros((S, G.O), np.float32)
             amd.rnn_bptt_clear_deltas(G.net)
             amd.rnn_amd_set_opinion(G.handle, rc.fptr(x), A, rc.fptr(outs))
@@ -152,7 +189,7 @@ for trial in range(trials):
             amd.rnn_amd_set_put_o_error(G.handle, rc.fptr(err), G.O)
             amd.rnn_amd_set_calc_deltas(G.handle, 1, None, rc.u8ptr(active))
             amd.rnn_amd_set_advance(G.handle)
-            amd.rnn_apply_learning(G.net, rc.NESTEROV, 0.9)
+            amd.rnn_apply_learning(G.net, methods[-1], 0.9)
             ref.rnn_bptt_clear_deltas(R.net)
             for j in range(S):
                 out = ref.rnn_opinion(R.nets[j], rc.fptr(np.ascontiguousarray(x[j])), R.nets[j].contents.presynaptic_noise)
@@ -163,7 +200,7 @@ for trial in range(trials):
                 if active[j]:
                     ref.rnn_bptt_calc_deltas(R.nets[j], 1, None)
                 ref.rnn_bptt_advance(R.nets[j])
-            ref.rnn_apply_learning(R.net, rc.NESTEROV, 0.9)
+            ref.rnn_apply_learning(R.net, methods[-1], 0.9)
         elif op == "set_onehot":  # one-hot opinion + softmax loss on the device against the reference's helpers
             hot = rs.integers(0, A, S).astype(np.int32)
             nxt = rs.integers(0, A, S).astype(np.int32)
@@ -171,12 +208,12 @@ for trial in range(trials):
             amd.rnn_amd_set_one_hot_opinion(G.handle, rc.iptr(hot), None)
             amd.rnn_amd_set_softmax_error(G.handle, rc.iptr(nxt))
             amd.rnn_amd_set_calc_deltas(G.handle, 0, None, None)
-            amd.rnn_apply_learning(G.net, rc.WEIGHTED, 0.9)
+            amd.rnn_apply_learning(G.net, methods[0], 0.9)
             for j in range(S):
                 ref.rnn_bptt_advance(R.nets[j])
                 R.net_error_bptt(j, int(hot[j]), int(nxt[j]))
                 ref.rnn_bptt_calc_deltas(R.nets[j], 1 if j else 0, None)
-            ref.rnn_apply_learning(R.net, rc.WEIGHTED, 0.9)
+            ref.rnn_apply_learning(R.net, methods[0], 0.9)
         elif op == "read":  # nothing: the comparison below reads everything back
             pass
         elif op == "momentum":  # recur-nn-init.c:359-380
@@ -190,10 +227,16 @@ for trial in range(trials):
             flipped += 1
             print("   skip-mask flip (a value within rounding of 0 or of RECLIP20's 20) after %d operations: trial ends" % len(log))
             break
-        wrong = sc.compare(sg, sr, 2e-4, keys=KEYS, exact=EXACT)
+        wrong = sc.compare(sg, sr, 2e-4, keys=keys, exact=EXACT)
         if wrong or not ok:
             bad += 1
             print("   MISMATCH after %s: %s" % (log, str(wrong)[:400]), flush=True)
+            if os.environ.get("FUZZ_DEBUG") and "b_o_error" in sg:
+                np.set_printoptions(precision=5, linewidth=200)
+                print("      b_o_error product  ", sg["b_o_error"])
+                print("      b_o_error reference", sr["b_o_error"])
+                print("      b_delta rows differing:", np.argwhere(np.abs(sg["b_delta"] - sr["b_delta"]).max(axis=1) > 1e-4 * np.abs(sr["b_delta"]).max()).ravel())
+                print("      input rows (hist, current slot) max:", np.abs(sr["hist"]).max(), " ih_scale", sr["ih_scale"], sg["ih_scale"])
             for k in ("ih_delta", "ho_delta"):
                 print("      %s: product norm %.6g, reference norm %.6g, difference %.6g" % (
                     k, np.linalg.norm(sg[k]), np.linalg.norm(sr[k]), np.linalg.norm(sg[k] - sr[k])))
