@@ -37,9 +37,13 @@ for trial in range(trials):
     hidden = int(rs.choice([12, 20, 48, 99, 128, 130]))
     A = int(rs.integers(3, 50))
     S = int(rs.integers(1, 10))
+    large = bool(rs.random() < float(os.environ.get("FUZZ_LARGE", "0.2")))
+    if large:  # the one-launch chain's shapes, whole and ragged tiles, the LDS-DMA delta kernel
+        hidden = int(rs.choice([256, 512, 256]))
+        S = int(rs.integers(10, 70))
     if os.environ.get("FUZZ_SHAPE"):
         hidden, S = (int(x) for x in os.environ["FUZZ_SHAPE"].split(","))
-    D = int(rs.integers(2, 9))
+    D = int(rs.integers(2, 6 if large else 9))
     act = int(rs.choice([rc.RELU, rc.RESQRT, rc.RECLIP20]))
     noise = float(rs.choice([0.0, 0.0, 0.02]))
     kw = dict(input_size=A, hidden_size=hidden, output_size=A, S=S, D=D, learn_rate=float(os.environ.get("FUZZ_LR") or rs.choice([3e-4, 1e-3])),
@@ -51,8 +55,12 @@ for trial in range(trials):
     bottom = int(rs.choice([0, 0, 0, int(rs.integers(4, 24))]))
     family = os.environ.get("FUZZ_FAMILY", family)
     bottom = int(os.environ.get("FUZZ_BOTTOM", bottom))
+    flags = rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR
+    if rs.random() < 0.3:  # every conditioning step of rnn_condition_net (recur-nn.c:782-855) as generations pass
+        flags |= rc.COND_USE_SCALE | rc.COND_USE_LAWN_MOWER | rc.COND_USE_TALL_POPPY | rc.COND_USE_RAND
     if family in ("adadelta", "rprop"):
-        kw["flags"] = rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR | rc.FLAG_AUX_ARRAYS
+        flags |= rc.FLAG_AUX_ARRAYS
+    kw["flags"] = flags
     if bottom:  # text-predict --bottom-layer: A symbols -> `bottom` rectified nodes -> the net
         kw.update(input_size=bottom, bottom_inputs=A, bottom_rate_scale=float(rs.choice([1.0, 0.5])))
     if os.environ.get("FUZZ_KW"):  # a whole trial given: the dict a failing run printed
@@ -75,7 +83,7 @@ for trial in range(trials):
     allowed = None
     if family != "momentum":  # (the fused call and the ballast operation treat the momentum arrays as momentums)
         allowed = ["pernet", "batched", "noise", "forget", "edit", "ranges", "clone", "accumulate", "read", "set_dense",
-                   "set_onehot"]
+                   "set_onehot", "set_ranges"]
     if bottom:
         allowed = ["pernet", "batched", "noise", "forget", "accumulate", "read", "set_dense"]
     i = 0
@@ -85,7 +93,7 @@ for trial in range(trials):
     for step in range(len(forced) if forced else n_ops):
         op = forced[step] if forced else str(rs.choice(["pernet", "pernet", "batched", "batched", "batched", "noise", "forget", "edit", "fused",
                             "ranges", "clone", "accumulate", "read", "momentum", "set_dense", "set_dense",
-                            "set_onehot"]))
+                            "set_onehot", "condition", "set_ranges"]))
         if forced:
             rs.choice(3)  # keep drawing
         elif allowed is not None and op not in allowed:
@@ -213,6 +221,33 @@ for trial in range(trials):
                 ref.rnn_bptt_advance(R.nets[j])
                 R.net_error_bptt(j, int(hot[j]), int(nxt[j]))
                 ref.rnn_bptt_calc_deltas(R.nets[j], 1 if j else 0, None)
+            ref.rnn_apply_learning(R.net, methods[0], 0.9)
+        elif op == "condition":  # recur-nn.c:782-855: what it does depends on the prototype's generation counter
+            both(lambda s, lib: [lib.rnn_condition_net(s.net) for _ in range(1)])
+        elif op == "set_ranges":  # the set call with ONE error-range list for all streams, against the per-net loop
+            a0 = int(rs.integers(0, max(1, A - 2)))
+            ln = int(rs.integers(1, A - a0 + 1))
+            ranges = (rc.ErrorRange * 2)((a0, ln), (-1, 0))
+            hot = rs.integers(0, A, S).astype(np.int32)
+            nxt = rs.integers(0, A, S).astype(np.int32)
+            amd.rnn_amd_set_advance(G.handle)
+            amd.rnn_amd_set_one_hot_opinion(G.handle, rc.iptr(hot), None)
+            amd.rnn_amd_set_softmax_error(G.handle, rc.iptr(nxt))
+            amd.rnn_amd_sync_host(G.net, rc.RNN_AMD_EVERYTHING)   # the caller trims the error rows on the host
+            for j in range(S):
+                e = rc.view(G.nets[j].contents.bptt.contents.o_error, G.O)
+                e[:a0] = 0
+                e[a0 + ln:] = 0
+            amd.rnn_amd_host_written(G.net, rc.RNN_AMD_EVERYTHING)
+            amd.rnn_amd_set_calc_deltas(G.handle, 0, ranges, None)
+            amd.rnn_apply_learning(G.net, methods[0], 0.9)
+            for j in range(S):
+                ref.rnn_bptt_advance(R.nets[j])
+                R.net_error_bptt(j, int(hot[j]), int(nxt[j]))
+                e = rc.view(R.nets[j].contents.bptt.contents.o_error, R.O)
+                e[:a0] = 0
+                e[a0 + ln:] = 0
+                ref.rnn_bptt_calc_deltas(R.nets[j], 1 if j else 0, ranges)
             ref.rnn_apply_learning(R.net, methods[0], 0.9)
         elif op == "read":  # nothing: the comparison below reads everything back
             pass
