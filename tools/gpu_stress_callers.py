@@ -22,6 +22,7 @@ rs = np.random.default_rng(seed)
 KEYS = ["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "output", "hist", "o_error",
         "min_error_factor", "ih_scale"]
 bad = 0
+LR = float(os.environ.get("LR_SCALE", "1"))  # hotter regimes: clipped error gains, early exits
 
 
 def verdict(label, g, o, exact):
@@ -51,7 +52,7 @@ def multi(trial):
     noise = float(rs.choice([0.0, 0.02]))
     act = int(rs.choice([rc.RELU, rc.RESQRT]))
     method = int(rs.choice([rc.WEIGHTED, rc.NESTEROV, rc.WEIGHTED]))  # ADAGRAD from a cold start without ballast is 0 / 0 on both sides
-    kw = dict(input_size=A, hidden_size=hidden, output_size=A * NC, S=S, D=D, learn_rate=1e-3 if hidden < 256 else 1e-4,
+    kw = dict(input_size=A, hidden_size=hidden, output_size=A * NC, S=S, D=D, learn_rate=LR * (1e-3 if hidden < 256 else 1e-4),
               seed=300 + trial, noise=noise, activation=act)
     print("next: multi", kw, "leak", leak, "method", method, flush=True)
     g, o = sc.AmdBatchedSet(amd, **kw), sc.OracleSet(**kw)
@@ -81,7 +82,7 @@ def classify(trial):
     S = int(rs.integers(1, 150)) if hidden <= 256 else int(rs.integers(1, 70))
     D = int(rs.integers(2, 9))
     method = int(rs.choice([rc.WEIGHTED, rc.NESTEROV]))
-    kw = dict(input_size=NIN, hidden_size=hidden, output_size=O, S=S, D=D, learn_rate=1e-3 if hidden < 256 else 1e-4,
+    kw = dict(input_size=NIN, hidden_size=hidden, output_size=O, S=S, D=D, learn_rate=LR * (1e-3 if hidden < 256 else 1e-4),
               seed=500 + trial)
     print("next: classify", kw, list(gsize), flush=True)
     g, o = sc.AmdBatchedSet(amd, **kw), sc.OracleSet(**kw)
@@ -123,7 +124,7 @@ def rnnca(trial):
     hidden = int(rs.choice([32, 64, 128, 256, 512]))
     S = int(rs.integers(1, 300)) if hidden <= 128 else int(rs.integers(1, 100))
     D = int(rs.integers(1, 7))
-    kw = dict(input_size=NIN, hidden_size=hidden, output_size=NO, S=S, D=D, learn_rate=1e-3 if hidden < 256 else 1e-4,
+    kw = dict(input_size=NIN, hidden_size=hidden, output_size=NO, S=S, D=D, learn_rate=LR * (1e-3 if hidden < 256 else 1e-4),
               seed=700 + trial, momentum=0.95)
     print("next: rnnca", kw, flush=True)
     g, o = sc.AmdBatchedSet(amd, **kw), sc.OracleSet(**kw)
