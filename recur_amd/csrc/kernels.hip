@@ -4488,7 +4488,10 @@ static void launch_chain_persist_k(hipStream_t st, const View *d_view, const Ram
 }
 
 /* row tiles per launch: 8 XCDs x (32 seats / column tiles) */
-static int chain_persist_seats(const RamdShape *sh) { return 8 * (32 / (sh->hidden_size / 32)); }
+static int chain_persist_seats(const RamdShape *sh) {
+  const int nt = sh->hidden_size / 32; /* column tiles; the one-launch chain exists for 8, 16 and 32 of them */
+  return nt > 0 && nt <= 32 ? 8 * (32 / nt) : 0;
+}
 /* 16-stream row tiles (one sub-chain per workgroup) when they all still fit one launch: twice the
  * CUs for a small set; otherwise 32-stream tiles, which move more streams per microsecond */
 static bool chain_persist_one(const RamdShape *sh, int nrows) {
@@ -4874,8 +4877,8 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     /* ... and a small set that does not start on a tile boundary (a per-net call on stream j):
      * the tiles from the boundary below it, one launch */
     const int span_base = row0 & ~15, span = ((row0 + nrows + 15) & ~15) - span_base;
-    const bool windowed = span_base != row0 && span / 16 <= chain_persist_seats(sh) && span_base + span <= sh->Scap &&
-                          chain_persist_ok(sh, b, span);
+    const bool windowed = span_base != row0 && span_base + span <= sh->Scap && chain_persist_ok(sh, b, span) &&
+                          span / 16 <= chain_persist_seats(sh);
     if (windowed) {
       launch_chain_persist(st, d_view, sh, b, span_base, span, true, row0 - span_base + nrows, row0 - span_base);
     }

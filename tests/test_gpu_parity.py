@@ -289,6 +289,46 @@ def test_reclip20_units_at_the_ceiling_are_skipped_like_zeros(amd, orc, hidden, 
     o.close()
 
 
+@pytest.mark.parametrize("hidden,S,cuts", [(20, 3, (0, 1, 3)), (48, 7, (0, 2, 5, 7)), (256, 48, (0, 4, 24, 48)),
+                                           (512, 40, (0, 17, 40))])
+def test_sets_over_sub_ranges_of_a_training_set(amd, orc, hidden, S, cuts):
+    """A training set driven as several sets over contiguous sub-ranges of its streams (rnn_amd_set_open on
+    nets + offset): row offsets that are not tile boundaries, i.e. windowed and padded launches of the one-launch
+    chain for the big nets, and -- the case tools/gpu_fuzz_api.py crashed on, an integer division by zero in the
+    launcher -- a net with fewer than 32 hidden units under a set that does not start at stream 0.  Against the
+    oracle's per-stream loop over all the streams."""
+    lib = amd
+    kw = dict(input_size=21, hidden_size=hidden, output_size=21, S=S, D=4, learn_rate=1e-3 if hidden < 256 else 1e-4,
+              seed=91)
+    g = sc.AmdBatchedSet(lib, **kw)
+    o = sc.OracleSet(**kw)
+    rs = np.random.default_rng(5)
+    c = C.c_int(0)
+    for step in range(7):
+        hot = rs.integers(0, 21, S).astype(np.int32)
+        nxt = rs.integers(0, 21, S).astype(np.int32)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            arr = (rc.NetP * (b - a))(*[g.nets[j] for j in range(a, b)])
+            h = lib.rnn_amd_set_open(arr, b - a)
+            lib.rnn_amd_set_advance(h)
+            lib.rnn_amd_set_one_hot_opinion(h, rc.iptr(np.ascontiguousarray(hot[a:b])), None)
+            lib.rnn_amd_set_softmax_error(h, rc.iptr(np.ascontiguousarray(nxt[a:b])))
+            lib.rnn_amd_set_calc_deltas(h, 1 if a else 0, None, None)
+            lib.rnn_amd_set_close(h)
+        lib.rnn_apply_learning(g.net, rc.WEIGHTED, 0.9)
+        for j in range(S):
+            o.orc.orc_advance(o.z, j)
+            o.orc.orc_net_error_bptt(o.z, j, int(hot[j]), int(nxt[j]), C.byref(c))
+            o.orc.orc_calc_deltas(o.z, j, 1 if j else 0, None)
+        o.orc.orc_apply_learning(o.z, rc.WEIGHTED, 0.9)
+    sg, so = g.snapshot(), o.snapshot()
+    assert np.array_equal(sg["hidden"] != 0, so["hidden"] != 0)
+    replay.check(sg, so, RTOL, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "output", "hist",
+                                     "o_error", "min_error_factor", "ih_scale"], exact=("index", "generation"))
+    g.close()
+    o.close()
+
+
 @pytest.mark.parametrize("batched", [False, True])
 def test_sparse_error_ranges(amd, batched):
     got = replay.sparse_api(amd, batched=batched)

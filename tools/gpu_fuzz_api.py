@@ -83,7 +83,7 @@ for trial in range(trials):
     allowed = None
     if family != "momentum":  # (the fused call and the ballast operation treat the momentum arrays as momentums)
         allowed = ["pernet", "batched", "noise", "forget", "edit", "ranges", "clone", "accumulate", "read", "set_dense",
-                   "set_onehot", "set_ranges"]
+                   "set_onehot", "set_ranges", "subsets"]
     if bottom:
         allowed = ["pernet", "batched", "noise", "forget", "accumulate", "read", "set_dense"]
     i = 0
@@ -93,11 +93,13 @@ for trial in range(trials):
     for step in range(len(forced) if forced else n_ops):
         op = forced[step] if forced else str(rs.choice(["pernet", "pernet", "batched", "batched", "batched", "noise", "forget", "edit", "fused",
                             "ranges", "clone", "accumulate", "read", "momentum", "set_dense", "set_dense",
-                            "set_onehot", "condition", "set_ranges"]))
+                            "set_onehot", "condition", "set_ranges", "subsets", "subsets"]))
         if forced:
             rs.choice(3)  # keep drawing
         elif allowed is not None and op not in allowed:
             op = "read"
+        if os.environ.get("FUZZ_DEBUG"):
+            print("   op", op, flush=True)
         if op == "pernet":  # the reference's per-stream loop on both
             m = int(rs.choice(methods))
             sc.ApiSet.char_step(G, text, i, m, 0.9)
@@ -249,6 +251,31 @@ for trial in range(trials):
                 e[a0 + ln:] = 0
                 ref.rnn_bptt_calc_deltas(R.nets[j], 1 if j else 0, ranges)
             ref.rnn_apply_learning(R.net, methods[0], 0.9)
+        elif op == "subsets":  # the training set driven as two or three sets over contiguous sub-ranges of its streams
+            # (row offsets that are not tile boundaries: windowed and padded launches of the one-launch chain)
+            hot = rs.integers(0, A, S).astype(np.int32)
+            nxt = rs.integers(0, A, S).astype(np.int32)
+            cuts = sorted(set([0, S] + [int(c) for c in rs.integers(1, max(2, S), int(rs.integers(1, 3)))]))
+            cuts = [c for c in cuts if 0 <= c <= S]
+            if os.environ.get("FUZZ_DEBUG"):
+                print("   cuts", cuts, flush=True)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                if b <= a:
+                    continue
+                arr = (rc.NetP * (b - a))(*[G.nets[j] for j in range(a, b)])
+                h = amd.rnn_amd_set_open(arr, b - a)
+                amd.rnn_amd_set_advance(h)
+                amd.rnn_amd_set_one_hot_opinion(h, rc.iptr(np.ascontiguousarray(hot[a:b])), None)
+                amd.rnn_amd_set_softmax_error(h, rc.iptr(np.ascontiguousarray(nxt[a:b])))
+                amd.rnn_amd_set_calc_deltas(h, 1 if a else 0, None, None)
+                amd.rnn_amd_set_close(h)
+            amd.rnn_apply_learning(G.net, methods[0], 0.9)
+            for j in range(S):
+                ref.rnn_bptt_advance(R.nets[j])
+                R.net_error_bptt(j, int(hot[j]), int(nxt[j]))
+                ref.rnn_bptt_calc_deltas(R.nets[j], 1 if j else 0, None)
+            ref.rnn_apply_learning(R.net, methods[0], 0.9)
+            op = "subsets%s" % cuts
         elif op == "read":  # nothing: the comparison below reads everything back
             pass
         elif op == "momentum":  # recur-nn-init.c:359-380
