@@ -1463,7 +1463,9 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
   }
   engine_need_dev(e, RNN_AMD_WEIGHTS | (accumulate ? RNN_AMD_DELTAS : 0));
   if (fused) {
-    engine_need_dev(e, RNN_AMD_MOMENTUMS);
+    /* (the fused path rewrites ih_delta only: the rest of the delta arrays has to be the device's
+     * own before they are declared written -- after a regrow the device copy is blank) */
+    engine_need_dev(e, RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
   }
   float *keep = malloc(sizeof(float) * s->O);
   memcpy(keep, net->bptt->o_error, sizeof(float) * s->O);

@@ -5,7 +5,7 @@ tools/gpu_fuzz_api.py.  Per-net calls, batched set calls, host-side edits, forgo
 made and deleted in between, weight noise, the fused single-net call with and without batching,
 accumulation after rnn_bptt_clear_deltas, error ranges, dense inputs with an active mask, every
 conditioning step, the optimiser families, bottom-layer nets, shapes up to hidden 512 / 70 streams.
-Fixed seeds: the run is deterministic.  (In development the tool found the six defects whose
+Fixed seeds: the run is deterministic.  (In development the tool found the seven defects whose
 regression tests sit in test_gpu_parity.py: split-K workspace of narrow nets under wide output layers,
 the delta arrays after rnn_bptt_calculate, RECLIP20 units at the ceiling, the bottom layer's shared
 input buffer and its error accumulator under a clipped stream, a division by zero for sub-range sets of tiny nets.)"""

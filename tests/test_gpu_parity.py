@@ -289,6 +289,41 @@ def test_reclip20_units_at_the_ceiling_are_skipped_like_zeros(amd, orc, hidden, 
     o.close()
 
 
+def test_fused_call_after_a_regrow_keeps_the_top_layer_deltas(amd, orc):
+    """rnn_bptt_calculate rewrites ih_delta only; ho_delta is whatever the last rnn_bptt_calc_deltas left.  A clone
+    made in between regrows the device image (blank delta arrays on the device, the valid ones on the host): the
+    fused call has to fetch them before it declares the delta arrays device-written (tools/gpu_fuzz_api.py:
+    ho_delta came back as zeros)."""
+    lib = amd
+    kw = dict(input_size=14, hidden_size=20, output_size=14, S=5, D=6, learn_rate=1e-3, seed=9054, activation=rc.RESQRT)
+    g = sc.AmdBatchedSet(lib, softmax_best_guess=orc.orc_softmax_best_guess, **kw)
+    o = sc.OracleSet(**kw)
+    t = sc.synthetic_text(2000, alphabet=14)
+    for i in range(3):
+        g.char_step(t, i, rc.WEIGHTED, 0.9)
+        o.char_step(t, i, rc.WEIGHTED, 0.9)
+    fl = g.net.contents.flags & ~(rc.FLAG_OWN_BPTT | rc.FLAG_OWN_WEIGHTS)
+    clones = [lib.rnn_clone(g.net, fl, 5, None) for _ in range(3)]   # a fixed seed: no draw from the prototype
+    rc.view(clones[2].contents.real_inputs, 14)[:] = 0
+    lib.rnn_opinion(clones[2], None, 0.0)
+    for cl in clones:
+        lib.rnn_delete_net(cl)
+    c = C.c_int(0)
+    lib.rnn_bptt_advance(g.net)
+    g.net_error_bptt(0, int(t[3]), int(t[4]))
+    g.net.contents.bptt.contents.momentum = 0.9
+    lib.rnn_bptt_calculate(g.net, 1)
+    o.orc.orc_advance(o.z, 0)
+    o.orc.orc_net_error_bptt(o.z, 0, int(t[3]), int(t[4]), C.byref(c))
+    o.orc.orc_bptt_calculate(o.z, 0, 1, 0.9)
+    sg, so = g.snapshot(), o.snapshot()
+    assert np.abs(so["ho_delta"]).max() > 0
+    replay.check(sg, so, RTOL, keys=["ho_delta", "ih_delta", "ih_w", "ho_w", "ih_m", "ho_m", "hidden", "hist"],
+                 exact=("index", "generation"))
+    g.close()
+    o.close()
+
+
 @pytest.mark.parametrize("hidden,S,cuts", [(20, 3, (0, 1, 3)), (48, 7, (0, 2, 5, 7)), (256, 48, (0, 4, 24, 48)),
                                            (512, 40, (0, 17, 40))])
 def test_sets_over_sub_ranges_of_a_training_set(amd, orc, hidden, S, cuts):

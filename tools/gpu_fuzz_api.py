@@ -83,7 +83,7 @@ for trial in range(trials):
     allowed = None
     if family != "momentum":  # (the fused call and the ballast operation treat the momentum arrays as momentums)
         allowed = ["pernet", "batched", "noise", "forget", "edit", "ranges", "clone", "accumulate", "read", "set_dense",
-                   "set_onehot", "set_ranges", "subsets"]
+                   "set_onehot", "set_ranges", "subsets", "fwd_set"]
     if bottom:
         allowed = ["pernet", "batched", "noise", "forget", "accumulate", "read", "set_dense"]
     i = 0
@@ -93,7 +93,7 @@ for trial in range(trials):
     for step in range(len(forced) if forced else n_ops):
         op = forced[step] if forced else str(rs.choice(["pernet", "pernet", "batched", "batched", "batched", "noise", "forget", "edit", "fused",
                             "ranges", "clone", "accumulate", "read", "momentum", "set_dense", "set_dense",
-                            "set_onehot", "condition", "set_ranges", "subsets", "subsets"]))
+                            "set_onehot", "condition", "set_ranges", "subsets", "subsets", "fwd_set"]))
         if forced:
             rs.choice(3)  # keep drawing
         elif allowed is not None and op not in allowed:
@@ -276,6 +276,30 @@ for trial in range(trials):
                 ref.rnn_bptt_calc_deltas(R.nets[j], 1 if j else 0, None)
             ref.rnn_apply_learning(R.net, methods[0], 0.9)
             op = "subsets%s" % cuts
+        elif op == "fwd_set":  # rnnca's frame fill in small: forward-only clones made now, driven as ONE set with dense
+            # inputs for a few steps, their answers against the per-net calls on the reference's own clones
+            n_c, n_steps = int(rs.integers(1, 40)), int(rs.integers(1, 4))
+            xs = [np.ascontiguousarray((rs.standard_normal((n_c, A)) * 0.5).astype(np.float32)) for _ in range(n_steps)]
+            fl = G.net.contents.flags & ~(rc.FLAG_OWN_BPTT | rc.FLAG_OWN_WEIGHTS)
+            gc_ = [amd.rnn_clone(G.net, fl, rc.SUBSEED, None) for _ in range(n_c)]
+            rc_ = [ref.rnn_clone(R.net, fl, rc.SUBSEED, None) for _ in range(n_c)]
+            arr = (rc.NetP * n_c)(*gc_)  # (the set refers to the caller's array: it has to outlive the set)
+            h = amd.rnn_amd_set_open(arr, n_c)
+            outs = np.zeros((n_c, G.O), np.float32)
+            worst = 0.0
+            for x in xs:
+                amd.rnn_amd_set_opinion(h, rc.fptr(x), A, rc.fptr(outs))
+                for q in range(n_c):
+                    out = ref.rnn_opinion(rc_[q], rc.fptr(np.ascontiguousarray(x[q])), rc_[q].contents.presynaptic_noise)
+                    want = np.ctypeslib.as_array(out, (A,))
+                    worst = max(worst, float(np.abs(outs[q, :A] - want).max() / max(np.abs(want).max(), 1e-30)))
+            amd.rnn_amd_set_close(h)
+            for q in range(n_c):
+                amd.rnn_delete_net(gc_[q])
+                ref.rnn_delete_net(rc_[q])
+            if worst > 2e-4:
+                print("   forward-only set: answers differ by %.3g" % worst)
+                ok = False
         elif op == "read":  # nothing: the comparison below reads everything back
             pass
         elif op == "momentum":  # recur-nn-init.c:359-380
