@@ -361,7 +361,7 @@ void rnn_amd_host_written(RecurNN *net, int what);
 /* A training set opened for batched work: nets[0] is the prototype and the
  * others are its rnn_new_training_set() clones. */
 typedef struct RnnAmdSet RnnAmdSet;
-RnnAmdSet *rnn_amd_set_open(RecurNN **nets, int n_nets);
+RnnAmdSet *rnn_amd_set_open(RecurNN **nets, int n_nets); /* (the array is copied: it need not outlive the call) */
 void rnn_amd_set_close(RnnAmdSet *set);
 int rnn_amd_set_size(const RnnAmdSet *set);
 

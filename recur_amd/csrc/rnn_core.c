@@ -1833,7 +1833,9 @@ RnnAmdSet *rnn_amd_set_open(RecurNN **nets, int n_nets) {
   engine_ensure_device(e);
   RnnAmdSet *set = ramd_zalloc(sizeof(RnnAmdSet));
   set->eng = e;
-  set->nets = nets;
+  /* the set keeps its own copy of the pointer array: the caller's may be a temporary */
+  set->nets = ramd_zalloc(n_nets * sizeof(RecurNN *));
+  memcpy(set->nets, nets, n_nets * sizeof(RecurNN *));
   set->n = n_nets;
   set->row0 = row0;
   set->fwd_only = fwd_only;
@@ -1851,6 +1853,7 @@ void rnn_amd_set_close(RnnAmdSet *set) {
     return;
   }
   ramd_need_host(set->nets[0], RNN_AMD_EVERYTHING);
+  free(set->nets);
   free(set);
 }
 

@@ -83,9 +83,9 @@ for trial in range(trials):
     allowed = None
     if family != "momentum":  # (the fused call and the ballast operation treat the momentum arrays as momentums)
         allowed = ["pernet", "batched", "noise", "forget", "edit", "ranges", "clone", "accumulate", "read", "set_dense",
-                   "set_onehot", "set_ranges", "subsets", "fwd_set"]
+                   "set_onehot", "set_ranges", "subsets", "fwd_set", "dense_pernet", "other_net"]
     if bottom:
-        allowed = ["pernet", "batched", "noise", "forget", "accumulate", "read", "set_dense"]
+        allowed = ["pernet", "batched", "noise", "forget", "accumulate", "read", "set_dense", "dense_pernet", "other_net"]
     i = 0
     log = []
     ok = True
@@ -93,7 +93,8 @@ for trial in range(trials):
     for step in range(len(forced) if forced else n_ops):
         op = forced[step] if forced else str(rs.choice(["pernet", "pernet", "batched", "batched", "batched", "noise", "forget", "edit", "fused",
                             "ranges", "clone", "accumulate", "read", "momentum", "set_dense", "set_dense",
-                            "set_onehot", "condition", "set_ranges", "subsets", "subsets", "fwd_set"]))
+                            "set_onehot", "condition", "set_ranges", "subsets", "subsets", "fwd_set", "dense_pernet",
+                            "other_net"]))
         if forced:
             rs.choice(3)  # keep drawing
         elif allowed is not None and op not in allowed:
@@ -299,6 +300,40 @@ for trial in range(trials):
                 ref.rnn_delete_net(rc_[q])
             if worst > 2e-4:
                 print("   forward-only set: answers differ by %.3g" % worst)
+                ok = False
+        elif op == "dense_pernet":  # dense inputs through the per-net calls (rnn_opinion with an inputs pointer)
+            x = np.ascontiguousarray((rs.standard_normal((S, A)) * 0.5).astype(np.float32))
+            tgt = np.ascontiguousarray(rs.random((S, A)).astype(np.float32))
+
+            def dense(s, lib):
+                for j in range(S):
+                    lib.rnn_bptt_advance(s.nets[j])
+                    out = lib.rnn_opinion(s.nets[j], rc.fptr(np.ascontiguousarray(x[j])), s.nets[j].contents.presynaptic_noise)
+                    out = np.ctypeslib.as_array(out, (A,))
+                    e = rc.view(s.nets[j].contents.bptt.contents.o_error, s.O)
+                    e[:] = 0
+                    e[:A] = (tgt[j] - out) * np.float32(0.3)
+                    lib.rnn_bptt_calc_deltas(s.nets[j], 1 if j else 0, None)
+                lib.rnn_apply_learning(s.net, methods[0], 0.9)
+            both(dense)
+        elif op == "other_net":  # an unrelated net (its own engine) made, trained a little and deleted in between
+            kw2 = dict(input_size=int(rs.integers(3, 30)), hidden_size=int(rs.choice([10, 33, 64, 256])), output_size=int(rs.integers(2, 30)),
+                       S=int(rs.integers(1, 20)), D=int(rs.integers(1, 5)), learn_rate=1e-3, seed=int(rs.integers(1, 1000)))
+            kw2["output_size"] = kw2["input_size"]
+            t2 = sc.synthetic_text(2000, alphabet=kw2["input_size"])
+            g2 = sc.AmdBatchedSet(amd, softmax_best_guess=orc.orc_softmax_best_guess, **kw2)
+            r2 = sc.ApiSet(ref, softmax_best_guess=orc.orc_softmax_best_guess, **kw2)
+            for q in range(3):
+                if q == 1:
+                    sc.ApiSet.char_step(g2, t2, q, rc.WEIGHTED, 0.9)
+                else:
+                    g2.char_step(t2, q, rc.WEIGHTED, 0.9)
+                r2.char_step(t2, q, rc.WEIGHTED, 0.9)
+            w2 = sc.compare(g2.snapshot(), r2.snapshot(), 2e-4, keys=["ih_w", "ho_w", "hidden", "ih_delta"], exact=["index", "rng"])
+            g2.close()
+            r2.close()
+            if w2:
+                print("   the other net differs: %s" % str(w2)[:300])
                 ok = False
         elif op == "read":  # nothing: the comparison below reads everything back
             pass
