@@ -83,9 +83,9 @@ for trial in range(trials):
     allowed = None
     if family != "momentum":  # (the fused call and the ballast operation treat the momentum arrays as momentums)
         allowed = ["pernet", "batched", "noise", "forget", "edit", "ranges", "clone", "accumulate", "read", "set_dense",
-                   "set_onehot", "set_ranges", "subsets", "fwd_set", "dense_pernet", "other_net"]
+                   "set_onehot", "set_ranges", "subsets", "fwd_set", "dense_pernet", "other_net", "save_load"]
     if bottom:
-        allowed = ["pernet", "batched", "noise", "forget", "accumulate", "read", "set_dense", "dense_pernet", "other_net"]
+        allowed = ["pernet", "batched", "noise", "forget", "accumulate", "read", "set_dense", "dense_pernet", "other_net", "save_load"]
     i = 0
     log = []
     ok = True
@@ -94,7 +94,7 @@ for trial in range(trials):
         op = forced[step] if forced else str(rs.choice(["pernet", "pernet", "batched", "batched", "batched", "noise", "forget", "edit", "fused",
                             "ranges", "clone", "accumulate", "read", "momentum", "set_dense", "set_dense",
                             "set_onehot", "condition", "set_ranges", "subsets", "subsets", "fwd_set", "dense_pernet",
-                            "other_net"]))
+                            "other_net", "save_load"]))
         if forced:
             rs.choice(3)  # keep drawing
         elif allowed is not None and op not in allowed:
@@ -335,6 +335,41 @@ for trial in range(trials):
             if w2:
                 print("   the other net differs: %s" % str(w2)[:300])
                 ok = False
+        elif op == "save_load":  # the product alone: what rnn_save_net writes is what the device holds NOW
+            import tempfile
+            cwd = os.getcwd()
+            with tempfile.TemporaryDirectory() as td:
+                os.chdir(td)  # rnn_save_net makes its temporary file in the cwd (recur-nn-io.c:17-21)
+                try:
+                    assert amd.rnn_save_net(G.net, b"fuzz.net", 1) == 0
+                    n2 = amd.rnn_load_net(b"fuzz.net")
+                finally:
+                    os.chdir(cwd)
+            assert n2, "rnn_load_net failed"
+            sg0 = G.snapshot()
+            a2, b2 = n2.contents, n2.contents.bptt.contents
+            # (the format holds the weights, the scalars and the generator; no training arrays: recur-nn-io.c:38, 72-74)
+            got2 = {"ih_w": rc.view(a2.ih_weights, G.I, G.H), "ho_w": rc.view(a2.ho_weights, G.H, G.O)}
+            live = G.net.contents
+            if (a2.rng.a, a2.rng.b, a2.rng.c, a2.rng.d) != (live.rng.a, live.rng.b, live.rng.c, live.rng.d):
+                print("   the generator was saved stale")
+                ok = False
+            if b2.index != live.bptt.contents.index or b2.min_error_factor != live.bptt.contents.min_error_factor:
+                print("   bptt scalars were saved stale")
+                ok = False
+            if bottom:
+                bl2, bl1 = a2.bottom_layer.contents, live.bottom_layer.contents
+                if not np.array_equal(rc.view(bl2.weights, bl2.i_size, bl2.o_size), sg0["b_w"]):
+                    print("   the bottom layer's weights were saved stale")
+                    ok = False
+            for k2, v2 in got2.items():
+                if not np.array_equal(v2, sg0[k2]):
+                    print("   saved and reloaded %s differs from the live net (max %.3g)" % (k2, np.abs(v2 - sg0[k2]).max()))
+                    ok = False
+            if a2.generation != G.net.contents.generation:
+                print("   generation %d saved as %d" % (G.net.contents.generation, a2.generation))
+                ok = False
+            amd.rnn_delete_net(n2)
         elif op == "read":  # nothing: the comparison below reads everything back
             pass
         elif op == "momentum":  # recur-nn-init.c:359-380
