@@ -772,7 +772,8 @@ static void multi_text_train(RecurNN *net, u8 *text, int len, int learning_style
       report->training_error = (float)st.error * report_scale;
     }
     rnn_amd_synchronize();
-    free(set); /* the net's state stays on the device; nothing to copy back here */
+    free(set->nets); /* (the set's own copy of the pointer array) */
+    free(set);       /* the net's state stays on the device; nothing to copy back here */
   }
   if (mc && mc->period && i % mc->period == 0) {
     char *confab_line = malloc(mc->byte_len + 1);
@@ -806,11 +807,15 @@ void rnn_char_multitext_spin(RecurNN *net, u8 *text, int len, TemporalPPM *input
     fprintf(stderr, "librecur_amd: rnn_char_multitext_spin needs a net with its own bptt\n");
     abort();
   }
-  if (len == 1) { /* the device text wants two symbols: give the one a dummy successor */
-    u8 two[2] = {text[0], text[0]};
-    rnn_amd_set_load_text(set, two, 2);
-  } else {
-    rnn_amd_set_load_text(set, text, len);
+  {
+    /* every one of the len symbols is an input here (charmodel-multi-predict.c:298-302), the last one
+     * too; the device text steps read positions modulo len - 1 (a training step's input always has a
+     * successor): give the text one more symbol, so that position len - 1 is an input and not a wrap */
+    u8 *padded = malloc((size_t)len + 1);
+    memcpy(padded, text, len);
+    padded[len] = text[len - 1];
+    rnn_amd_set_load_text(set, padded, len + 1);
+    free(padded);
   }
   const int dump = input_ppm || error_ppm || periodic_pgm_period;
   for (int i = 0; i < len; i++) {
@@ -821,6 +826,7 @@ void rnn_char_multitext_spin(RecurNN *net, u8 *text, int len, TemporalPPM *input
     }
   }
   rnn_amd_synchronize();
+  free(set->nets);
   free(set);
 }
 

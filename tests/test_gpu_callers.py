@@ -155,6 +155,11 @@ def test_multitext_trainer_loop_matches_oracle(amd, method, batch, leakage, nois
     for i in range(9):
         o.orc.orc_advance(o.z, 0)
         o.orc.orc_one_hot_opinion(o.z, 0, int(text[i]), noise)
+    # (checked right here: every one of the symbols is an input, the last one too -- the device text steps wrap
+    # at len - 1, and the spin fed text[0] for the last symbol until tools/gpu_stress_multitext.py compared the
+    # state at this point; sixty symbols of cross entropy further on the difference had decayed below 1e-4)
+    sg, so = g.snapshot(), o.snapshot()
+    replay.check(sg, so, RTOL, keys=["hidden", "output", "hist"], exact=("index", "generation", "rng"))
     # per-head cross entropy of a third text
     text = np.ascontiguousarray(rs.integers(0, A, 60).astype(np.uint8))
     ent_g = (C.c_double * NC)(*([0.0] * NC))
