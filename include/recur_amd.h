@@ -451,6 +451,10 @@ void rnn_amd_set_load_text(RnnAmdSet *set, const u8 *text, int len);
  * rnn_apply_learning(nets[0], learning_style, momentum).  Nothing is copied to
  * the host. */
 void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float momentum);
+/* The same for ONE net on the fused single-net path (charmodel-predict.c:312-321): advance, opinion of
+ * text[i], the loss against text[i + 1] on the device, rnn_bptt_calculate(net, batch_size); the caller
+ * sets bptt->momentum first, as the reference's loop does.  No host round trip per symbol. */
+void rnn_amd_set_char_step_fused(RnnAmdSet *set, int i, unsigned batch_size);
 
 typedef struct RnnAmdStats {
   double error;   /* sum of target-class errors                */

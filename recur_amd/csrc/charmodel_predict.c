@@ -428,6 +428,18 @@ int rnn_char_epoch(RnnCharModel *model, RecurNN *confab_net, RnnCharVentropy *v,
   /* the whole set per call when the nets are one training set; the text goes to the
    * device once per epoch */
   RnnAmdSet *set = NULL;
+  /* ... and the single-net branch as a set of one: the loss and rnn_bptt_calculate's work stay on the device
+   * (a net with a log file keeps the per-call route, which writes the core's log lines) */
+  RecurNN *one_net[1] = {net};
+  const int fused_set = !multi_tap && !net->log && net->bptt;
+  if (fused_set) {
+    set = rnn_amd_set_open(one_net, 1);
+    if (set) {
+      RnnAmdStats drop;
+      rnn_amd_set_load_text(set, text, len);
+      rnn_amd_set_read_stats(set, &drop, 1);
+    }
+  }
   if (multi_tap && nets && nets[0] == net) {
     set = rnn_amd_set_open(nets, n_nets);
     if (set) {
@@ -441,7 +453,10 @@ int rnn_char_epoch(RnnCharModel *model, RecurNN *confab_net, RnnCharVentropy *v,
   for (int i = start; i < len - 1; i++) {
     float momentum = rnn_calculate_momentum_soft_start(net->generation, model->momentum,
                                                        model->momentum_soft_start);
-    if (set) {
+    if (set && fused_set) {
+      net->bptt->momentum = momentum;
+      rnn_amd_set_char_step_fused(set, i, model->batch_size);
+    } else if (set) {
       rnn_amd_set_char_step(set, i, model->learning_style, momentum);
     } else if (multi_tap) {
       for (int j = 0; j < n_nets; j++) {

@@ -4841,7 +4841,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   int tn_parts = tn; /* partial sums of squares per (step, stream): one per column tile of the chain kernel used */
   const int nx = sh->I - sh->hidden_size; /* column 0 + the input columns */
   const int nxp = (nx + 3) & ~3;
-  if (nrows == 1 && !active && !defer && row0 < sh->Scap && sh->H <= 256 &&
+  if (nrows == 1 && !active && row0 < sh->Scap && sh->H <= 256 &&
       env_int("RECUR_AMD_BPTT_SMALL", 1)) {
     /* one stream of a small net (the per-net calls): chain, extras, control and weight deltas
      * in one workgroup */
@@ -4855,6 +4855,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
       }
+      if (defer) defer->slab = nullptr; /* ih_delta is written here: nothing left for the optimiser to sum */
       int ev = timing_begin(st, T_CHAIN, 1);
       RAMD_LAUNCH(k_bptt_small, dim3(1), dim3(1024), shm, st, v, row0, accumulate, flags, nx, nxp);
       timing_end(st, ev);

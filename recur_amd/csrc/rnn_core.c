@@ -2409,6 +2409,67 @@ void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float mome
   apply_learning(set->nets[0], learning_style, momentum, (pend.slab || pend.ho_slab) ? &pend : NULL);
 }
 
+/* The single-net text step of rnn_char_epoch (charmodel-predict.c:312-321) without a host round trip per
+ * symbol: rnn_bptt_advance, one_hot_opinion of text[i], net_error_bptt's loss against text[i + 1] (on the
+ * device, into the set's statistics) and rnn_bptt_calculate(net, batch_size) -- the top layer updated at once
+ * with bptt->momentum, the recurrent layer every batch_size generations (recur-nn.c:919-1019).  For a set of
+ * ONE net; the caller sets bptt->momentum as the reference's loop does. */
+void rnn_amd_set_char_step_fused(RnnAmdSet *set, int i, unsigned batch_size) {
+  RamdEngine *e = set->eng;
+  set_need_training(set, "rnn_amd_set_char_step_fused");
+  if (set->n != 1) {
+    fprintf(stderr, "librecur_amd: rnn_amd_set_char_step_fused is the single-net path (set of %d)\n", set->n);
+    abort();
+  }
+  check_text_pos(e, i, 0, "rnn_amd_set_char_step_fused");
+  RecurNN *net = set->nets[0];
+  RecurNNBPTT *bptt = net->bptt;
+  const RamdShape *s = &e->sh;
+  const int j = set->row0;
+  const int batched = batch_size > 1;
+  unsigned top_done = 0;
+  if (ramd_text_top_ok(s)) { /* advance + hidden layer, then output layer, loss and top backprop in one launch */
+    int fwd_ks = set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 1);
+    ramd_launch_text_top(g_stream, s, &e->b, j, 1, fwd_ks);
+    top_done = RAMD_TOP_DONE;
+  } else {
+    set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 0); /* advance + one-hot opinion */
+    ramd_launch_softmax_error(g_stream, s, &e->b, j, 1);
+  }
+  int accumulate = batched;
+  if (e->deltas_zero_pending) {
+    accumulate = 0;
+    e->deltas_zero_pending = 0;
+  }
+  engine_need_dev(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+  push_learn_rates(e, j, 1);
+  if (e->err_pending && (e->err_row0 != j || e->err_nrows != 1)) {
+    err_flush(e);
+  }
+  set_uniform_idx(e, j, 1);
+  ramd_launch_calc_deltas(g_stream, s, &e->b, j, 1, accumulate, NULL, 0, NULL,
+                          net->flags | 0x80000000u | (batched ? 0 : 0x20000000u) | top_done, NULL);
+  if (ramd_calc_wrote_images()) {
+    e->err_pending = 0;
+  } else {
+    e->err_pending = 1;
+    e->err_row0 = j;
+    e->err_nrows = 1;
+  }
+  net->generation++;
+  ramd_launch_top_apply_now(g_stream, s, &e->b, j, bptt->learn_rate, bptt->momentum, bptt->momentum_weight);
+  if (!batched || ((net->generation - 1) % batch_size) == 0) {
+    ramd_launch_apply(g_stream, RNN_MOMENTUM_WEIGHTED, e->b.ih_w, e->b.ih_delta, e->b.ih_m, NULL, e->ih_size,
+                      bptt->learn_rate, bptt->momentum, bptt->momentum_weight, batched ? NULL : e->b.ih_scale + j);
+    if (batched) {
+      HIP_OK(hipMemsetAsync(e->b.ih_delta, 0, e->ih_size * sizeof(float), g_stream));
+    }
+  }
+  engine_dev_wrote(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+  set_streams_dev_wrote(set);
+  rnn_condition_net(net);
+}
+
 void rnn_amd_set_read_stats(RnnAmdSet *set, RnnAmdStats *stats, int clear) {
   RamdEngine *e = set->eng;
   set_need_training(set, "rnn_amd_set_read_stats");

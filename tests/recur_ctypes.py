@@ -231,6 +231,7 @@ AMD_API = {
     "rnn_amd_set_calc_deltas": (None, [C.c_void_p, C.c_int, C.POINTER(ErrorRange), c_u8_p]),
     "rnn_amd_set_load_text": (None, [C.c_void_p, c_u8_p, C.c_int]),
     "rnn_amd_set_char_step": (None, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
+    "rnn_amd_set_char_step_fused": (None, [C.c_void_p, C.c_int, C.c_uint]),
     "rnn_amd_set_read_stats": (None, [C.c_void_p, C.POINTER(AmdStats), C.c_int]),
     "rnn_amd_set_external_delta": (None, [C.c_void_p, C.c_void_p]),
     "rnn_amd_set_char_step_deltas": (None, [C.c_void_p, C.c_int]),

@@ -219,3 +219,41 @@ def test_epoch_driver_single_net_branch_matches_oracle(amd, tmp_path):
         lib.rnn_char_delete_ventropy(C.byref(v))
         a.close()
         o.close()
+
+
+@pytest.mark.parametrize("hidden,D,batch,noise", [(99, 30, 1, 0.0), (39, 8, 4, 0.02), (256, 6, 1, 0.0), (130, 5, 3, 0.0)])
+def test_fused_single_net_step_on_the_device_matches_oracle(amd, hidden, D, batch, noise):
+    """rnn_amd_set_char_step_fused: the single-net branch of rnn_char_epoch (charmodel-predict.c:312-321: advance,
+    one_hot_opinion, net_error_bptt's loss, rnn_bptt_calculate with temporal batching) without a host round trip
+    per symbol -- what text-predict's default configuration (BASELINE.json configs[0]: one net, 99 hidden units,
+    depth 30) runs through the library's rnn_char_epoch.  Step by step against the oracle, loss statistics included."""
+    lib = amd
+    kw = dict(input_size=42, hidden_size=hidden, output_size=42, S=1, D=D, learn_rate=3e-3, seed=33, noise=noise)
+    a = sc.AmdBatchedSet(lib, **kw)
+    o = sc.OracleSet(**kw)
+    text = sc.synthetic_text(3000)
+    a.load_text(text)
+    a.stats(clear=True)
+    err = ent = 0.0
+    correct = 0
+    steps = D + 9
+    for i in range(steps):
+        m = 0.9 if i % 2 else 0.8                      # the epoch's momentum soft start changes it per step
+        a.net.contents.bptt.contents.momentum = m
+        lib.rnn_amd_set_char_step_fused(a.handle, i, batch)
+        c = C.c_int(0)
+        o.orc.orc_advance(o.z, 0)
+        e = o.orc.orc_net_error_bptt(o.z, 0, int(text[i]), int(text[i + 1]), C.byref(c))
+        o.orc.orc_bptt_calculate(o.z, 0, batch, m)
+        err += e
+        ent += np.log2(max(1.0 - e, 1e-30))
+        correct += c.value
+    sg, so = a.snapshot(), o.snapshot()
+    assert np.array_equal(sg["hidden"] != 0, so["hidden"] != 0)
+    replay.check(sg, so, 1e-4, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "hidden", "output", "hist", "o_error",
+                                     "min_error_factor", "ih_scale"], exact=("index", "generation", "rng"))
+    st = a.stats()
+    assert st.count == steps and st.correct == correct
+    assert abs(st.error - err) < 1e-4 * abs(err) and abs(st.entropy - ent) < 1e-3 * abs(ent)
+    a.close()
+    o.close()

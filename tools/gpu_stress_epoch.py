@@ -18,17 +18,21 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
     A = int(rs.integers(2, 60))
     hidden = int(rs.choice([9, 40, 99, 128, 256]))
     S = int(rs.integers(1, 40))
+    single = bool(rs.random() < 0.35)  # the single-net branch: rnn_bptt_calculate per symbol, temporal batching
+    if single:
+        S = 1
+    batch = int(rs.choice([1, 1, 3, 5])) if single else 1
     D = int(rs.integers(1, 7))
     L = int(rs.integers(S + 3, S + 120))
     start = int(rs.integers(0, max(1, L - 3)))
     n_gen = int(rs.integers(1, 14))
     use_stop = bool(rs.integers(0, 2))
-    method = int(rs.choice([rc.WEIGHTED, rc.NESTEROV, rc.SIMPLIFIED_NESTEROV, rc.CLASSICAL]))
+    method = rc.WEIGHTED if single else int(rs.choice([rc.WEIGHTED, rc.NESTEROV, rc.SIMPLIFIED_NESTEROV, rc.CLASSICAL]))
     soft = float(rs.choice([0.0, 50.0, 2000.0]))
     noise = float(rs.choice([0.0, 0.02]))
     kw = dict(input_size=A, hidden_size=hidden, output_size=A, S=S, D=D, learn_rate=1e-3, seed=int(rs.integers(1, 1000)),
               activation=int(rs.choice([rc.RELU, rc.RESQRT])), noise=noise)
-    print("next:", kw, "len", L, "start", start, "generations", n_gen, "stop" if use_stop else "to the end", "method", method,
+    print("next:", kw, "len", L, "start", start, "single net, batch %d," % batch if single else "multi-tap,", "generations", n_gen, "stop" if use_stop else "to the end", "method", method,
           "soft start", soft, flush=True)
     text = np.ascontiguousarray(sc.synthetic_text(8000, alphabet=A)[:L])
     a = sc.ApiSet(amd, **kw)
@@ -37,13 +41,13 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
     model.net = a.net
     model.training_nets = a.nets
     model.n_training_nets = S
-    model.batch_size = 1
+    model.batch_size = batch
     model.momentum = 0.9
     model.momentum_soft_start = soft
     model.learning_style = method
     model.report_interval = int(rs.choice([3, 100]))
     model.save_net = False
-    model.use_multi_tap_path = True
+    model.use_multi_tap_path = not single
     amd.rnn_char_init_schedule(C.byref(model.schedule), 0, 0.0, 1.0, 0)
     v = rc.CharVentropy()
     amd.rnn_char_init_ventropy(C.byref(v), a.net, rc.u8ptr(text), 0, 1)  # no validation text
@@ -53,7 +57,12 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
     want_done = 0
     for i in range(start, L - 1):
         m = amd.rnn_calculate_momentum_soft_start(float(gen), 0.9, soft)
-        o.char_step(text, i, method, m)
+        if single:
+            o.orc.orc_advance(o.z, 0)
+            o.orc.orc_net_error_bptt(o.z, 0, int(text[i]), int(text[i + 1]), C.byref(C.c_int(0)))
+            o.orc.orc_bptt_calculate(o.z, 0, batch, m)
+        else:
+            o.char_step(text, i, method, m)
         gen += 1
         if stop and gen >= stop:
             want_done = 1
