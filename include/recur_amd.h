@@ -442,7 +442,9 @@ void rnn_amd_set_sigmoid_mse_error(RnnAmdSet *set, const float *targets, int ld,
  * o_size, may be NULL) receives the answer rows, which synchronises. */
 void rnn_amd_set_sigmoid_outputs(RnnAmdSet *set, int n, float *outputs);
 
-/* Text on the device, for a host-free epoch loop (charmodel-predict.c:288-311). */
+/* Text on the device, for a host-free epoch loop (charmodel-predict.c:288-311).  The resident text belongs
+ * to the set's ENGINE (the weight-owning net and its clones): every set opened on the same nets sees the
+ * text loaded last, and a text step at a position outside it aborts with a message. */
 void rnn_amd_set_load_text(RnnAmdSet *set, const u8 *text, int len);
 /* One generation of rnn_char_epoch's multi-tap branch for text position i:
  * stream j reads text[off] and is scored against text[off + 1], with

@@ -94,7 +94,7 @@ for trial in range(trials):
         op = forced[step] if forced else str(rs.choice(["pernet", "pernet", "batched", "batched", "batched", "noise", "forget", "edit", "fused",
                             "ranges", "clone", "accumulate", "read", "momentum", "set_dense", "set_dense",
                             "set_onehot", "condition", "set_ranges", "subsets", "subsets", "fwd_set", "dense_pernet",
-                            "other_net", "save_load"]))
+                            "other_net", "save_load", "fused_set"]))
         if forced:
             rs.choice(3)  # keep drawing
         elif allowed is not None and op not in allowed:
@@ -370,6 +370,23 @@ for trial in range(trials):
                 print("   generation %d saved as %d" % (G.net.contents.generation, a2.generation))
                 ok = False
             amd.rnn_delete_net(n2)
+        elif op == "fused_set":  # rnn_char_epoch's single-net branch on the device against the per-call loop
+            n_st, batch = int(rs.integers(1, 6)), int(rs.choice([1, 1, 3]))
+            seg = np.ascontiguousarray(text[i:i + n_st + 2])
+            one = (rc.NetP * 1)(G.net)
+            h = amd.rnn_amd_set_open(one, 1)
+            amd.rnn_amd_set_load_text(h, rc.u8ptr(seg), len(seg))
+            for q in range(n_st):
+                G.net.contents.bptt.contents.momentum = 0.9
+                amd.rnn_amd_set_char_step_fused(h, q, batch)
+            amd.rnn_amd_set_close(h)
+            G._text = None  # (the resident text belongs to the ENGINE: the other set has to load its own again)
+            for q in range(n_st):
+                ref.rnn_bptt_advance(R.net)
+                R.net_error_bptt(0, int(seg[q]), int(seg[q + 1]))
+                R.net.contents.bptt.contents.momentum = 0.9
+                ref.rnn_bptt_calculate(R.net, batch)
+            op = "fused_set/%d/%d" % (n_st, batch)
         elif op == "read":  # nothing: the comparison below reads everything back
             pass
         elif op == "momentum":  # recur-nn-init.c:359-380
