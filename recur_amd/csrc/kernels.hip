@@ -4120,23 +4120,46 @@ __global__ __launch_bounds__(256) void k_apply(ApplySegs sg, float momentum, flo
     *reinterpret_cast<float4 *>(aux + 4 * q) = make_float4(av[0], av[1], av[2], av[3]);
 }
 
-// apply_sgd_top_layer's immediate update for one stream (recur-nn.c:941-964)
-__global__ void k_top_apply_now(View v, int row, float rate, float momentum, float mw) {
+// rnn_bptt_calculate's two updates in ONE launch: workgroups below `top_blocks` do apply_sgd_top_layer's
+// immediate update for one stream (recur-nn.c:941-964), the others apply_learning_with_momentum on the recurrent layer (k_apply<0>'s
+// arithmetic, recur-nn.c:482-487) when the call is due to apply it; *rs (ih_scale) multiplies its rate.
+__global__ __launch_bounds__(256) void k_fused_updates(View v, int row, float rate, float momentum, float mw,
+                                                       unsigned top_blocks, const float *rs) {
   const RamdShape &s = v.sh;
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= s.H * s.O) return;
-  int y = e / s.O, x = e - y * s.O;
-  float h = v.b.hidden[(size_t)row * s.H + y];
-  float mm = v.b.ho_m[e];
-  if (h != 0.0f) {
-    float d = v.b.o_error[(size_t)row * s.O + x] * (h * rate);
-    v.b.ho_w[e] += d + mm * mw;
-    mm += d;
-    v.b.ho_m[e] = mm * momentum;
-  } else {
-    v.b.ho_w[e] += mm * mw;
-    v.b.ho_m[e] = mm * momentum;
+  if (blockIdx.x < top_blocks) {
+    int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= s.H * s.O) return;
+    int y = e / s.O, x = e - y * s.O;
+    float h = v.b.hidden[(size_t)row * s.H + y];
+    float mm = v.b.ho_m[e];
+    if (h != 0.0f) {
+      float d = v.b.o_error[(size_t)row * s.O + x] * (h * rate);
+      v.b.ho_w[e] += d + mm * mw;
+      mm += d;
+      v.b.ho_m[e] = mm * momentum;
+    } else {
+      v.b.ho_w[e] += mm * mw;
+      v.b.ho_m[e] = mm * momentum;
+    }
+    return;
   }
+  const size_t q = (size_t)(blockIdx.x - top_blocks) * 256 + threadIdx.x;
+  if (q >= (size_t)s.I * s.H / 4) return;
+  float r = rate;
+  if (rs) r *= *rs;
+  float4 W = ld4(v.b.ih_w + 4 * q), M = ld4(v.b.ih_m + 4 * q);
+  const float4 Dl = ld4(v.b.ih_delta + 4 * q);
+  float wv[4] = {W.x, W.y, W.z, W.w}, mv[4] = {M.x, M.y, M.z, M.w};
+  const float dv[4] = {Dl.x, Dl.y, Dl.z, Dl.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float t = dv[i] * r;
+    float mm = mv[i];
+    wv[i] += t + mm * mw;
+    mv[i] = (mm + t) * momentum;
+  }
+  *reinterpret_cast<float4 *>(v.b.ih_w + 4 * q) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+  *reinterpret_cast<float4 *>(v.b.ih_m + 4 * q) = make_float4(mv[0], mv[1], mv[2], mv[3]);
 }
 
 // -------------------------------------------------------- K12: conditioning --
@@ -5246,14 +5269,14 @@ extern "C" void ramd_launch_apply(ramd_stream_t st_, int method, float *w, const
   ramd_launch_apply_multi(st_, method, 1, &w, &delta, &m, &aux, &n, &rate, momentum, mw, rs, nullptr);
 }
 
-extern "C" void ramd_launch_top_apply_now(ramd_stream_t st_, const RamdShape *sh,
-                                          const RamdBuffers *b, int row, float rate,
-                                          float momentum, float mw) {
+extern "C" void ramd_launch_fused_updates(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b, int row,
+                                          float rate, float momentum, float mw, int apply_ih, const float *rs) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  int ho = sh->H * sh->O;
-  RAMD_LAUNCH(k_top_apply_now, dim3((ho + 255) / 256), dim3(256), 0, st, v, row, rate,
-                     momentum, mw);
+  const unsigned top_blocks = (unsigned)((sh->H * sh->O + 255) / 256);
+  const unsigned ih_blocks = apply_ih ? (unsigned)(((size_t)sh->I * sh->H / 4 + 255) / 256) : 0u;
+  RAMD_LAUNCH(k_fused_updates, dim3(top_blocks + ih_blocks), dim3(256), 0, st, v, row, rate, momentum, mw, top_blocks,
+              rs);
 }
 
 extern "C" void ramd_launch_scale(ramd_stream_t st, float *a, size_t n, float scale) {

@@ -230,9 +230,8 @@ void ramd_launch_tall_poppy(ramd_stream_t st, float *a, size_t n, float threshol
                             float scale, void *scratch);
 void ramd_launch_add_at(ramd_stream_t st, float *a, size_t index, float v);
 /* the immediate top-layer update of rnn_bptt_calculate (recur-nn.c:941-964) */
-void ramd_launch_top_apply_now(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,
-                               int row, float rate, float momentum, float momentum_weight);
-
+void ramd_launch_fused_updates(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row, float rate,
+                               float momentum, float mw, int apply_ih, const float *rs);
 /* non-zero once the one-launch BPTT chain has given up (its workgroups were not all
  * resident, or a poll timed out): the results of that launch are not valid */
 unsigned ramd_chain_abort_word(void);

@@ -1675,17 +1675,14 @@ void rnn_bptt_calculate(RecurNN *net, uint batch_size) {
   /* without batching the reference leaves the unscaled sum in ih_delta and multiplies the rate by
    * ih_scale (recur-nn.c:966-975); batched, ih_scale goes into the sum (977-994) */
   calc_deltas_one(net, batched, NULL, batched ? 1 : 2); /* also does generation++ */
-  ramd_launch_top_apply_now(g_stream, &e->sh, &e->b, p->stream, bptt->learn_rate, bptt->momentum,
-                            bptt->momentum_weight);
   /* generation was already incremented; the reference tests the value before
    * its increment (recur-nn.c:991, 1010) */
-  if (!batched || ((net->generation - 1) % batch_size) == 0) {
-    ramd_launch_apply(g_stream, RNN_MOMENTUM_WEIGHTED, e->b.ih_w, e->b.ih_delta, e->b.ih_m, NULL,
-                      e->ih_size, bptt->learn_rate, bptt->momentum, bptt->momentum_weight,
-                      batched ? NULL : e->b.ih_scale + p->stream);
-    if (batched) { /* ih_delta only (recur-nn.c:991): ho_delta is not this path's */
-      HIP_OK(hipMemsetAsync(e->b.ih_delta, 0, e->ih_size * sizeof(float), g_stream));
-    }
+  const int due = !batched || ((net->generation - 1) % batch_size) == 0;
+  /* the top layer's immediate update and, when due, the recurrent layer's: one launch */
+  ramd_launch_fused_updates(g_stream, &e->sh, &e->b, p->stream, bptt->learn_rate, bptt->momentum,
+                            bptt->momentum_weight, due, batched ? NULL : e->b.ih_scale + p->stream);
+  if (due && batched) { /* ih_delta only (recur-nn.c:991): ho_delta is not this path's */
+    HIP_OK(hipMemsetAsync(e->b.ih_delta, 0, e->ih_size * sizeof(float), g_stream));
   }
   engine_dev_wrote(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
   if (net->log) {
@@ -2457,13 +2454,11 @@ void rnn_amd_set_char_step_fused(RnnAmdSet *set, int i, unsigned batch_size) {
     e->err_nrows = 1;
   }
   net->generation++;
-  ramd_launch_top_apply_now(g_stream, s, &e->b, j, bptt->learn_rate, bptt->momentum, bptt->momentum_weight);
-  if (!batched || ((net->generation - 1) % batch_size) == 0) {
-    ramd_launch_apply(g_stream, RNN_MOMENTUM_WEIGHTED, e->b.ih_w, e->b.ih_delta, e->b.ih_m, NULL, e->ih_size,
-                      bptt->learn_rate, bptt->momentum, bptt->momentum_weight, batched ? NULL : e->b.ih_scale + j);
-    if (batched) {
-      HIP_OK(hipMemsetAsync(e->b.ih_delta, 0, e->ih_size * sizeof(float), g_stream));
-    }
+  const int due = !batched || ((net->generation - 1) % batch_size) == 0;
+  ramd_launch_fused_updates(g_stream, s, &e->b, j, bptt->learn_rate, bptt->momentum, bptt->momentum_weight, due,
+                            batched ? NULL : e->b.ih_scale + j);
+  if (due && batched) {
+    HIP_OK(hipMemsetAsync(e->b.ih_delta, 0, e->ih_size * sizeof(float), g_stream));
   }
   engine_dev_wrote(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
   set_streams_dev_wrote(set);
