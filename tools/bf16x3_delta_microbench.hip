@@ -40,6 +40,9 @@ constexpr int BM = 128, BN = 128, BK = 32; // block tile; two MFMA K steps per s
 #ifndef NOSTAGE
 #define NOSTAGE 0 // 1: timing only (wrong results): no fetch / split / LDS write / barrier in the loop
 #endif
+#ifndef XCD_MAP
+#define XCD_MAP 1
+#endif
 #ifndef KSPLIT_N
 #define KSPLIT_N 4
 #endif
@@ -84,7 +87,15 @@ __global__ __launch_bounds__(256) void k_delta_bf16x3(const float *__restrict__ 
   // one MFMA, rows contiguous -> fragment reads are lane-contiguous ds_read_b128
   __shared__ u32x4 sm[2][2][3][4][128];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // XCD-aware placement (workgroups go round-robin over the 8 XCDs): an XCD owns ONE K slab of
+  // half the row tiles and all column tiles, so its L2 sees 4 + 8 operand panels, not 32 + 4
+  static_assert(KSPLIT == 4, "the placement below is written for 8 x 8 tiles x 4 K slabs");
+  const int wg = blockIdx.x + 8 * blockIdx.y + 64 * blockIdx.z, xcd = wg & 7, slot = wg >> 3;
+#if XCD_MAP
+  const int kz = xcd >> 1, m0 = ((xcd & 1) * 4 + (slot >> 3)) * BM, n0 = (slot & 7) * BN;
+#else
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, kz = blockIdx.z;
+#endif
   // staging: waves 0-1 fetch and split X, waves 2-3 E; a thread owns 4 adjacent rows of one k group:
   // eight 16-byte loads (k = 0..7 of the group), each lane-contiguous over the rows
   const int op = tid >> 7, kg = (tid >> 5) & 3, rq = tid & 31;
@@ -200,6 +211,110 @@ __global__ __launch_bounds__(256) void k_delta_bf16x3(const float *__restrict__ 
       }
 }
 
+
+// ---- the same product with the split made ONCE by a producer pass ------------------------
+// Planes: P[term][k / 8][row][8] bf16 = 16-byte entries, exactly one lane's operand of one MFMA.
+__global__ __launch_bounds__(256) void k_split_planes(const float *__restrict__ src, int ld, int rows,
+                                                      int K, u32x4 *__restrict__ planes) {
+  const int row = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y; // k group
+  if (row >= rows) return;
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) x[j] = src[(size_t)(g * 8 + j) * ld + row + COL0];
+  u32x4 h, m, l;
+  split8(x, h, m, l);
+  const size_t plane = (size_t)(K / 8) * rows, at = (size_t)g * rows + row;
+  planes[at] = h;
+  planes[plane + at] = m;
+  planes[2 * plane + at] = l;
+}
+
+// the GEMM over the planes: per stage (K = 32) a workgroup copies 2 operands x 3 terms x 4 k groups
+// x 128 rows x 16 bytes = 48 KB global -> registers -> LDS (12 entries per thread, no arithmetic)
+__global__ __launch_bounds__(256) void k_delta_presplit(const u32x4 *__restrict__ PX,
+                                                        const u32x4 *__restrict__ PE,
+                                                        float *__restrict__ slab, int M, int N, int K,
+                                                        int kper) {
+  __shared__ u32x4 sm[2][2 * 3 * 4 * 128];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // XCD-aware placement (workgroups go round-robin over the 8 XCDs): an XCD owns ONE K slab of
+  // half the row tiles and all column tiles, so its L2 sees 4 + 8 operand panels, not 32 + 4
+  static_assert(KSPLIT == 4, "the placement below is written for 8 x 8 tiles x 4 K slabs");
+  const int wg = blockIdx.x + 8 * blockIdx.y + 64 * blockIdx.z, xcd = wg & 7, slot = wg >> 3;
+#if XCD_MAP
+  const int kz = xcd >> 1, m0 = ((xcd & 1) * 4 + (slot >> 3)) * BM, n0 = (slot & 7) * BN;
+#else
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, kz = blockIdx.z;
+#endif
+  const int wm = w >> 1, wn = w & 1, fr = lane & 31, fk = lane >> 5;
+  const size_t planeX = (size_t)(K / 8) * M, planeE = (size_t)(K / 8) * N;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+  const int nst = kper / BK;
+  u32x4 raw[12];
+  auto fetch = [&](int s) {
+    s = s < nst ? s : nst - 1;
+#pragma unroll
+    for (int e = 0; e < 12; e++) { // entry e * 256 + tid of the stage image [op][term][kg][row]
+      const int op = e / 6, t = (e >> 1) % 3, kg = (e & 1) * 2 + (tid >> 7), row = tid & 127;
+      const size_t g = (size_t)(kz * kper + s * BK) / 8 + kg;
+      raw[e] = op ? PE[t * planeE + g * N + n0 + row] : PX[t * planeX + g * M + m0 + row];
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 12; e++) sm[buf][e * 256 + tid] = raw[e];
+  };
+  fetch(0);
+  stage(0);
+  fetch(1);
+  __syncthreads();
+  for (int s = 0; s < nst; s++) {
+    const int buf = s & 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      u32x4 a[2][3], b[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          a[i][t] = sm[buf][((0 * 3 + t) * 4 + ks * 2 + fk) * 128 + wm * 64 + i * 32 + fr];
+          b[i][t] = sm[buf][((1 * 3 + t) * 4 + ks * 2 + fk) * 128 + wn * 64 + i * 32 + fr];
+        }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc[i][j] = mfma(a[i][1], b[j][1], acc[i][j]);
+          acc[i][j] = mfma(a[i][0], b[j][2], acc[i][j]);
+          acc[i][j] = mfma(a[i][2], b[j][0], acc[i][j]);
+          acc[i][j] = mfma(a[i][0], b[j][1], acc[i][j]);
+          acc[i][j] = mfma(a[i][1], b[j][0], acc[i][j]);
+          acc[i][j] = mfma(a[i][0], b[j][0], acc[i][j]);
+        }
+    }
+    stage(buf ^ 1);
+    fetch(s + 2);
+    __syncthreads();
+  }
+  float *out = slab + (size_t)kz * M * N;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fk;
+        int col = n0 + wn * 64 + j * 32 + fr;
+        out[(size_t)row * N + col] = acc[i][j][e];
+      }
+}
+
 static unsigned long long rs = 88172645463325252ull;
 static double urand() {
   rs ^= rs << 13;
@@ -209,26 +324,9 @@ static double urand() {
 }
 static double nrand() { return sqrt(-2.0 * log(urand() + 1e-300)) * cos(6.283185307179586 * urand()); }
 
-template <int NPROD>
-static void run(const char *name, const float *dX, int ldx, const float *dE, int lde, float *dS, int M,
-                int N, int K, const std::vector<float> &X, const std::vector<float> &E, int reps) {
-  dim3 grid(N / BN, M / BM, KSPLIT), block(256);
-  const int kper = K / KSPLIT;
-  if (kper % (2 * BK)) exit(2);
-  for (int i = 0; i < 20; i++)
-    hipLaunchKernelGGL(k_delta_bf16x3<NPROD>, grid, block, 0, 0, dX, ldx, dE, lde, dS, M, N, kper);
-  CHECK(hipGetLastError());
-  hipEvent_t e0, e1;
-  CHECK(hipEventCreate(&e0));
-  CHECK(hipEventCreate(&e1));
-  CHECK(hipEventRecord(e0, 0));
-  for (int i = 0; i < reps; i++)
-    hipLaunchKernelGGL(k_delta_bf16x3<NPROD>, grid, block, 0, 0, dX, ldx, dE, lde, dS, M, N, kper);
-  CHECK(hipEventRecord(e1, 0));
-  CHECK(hipEventSynchronize(e1));
-  float ms = 0;
-  CHECK(hipEventElapsedTime(&ms, e0, e1));
-  const double us = 1e3 * ms / reps, flop = 2.0 * M * N * K;
+static void report(const char *name, double us, const float *dS, int M, int N, int K, int ldx, int lde,
+                   const std::vector<float> &X, const std::vector<float> &E) {
+  const double flop = 2.0 * M * N * K;
   std::vector<float> S((size_t)KSPLIT * M * N);
   CHECK(hipMemcpy(S.data(), dS, S.size() * sizeof(float), hipMemcpyDeviceToHost));
   // error against fp64 on a sample of outputs, in units of eps32 * sum |x||e| (the scale of an
@@ -261,6 +359,62 @@ static void run(const char *name, const float *dX, int ldx, const float *dE, int
          sqrt(rms_c / n));
 }
 
+template <int NPROD>
+static void run(const char *name, const float *dX, int ldx, const float *dE, int lde, float *dS, int M,
+                int N, int K, const std::vector<float> &X, const std::vector<float> &E, int reps) {
+  dim3 grid(N / BN, M / BM, KSPLIT), block(256);
+  const int kper = K / KSPLIT;
+  if (kper % (2 * BK)) exit(2);
+  for (int i = 0; i < 20; i++)
+    hipLaunchKernelGGL(k_delta_bf16x3<NPROD>, grid, block, 0, 0, dX, ldx, dE, lde, dS, M, N, kper);
+  CHECK(hipGetLastError());
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  CHECK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; i++)
+    hipLaunchKernelGGL(k_delta_bf16x3<NPROD>, grid, block, 0, 0, dX, ldx, dE, lde, dS, M, N, kper);
+  CHECK(hipEventRecord(e1, 0));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  report(name, 1e3 * ms / reps, dS, M, N, K, ldx, lde, X, E);
+}
+
+static void run_presplit(const float *dX, int ldx, const float *dE, int lde, float *dS, int M, int N, int K,
+                         const std::vector<float> &X, const std::vector<float> &E, int reps) {
+  u32x4 *pX, *pE;
+  CHECK(hipMalloc(&pX, (size_t)3 * (K / 8) * M * 16));
+  CHECK(hipMalloc(&pE, (size_t)3 * (K / 8) * N * 16));
+  dim3 grid(N / BN, M / BM, KSPLIT), block(256), sgx(M / 256, K / 8), sge(N / 256, K / 8);
+  const int kper = K / KSPLIT;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  float ms = 0;
+  for (int pass = 0; pass < 2; pass++) { // 0: the split of both operands, 1: the GEMM
+    for (int i = 0; i < reps + 20; i++) {
+      if (i == 20) CHECK(hipEventRecord(e0, 0));
+      if (pass == 0) {
+        hipLaunchKernelGGL(k_split_planes, sgx, block, 0, 0, dX, ldx, M, K, pX);
+        hipLaunchKernelGGL(k_split_planes, sge, block, 0, 0, dE, lde, N, K, pE);
+      } else {
+        hipLaunchKernelGGL(k_delta_presplit, grid, block, 0, 0, pX, pE, dS, M, N, K, kper);
+      }
+    }
+    CHECK(hipGetLastError());
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (pass == 0)
+      printf("split of X and E into bf16 planes (stand-alone pass; in a product the producers' epilogues): %.2f us "
+             "(%.0f MB read, %.0f MB written)\n", 1e3 * ms / reps, (M + N) * (double)K * 4e-6, (M + N) * (double)K * 6e-6);
+  }
+  report("bf16x3 over pre-split planes", 1e3 * ms / reps, dS, M, N, K, ldx, lde, X, E);
+  CHECK(hipFree(pX));
+  CHECK(hipFree(pE));
+}
+
 int main() {
   // the north-star generation: hidden 1024, 256 streams, depth 20; rows padded as in the product
   const int M = 1024, N = 1024, K = 5120, ldx = 1068, lde = 1068;
@@ -278,5 +432,6 @@ int main() {
   run<6>("bf16x3, 6 products", dX, ldx, dE, lde, dS, M, N, K, X, E, 200);
   run<3>("bf16x2, 3 products", dX, ldx, dE, lde, dS, M, N, K, X, E, 200);
   run<1>("plain bf16, 1 product", dX, ldx, dE, lde, dS, M, N, K, X, E, 200);
+  run_presplit(dX, ldx, dE, lde, dS, M, N, K, X, E, 200);
   return 0;
 }
