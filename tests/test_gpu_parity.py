@@ -521,6 +521,10 @@ def test_full_size_generation_matches_oracle(amd, full_set):
                                              activation=rc.RESQRT)),
     ("wide_step_resqrt_1536_512_4", dict(input_size=42, hidden_size=1536, output_size=42, S=512, D=4,
                                          activation=rc.RESQRT)),
+    # far more streams than the north star: the one-launch chain in many windows, the delta GEMM over
+    # K = S * D = 24,576 and 6,144 rows (tools/gpu_large_sets.py goes on to 16,384 streams)
+    ("many_streams_256_4096_6", dict(input_size=42, hidden_size=256, output_size=42, S=4096, D=6)),
+    ("many_streams_1024_1536_4", dict(input_size=42, hidden_size=1024, output_size=42, S=1536, D=4)),
 ])
 def test_baseline_config_shapes_one_generation_matches_oracle(amd, label, kw):
     """BASELINE.json's other configurations at their full hidden / stream / depth sizes:
