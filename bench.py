@@ -416,8 +416,9 @@ def main():
             "bptt_chain_gemm": 2.0 * S * Hd * Hd * D,
             "delta_gemm": 2.0 * I * Hd * S * d_exec,
         }
-        per_gen_bytes = {  # algorithmic: W once per step, E in, X mask, E out / X, E, dW once
-            "bptt_chain_gemm": 4.0 * (Hd * Hd + 3 * S * Hd) * D,
+        per_gen_bytes = {  # algorithmic: W ONCE PER LAUNCH (it stays in registers) + per step E in, X mask,
+            # E out / X, E, dW once
+            "bptt_chain_gemm": 4.0 * (Hd * Hd + 3 * S * Hd * D),
             "delta_gemm": 4.0 * (2 * S * D * Hd + I * Hd),
         }
         dom = max(per_gen_flops, key=lambda k: cls[k][0])

@@ -362,7 +362,8 @@ void rnn_amd_host_written(RecurNN *net, int what);
  * others are its rnn_new_training_set() clones. */
 typedef struct RnnAmdSet RnnAmdSet;
 RnnAmdSet *rnn_amd_set_open(RecurNN **nets, int n_nets); /* (the array is copied: it need not outlive the call) */
-void rnn_amd_set_close(RnnAmdSet *set);
+void rnn_amd_set_close(RnnAmdSet *set); /* brings the host structs up to date first */
+void rnn_amd_set_drop(RnnAmdSet *set);  /* the same without the copy-back: state stays on the device */
 int rnn_amd_set_size(const RnnAmdSet *set);
 
 /* == rnn_bptt_advance() on every net of the set. */
@@ -479,6 +480,13 @@ void rnn_amd_set_read_stats(RnnAmdSet *set, RnnAmdStats *stats, int clear);
  * themselves) sum ih_delta||ho_delta over the ranks with ONE RCCL all-reduce on the
  * library's stream between the deltas and the update; rnn_amd_set_open shards the text
  * offsets as rnn_amd_set_shard(rank * n_nets, world * n_nets) unless told otherwise.
+ * COLLECTIVE BEHAVIOUR of host draws: on a net whose training set is sharded over the group
+ * (made by rnn_amd_new_training_set_shard with n_local != global_count, opened as a training set
+ * while the group is joined, or given a shard by rnn_amd_set_shard), rnn_weight_noise,
+ * rnn_perforate_weights and the random damage of rnn_condition_net draw from RANK 0's generator
+ * (a 32-byte broadcast) so that the replicas stay identical: EVERY rank must make that call on
+ * its replica.  Nets that are not part of a sharded set (validation / confabulation clone
+ * families of their own, side nets) are untouched by the group and draw locally.
  * All return 0 on success, -1 on failure (RCCL not loadable, bad arguments). */
 #define RNN_AMD_DIST_ID_BYTES 128
 int rnn_amd_dist_get_id(void *id);

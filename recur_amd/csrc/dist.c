@@ -186,9 +186,15 @@ void ramd_dist_bcast(void *host, size_t bytes, int root) {
  * (on the others nets[0]->rng is the generator of THEIR first stream).  Draws that every
  * replica has to make identically -- weight noise, perforation, the random damage of
  * rnn_condition_net -- therefore take rank 0's state: rank 0 draws from its own generator
- * (which advances, as in the reference), the others from a copy that is dropped. */
+ * (which advances, as in the reference), the others from a copy that is dropped.
+ *
+ * This is a COLLECTIVE (a 32-byte ncclBroadcast on the library's stream) and therefore only
+ * taken for nets whose engine hosts a shard of a distributed training set (RamdEngine.sharded):
+ * every rank of the group has to make the same call on its replica.  Any other net -- a
+ * validation or confabulation clone family of its own, a side net that only one rank touches --
+ * draws from its own generator as it does without a process group. */
 rand_ctx *ramd_shared_rng(RecurNN *net, rand_ctx *tmp) {
-  if (!g_comm || g_world < 2) {
+  if (!g_comm || g_world < 2 || !ramd_engine_of(net)->sharded) {
     return &net->rng;
   }
   *tmp = net->rng;

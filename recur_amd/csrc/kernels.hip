@@ -2658,7 +2658,12 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
          * issued (141-150); the two sub-chains on wave groups of their own with LDS counters
          * instead of barriers (195 us: a wave issuing f32 MFMAs back to back leaves its SIMD
          * partners neither vector-ALU issue nor timely store completion, at any s_setprio). */
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        /* vmcnt(2) is only right when exactly the two sum-of-squares stores are younger than the row
+         * stores.  In the PAD instantiation every store is conditional (s_and_saveexec + branch): a
+         * wave straddling the set's boundary issues fewer, and "all but the two youngest" would then
+         * let a row store stay in flight behind the flag -- there the wave drains completely. */
+        if (PAD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         if (lane == 0) *(volatile unsigned *)&sy->flags[g][xf][wv][j] = epoch0 + (unsigned)t + 1u;
         PC_STAMP(0, k, 3);
       }
@@ -4458,6 +4463,13 @@ static ChainSync *g_chain_sync = nullptr;
 static unsigned *g_chain_abort_host = nullptr, *g_chain_abort_dev = nullptr;
 static unsigned g_chain_seq = 0;
 static int g_chain_cus = -1;
+/* The first one-launch chain of a process is checked synchronously: where its 256 workgroups cannot all be
+ * resident (a CU-masked queue, a partition mode that still reports 256 CUs, a co-tenant holding CUs) it
+ * raises the abort word; the launcher then resets it, stops using the kernel for the rest of the process
+ * and the caller runs the launch-per-step chain for that very call (the one-launch chain reads error plane
+ * 0 and writes planes >= 1 only, so its input is intact).  Later give-ups -- a co-tenant that arrives in
+ * mid-run -- are still caught at the next synchronisation (rnn_core.c: dsync), where nothing can be redone. */
+static bool g_chain_validated = false, g_chain_broken = false;
 
 #ifdef PC_STAMPS
 extern "C" void ramd_chain_stamps(unsigned long long *out) {
@@ -4473,7 +4485,7 @@ extern "C" unsigned ramd_chain_abort_word(void) {
 static bool chain_persist_ok(const RamdShape *sh, const RamdBuffers *b, int nrows) {
   const int hs = sh->hidden_size;
   if (b->uniform_idx < 0 || (hs != 1024 && hs != 512 && hs != 256) || nrows < 1 || nrows % 16 != 0 ||
-      sh->D > 60 || !env_int("RECUR_AMD_CHAIN_PERSIST", 1))
+      sh->D > 60 || g_chain_broken || !env_int("RECUR_AMD_CHAIN_PERSIST", 1))
     return false;
   if (g_chain_cus < 0) {
     int dev = 0;
@@ -4522,7 +4534,7 @@ static bool chain_persist_one(const RamdShape *sh, int nrows) {
 }
 static int chain_persist_rows(const RamdShape *sh, bool one) { return chain_persist_seats(sh) * (one ? 16 : 32); }
 
-static void launch_chain_persist(hipStream_t st, const View *d_view, const RamdShape *sh,
+static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdShape *sh,
                                  const RamdBuffers *b, int row0, int nrows, bool one, int nvalid, int vlo = 0) {
   if (!g_chain_sync) {
     HIP_CHECK(hipMalloc(&g_chain_sync, sizeof(ChainSync)));
@@ -4544,6 +4556,22 @@ static void launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
   else CHAIN_PERSIST(1);
 #undef CHAIN_PERSIST
   timing_end(st, ev);
+  if (!g_chain_validated) {
+    HIP_CHECK(hipStreamSynchronize(st));
+    /* (RECUR_AMD_CHAIN_TEST_GIVEUP=1: the tests' way of taking this branch on a healthy device) */
+    if (*(volatile unsigned *)g_chain_abort_host || env_int("RECUR_AMD_CHAIN_TEST_GIVEUP", 0)) {
+      fprintf(stderr, "librecur_amd: the one-launch BPTT chain gave up on its first launch (code %u: its 256 "
+                      "workgroups were not all resident, one per CU); using the launch-per-step chain from here on\n",
+              *(volatile unsigned *)g_chain_abort_host);
+      *(volatile unsigned *)g_chain_abort_host = 0;
+      HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
+      g_chain_seq = 0;
+      g_chain_broken = true;
+      return false;
+    }
+    g_chain_validated = true;
+  }
+  return true;
 }
 
 /* assemble + hidden layer in one launch for the text step (k_fwd_fused); returns what
@@ -4903,11 +4931,12 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     const int span_base = row0 & ~15, span = ((row0 + nrows + 15) & ~15) - span_base;
     const bool windowed = span_base != row0 && span_base + span <= sh->Scap && chain_persist_ok(sh, b, span) &&
                           span / 16 <= chain_persist_seats(sh);
+    bool windowed_done = false;
     if (windowed) {
-      launch_chain_persist(st, d_view, sh, b, span_base, span, true, row0 - span_base + nrows, row0 - span_base);
+      windowed_done = launch_chain_persist(st, d_view, sh, b, span_base, span, true, row0 - span_base + nrows, row0 - span_base);
     }
-    const bool persist = windowed || chain_persist_ok(sh, b, chain_rows);
-    if (persist && !windowed) { /* as many row tiles per launch as there are seats; more streams: more launches */
+    bool persist = windowed_done || chain_persist_ok(sh, b, chain_rows);
+    if (persist && !windowed_done) { /* as many row tiles per launch as there are seats; more streams: more launches */
       /* (an odd number of 16-stream tiles beyond one launch: 32-stream tiles, the last 16 streams alone) */
       for (int r = 0; r < chain_rows;) {
         const int left = chain_rows - r, real_left = nrows - r;
@@ -4922,7 +4951,10 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
           n = chain_persist_rows(sh, true);
           if (n > left) n = left;
         }
-        launch_chain_persist(st, d_view, sh, b, row0 + r, n, one, real_left < n ? real_left : n);
+        if (!launch_chain_persist(st, d_view, sh, b, row0 + r, n, one, real_left < n ? real_left : n)) {
+          persist = false; /* (only a process's first launch can fail here: r == 0, nothing done yet) */
+          break;
+        }
         r += n;
       }
     }

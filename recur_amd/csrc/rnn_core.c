@@ -367,6 +367,11 @@ static void engine_delete(RamdEngine *e) {
     dsync();
   }
   engine_free_device(e);
+  if (e->spec_go) { /* noise_speculate's hand-over events */
+    HIP_OK(hipEventDestroy((hipEvent_t)e->spec_go));
+    HIP_OK(hipEventDestroy((hipEvent_t)e->spec_done));
+    e->spec_go = e->spec_done = NULL;
+  }
   /* clones may outlive the net that owns the weights (text-predict.c:654-656 deletes the
    * training set, then its confab and validation clones): detach them so that their own
    * rnn_delete_net finds no engine instead of a freed one */
@@ -1216,6 +1221,9 @@ RecurNN **rnn_amd_new_training_set_shard(RecurNN *prototype, int n_local, int gl
      * prototype's (which belongs to global stream 0 on rank 0; see ramd_shared_rng) */
     ramd_init_rand64_maybe_randomly(&prototype->rng, first_seed);
   }
+  if (ramd_priv(prototype)->eng && n_local != global_count) {
+    ramd_priv(prototype)->eng->sharded = 1;
+  }
   return nets;
 }
 
@@ -1457,6 +1465,11 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
   engine_ensure_device(e);
   const RamdShape *s = &e->sh;
   int j = p->stream;
+  if (fused) {
+    /* rnn_bptt_calculate never writes ho_delta: after rnn_bptt_clear_deltas the reference has
+     * zeros there (recur-nn.c:681-693), so the pending clear is carried out, not dropped */
+    deltas_materialize(e);
+  }
   if (e->deltas_zero_pending) { /* the sum into zeros is the sum */
     accumulate = 0;
     e->deltas_zero_pending = 0;
@@ -1841,6 +1854,7 @@ RnnAmdSet *rnn_amd_set_open(RecurNN **nets, int n_nets) {
   if (ramd_dist_active() && !fwd_only) { /* rank r holds global streams [r n, (r + 1) n) */
     set->global_first = rnn_amd_dist_rank() * n_nets;
     set->global_count = rnn_amd_dist_world() * n_nets;
+    e->sharded = 1;
   }
   return set;
 }
@@ -1850,6 +1864,15 @@ void rnn_amd_set_close(RnnAmdSet *set) {
     return;
   }
   ramd_need_host(set->nets[0], RNN_AMD_EVERYTHING);
+  free(set->nets);
+  free(set);
+}
+
+/* the same without fetching anything: the streams' state stays current on the device only */
+void rnn_amd_set_drop(RnnAmdSet *set) {
+  if (!set) {
+    return;
+  }
   free(set->nets);
   free(set);
 }
@@ -1864,7 +1887,7 @@ void rnn_amd_set_shard(RnnAmdSet *set, int global_first, int global_count) {
   }
   set->global_first = global_first;
   set->global_count = global_count;
-  set->shard_set = 1;
+  set->eng->sharded = global_count != set->n;
 }
 
 void rnn_amd_set_dist_all_reduce_deltas(RnnAmdSet *set) {
@@ -2434,10 +2457,7 @@ void rnn_amd_set_char_step_fused(RnnAmdSet *set, int i, unsigned batch_size) {
     ramd_launch_softmax_error(g_stream, s, &e->b, j, 1);
   }
   int accumulate = batched;
-  if (e->deltas_zero_pending) {
-    accumulate = 0;
-    e->deltas_zero_pending = 0;
-  }
+  deltas_materialize(e); /* a pending rnn_bptt_clear_deltas: this path never writes ho_delta (see calc_deltas_one) */
   engine_need_dev(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
   push_learn_rates(e, j, 1);
   if (e->err_pending && (e->err_row0 != j || e->err_nrows != 1)) {

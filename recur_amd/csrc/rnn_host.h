@@ -70,6 +70,11 @@ typedef struct RamdEngine {
   float spec_dev;
   void *spec_go, *spec_done; /* hipEvent_t */
   int scalars_dev_valid; /* device mef/ih_scale newer than the host structs */
+  /* this engine hosts ONE SHARD of a training set spread over the ranks of the process group
+   * (rnn_amd_new_training_set_shard, rnn_amd_set_shard, or a training set opened after
+   * rnn_amd_dist_init): only then are the replicated host draws (weight noise, perforation,
+   * random damage) a collective that takes rank 0's generator (ramd_shared_rng) */
+  int sharded;
 } RamdEngine;
 
 struct RnnAmdSet {
@@ -79,7 +84,6 @@ struct RnnAmdSet {
   int row0;     /* first training-stream row, or first forward-only index when fwd_only */
   int fwd_only; /* the set is made of forward-only clones (no bptt): opinion calls only */
   int global_first, global_count;
-  int shard_set; /* rnn_amd_set_shard was called: do not derive the shard from the rank */
 };
 
 static inline RamdPriv *ramd_priv(const RecurNN *net) {

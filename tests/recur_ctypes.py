@@ -222,6 +222,7 @@ AMD_API = {
     "rnn_amd_host_written": (None, [NetP, C.c_int]),
     "rnn_amd_set_open": (C.c_void_p, [C.POINTER(NetP), C.c_int]),
     "rnn_amd_set_close": (None, [C.c_void_p]),
+    "rnn_amd_set_drop": (None, [C.c_void_p]),
     "rnn_amd_set_size": (C.c_int, [C.c_void_p]),
     "rnn_amd_set_advance": (None, [C.c_void_p]),
     "rnn_amd_set_opinion": (None, [C.c_void_p, c_float_p, C.c_int, c_float_p]),

@@ -4,9 +4,10 @@
 
     python tools/pmc_mfma_lds.py <dir of the MFMA pass> <dir of the LDS pass> > profiles/rNN_pmc_mfma_lds_per_kernel.txt
 
-MFMA pass: SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE  (MfmaUtil = busy / (active x 4 SIMDs x 256 CUs),
-rocprofv3's own derived-metric definition); GRBM_GUI_ACTIVE / kernel duration = the clock
-the kernel ran at.  LDS pass: SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE (conflict cycles per
+MFMA pass: SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE.  rocprofv3 reports GRBM_GUI_ACTIVE as the SUM over
+the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back), so cycles = GRBM_GUI_ACTIVE / 8; GHz = cycles / kernel
+duration = the clock the kernel ran at; MfmaUtil = busy / (cycles x 4 SIMDs x 256 CUs) = the share of
+SIMD-cycles with the matrix pipe busy.  LDS pass: SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE (conflict cycles per
 active LDS cycle).
 """
 import csv
@@ -31,6 +32,9 @@ def load(d):
     return acc, dur
 
 
+XCDS = 8  # GRBM_GUI_ACTIVE comes summed over the XCDs
+
+
 def avg(a):
     return a[1] / max(a[0], 1)
 
@@ -40,12 +44,12 @@ def main():
     l, _ = load(sys.argv[2])
     print("# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, and in a separate pass")
     print("# --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE; averages per launch")
-    print("%-56s %8s %9s %12s %9s %9s %12s" % ("kernel", "launches", "avg_us", "gui_active", "GHz", "MfmaUtil%", "LDS_conflict"))
+    print("%-56s %8s %9s %12s %9s %9s %12s" % ("kernel", "launches", "avg_us", "cycles", "GHz", "MfmaUtil%", "LDS_conflict"))
     rows = []
     for k, c in m.items():
         if "GRBM_GUI_ACTIVE" not in c:
             continue
-        act = avg(c["GRBM_GUI_ACTIVE"])
+        act = avg(c["GRBM_GUI_ACTIVE"]) / XCDS
         busy = avg(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [1, 0.0]))
         us = avg(mdur[k]) / 1e3 if k in mdur else 0.0
         lc = l.get(k, {})
