@@ -14,6 +14,8 @@
 // the per-stream control logic are plain VALU kernels.
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <utility>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -2459,19 +2461,46 @@ __global__ __launch_bounds__(512) void k_fwd_wide(const View *__restrict__ vp, i
 constexpr int PC_SUB = 16;                  /* streams per sub-chain                */
 constexpr int PC_RED_FLOATS = 4 * PC_SUB * 32;
 constexpr int pc_lds_bytes(int K) { return (2 * PC_SUB * K + 2 * PC_RED_FLOATS) * 4 + 64; }
+/* s_sleep units (64 cycles) between the barrier and the first poll; the producers publish ~0.35 us after
+ * the barrier and the flag is visible in the XCD's L2 ~0.2 us later.  Round 3 (20 steps of 1024 / 256,
+ * us per chain): first poll after 16 / 18 / 22 / 24 / 26 / 32 units with gaps from K block 3 on =
+ * 114 / 105 / 100.6 / 100.7 / 101.3 / 105. */
 #ifndef PC_SLEEP0
-#define PC_SLEEP0 56
+#define PC_SLEEP0 22
 #endif
 #ifndef PC_SLEEP1
-#define PC_SLEEP1 8
+#define PC_SLEEP1 1
 #endif
 #ifndef PC_SLEEP0_ONE
-#define PC_SLEEP0_ONE 32 /* 16-stream row tiles: the producers publish ~1 us after the barrier the poll starts at */
+#define PC_SLEEP0_ONE 12 /* 16-stream row tiles: the publish comes in an otherwise empty half-step */
 #endif
 #ifndef PC_SLEEP0_SMALL
-#define PC_SLEEP0_SMALL 36 /* hidden 512 / 256: the half-step is shorter, the publish comes at the same ~1 us */
+#define PC_SLEEP0_SMALL 14 /* hidden 512 / 256: the half-step is shorter, the publish comes at the same ~0.35 us */
 #endif
 constexpr unsigned PC_EPOCH = 64;           /* flag values per launch (depth <= 60)  */
+#ifndef PC_POLL_SCALAR
+#define PC_POLL_SCALAR 0
+#endif
+/* K blocks (8 MFMAs each) after which the multiplying waves pause for 64 cycles, per hidden size:
+ * measured at 1024: after blocks 3-6 100.6 us per chain, 3-7 100.8, 4-7 100.7, 3-8 100.9, 2-6 105.5,
+ * 2-9 104.6, every block from 3 on 109.9, blocks 5 / 7 / 9 / 11 103.6-105.1, none (the poll then
+ * completes when the burst has ended) 133. */
+#ifndef PC_GAPS
+#define PC_GAPS (PC_POLL_SCALAR ? 0x0 : 0x78)
+#endif
+#ifndef PC_GAPS_512
+#define PC_GAPS_512 (PC_POLL_SCALAR ? 0x0 : 0x3c)
+#endif
+#ifndef PC_GAPS_256
+#define PC_GAPS_256 (PC_POLL_SCALAR ? 0x0 : 0xe)
+#endif
+#ifndef PC_FETCH_PRIO
+#define PC_FETCH_PRIO 0
+#endif
+#ifndef PC_GAP_NOPS
+#define PC_GAP_NOPS 0
+#endif
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
 
 // one LDS-DMA piece (64 lanes x 16 bytes, L1 bypassed) with a wave-uniform global base, a
 // per-lane byte offset and a wave-uniform LDS destination: no vector-ALU instruction at all
@@ -2494,6 +2523,38 @@ __device__ __forceinline__ void lds_dma4(const void *sbase, unsigned voff, uint3
                :
                : "v"(voff), "s"(sbase), "s"(lds_addr)
                : "memory");
+}
+
+// --- inline-asm memory helpers of the one-launch chain.  hipcc neither sees nor waits for these
+// accesses: every use is followed by an explicit s_waitcnt that names the registers it protects.
+__device__ __forceinline__ void g_store_saddr(unsigned voff, float val, const void *sbase) {
+  asm volatile("global_store_dword %0, %1, %2" : : "v"(voff), "v"(val), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ float g_load_saddr(unsigned voff, const void *sbase) {
+  float r;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  return r;
+}
+template <int OFF> __device__ __forceinline__ f32x4 lds_read_b128_off(uint32_t addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF> __device__ __forceinline__ float lds_read_b32_off(uint32_t addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+/* wait until at most N LDS operations issued after `v`'s read are outstanding (they return in order) */
+template <int N> __device__ __forceinline__ void lgkm_wait(f32x4 &v) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
 struct ChainSync {
@@ -2552,10 +2613,11 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     wg_info[1] = t;
   }
   __syncthreads();
-  const unsigned seat = wg_info[1];
+  /* (wave-uniform by construction: say so, or every address built from them goes through the vector ALU) */
+  const unsigned seat = __builtin_amdgcn_readfirstlane(wg_info[1]);
   /* row tile = XCD + 8 x (seat / column tiles): the first 8 row tiles spread over the 8 XCDs
    * before any XCD takes a second one; column tile = seat % column tiles */
-  const int g = (int)wg_info[0] + 8 * (int)(seat / NT);
+  const int g = __builtin_amdgcn_readfirstlane((int)wg_info[0]) + 8 * (int)(seat / NT);
   if (seat >= 32u) { /* cannot happen with one workgroup per CU on a 256-CU part */
     if (threadIdx.x == 0) {
       __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2575,11 +2637,29 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     // ============================================ multiply, finish, publish
     // Waves 4-7, one per SIMD.  Wave wv multiplies the K quarter wv of BOTH 16 x 16 tiles of
     // every half-step and, after the barrier, finishes rows 4 wv .. 4 wv + 3 of the tile
-    // pair: the four K quarters summed from LDS, the zero-row mask, the RESQRT derivative,
-    // the sum of squares, the store, and -- once the stores have drained, a few MFMAs into
-    // the next half-step -- the flag that the 32 consumers of those rows poll.  (The f32
-    // MFMA runs on the SIMD's vector ALU at the vector rate: a partner wave's VALU work does
-    // not overlap with it, so the epilogue belongs in the wave that owns the ALU.)
+    // pair: the four K quarters summed from LDS, the zero-row mask, the RESQRT derivative, the
+    // store, and -- once the stores have drained -- the flag that the 32 consumers of those rows
+    // poll.  (The f32 MFMA runs on the SIMD's vector ALU at the vector rate: a partner wave's VALU
+    // work does not overlap with it, so the epilogue belongs in the wave that owns the ALU.)
+    //
+    // Round 3: everything between the barrier and the flag is on the critical path of all 32
+    // consumers, so it is written instruction by instruction:
+    //   * the row stores, the gate loads and the flag go through an SGPR base + a launch-invariant
+    //     per-lane byte offset (inline asm, `global_*` with saddr): no 64-bit address arithmetic,
+    //     no register arrays indexed by the sub-chain (hipcc had turned those into a dozen
+    //     v_cndmask per store and FLAT stores);
+    //   * the flag is a PLAIN store (it stays in this XCD's L2, where the consumers' L1-bypassing
+    //     polls find it).  As a `volatile` store hipcc made it `sc0 sc1` and put an
+    //     `s_waitcnt vmcnt(0)` BEHIND it (SIMemoryLegalizer's rule for volatile accesses): every
+    //     half-step waited a second time, for the flag's own acknowledgement, before its MFMAs;
+    //   * the sum of squares of each error row (recur-nn.c:371) is no longer taken here (two
+    //     multiplies, ten LDS-crossbar shuffles in five dependent round trips and two more stores
+    //     in front of the drain): k_extras_control holds every error row in registers anyway and
+    //     sums it there (tn = 0 in its arguments);
+    //   * the A fragments come from LDS by inline-asm ds_read_b128 three K blocks ahead of the
+    //     MFMAs that use them, with counted lgkmcnt waits (hipcc's own schedule had half of the
+    //     sixteen reads directly in front of their first MFMA: 60-100 cycles of idle matrix pipe
+    //     each), the first three before the finish, whose drain covers their latency.
     const int wv = __builtin_amdgcn_readfirstlane(wave8) - 4, m = lane & 15, kq = lane >> 4;
     const int col = lane & 31, rh = lane >> 5;
     float wreg[KB][4][2];
@@ -2591,95 +2671,112 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
         for (int i = 0; i < 4; i++)
 #pragma unroll
           for (int h = 0; h < 2; h++) wreg[u][i][h] = wb[(size_t)16 * h * s.H + 16 * u + i];
+      /* The panel has to have LANDED before the loop, as far as hipcc can tell: otherwise it puts the
+       * `s_waitcnt vmcnt(0)` for these loads in front of the loop's first MFMA, where it waits in EVERY
+       * half-step for the gate loads issued just before (inline asm, not on its scoreboard).  An empty
+       * asm that reads the registers makes it wait here. */
+#pragma unroll
+      for (int u = 0; u < KB; u++)
+        asm volatile("" : : "v"(wreg[u][0][0]), "v"(wreg[u][0][1]), "v"(wreg[u][1][0]), "v"(wreg[u][1][1]),
+                     "v"(wreg[u][2][0]), "v"(wreg[u][2][1]), "v"(wreg[u][3][0]), "v"(wreg[u][3][1]));
     }
     // this thread's two outputs per half-step: rows 4 wv + rh and + 2 of the sub-chain, column
-    // n0 + col; per sub-chain x the global row, whether it exists, where its gate values and
-    // its outputs live (step 0 / plane 1; both move by a fixed stride per step)
-    int srow[2][2]; /* (whole row tiles only: the launcher sees to it) */
-    float *out_p[2][2];
-    float *esum_p[2][2];
+    // n0 + col.  Byte offset of (row, column) within a plane of [Scap][I] floats, relative to
+    // the sub-chain's first row: the same for the error planes and the history slots.
+    unsigned voff[2];
+    bool mine[2][2]; /* PAD: is the row one of the set's own */
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      voff[q] = (unsigned)(((size_t)(4 * wv + rh + 2 * q) * s.I + n0 + col) * sizeof(float));
+#pragma unroll
+      for (int x = 0; x < 2; x++) {
+        const int sr = m0 + PC_SUB * x + 4 * wv + rh + 2 * q;
+        mine[x][q] = !PAD || (sr >= vlo && sr < nvalid);
+      }
+    }
+    const float *ehi_sub = v.b.ehi + (size_t)(row0 + m0) * s.I; /* plane 0, sub-chain a, row 0 */
+    // LDS addresses.  A fragment of K block u: chunk ((K / 16) wv + 4 u + kq) ^ m of row m; the
+    // xor only touches the low four bits, i.e. (4 (u & 3) + kq) ^ m: four per-lane addresses per
+    // sub-chain, the rest of u is an immediate offset.
+    uint32_t a_addr[2][4];
 #pragma unroll
     for (int x = 0; x < 2; x++)
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
-        srow[x][q] = m0 + PC_SUB * x + 4 * wv + rh + 2 * q;
-        out_p[x][q] = v.b.ehi + plane_stride + (size_t)(row0 + srow[x][q]) * s.I + n0 + col;
-        esum_p[x][q] = v.b.esum_part + (size_t)j * s.Scap + row0 + srow[x][q];
-      }
-    auto gates = [&](int k, float (&xg)[2]) { /* X[t][row][n0 + col], t = k >> 1 */
-      const int x = k & 1, t = k >> 1;
-#pragma unroll
-      for (int q = 0; q < 2; q++) xg[q] = input_row<true>(v, row0 + srow[x][q], t)[n0 + col];
-    };
-    float xg[2] = {0.f, 0.f};
+      for (int i = 0; i < 4; i++)
+        a_addr[x][i] = lds_byte_addr(abuf + x * BUF + m * K) + 16u * (uint32_t)((K / 16) * wv + ((4 * i + kq) ^ m));
+    const uint32_t red_rd = lds_byte_addr(red) + 4u * (uint32_t)((4 * wv + rh) * 32 + col);
+    float xg0 = 0.f, xg1 = 0.f;
+    f32x4 af[4];
     __syncthreads(); /* barrier 0: both operands of the first two half-steps have landed */
-    for (int k = 0; k <= halfsteps; k++) {
-      const int x = k & 1;
+
+    // one half-step; XC: which sub-chain it MULTIPLIES (it finishes the other one's previous half-step)
+    auto half = [&](auto XC, const int k) -> bool {
+      constexpr int x = decltype(XC)::value, xf = x ^ 1;
+      const bool multiplies = k < halfsteps && !(ONE && x == 1);
       PC_STAMP(0, k, 0);
+      if (multiplies) { /* the first fragments: their latency hides under the finish */
+        af[0] = lds_read_b128_off<0>(a_addr[x][0]);
+        if (KB > 1) af[1] = lds_read_b128_off<0>(a_addr[x][1]);
+        if (KB > 2) af[2] = lds_read_b128_off<0>(a_addr[x][2]);
+      }
       if (k >= 1 && !(ONE && x == 0)) {
-        // ---- finish half-step k - 1 (sub-chain x ^ 1, step (k - 1) >> 1)
-        const int xf = x ^ 1, t = (k - 1) >> 1;
-        const float *rd = red + xf * PC_RED_FLOATS;
-        float sq[2];
+        // ---- finish half-step k - 1 (sub-chain xf, step (k - 1) >> 1)
+        const int t = (k - 1) >> 1;
+        float ev[2];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xg0), "+v"(xg1)); /* the gate loads of the last half-step */
+        {
+          const uint32_t ra = red_rd + 4u * (uint32_t)(xf * PC_RED_FLOATS);
+          float p[2][4];
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            p[q][0] = q ? lds_read_b32_off<256 + 0 * 2048>(ra) : lds_read_b32_off<0 * 2048>(ra);
+            p[q][1] = q ? lds_read_b32_off<256 + 1 * 2048>(ra) : lds_read_b32_off<1 * 2048>(ra);
+            p[q][2] = q ? lds_read_b32_off<256 + 2 * 2048>(ra) : lds_read_b32_off<2 * 2048>(ra);
+            p[q][3] = q ? lds_read_b32_off<256 + 3 * 2048>(ra) : lds_read_b32_off<3 * 2048>(ra);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(p[0][0]), "+v"(p[0][1]), "+v"(p[0][2]), "+v"(p[0][3]), "+v"(p[1][0]), "+v"(p[1][1]),
+                         "+v"(p[1][2]), "+v"(p[1][3]));
+          ev[0] = (p[0][0] + p[0][1]) + (p[0][2] + p[0][3]);
+          ev[1] = (p[1][0] + p[1][1]) + (p[1][2] + p[1][3]);
+        }
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-          const int r = 4 * wv + rh + 2 * q;
-          const float p0 = rd[(0 * PC_SUB + r) * 32 + col], p1 = rd[(1 * PC_SUB + r) * 32 + col];
-          const float p2 = rd[(2 * PC_SUB + r) * 32 + col], p3 = rd[(3 * PC_SUB + r) * 32 + col];
-          float ev = (p0 + p1) + (p2 + p3);
-          const float xi = xg[q];
+          const float xi = q ? xg1 : xg0;
           const bool on = xi != 0.0f && (ACT != 5 || xi < 20.0f);
-          ev = on ? ev : 0.0f;
-          if (on && ACT == 2) ev /= 2 * (xi + 1.0f);
-          if (!PAD || (srow[xf][q] >= vlo && srow[xf][q] < nvalid)) out_p[xf][q][(size_t)t * plane_stride] = ev;
-          sq[q] = ev * ev;
+          ev[q] = on ? ev[q] : 0.0f;
+          if (ACT == 2) ev[q] = on ? ev[q] / (2 * (xi + 1.0f)) : 0.0f;
         }
-        /* (xor shuffles through the LDS crossbar: measured 3.7 us per chain faster than a DPP
-         * reduction, whose ten extra vector-ALU instructions come out of this wave's MFMA time) */
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-          sq[0] += __shfl_xor(sq[0], off, 64);
-          sq[1] += __shfl_xor(sq[1], off, 64);
-        }
-        if (col == 0) {
-#pragma unroll
-          for (int q = 0; q < 2; q++)
-            if (!PAD || (srow[xf][q] >= vlo && srow[xf][q] < nvalid)) esum_p[xf][q][(size_t)t * (tn + 1) * s.Scap] = sq[q];
-        }
+        const float *obase = ehi_sub + (size_t)(t + 1) * plane_stride + (size_t)xf * PC_SUB * s.I;
+        if (mine[xf][0]) g_store_saddr(voff[0], ev[0], obase);
+        if (mine[xf][1]) g_store_saddr(voff[1], ev[1], obase);
         PC_STAMP(0, k, 2);
-        /* (the two sum-of-squares stores above are the wave's youngest memory operations and
-         * nobody in this launch reads them: the wait below leaves them in flight)
-         * Drain and publish BEFORE the next MFMAs, with the vector ALU idle (0.45 us).  Every
-         * way of hiding this wait under the multiply was slower: stores of this wave issued
-         * ahead of its MFMAs and waited for 8 / 16 / 48 MFMAs later (135 / 136 / 147 us per
-         * chain against 135); the finished tile handed through LDS to the fetching waves,
-         * which store, drain and publish beside the MFMAs (150-155 us: their stores are
-         * acknowledged ~2 us late), also with the multiply held back until those stores were
-         * issued (141-150); the two sub-chains on wave groups of their own with LDS counters
-         * instead of barriers (195 us: a wave issuing f32 MFMAs back to back leaves its SIMD
-         * partners neither vector-ALU issue nor timely store completion, at any s_setprio). */
-        /* vmcnt(2) is only right when exactly the two sum-of-squares stores are younger than the row
-         * stores.  In the PAD instantiation every store is conditional (s_and_saveexec + branch): a
-         * wave straddling the set's boundary issues fewer, and "all but the two youngest" would then
-         * let a row store stay in flight behind the flag -- there the wave drains completely. */
-        if (PAD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        if (lane == 0) *(volatile unsigned *)&sy->flags[g][xf][wv][j] = epoch0 + (unsigned)t + 1u;
+        /* Drain and publish BEFORE the next MFMAs, with the vector ALU idle.  Every way of hiding
+         * this wait under the multiply was slower (round 2: stores waited for 8 / 16 / 48 MFMAs
+         * later 135 / 136 / 147 us per chain against 135; the finished tile handed through LDS to
+         * the fetching waves 150-155 us; wave groups of their own per sub-chain 195 us): beside a
+         * wave that issues f32 MFMAs back to back a store's acknowledgement comes 1-4 us late. */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) g_store_saddr(0u, __uint_as_float(epoch0 + (unsigned)t + 1u), &sy->flags[g][xf][wv][j]);
         PC_STAMP(0, k, 3);
       }
-      if (k == halfsteps) { /* nothing left to multiply: drain and publish (nobody polls it) */
-        break;
-      }
-      if (ONE && x == 1) { /* sub-chain b does not exist: an empty half-step */
+      if (k == halfsteps) return false; /* nothing left to multiply (nobody polls the last flag) */
+      if (!multiplies) {                /* ONE: sub-chain b does not exist, an empty half-step */
         __syncthreads();
-        continue;
+        return true;
       }
-      const float *arow = abuf + x * BUF + m * K;
+      { /* the gate values X[t][row][n0 + col] for the finish of THIS half-step, one barrier from now */
+        const float *gbase = input_row<true>(v, row0 + m0 + PC_SUB * x, k >> 1);
+        xg0 = g_load_saddr(voff[0], gbase);
+        xg1 = g_load_saddr(voff[1], gbase);
+      }
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < KB; u++) {
-        const int c = ((K / 16) * wv + 4 * u + kq) ^ m;
-        const float4 a = *reinterpret_cast<const float4 *>(arow + 4 * c);
+      static_for<KB>([&](auto UC) {
+        constexpr int u = decltype(UC)::value;
+        constexpr int ahead = KB - 1 - u < 2 ? KB - 1 - u : 2; /* reads issued after this block's */
+        lgkm_wait<ahead>(af[u & 3]);
+        if (u + 3 < KB) af[(u + 3) & 3] = lds_read_b128_off<((u + 3) >> 2) * 256>(a_addr[x][(u + 3) & 3]);
+        const f32x4 a = af[u & 3];
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wreg[u][0][0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wreg[u][0][1], acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wreg[u][1][0], acc0, 0, 0, 0);
@@ -2688,22 +2785,37 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wreg[u][2][1], acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wreg[u][3][0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wreg[u][3][1], acc1, 0, 0, 0);
-        if (u == 0) {
+        /* a short pause of the MFMA stream (64 cycles asleep = the last MFMA's 32 + 32 with the vector ALU
+         * free): the fetching wave's one v_cmp per poll gets through here and nowhere else */
+        if (((K == 1024 ? PC_GAPS : K == 512 ? PC_GAPS_512 : PC_GAPS_256) >> u) & 1) {
           __builtin_amdgcn_sched_barrier(0);
-          gates(k, xg); /* for the finish of THIS half-step, one barrier from now */
+#if PC_GAP_NOPS
+          asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#else
+          __builtin_amdgcn_s_sleep(1);
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
-      }
+      });
       /* this wave's K quarter of the 16 x 32 tile: register r of the accumulator is row
        * 4 (lane >> 4) + r, column lane & 15 (+ 16 for the second accumulator) */
-      float *rdw = red + x * PC_RED_FLOATS + wv * (PC_SUB * 32);
+      /* (plain stores: hipcc knows how many wait states an MFMA result needs before an LDS write may
+       * read it -- an inline-asm ds_write directly behind the last MFMA read the OLD accumulator) */
+      {
+        float *rdw = red + x * PC_RED_FLOATS + wv * (PC_SUB * 32);
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        rdw[(4 * kq + r) * 32 + m] = acc0[r];
-        rdw[(4 * kq + r) * 32 + 16 + m] = acc1[r];
+        for (int r = 0; r < 4; r++) {
+          rdw[(4 * kq + r) * 32 + m] = acc0[r];
+          rdw[(4 * kq + r) * 32 + 16 + m] = acc1[r];
+        }
       }
       PC_STAMP(0, k, 1);
       __syncthreads(); /* barrier k + 1 */
+      return true;
+    };
+    for (int k = 0;; k += 2) {
+      if (!half(std::integral_constant<int, 0>{}, k)) break;
+      if (!half(std::integral_constant<int, 1>{}, k + 1)) break;
     }
     return;
   }
@@ -2739,29 +2851,50 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     for (int i = 0; i < 4 * PPR; i++)
       lds_dma16_sc1(base, voff[i], dst + (uint32_t)(((i / PPR) * K + 256 * (i % PPR)) * sizeof(float)));
   };
-  // wait until all 32 column tiles have published step t of sub-chain x (rows of this wave)
+  // wait until all NT column tiles have published step t of sub-chain x (rows of this wave).
+  // Beside a wave that issues f32 MFMAs back to back this wave gets NO vector-ALU instruction through
+  // (round 3, once the multiplying waves' own stalls were gone: the twelve VALU instructions of the
+  // compiler's poll loop completed only when the 128-MFMA burst had ended, stamps: flags published
+  // 0.4 us after the barrier, "seen" at 2.5 us).  So the poll is
+  //   PC_POLL_SCALAR: scalar loads (s_load_dwordx8 glc: past the scalar cache) of the NT flag words and
+  //     scalar compares -- no vector instruction at all; or
+  //   otherwise: one L1-bypassing vector load per lane and ONE v_cmp, which takes the next of the short
+  //     gaps that the multiplying waves leave in their MFMA stream for exactly this (PC_GAPS).
+  // Flags compare as unsigned numbers: the launcher restarts the sequence long before it wraps.
+  const unsigned poll_off = (unsigned)((lane % NT) * sizeof(unsigned));
+  auto give_up = [&]() {
+    if (lane == 0) {
+      __hip_atomic_store(aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    dead = true;
+  };
   auto wait_for = [&](int x, int t) {
     const unsigned want = epoch0 + (unsigned)t + 1u;
-    gu32 *f = (gu32 *)&sy->flags[g][x][lw][col];
-    /* the producers are finishing these rows right now and publish ~1 us after the barrier.
-     * Polling earlier or harder is not free: L1-bypassing loads from this CU delay the
-     * acknowledgement of the multiplying waves' stores, which sits on the critical path
-     * (measured over the whole chain: first poll after 8 / 24 / 48 / 56 / 100 sleep units
-     * = 207 / 166 / 136 / 135 / 165 us) */
+    const unsigned *fbase = &sy->flags[g][x][lw][0];
     __builtin_amdgcn_s_sleep(ONE ? PC_SLEEP0_ONE : K == 1024 ? PC_SLEEP0 : PC_SLEEP0_SMALL);
     for (unsigned spins = 0;; spins++) {
-      unsigned got = 0u;
-      if (!rh && col < NT) got = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else if (rh && (spins & 63u) == 63u) got = __hip_atomic_load(aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool ok = rh ? got == 0u : (col >= NT || (int)(got - want) >= 0); /* NT producers */
-      if (__all(ok)) return;
-      if (__any(rh && got != 0u) || spins > (1u << 15)) { /* ~tens of ms: the group is not all there */
-        if (lane == 0) {
-          __hip_atomic_store(aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#if PC_POLL_SCALAR
+      unsigned behind = 0u; /* any flag still below `want` */
+#pragma unroll
+      for (int i = 0; i < NT / 8; i++) {
+        u32x8 f;
+        asm volatile("s_load_dwordx8 %0, %1, %2 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(f) : "s"(fbase), "n"(32 * i) : "memory");
+#pragma unroll
+        for (int e = 0; e < 8; e++) behind |= (f[e] - want) >> 31;
+      }
+      if (!behind) return;
+#else
+      unsigned got;
+      asm volatile("global_load_dword %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(got) : "v"(poll_off), "s"(fbase) : "memory");
+      if (__all(got >= want)) return;
+#endif
+      if ((spins & 1023u) == 1023u) { /* rarely: has somebody else given up; have we been here for tens of ms */
+        const unsigned ab = __hip_atomic_load(aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__any(ab != 0u) || spins > (1u << 16)) {
+          give_up();
+          return;
         }
-        dead = true;
-        return;
       }
       __builtin_amdgcn_s_sleep(PC_SLEEP1);
     }
@@ -2778,7 +2911,13 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
        * waves of all 32 column tiles are finishing right now */
       wait_for((k - 1) & 1, (k - 1) >> 1);
       PC_STAMP(1, k, 2);
+#if PC_FETCH_PRIO
+      __builtin_amdgcn_s_setprio(3);
+#endif
       if (!dead) fetch((k + 1) & 1, (k + 1) >> 1);
+#if PC_FETCH_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       PC_STAMP(1, k, 3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3117,6 +3256,27 @@ __device__ __forceinline__ void extras_load(const View &v, int t, int r, int nx,
   in.xi = (lane < nx) ? x[lane == 0 ? 0 : s.hidden_size + lane] : 0.0f;
   in.pv = (lane < tn) ? v.b.esum_part[((size_t)t * (tn + 1) + lane) * s.Scap + r] : 0.0f;
 }
+/* sum of squares of the error row an item holds (column 0 and the padding are zero): the same in every lane */
+template <int MAXQ> __device__ __forceinline__ float row_sumsq(const ExtrasIn<MAXQ> &in) {
+  float a = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXQ; i++)
+    a += (in.ev[i].x * in.ev[i].x + in.ev[i].y * in.ev[i].y) + (in.ev[i].z * in.ev[i].z + in.ev[i].w * in.ev[i].w);
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+  return a;
+}
+/* the same for row r of error plane `plane`, fetched here */
+__device__ __forceinline__ float row_sumsq_load(const View &v, int plane, int r, int lane) {
+  const RamdShape &s = v.sh;
+  const float *erow = v.b.ehi + ((size_t)plane * s.Scap + r) * s.I;
+  float a = 0.0f;
+  for (int k4 = lane; 4 * k4 < s.H; k4 += 64) {
+    const float4 e = ld4(erow + 4 * k4);
+    a += (e.x * e.x + e.y * e.y) + (e.z * e.z + e.w * e.w);
+  }
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+  return a;
+}
 template <int MAXQ>
 __device__ __forceinline__ float extras_compute(const View &v, int t, int r, int nx, int nxp, int tn,
                                                 int lane, const ExtrasIn<MAXQ> &in) {
@@ -3176,7 +3336,9 @@ __device__ __forceinline__ float extras_compute(const View &v, int t, int r, int
     }
   }
   // the step's total: the column-tile partials of k_chain_main in index order (each lane
-  // fetches one, every lane adds them in order), then the extras
+  // fetches one, every lane adds them in order), then the extras.  tn == 0 (the one-launch
+  // chain leaves no partials): the caller adds the hidden columns' part (row_sumsq of the
+  // step's OUTPUT row, error plane t + 1) itself.
   float sum = 0.0f;
   for (int p0 = 0; p0 < tn; p0 += 64) {
     int p = p0 + lane;
@@ -3199,6 +3361,7 @@ __global__ __launch_bounds__(256) void k_extras_gather(View v, int row0, int nro
   ExtrasIn<MAXQ> in;
   extras_load<MAXQ>(v, t, r, nx, tn, lane, in);
   float es = extras_compute<MAXQ>(v, t, r, nx, nxp, tn, lane, in);
+  if (tn == 0) es += row_sumsq_load(v, t + 1, r, lane);
   if (lane == 0) v.b.esum[(size_t)t * s.Scap + r] = es;
 }
 
@@ -3227,9 +3390,11 @@ __global__ __launch_bounds__(64) void k_extras_finalize(View v, int row0, int nr
   }
   for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
   /* the step's total: the column-tile partials of k_chain_main in index order, then
-   * the extras (a fixed order, so the break decisions are reproducible) */
+   * the extras (a fixed order, so the break decisions are reproducible); tn == 0: the one-launch
+   * chain left no partials, the hidden columns' part is summed from the row */
+  const float hsq = tn == 0 ? row_sumsq_load(v, t + 1, r, threadIdx.x) : 0.0f;
   if (threadIdx.x == 0) {
-    float sum = 0.0f;
+    float sum = hsq;
     for (int p = 0; p < tn; p++) sum += v.b.esum_part[((size_t)t * (tn + 1) + p) * s.Scap + r];
     v.b.esum[(size_t)t * s.Scap + r] = sum + sq;
   }
@@ -3610,25 +3775,48 @@ __global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, in
                                                             int nxp, int tn,
                                                             const unsigned char *active,
                                                             unsigned flags) {
-  extern __shared__ float es_sh[]; /* [D] */
+  extern __shared__ float es_sh[]; /* [D] the steps' totals; tn == 0: then [D + 1] the rows' own sums of squares */
   const RamdShape &s = v.sh;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = blockIdx.x, r = row0 + j;
+  /* tn == 0 (after the one-launch chain, which leaves no per-tile partial sums): the hidden columns'
+   * part of step t's sum of squares (recur-nn.c:371) is the sum over the step's OUTPUT row, error
+   * plane t + 1 -- the row that the item of step t + 1 holds in registers for its dot products.  So
+   * every item also sums its own row, one more item (t = D) does only that, and the totals are put
+   * together after the barrier. */
+  const int items = tn == 0 ? s.D + 1 : s.D;
+  float *hs_sh = es_sh + s.D;
   /* the next item's reads are requested before the current one is worked on */
   ExtrasIn<MAXQ> cur, nxt;
-  if (wave < s.D) extras_load<MAXQ>(v, wave, r, nx, tn, lane, cur);
-  for (int t = wave; t < s.D; t += THREADS / 64) {
+  if (wave < items) extras_load<MAXQ>(v, wave, r, nx, tn, lane, cur);
+  for (int t = wave; t < items; t += THREADS / 64) {
     const int tnext = t + THREADS / 64;
-    if (tnext < s.D) extras_load<MAXQ>(v, tnext, r, nx, tn, lane, nxt);
-    float es = extras_compute<MAXQ>(v, t, r, nx, nxp, tn, lane, cur);
-    if (lane == 0) {
-      v.b.esum[(size_t)t * s.Scap + r] = es;
-      es_sh[t] = es;
+    if (tnext < items) extras_load<MAXQ>(v, tnext, r, nx, tn, lane, nxt);
+    if (tn == 0) {
+      const float hs = row_sumsq<MAXQ>(cur);
+      if (lane == 0) hs_sh[t] = hs;
+    }
+    if (t < s.D) {
+      float es = extras_compute<MAXQ>(v, t, r, nx, nxp, tn, lane, cur);
+      if (lane == 0) {
+        if (tn != 0) v.b.esum[(size_t)t * s.Scap + r] = es;
+        es_sh[t] = es;
+      }
     }
     cur = nxt;
   }
   __syncthreads();
-  if (wave == 0) bptt_control_wave(v, r, j, lane, active, flags, es_sh, 1);
+  if (wave == 0) {
+    if (tn == 0) {
+      for (int k = lane; k < s.D; k += 64) {
+        const float es = hs_sh[k + 1] + es_sh[k];
+        es_sh[k] = es;
+        v.b.esum[(size_t)k * s.Scap + r] = es;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the wave's own LDS writes before it reads them back */
+    }
+    bptt_control_wave(v, r, j, lane, active, flags, es_sh, 1);
+  }
 }
 
 // ------------------------------------ one stream, small net: forward in one launch --
@@ -4543,6 +4731,11 @@ static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
     *g_chain_abort_host = 0;
     HIP_CHECK(hipHostGetDevicePointer((void **)&g_chain_abort_dev, g_chain_abort_host, 0));
   }
+  if (g_chain_seq >= (1u << 25)) { /* flags are seq * 64 + step and compare as unsigned numbers: start over */
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
+    g_chain_seq = 0;
+  }
   const unsigned seq = ++g_chain_seq;
   int ev = timing_begin(st, T_CHAIN, 1);
 #define CHAIN_PERSIST(ACT)                                                                  \
@@ -4958,6 +5151,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
         r += n;
       }
     }
+    if (persist) tn_parts = 0; /* the one-launch chain leaves no partial sums: the extras sum the rows themselves */
     /* big sets of a wide net: 64 x 64 tiles (k_chain_wide), one partial sum per 64 columns */
     const int wide_ns = sh->hidden_size / WK;
     const bool wide = !persist && b->uniform_idx >= 0 && nrows % WM == 0 && sh->hidden_size % WN == 0 &&
@@ -5024,7 +5218,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
                              nxp, tn_parts);
       } else {
         /* extras and control in one launch, one workgroup per stream */
-        const size_t shm = (size_t)sh->D * sizeof(float);
+        const size_t shm = (size_t)(2 * sh->D + 1) * sizeof(float);
         if (nq <= 5)
           RAMD_LAUNCH((k_extras_control<5, 1024>), dim3(nrows), dim3(1024), shm, st, v, row0, nrows,
                              nx, nxp, tn_parts, active, flags);

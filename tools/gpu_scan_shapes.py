@@ -4,8 +4,11 @@ sys.path.insert(0, "tests")
 import recur_ctypes as rc, scenarios as sc
 amd = rc.load_amd()
 text = sc.synthetic_text(60000)
-for H, S, D in [(1024, 16, 20), (1024, 32, 20), (1024, 64, 20), (1024, 128, 20), (1024, 256, 20), (1024, 512, 20), (1024, 1024, 20), (1024, 2048, 20),
-                (1024, 256, 10), (1024, 256, 40), (512, 256, 20), (512, 1024, 20), (256, 1024, 20), (2048, 256, 20), (2048, 1024, 20)]:
+SHAPES = [(1024, 16, 20), (1024, 32, 20), (1024, 64, 20), (1024, 128, 20), (1024, 256, 20), (1024, 512, 20), (1024, 1024, 20), (1024, 2048, 20),
+                (1024, 256, 10), (1024, 256, 40), (512, 256, 20), (512, 1024, 20), (256, 1024, 20), (2048, 256, 20), (2048, 1024, 20)]
+if len(sys.argv) > 1 and sys.argv[1] == "small":  # the shapes the one-sub-chain variants serve
+    SHAPES = [(1024, 32, 20), (1024, 64, 20), (512, 128, 30), (512, 256, 20), (256, 128, 20), (256, 1024, 20)]
+for H, S, D in SHAPES:
     g = sc.AmdBatchedSet(amd, input_size=42, hidden_size=H, output_size=42, S=S, D=D, learn_rate=1e-5, seed=1)
     g.load_text(text)
     for i in range(D + 6): g.char_step(text, i)
