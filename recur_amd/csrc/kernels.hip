@@ -2549,6 +2549,21 @@ template <int OFF> __device__ __forceinline__ float lds_read_b32_off(uint32_t ad
 template <int N> __device__ __forceinline__ void lgkm_wait(f32x4 &v) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
 }
+/* two floats 64 * O0 and 64 * O1 floats from `addr` (bytes) */
+template <int O0, int O1> __device__ __forceinline__ f32x2 lds_read2st64(uint32_t addr) {
+  static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "ds_read2st64_b32 offsets are 8 bits");
+  f32x2 v;
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
+  return v;
+}
+/* wait until at most N LDS instructions issued after a fragment's reads are outstanding */
+template <int N> __device__ __forceinline__ void frag_wait(f32x4 &cf, f32x2 (&a)[2][2], f32x2 (&e)[2][2]) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+  asm volatile("s_waitcnt lgkmcnt(%9)"
+               : "+v"(cf), "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(e[0][0]), "+v"(e[0][1]),
+                 "+v"(e[1][0]), "+v"(e[1][1])
+               : "n"(N));
+}
 template <int... Is, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
   (f(std::integral_constant<int, Is>{}), ...);
@@ -2891,7 +2906,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
 #endif
       if ((spins & 1023u) == 1023u) { /* rarely: has somebody else given up; have we been here for tens of ms */
         const unsigned ab = __hip_atomic_load(aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__any(ab != 0u) || spins > (1u << 16)) {
+        if (__any(ab != 0u) || spins > (1u << 21)) { /* ~1 s: a co-tenant's long kernel may hold CUs for a while */
           give_up();
           return;
         }
@@ -3554,10 +3569,17 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
   // The fragments of K group u + 1 (8 k: four MFMA steps of two k each) are read from LDS
   // before the 16 MFMAs of group u are issued and used after them, so the LDS latency
   // and, at a stage boundary, the barrier sit in the shadow of the matrix pipe.
+  // Round 3: the reads are inline asm with COUNTED waits.  As plain loads hipcc put an
+  // `s_waitcnt lgkmcnt(0)` behind the reads of every second group, in front of the CURRENT group's
+  // multiplies -- the read-ahead it was meant to be waited for its own reads twice per K tile -- and
+  // spent five vector-ALU instructions per group on LDS addresses.  Now: `ds_read2st64_b32` (two k
+  // rows, 128 floats apart, per instruction; immediate offsets in units of 64 floats reach every k of
+  // a stage), four address registers per STAGE, and each group waits only for what was issued before
+  // the reads of the group after it (lgkmcnt(n), n = that group's instruction count <= 13).
   struct Frag {
-    float a[2][4], e[2][4];
-    float4 cf;
-    float ar[RI ? RI : 1][4]; /* rest rows (REST stages only) */
+    f32x2 a[2][2], e[2][2]; /* [i or jn][k pair]: k = 8 g + 4 kh + 2 pair, + 1 */
+    f32x4 cf;
+    f32x2 ar[RI ? RI : 1][2]; /* rest rows (REST stages only) */
   };
   f32x16 racc[RI ? RI : 1][2];
 #pragma unroll
@@ -3566,29 +3588,49 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int g = 0; g < 16; g++) racc[i][j][g] = 0.0f;
-  const int lane_off = 4 * kh * 128 + lm;
-  auto rd = [&](int st, int g, Frag &f, bool rest) {
-    if (REST && rest) { /* wave-uniform */
-      const float *lr = rest_ring + rest_slot(st) + (8 * g + 4 * kh) * RR + wm * (RR / 2) + lm;
-#pragma unroll
-      for (int i = 0; i < RI; i++)
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) f.ar[i][jj] = lr[jj * RR + i * 32];
-    }
-    const float *la = dsm + (st % DD_STAGES) * DD_STAGE_FLOATS + 8 * g * 128 + lane_off;
-    const float *lb = la + BK * 128;
-    f.cf = *reinterpret_cast<const float4 *>(dsm + (st % DD_STAGES) * DD_STAGE_FLOATS + 2 * BK * 128 +
-                                             8 * g + 4 * kh);
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int jj = 0; jj < 4; jj++) {
-        f.a[i][jj] = la[jj * 128 + wm * 64 + i * 32];
-        f.e[i][jj] = lb[jj * 128 + wn * 64 + i * 32];
-      }
+  /* per-lane byte addresses within a stage: A rows i = 0, 1; E columns jn = 0, 1; the coefficients; the rest rows */
+  const uint32_t dsm0 = lds_byte_addr(dsm);
+  const uint32_t la_lane = dsm0 + 4u * (uint32_t)(4 * kh * 128 + wm * 64 + lm);
+  const uint32_t le_lane = dsm0 + 4u * (uint32_t)(BK * 128 + 4 * kh * 128 + wn * 64 + lm);
+  const uint32_t lc_lane = dsm0 + 4u * (uint32_t)(2 * BK * 128 + 4 * kh);
+  const uint32_t lr_lane = lds_byte_addr(rest_ring) + 4u * (uint32_t)(4 * kh * RR + wm * (RR / 2) + lm);
+  uint32_t ad_a0 = 0, ad_a1 = 0, ad_e0 = 0, ad_e1 = 0, ad_c = 0, ad_r = 0; /* of the stage being READ */
+  auto stage_addr = [&](int st, bool rest) {
+    const uint32_t sb = (uint32_t)((st % DD_STAGES) * DD_STAGE_FLOATS * (int)sizeof(float));
+    ad_a0 = la_lane + sb;
+    ad_a1 = ad_a0 + 128u;
+    ad_e0 = le_lane + sb;
+    ad_e1 = ad_e0 + 128u;
+    ad_c = lc_lane + sb;
+    if (REST && rest) ad_r = lr_lane + (uint32_t)(rest_slot(st) * (int)sizeof(float));
   };
-  auto mm = [&](const Frag &f, bool rest) {
-    const float cfv[4] = {f.cf.x, f.cf.y, f.cf.z, f.cf.w};
+  /* group G of the stage whose addresses are set: 9 LDS instructions (+ 2 RI for a rest stage) */
+  auto rd = [&](auto GC, Frag &f, bool rest) {
+    constexpr int G = decltype(GC)::value;
+    constexpr int RU = RR ? RR / 64 : 1; /* k rows of the rest tile are RR floats apart: RR / 64 offset units */
+    if (REST && rest) { /* wave-uniform */
+#pragma unroll
+      for (int i = 0; i < RI; i++) {
+        f.ar[i][0] = lds_read2st64<(8 * G + 0) * RU, (8 * G + 1) * RU>(ad_r + 128u * (uint32_t)i);
+        f.ar[i][1] = lds_read2st64<(8 * G + 2) * RU, (8 * G + 3) * RU>(ad_r + 128u * (uint32_t)i);
+      }
+    }
+    f.cf = lds_read_b128_off<32 * G>(ad_c);
+    f.a[0][0] = lds_read2st64<2 * (8 * G + 0), 2 * (8 * G + 1)>(ad_a0);
+    f.e[0][0] = lds_read2st64<2 * (8 * G + 0), 2 * (8 * G + 1)>(ad_e0);
+    f.a[1][0] = lds_read2st64<2 * (8 * G + 0), 2 * (8 * G + 1)>(ad_a1);
+    f.e[1][0] = lds_read2st64<2 * (8 * G + 0), 2 * (8 * G + 1)>(ad_e1);
+    f.a[0][1] = lds_read2st64<2 * (8 * G + 2), 2 * (8 * G + 3)>(ad_a0);
+    f.e[0][1] = lds_read2st64<2 * (8 * G + 2), 2 * (8 * G + 3)>(ad_e0);
+    f.a[1][1] = lds_read2st64<2 * (8 * G + 2), 2 * (8 * G + 3)>(ad_a1);
+    f.e[1][1] = lds_read2st64<2 * (8 * G + 2), 2 * (8 * G + 3)>(ad_e1);
+  };
+  /* Every group waits for "at most nine LDS instructions behind my reads": the next group's nine (a
+   * rest stage issues its 2 RI extra reads FIRST, so there the wait also covers those: a few dozen
+   * cycles once per tm stages).  A count chosen at run time would put the wait into branches, and
+   * hipcc then copies the whole fragment (ten v_mov_b64) in front of the multiplies in each of them. */
+  auto mm = [&](Frag &f, bool rest) {
+    frag_wait<9>(f.cf, f.a, f.e);
     float b[2][4];
     /* v_mul_legacy_f32: 0 * x is 0 for ANY x (a step past the break may hold inf), otherwise the
      * IEEE product: select and multiply in one instruction of the MFMAs' own ALU.  All eight in
@@ -3601,30 +3643,39 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
                  "v_mul_legacy_f32 %6, %10, %18\n\tv_mul_legacy_f32 %7, %11, %19\n\ts_nop 1"
                  : "=&v"(b[0][0]), "=&v"(b[0][1]), "=&v"(b[0][2]), "=&v"(b[0][3]), "=&v"(b[1][0]),
                    "=&v"(b[1][1]), "=&v"(b[1][2]), "=&v"(b[1][3])
-                 : "v"(cfv[0]), "v"(cfv[1]), "v"(cfv[2]), "v"(cfv[3]), "v"(f.e[0][0]), "v"(f.e[0][1]),
-                   "v"(f.e[0][2]), "v"(f.e[0][3]), "v"(f.e[1][0]), "v"(f.e[1][1]), "v"(f.e[1][2]),
-                   "v"(f.e[1][3]));
+                 : "v"(f.cf[0]), "v"(f.cf[1]), "v"(f.cf[2]), "v"(f.cf[3]), "v"(f.e[0][0][0]), "v"(f.e[0][0][1]),
+                   "v"(f.e[0][1][0]), "v"(f.e[0][1][1]), "v"(f.e[1][0][0]), "v"(f.e[1][0][1]), "v"(f.e[1][1][0]),
+                   "v"(f.e[1][1][1]));
 #pragma unroll
     for (int jj = 0; jj < 4; jj++)
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int jn = 0; jn < 2; jn++)
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][jj], b[jn][jj], acc[i][jn], 0, 0, 0);
-    if (REST && rest) { /* wave-uniform: this wave's 32 or 64 rest rows x its 64 columns */
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][jj >> 1][jj & 1], b[jn][jj], acc[i][jn], 0, 0, 0);
+    if (REST && rest) { /* wave-uniform: this wave's 32 or 64 rest rows x its 64 columns (their reads are older
+                         * than the nine waited for above) */
 #pragma unroll
       for (int jj = 0; jj < 4; jj++)
 #pragma unroll
         for (int i = 0; i < RI; i++)
 #pragma unroll
           for (int jn = 0; jn < 2; jn++)
-            racc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.ar[i][jj], b[jn][jj], racc[i][jn], 0, 0, 0);
+            racc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.ar[i][jj >> 1][jj & 1], b[jn][jj], racc[i][jn], 0, 0, 0);
     }
   };
-  auto step = [&](int st, int g, Frag &cur, Frag &nxt, bool rest, bool rest_next) {
-    if (g < 3) {
-      rd(st, g + 1, nxt, rest);
-    } else if (st + 1 < nst) {
+  /* groups 0-2 of a stage: read the next group of the same stage, multiply this one */
+  auto step = [&](auto GC, Frag &cur, Frag &nxt, bool rest) {
+    constexpr int g = decltype(GC)::value;
+    rd(std::integral_constant<int, g + 1>{}, nxt, rest);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(cur, rest);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  /* group 3: across the stage boundary.  After the last stage group 0 of the same stage is read once more
+   * (into the idle fragment), so that "nine instructions behind" holds for every group of the launch. */
+  auto step3 = [&](int st, Frag &cur, Frag &nxt, bool rest, bool rest_next) {
+    if (st + 1 < nst) {
 #ifdef PC_STAMPS
       if (blockIdx.x == 0 && threadIdx.x == 0 && st < 63) g_pc_stamps[0][st + 1][4] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -3633,8 +3684,11 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
 #ifdef PC_STAMPS
       if (blockIdx.x == 0 && threadIdx.x == 0 && st < 63) g_pc_stamps[0][st + 1][5] = __builtin_amdgcn_s_memrealtime();
 #endif
-      rd(st + 1, 0, nxt, rest_next);
+      stage_addr(st + 1, rest_next);
+    } else {
+      rest_next = false;
     }
+    rd(std::integral_constant<int, 0>{}, nxt, rest_next);
     __builtin_amdgcn_sched_barrier(0);
     mm(cur, rest);
     __builtin_amdgcn_sched_barrier(0);
@@ -3646,14 +3700,15 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
   if (nst > 0) {
     __builtin_amdgcn_s_barrier(); /* stage 0 has landed */
     asm volatile("" ::: "memory");
-    rd(0, 0, f0, is_rest(0));
+    stage_addr(0, is_rest(0));
+    rd(std::integral_constant<int, 0>{}, f0, is_rest(0));
   }
   for (int st = 0; st < nst; st++) {
     const bool r = is_rest(st), rn = is_rest(st + 1);
-    step(st, 0, f0, f1, r, rn);
-    step(st, 1, f1, f0, r, rn);
-    step(st, 2, f0, f1, r, rn);
-    step(st, 3, f1, f0, r, rn);
+    step(std::integral_constant<int, 0>{}, f0, f1, r);
+    step(std::integral_constant<int, 1>{}, f1, f0, r);
+    step(std::integral_constant<int, 2>{}, f0, f1, r);
+    step3(st, f1, f0, r, rn);
   }
 #ifdef PC_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0) g_pc_stamps[0][0][6] = __builtin_amdgcn_s_memrealtime();
