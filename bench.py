@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--hidden", type=int, default=HIDDEN)
     ap.add_argument("--streams", type=int, default=STREAMS, help="streams per GPU")
     ap.add_argument("--depth", type=int, default=DEPTH)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default, the driver's contract): --streams per GPU; strong: --streams-global "
+                         "streams in all, split evenly over the ranks (BASELINE.json configs[3]: 256 over 8)")
+    ap.add_argument("--streams-global", type=int, default=STREAMS, help="--scaling strong: streams of the whole job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of EACH cpu leg")
     ap.add_argument("--no-roofline", action="store_true")
@@ -328,6 +332,11 @@ def main():
     import recur_ctypes as rc
     import scenarios as sc
 
+    if args.scaling == "strong":
+        if args.streams_global % world or (args.streams_global // world) % 16:
+            raise SystemExit("bench.py --scaling strong: %d streams over %d ranks is not whole 16-stream tiles per rank"
+                             % (args.streams_global, world))
+        args.streams = args.streams_global // world
     S, D, Hd = args.streams, args.depth, args.hidden
     # untimed, before the warm-up: the history ring is full whatever --warmup is (D + 5), and the
     # device has ramped to the clocks it holds under this load (measured: a 20-step timed region
@@ -457,14 +466,14 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
             "workload": "text-predict multi-tap generation: hidden %d, %d streams/GPU, BPTT depth "
                         "%d, 42 symbols, RELU, weighted momentum, lr 1e-5" % (Hd, S, D),
-            "streams_per_gpu": S, "global_streams": S * world,
+            "streams_per_gpu": S, "global_streams": S * world, "scaling_mode": args.scaling,
             "parallelism": ("streams sharded x%d, one RCCL all-reduce of the weight deltas per generation "
                             "(in librecur_amd)" % world) if dist else "single GPU",
             "rccl_ranks": amd.rnn_amd_dist_world() if dist else 0,

@@ -2,8 +2,7 @@
  * symbol <-> text conversions (charmodel-init.c:352-372, 430-800 of the reference).
  * Host-only C; same names, formats and return values, because saved nets carry the
  * metadata string and the file name embeds its hash. */
-#include "rnn_host.h"
-#include "recur_amd_char.h"
+#include "char_host.h"
 #include <inttypes.h>
 
 #define C_NORMAL "\033[00m"
@@ -11,252 +10,178 @@
 
 /* ------------------------------------------------------------- code points -- */
 
-/* utf8.h:31-57: 0 for a code point that does not fit four bytes */
-static int put_utf8(unsigned code, char *s) {
-  if (code < 0x80) {
-    s[0] = (char)code;
-    return 1;
+/* One UTF-8 sequence from *s (advanced past it).  -1: malformed (a stray or missing continuation
+ * byte, an over-long form); -2: a lead byte of a sequence longer than four bytes (utf8.h:79-160's
+ * verdicts). */
+static int take_codepoint(const char **s) {
+  static const struct {
+    unsigned char mask, lead, extra;
+    int smallest; /* below this the sequence is longer than the value needs */
+  } form[] = {{0x80, 0x00, 0, 0}, {0xE0, 0xC0, 1, 0x80}, {0xF0, 0xE0, 2, 0x800}, {0xF8, 0xF0, 3, 0x10000}};
+  const unsigned char first = (unsigned char)*(*s)++;
+  for (size_t f = 0; f < sizeof(form) / sizeof(form[0]); f++) {
+    if ((first & form[f].mask) != form[f].lead) {
+      continue;
+    }
+    int value = first & ~form[f].mask;
+    for (int k = 0; k < form[f].extra; k++) {
+      const unsigned char more = (unsigned char)*(*s)++;
+      if ((more & 0xC0) != 0x80) {
+        return -1;
+      }
+      value = (value << 6) | (more & 0x3F);
+    }
+    return value < form[f].smallest ? -1 : value;
   }
-  if (code < 0x800) {
-    s[0] = (char)(0xC0 | (code >> 6));
-    s[1] = (char)(0x80 | (code & 63));
-    return 2;
-  }
-  if (code < 0x10000) {
-    s[0] = (char)(0xE0 | (code >> 12));
-    s[1] = (char)(0x80 | ((code >> 6) & 63));
-    s[2] = (char)(0x80 | (code & 63));
-    return 3;
-  }
-  if (code < 0x200000) {
-    s[0] = (char)(0xF0 | (code >> 18));
-    s[1] = (char)(0x80 | ((code >> 12) & 63));
-    s[2] = (char)(0x80 | ((code >> 6) & 63));
-    s[3] = (char)(0x80 | (code & 63));
-    return 4;
-  }
-  return 0;
+  return (first & 0xC0) == 0x80 ? -1 : -2;
 }
 
-/* utf8.h:79-160 (read_utf8_char): -1 for malformed input, -2 for a lead byte beyond
- * four-byte sequences; over-long encodings are malformed */
-static int get_utf8(const char **s) {
-  int c = (unsigned char)**s, extra;
-  (*s)++;
-  if (!(c & 0x80)) {
-    return c;
-  } else if ((c & 0xE0) == 0xC0) {
-    c &= 31;
-    extra = 1;
-  } else if ((c & 0xF0) == 0xE0) {
-    c &= 15;
-    extra = 2;
-  } else if ((c & 0xF8) == 0xF0) {
-    c &= 7;
-    extra = 3;
-  } else if ((c & 0xC0) == 0x80) {
-    return -1;
-  } else {
-    return -2;
-  }
-  for (int i = 0; i < extra; i++) {
-    int x = (unsigned char)**s;
-    (*s)++;
-    if ((x & 0xC0) != 0x80) {
-      return -1;
+/* n code points as text (bytes when !utf8, where a zero ends the list); the caller frees */
+static char *text_of_points(const int *points, int n, int utf8) {
+  char *text = malloc((size_t)n * 4 + 1), *w = text;
+  for (int i = 0; i < n; i++) {
+    if (!utf8 && !points[i]) {
+      break;
     }
-    c = (c << 6) + (x & 63);
+    const int wrote = ramd_put_codepoint((unsigned)points[i], w, utf8);
+    if (!wrote) {
+      fprintf(stderr, "bad unicode code %d\n", points[i]);
+      break;
+    }
+    w += wrote;
   }
-  int min = 1 << (1 + extra * 5 + (extra == 1));
-  return c < min ? -1 : c;
+  *w = 0;
+  return text;
 }
 
-/* utf8.h:193-232 */
-static char *string_of_points(const int *points, int maxlen, int utf8) {
-  char *str = malloc((size_t)maxlen * (utf8 ? 4 : 1) + 1);
-  char *s = str;
-  for (int i = 0; i < maxlen; i++) {
-    int code = points[i];
-    if (utf8) {
-      int wrote = put_utf8((unsigned)code, s);
-      if (wrote == 0) {
-        fprintf(stderr, "bad unicode code %d\n", code);
-        break;
+/* the first `room` code points of a string; returns how many there were (a zero, or in utf-8 a bad
+ * sequence, ends it) */
+static int points_of_string(int *points, int room, const char *string, int utf8) {
+  int n = 0;
+  for (const char *s = string; n < room; n++) {
+    const int c = utf8 ? take_codepoint(&s) : (unsigned char)*s++;
+    if (c <= 0) {
+      if (!utf8) {
+        points[n] = 0; /* (the byte form stores its terminator, as the reference's loop does) */
       }
-      s += wrote;
-    } else {
-      if (!code) {
-        break;
-      }
-      *s++ = (char)code;
+      break;
     }
+    points[n] = c;
   }
-  *s = 0;
-  return str;
+  return n;
 }
 
-/* utf8.h:234-270 */
-static int points_of_string(int *points, int len, const char *string, int utf8) {
-  int i;
-  if (utf8) {
-    const char *s = string;
-    for (i = 0; i < len; i++) {
-      int c = get_utf8(&s);
-      if (c <= 0) {
-        break;
-      }
-      points[i] = c;
-    }
-  } else {
-    const unsigned char *s = (const unsigned char *)string;
-    for (i = 0; i < len; i++) {
-      points[i] = s[i];
-      if (!points[i]) {
-        break;
-      }
-    }
+static void show_points(const char *label, const int *points, int n, int utf8) {
+  char *text = text_of_points(points, n, utf8);
+  fprintf(stderr, "%s" C_DARK_YELLOW "\xc2\xbb\xc2\xbb" C_NORMAL "%s" C_DARK_YELLOW "\xc2\xab\xc2\xab" C_NORMAL "\n", label, text);
+  free(text);
+  for (int i = 0; i < n; i++) {
+    fprintf(stderr, "%d, ", points[i]);
   }
-  return i;
+  fputc('\n', stderr);
 }
 
-/* charmodel-init.c:351-372 */
+/* charmodel.h:230: the alphabet and the collapse set, as text and as numbers, on stderr */
 void rnn_char_dump_alphabet(RnnCharAlphabet *alphabet) {
-  int utf8 = alphabet->flags & RNN_CHAR_FLAG_UTF8;
-  char *s = string_of_points(alphabet->points, alphabet->len, utf8);
-  char *s2 = string_of_points(alphabet->collapsed_points, alphabet->collapsed_len, utf8);
-  fprintf(stderr, "alphabet:  " C_DARK_YELLOW "\xc2\xbb\xc2\xbb" C_NORMAL "%s" C_DARK_YELLOW
-                  "\xc2\xab\xc2\xab" C_NORMAL "\n", s);
-  for (int i = 0; i < alphabet->len; i++) {
-    fprintf(stderr, "%d, ", alphabet->points[i]);
-  }
-  putc('\n', stderr);
-  fprintf(stderr, "collapsed: " C_DARK_YELLOW "\xc2\xbb\xc2\xbb" C_NORMAL "%s" C_DARK_YELLOW
-                  "\xc2\xab\xc2\xab" C_NORMAL "\n", s2);
-  for (int i = 0; i < alphabet->collapsed_len; i++) {
-    fprintf(stderr, "%d, ", alphabet->collapsed_points[i]);
-  }
-  putc('\n', stderr);
-  free(s);
-  free(s2);
+  const int utf8 = (alphabet->flags & RNN_CHAR_FLAG_UTF8) != 0;
+  show_points("alphabet:  ", alphabet->points, alphabet->len, utf8);
+  show_points("collapsed: ", alphabet->collapsed_points, alphabet->collapsed_len, utf8);
 }
 
-/* charmodel-init.c:788-799: symbol number of the first character of s, or -1 */
+/* charmodel.h:232: which symbol of the alphabet is the first character of s; -1 if none */
 int rnn_char_get_codepoint(RnnCharAlphabet *a, const char *s) {
-  int p = 0;
-  points_of_string(&p, 1, s, a->flags & RNN_CHAR_FLAG_UTF8);
-  for (int i = 0; i < a->len; i++) {
-    if (a->points[i] == p) {
-      return i;
+  int wanted = 0;
+  points_of_string(&wanted, 1, s, (a->flags & RNN_CHAR_FLAG_UTF8) != 0);
+  for (int sym = 0; sym < a->len; sym++) {
+    if (wanted == a->points[sym]) {
+      return sym;
     }
   }
   return -1;
 }
 
-/* charmodel-init.c:429-440 */
+/* charmodel.h:172: symbols as bytes of a (byte) alphabet string into a file, for inspection */
 void rnn_char_dump_collapsed_text(const u8 *text, int len, const char *name,
                                   const char *alphabet) {
   FILE *f = fopen(name, "w");
-  if (!f) {
+  if (!f) { /* recur-common.h's fopen_or_abort */
     fprintf(stderr, "could not open '%s'\n", name);
-    abort(); /* fopen_or_abort, recur-common.h */
+    abort();
   }
-  for (int i = 0; i < len; i++) {
-    fputc(alphabet[text[i]], f);
+  for (const u8 *t = text; t < text + len; t++) {
+    fputc(alphabet[*t], f);
   }
   fclose(f);
 }
 
-/* charmodel-init.c:443-478: symbols back to text; stops at a zero code point */
+/* charmodel.h:170: symbols back to text (a symbol whose code point is zero ends it) */
 char *rnn_char_uncollapse_text(RnnCharAlphabet *alphabet, const u8 *orig, int len,
                                int *dest_len) {
-  int utf8 = alphabet->flags & RNN_CHAR_FLAG_UTF8;
-  char *mem = malloc((size_t)(len + 2) * (utf8 ? 4 : 1));
-  char *s = mem;
+  const int utf8 = (alphabet->flags & RNN_CHAR_FLAG_UTF8) != 0;
+  char *text = malloc((size_t)(len + 2) * (utf8 ? 4 : 1)), *w = text;
   for (int i = 0; i < len; i++) {
-    int code = alphabet->points[orig[i]];
-    if (code == 0) {
+    const int point = alphabet->points[orig[i]];
+    const int wrote = point ? ramd_put_codepoint((unsigned)point, w, utf8) : 0;
+    if (!wrote) {
+      if (point) {
+        fprintf(stderr, "bad unicode code %d\n", point);
+      }
       break;
     }
-    if (utf8) {
-      int wrote = put_utf8((unsigned)code, s);
-      if (wrote == 0) {
-        fprintf(stderr, "bad unicode code %d\n", code);
-        break;
-      }
-      s += wrote;
-    } else {
-      *s++ = (char)code;
-    }
+    w += wrote;
   }
-  *s = 0;
-  *dest_len = (int)(s - mem);
-  return realloc(mem, (size_t)(s - mem) + 1);
+  *w = 0;
+  *dest_len = (int)(w - text);
+  return realloc(text, (size_t)*dest_len + 1);
 }
 
 /* ----------------------------------------------------------------- metadata -- */
 
-/* charmodel-init.c:483-505: everything outside 33..126, and '%', as %xx (lower case) */
+/* The metadata string keeps its two text fields percent-encoded: every byte outside the printable
+ * ascii range 33..126, and '%' itself, as %xx in lower-case hex (charmodel-init.c:483-531). */
+static int plain_in_metadata(unsigned char c) { return c > 32 && c < 127 && c != '%'; }
+
 static char *urlencode_alloc(const char *orig) {
-  size_t len = strlen(orig);
-  char *s = malloc(len * 3 + 1);
-  static const char hex[] = "0123456789abcdef";
-  size_t j = 0;
-  for (size_t i = 0; i < len; i++) {
-    char c = orig[i];
-    if (c > 32 && c < 127 && c != '%') {
-      s[j++] = c;
-    } else {
-      unsigned char u = (unsigned char)c;
-      s[j++] = '%';
-      s[j++] = hex[u >> 4];
-      s[j++] = hex[u & 15];
-    }
+  const size_t n = strlen(orig);
+  char *enc = malloc(3 * n + 1), *w = enc;
+  for (const unsigned char *c = (const unsigned char *)orig; *c; c++) {
+    w += plain_in_metadata(*c) ? sprintf(w, "%c", *c) : sprintf(w, "%%%02x", *c);
   }
-  s[j] = 0;
-  return realloc(s, j + 1);
+  *w = 0;
+  return realloc(enc, (size_t)(w - enc) + 1);
 }
 
-/* charmodel-init.c:507-531 (same hex-digit arithmetic; stops at the end of the input) */
+/* value of a hex digit the way the reference reads it: letters (bit 6 set) count from 9, only the low
+ * four bits matter -- so a malformed escape decodes to SOMETHING rather than failing */
+static int lenient_hex(char c) { return ((c & 0x40) ? c + 9 : c) & 15; }
+
 static char *urldecode_alloc(const char *orig) {
-  size_t len = strlen(orig);
-  char *s = malloc(len + 1);
-  size_t i = 0, j = 0;
-  while (j < len) {
-    char c = orig[j];
-    if (c == '%' && j + 2 < len + 1) {
-      char hi = orig[j + 1], lo = orig[j + 2];
-      char d = (char)((((hi & 0x40) ? hi + 9 : hi) & 15) << 4);
-      d += ((lo & 0x40) ? lo + 9 : lo) & 15;
-      s[i++] = d;
-      j += 3;
+  const size_t n = strlen(orig);
+  char *dec = malloc(n + 1), *w = dec;
+  for (size_t r = 0; r < n;) {
+    if (orig[r] == '%' && r + 2 <= n) {
+      *w++ = (char)(lenient_hex(orig[r + 1]) << 4 | lenient_hex(orig[r + 2]));
+      r += 3;
     } else {
-      s[i++] = c;
-      j++;
+      *w++ = orig[r++];
     }
   }
-  s[i] = 0;
-  return realloc(s, i + 1);
+  *w = 0;
+  return realloc(dec, (size_t)(w - dec) + 1);
 }
 
-/* charmodel-init.c:534-560 */
+/* charmodel.h:262: the five lines a saved net carries.  Names and order are the file format. */
 char *rnn_char_construct_metadata(const struct RnnCharMetadata *m) {
-  char *metadata;
-  char *enc_alphabet = urlencode_alloc(m->alphabet);
-  char *enc_collapse = urlencode_alloc(m->collapse_chars);
-  int ret = asprintf(&metadata,
-                     "alphabet %s\n"
-                     "collapse_chars %s\n"
-                     "utf8 %d\n"
-                     "collapse_space %d\n"
-                     "case_insensitive %d\n",
-                     enc_alphabet, enc_collapse, m->utf8, m->collapse_space, m->case_insensitive);
-  if (ret == -1) {
-    fprintf(stderr, "can't alloc memory for metadata. or something.\n");
+  char *fields[2] = {urlencode_alloc(m->alphabet), urlencode_alloc(m->collapse_chars)};
+  char *text = NULL;
+  if (asprintf(&text, "alphabet %s\ncollapse_chars %s\nutf8 %d\ncollapse_space %d\ncase_insensitive %d\n", fields[0],
+               fields[1], m->utf8, m->collapse_space, m->case_insensitive) < 0) {
+    fprintf(stderr, "librecur_amd: out of memory for a metadata string\n");
     abort();
   }
-  free(enc_alphabet);
-  free(enc_collapse);
-  return metadata;
+  free(fields[0]);
+  free(fields[1]);
+  return text;
 }
 
 /* charmodel-init.c:562-628: five "key value" lines in a fixed order; 0 or -1 */
@@ -297,15 +222,13 @@ void rnn_char_free_metadata_items(struct RnnCharMetadata *m) {
   free(m->collapse_chars);
 }
 
-/* charmodel-init.c:636-650 */
+/* charmodel.h:261: dest becomes a deep copy of src (what dest held is released) */
 void rnn_char_copy_metadata_items(struct RnnCharMetadata *src, struct RnnCharMetadata *dest) {
-  free(dest->alphabet);
-  free(dest->collapse_chars);
-  dest->alphabet = strdup(src->alphabet);
-  dest->collapse_chars = strdup(src->collapse_chars);
-  dest->utf8 = src->utf8;
-  dest->collapse_space = src->collapse_space;
-  dest->case_insensitive = src->case_insensitive;
+  char *alphabet = strdup(src->alphabet), *collapse = strdup(src->collapse_chars);
+  rnn_char_free_metadata_items(dest);
+  *dest = *src; /* the three flags */
+  dest->alphabet = alphabet;
+  dest->collapse_chars = collapse;
 }
 
 /* recur-common.h:207-216 */
@@ -339,58 +262,80 @@ char *rnn_char_construct_net_filename(struct RnnCharMetadata *m, const char *bas
   return strdup(s);
 }
 
-/* charmodel-init.c:672-719: 0 = consistent (possibly after adopting one side), -1 bad
- * arguments, -2 mismatch with neither flag given */
+/* Does the net's stored description of its text encoding agree with the one the caller is about to
+ * use (charmodel.h:258-259; behaviour of charmodel-init.c:672-719)?  Returns 0 when the two are
+ * consistent on return -- they were equal, the net had none, or one side was made to follow the other:
+ * `trust_file_metadata` makes the CALLER adopt the net's (when it parses), `force_metadata` rewrites
+ * the NET's string -- -2 when they differ and neither was asked for, -1 for missing arguments. */
+enum meta_resolution { META_SAME, META_ADOPT_NETS, META_OVERWRITE_NETS, META_CONFLICT };
+
+static enum meta_resolution resolve_metadata(const char *nets, const char *callers, bool trust, bool force) {
+  if (!nets || strcmp(nets, callers) == 0) {
+    return META_SAME;
+  }
+  return trust ? META_ADOPT_NETS : force ? META_OVERWRITE_NETS : META_CONFLICT;
+}
+
 int rnn_char_check_metadata(RecurNN *net, struct RnnCharMetadata *m, bool trust_file_metadata,
                             bool force_metadata) {
-  if (net == NULL || m == NULL) {
+  if (!net || !m) {
     fprintf(stderr, "net is %p, metadata is %p, in %s\n", (void *)net, (void *)m, __func__);
     return -1;
   }
-  int ret = 0;
-  char *metadata = rnn_char_construct_metadata(m);
-  if (net->metadata && strcmp(metadata, net->metadata)) {
-    fprintf(stderr, "metadata doesn't match. Expected:\n%s\nLoaded from net:\n%s\n\n", metadata,
-            net->metadata);
-    if (trust_file_metadata) {
-      struct RnnCharMetadata m2 = {0};
-      if (rnn_char_load_metadata(net->metadata, &m2)) {
-        fprintf(stderr, "The net's metadata doesn't load. Using otherwise determined metadata\n");
-      } else {
-        fprintf(stderr, "Using the net's metadata. Use --force-metadata to override\n");
-        rnn_char_copy_metadata_items(&m2, m);
-        rnn_char_free_metadata_items(&m2);
-      }
-    } else if (force_metadata) {
-      fprintf(stderr, "Updating the net's metadata to match that requested "
-                      "(because --force-metadata)\n");
-      free(net->metadata);
-      net->metadata = strdup(metadata);
-    } else {
-      ret = -2;
-    }
+  char *callers = rnn_char_construct_metadata(m);
+  const enum meta_resolution what = resolve_metadata(net->metadata, callers, trust_file_metadata, force_metadata);
+  int verdict = 0;
+  if (what != META_SAME) {
+    fprintf(stderr, "metadata doesn't match. Expected:\n%s\nLoaded from net:\n%s\n\n", callers, net->metadata);
   }
-  free(metadata);
-  return ret;
+  switch (what) {
+  case META_SAME:
+    break;
+  case META_ADOPT_NETS: {
+    struct RnnCharMetadata stored = {0};
+    if (rnn_char_load_metadata(net->metadata, &stored) == 0) {
+      fprintf(stderr, "Using the net's metadata. Use --force-metadata to override\n");
+      rnn_char_copy_metadata_items(&stored, m);
+    } else {
+      fprintf(stderr, "The net's metadata doesn't load. Using otherwise determined metadata\n");
+    }
+    rnn_char_free_metadata_items(&stored);
+    break;
+  }
+  case META_OVERWRITE_NETS:
+    fprintf(stderr, "Updating the net's metadata to match that requested (because --force-metadata)\n");
+    free(net->metadata);
+    net->metadata = callers;
+    callers = NULL;
+    break;
+  case META_CONFLICT:
+    verdict = -2;
+    break;
+  }
+  free(callers);
+  return verdict;
 }
 
-/* charmodel-init.c:733-751 */
+/* charmodel.h:236: the alphabet a net was trained with, from the metadata it carries.  (Where the
+ * metadata is missing or does not parse the reference reads freed or unset memory; an empty alphabet
+ * comes back here.) */
 RnnCharAlphabet *rnn_char_new_alphabet_from_net(RecurNN *net) {
-  RnnCharMetadata m = {0};
+  RnnCharMetadata stored = {0};
   if (net->metadata) {
-    rnn_char_load_metadata(net->metadata, &m);
+    rnn_char_load_metadata(net->metadata, &stored);
   }
   RnnCharAlphabet *a = rnn_char_new_alphabet();
-  rnn_char_alphabet_set_flags(a, m.case_insensitive, m.utf8, m.collapse_space);
-  /* (the reference dereferences whatever a failed load left behind; an empty alphabet
-   * is returned here instead) */
-  a->len = m.alphabet ? points_of_string(a->points, 256, m.alphabet, m.utf8) : 0;
-  a->collapsed_len =
-      m.collapse_chars ? points_of_string(a->collapsed_points, 256, m.collapse_chars, m.utf8) : 0;
-  rnn_char_free_metadata_items(&m);
-  if (a->len != net->input_size || a->len != net->output_size) {
-    fprintf(stderr, "net sizes in %d out %d, alphabet length %d.\n", net->input_size,
-            net->output_size, a->len);
+  rnn_char_alphabet_set_flags(a, stored.case_insensitive, stored.utf8, stored.collapse_space);
+  if (stored.alphabet) {
+    a->len = points_of_string(a->points, 256, stored.alphabet, stored.utf8);
+  }
+  if (stored.collapse_chars) {
+    a->collapsed_len = points_of_string(a->collapsed_points, 256, stored.collapse_chars, stored.utf8);
+  }
+  rnn_char_free_metadata_items(&stored);
+  if (net->input_size != a->len || net->output_size != a->len) {
+    fprintf(stderr, "the net reads %d symbols and writes %d, its alphabet has %d.\n", net->input_size, net->output_size,
+            a->len);
   }
   return a;
 }

@@ -15,6 +15,8 @@
  */
 #include "rnn_host.h"
 #include <dlfcn.h>
+#include <pthread.h>
+#include <time.h>
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 
@@ -33,6 +35,8 @@ static struct {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *);
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
   ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*CommCount)(const ncclComm_t, int *);
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
   const char *(*GetErrorString)(ncclResult_t);
   ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
   ncclResult_t (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
@@ -87,6 +91,8 @@ static int bind_rccl(void) {
   SYM(GetUniqueId, "ncclGetUniqueId");
   SYM(CommInitRank, "ncclCommInitRank");
   SYM(CommDestroy, "ncclCommDestroy");
+  SYM(CommCount, "ncclCommCount");
+  SYM(CommUserRank, "ncclCommUserRank");
   SYM(GetErrorString, "ncclGetErrorString");
   SYM(AllReduce, "ncclAllReduce");
   SYM(Broadcast, "ncclBroadcast");
@@ -104,6 +110,22 @@ int rnn_amd_dist_get_id(void *id) {
   return 0;
 }
 
+struct init_job {
+  ncclUniqueId id;
+  int rank, world, device;
+  ncclComm_t comm;
+  ncclResult_t result;
+};
+static void *init_thread(void *p) {
+  struct init_job *j = p;
+  if (hipSetDevice(j->device) != hipSuccess) { /* (a new thread starts on device 0) */
+    j->result = 1;
+    return NULL;
+  }
+  j->result = rccl.CommInitRank(&j->comm, j->world, j->id, j->rank);
+  return NULL;
+}
+
 int rnn_amd_dist_init(int rank, int world, const void *id) {
   if (g_comm) {
     fprintf(stderr, "librecur_amd: rnn_amd_dist_init called twice\n");
@@ -117,11 +139,44 @@ int rnn_amd_dist_init(int rank, int world, const void *id) {
   if (bind_rccl()) {
     return -1;
   }
-  ncclUniqueId u;
-  memcpy(&u, id, sizeof(u));
-  RCCL_OK(rccl.CommInitRank(&g_comm, world, u, rank));
-  g_rank = rank;
-  g_world = world;
+  /* ncclCommInitRank blocks until EVERY rank has arrived; one that never does (a rank that died, a
+   * wrong id, ranks that cannot reach each other) would leave this process waiting for ever.  The call
+   * runs on a helper thread and is given RECUR_AMD_RCCL_INIT_TIMEOUT seconds (default 180). */
+  struct init_job job;
+  memset(&job, 0, sizeof(job));
+  memcpy(&job.id, id, sizeof(job.id));
+  job.rank = rank;
+  job.world = world;
+  HIP_OK(hipGetDevice(&job.device));
+  const char *te = getenv("RECUR_AMD_RCCL_INIT_TIMEOUT");
+  long limit = (te && atol(te) > 0) ? atol(te) : 180;
+  pthread_t th;
+  if (pthread_create(&th, NULL, init_thread, &job) != 0) {
+    fprintf(stderr, "librecur_amd: rnn_amd_dist_init cannot start its helper thread\n");
+    return -1;
+  }
+  struct timespec until;
+  clock_gettime(CLOCK_REALTIME, &until);
+  until.tv_sec += limit;
+  if (pthread_timedjoin_np(th, NULL, &until) != 0) {
+    fprintf(stderr, "librecur_amd: rank %d of %d has waited %ld s in ncclCommInitRank: not every rank joined the "
+                    "group (is each of the %d ranks running, with rank 0's id, on a GPU of its own, "
+                    "HSA_ENABLE_IPC_MODE_LEGACY=0 set?).  Giving up.\n", rank, world, limit, world);
+    abort();
+  }
+  if (job.result != 0) {
+    fprintf(stderr, "librecur_amd: ncclCommInitRank failed: %s\n", rccl.GetErrorString(job.result));
+    return -1;
+  }
+  g_comm = job.comm;
+  /* what the communicator says, not what the caller said */
+  RCCL_OK(rccl.CommCount(g_comm, &g_world));
+  RCCL_OK(rccl.CommUserRank(g_comm, &g_rank));
+  if (g_world != world || g_rank != rank) {
+    fprintf(stderr, "librecur_amd: the RCCL group has %d ranks and this is rank %d (asked for rank %d of %d)\n",
+            g_world, g_rank, rank, world);
+    abort();
+  }
   HIP_OK(hipMalloc(&g_scratch, 256));
   return 0;
 }

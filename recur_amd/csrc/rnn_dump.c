@@ -4,7 +4,7 @@
  * images/<basename>-<token>-<generation as %08d>-<w>x<h>.ppm whose pixels are
  * red for negative, green for positive, blue for exactly zero, scaled so the
  * largest magnitude is 255).  Cold path, host only. */
-#include "rnn_host.h"
+#include "char_host.h"
 
 void ramd_write_signed_ppm(const float *a, int width, int height, const char *name) {
   size_t n = (size_t)width * height;
@@ -110,4 +110,44 @@ void rnn_multi_pgm_dump(RecurNN *net, const char *dumpees, const char *basename)
     }
   }
   free(copy);
+}
+
+/* ---- rows of a "temporal" image: one row per time step, written out when full ----
+ * The struct is pgm_dump.h:227-237's; a caller that wants such images builds it with that header's
+ * constructor and hands it over in model->images (text-predict.c:575-600). */
+struct _TemporalPPM {
+  float *im;
+  int width, height;
+  int y; /* next row */
+  int id;
+  char *basename;
+  int counter; /* rows written to files so far */
+  int mode;    /* pgm_dump.h:222-225: 0 grey magnitudes, 1 signed colour */
+  float **source;
+};
+
+void ramd_temporal_row(TemporalPPM *ppm, const float *row) {
+  memcpy(ppm->im + (size_t)ppm->y * ppm->width, row, sizeof(float) * ppm->width);
+  if (++ppm->y < ppm->height) {
+    return;
+  }
+  char name[200]; /* pgm_dump.h:262-288: the file name carries the first row's time step */
+  snprintf(name, sizeof(name), "images/%s-%d-%08d-%dx%d.ppm", ppm->basename, ppm->id, ppm->counter, ppm->width,
+           ppm->height);
+  (ppm->mode == 0 ? ramd_write_abs_pgm : ramd_write_signed_ppm)(ppm->im, ppm->width, ppm->height, name);
+  ppm->counter += ppm->height;
+  ppm->y = 0;
+}
+
+void ramd_image_rows(RecurNN *net, TemporalPPM *input_ppm, TemporalPPM *error_ppm) {
+  if (!input_ppm && !error_ppm) {
+    return;
+  }
+  rnn_amd_sync_host(net, RNN_AMD_STREAM); /* the rows live on the device */
+  if (input_ppm) {
+    ramd_temporal_row(input_ppm, net->input_layer);
+  }
+  if (error_ppm) {
+    ramd_temporal_row(error_ppm, net->bptt->o_error);
+  }
 }

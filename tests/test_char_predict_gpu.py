@@ -1,5 +1,5 @@
 """The prediction layer of the character models on the device
-(recur_amd/csrc/charmodel_predict.c: rnn_char_epoch, rnn_char_cross_entropy,
+(recur_amd/csrc/char_epoch.c, char_sampling.c, char_multitext.c: rnn_char_epoch, rnn_char_cross_entropy,
 rnn_char_prime, rnn_char_confabulate, the validation-entropy object), i.e. SURVEY.md
 section 8(f) rank 1: the callers either side of the hot path, driven exactly the way
 text-predict.c:529-640 drives them."""

@@ -8,7 +8,8 @@ import numpy as np
 import recur_ctypes as rc, scenarios as sc
 amd = rc.load_amd()
 text = sc.synthetic_text(30000)
-g = sc.AmdBatchedSet(amd, input_size=42, hidden_size=1024, output_size=42, S=256, D=20, learn_rate=1e-5, seed=1)
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+g = sc.AmdBatchedSet(amd, input_size=42, hidden_size=1024, output_size=42, S=S, D=20, learn_rate=1e-5, seed=1)
 g.load_text(text)
 for i in range(30):
     amd.rnn_amd_set_char_step(g.handle, i, rc.WEIGHTED, 0.95)
