@@ -505,6 +505,10 @@ int orc_grouped_softmax_error(OrcSet *z, int s, int n_groups, const int *group_o
   return trained;
 }
 
+/* (Pinned since round 3: tests/golden/ref_callers.npz holds what the reference's own object code gives
+ * when walked through these callers' control flow -- tests/golden/make_golden_callers.py -- and
+ * tests/test_oracle_callers_golden.py holds orc_multi_softmax_error, orc_multitext_train,
+ * orc_multi_cross_entropy, orc_grouped_softmax_error and orc_sigmoid_mse_error to it.) */
 /* multi_softmax_error (charmodel-multi-predict.c:17-58): opinion, then every class head
  * of alphabet_len outputs is either trained (its own head always, the others when a draw
  * from the stream's generator falls under leakage) or left at zero; ranges_out receives

@@ -197,12 +197,18 @@ int rnn_amd_dist_rank(void) { return g_rank; }
 int rnn_amd_dist_world(void) { return g_world; }
 int ramd_dist_active(void) { return g_comm != NULL; }
 
-void rnn_amd_dist_all_reduce(void *device_buffer, size_t n_floats) {
+/* in-place sum over the ranks on a stream of the caller's choice (collectives of one communicator must
+ * be issued in the same order on every rank: the callers see to that) */
+void ramd_dist_all_reduce_on(void *device_buffer, size_t n_floats, void *stream) {
   if (!g_comm) {
     return; /* one process: the sum over ranks is the buffer itself */
   }
-  RCCL_OK(rccl.AllReduce(device_buffer, device_buffer, n_floats, RAMD_NCCL_FLOAT32, RAMD_NCCL_SUM,
-                         g_comm, (hipStream_t)rnn_amd_current_stream()));
+  RCCL_OK(rccl.AllReduce(device_buffer, device_buffer, n_floats, RAMD_NCCL_FLOAT32, RAMD_NCCL_SUM, g_comm,
+                         (hipStream_t)stream));
+}
+
+void rnn_amd_dist_all_reduce(void *device_buffer, size_t n_floats) {
+  ramd_dist_all_reduce_on(device_buffer, n_floats, rnn_amd_current_stream());
 }
 
 double rnn_amd_dist_max(double x) {

@@ -3466,7 +3466,7 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
   const int z = xcd / per, tile = q * per + (xcd % per);
   if (tile >= o.tm * o.tn) return;
   const int mt = tile / o.tn, nt = tile % o.tn;
-  const int m0 = mt * 128, n0 = o.col0 + nt * 128;
+  const int m0 = o.row0m + mt * 128, n0 = o.col0 + nt * 128; /* (row0m: a launch over the upper row tiles only) */
   const int kt0 = (int)(((long)o.nkt * z) / o.ks), kt1 = (int)(((long)o.nkt * (z + 1)) / o.ks);
   const int nst = kt1 - kt0;
   const int wave8 = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -5044,6 +5044,16 @@ extern "C" void ramd_launch_clear_deltas(ramd_stream_t st_, const RamdShape *sh,
 }
 
 static int g_calc_wrote_images = 0;
+/* Multi-GPU: the weight-delta GEMM in two row halves, so that the sum over the ranks of the first half
+ * can travel while the second half is still being multiplied (rnn_core.c sets the hook for the call it
+ * wants split; the launcher calls it after each half's deltas are complete in ih_delta || ho_delta,
+ * with the half's range in floats from ih_delta). */
+static void (*g_delta_half_hook)(void *ctx, int half, size_t first_float, size_t n_floats) = nullptr;
+static void *g_delta_half_ctx = nullptr;
+extern "C" void ramd_set_delta_half_hook(void (*hook)(void *, int, size_t, size_t), void *ctx) {
+  g_delta_half_hook = hook;
+  g_delta_half_ctx = ctx;
+}
 /* whether the last ramd_launch_calc_deltas also rebuilt bptt->h_error / i_error (reads and clears) */
 extern "C" int ramd_calc_wrote_images(void) {
   int w = g_calc_wrote_images;
@@ -5357,6 +5367,62 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       const bool rest_in = rest_rows > 0 && rest_rows <= 128 && o.tm >= 4 && kd * o.tm <= RAMD_MAX_REST_PLANES &&
                            (size_t)kd * n + (size_t)kd * o.tm * rest_plane <= b->slab_floats &&
                            env_int("RECUR_AMD_DELTA_REST_IN", 1);
+      /* ---- the two-halves form (see g_delta_half_hook): rows [0, tm / 2 tiles) with twice the K split
+       * (the same number of workgroups and of slab bytes), summed into ih_delta, hook; then the upper
+       * tiles with the rest rows riding along, the top layer's deltas, summed, hook */
+      if (g_delta_half_hook && !defer && rest_in && o.tm >= 8 && o.tm % 2 == 0 && ho_paired && ho_finalize_after &&
+          !ranges && env_int("RECUR_AMD_DIST_OVERLAP", 0)) {
+        /* OFF by default -- measured with ONE rank (bench.py --dist, round 3): 305 against 255 us per
+         * generation.  Two launches of half the rows with twice the K split cost the GEMM class +24 us
+         * (each workgroup's prologue, epilogue and ring fill amortise over 20 instead of 40 K tiles, the
+         * finalize sums 8 planes twice), the two event hand-overs and RCCL calls another ~25 us: more
+         * than the ~2.2 MB all-reduce it could hide is expected to take over xGMI.  And while a half's
+         * GEMM holds every CU with 148 KB of LDS, RCCL's own workgroups can only become resident as that
+         * launch drains.  Kept for the day a multi-GPU node says otherwise (RECUR_AMD_DIST_OVERLAP=1;
+         * results equal the one-launch form: tests/test_gpu_dist.py). */
+        const int tmh = o.tm / 2;
+        int kd2 = 8;
+        while (kd2 > 1 && (tmh * o.tn * kd2 > 256 || kd2 > nkt ||
+                           (size_t)kd2 * n + (size_t)kd2 * tmh * rest_plane > b->slab_floats))
+          kd2 >>= 1;
+        const int per2 = 8 / kd2;
+        const int blocks2 = ((tmh * o.tn + per2 - 1) / per2) * 8;
+        const size_t half_floats = (size_t)tmh * 128 * sh->H, n4h = half_floats / 4;
+        GemmOut oh = o;
+        oh.tm = tmh;
+        oh.ks = kd2;
+        int evh = timing_begin(st, T_DELTA, 2);
+        { /* lower half: no rest rows */
+          DeltaRest none = {};
+          oh.row0m = 0;
+          RAMD_LAUNCH(k_delta_dma<0>, dim3(blocks2), dim3(512), shm, st, v, row0, nrows, oh, none);
+          RAMD_LAUNCH(k_delta_finalize, dim3((unsigned)((n4h + 255) / 256)), dim3(256), 0, st, b->ih_delta, b->slab, n4h, n,
+                      kd2, accumulate, sh->H, sh->hidden_size, tmh * 128, 0, b->slab, (size_t)0, b->ho_delta,
+                      (const float *)nullptr, (size_t)0, 0);
+          g_delta_half_hook(g_delta_half_ctx, 0, 0, half_floats);
+        }
+        { /* upper half + rest rows + the top layer */
+          DeltaRest dr;
+          dr.planes = b->slab + (size_t)kd2 * n;
+          dr.stride = rest_plane;
+          dr.rows = rest_rows;
+          dr.col = rows_core;
+          oh.row0m = tmh * 128;
+          if (rest_rows <= 64)
+            RAMD_LAUNCH(k_delta_dma<64>, dim3(blocks2), dim3(512), shm_rest, st, v, row0, nrows, oh, dr);
+          else
+            RAMD_LAUNCH(k_delta_dma<128>, dim3(blocks2), dim3(512), shm_rest, st, v, row0, nrows, oh, dr);
+          timing_end(st, evh);
+          launch_gemm<true, true, ProbHoDelta>(st, ho_p, b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, T_DELTA);
+          const size_t up_floats = n - half_floats, n4u = up_floats / 4, ho_n = (size_t)sh->H * sh->O;
+          const unsigned fin_blocks = (unsigned)((n4u + 255) / 256) + (unsigned)((ho_n / 4 + 255) / 256);
+          RAMD_LAUNCH(k_delta_finalize, dim3(fin_blocks), dim3(256), 0, st, b->ih_delta + half_floats, b->slab + half_floats,
+                      n4u, n, kd2, accumulate, sh->H, sh->hidden_size, rows_core - tmh * 128, kd2 * tmh, dr.planes,
+                      rest_plane, b->ho_delta, b->ho_slab, ho_n, ho_ks);
+          g_delta_half_hook(g_delta_half_ctx, 1, half_floats, up_floats + ho_n);
+        }
+        return;
+      }
       int ev = timing_begin(st, T_DELTA);
       if (rest_in) {
         DeltaRest dr;

@@ -198,6 +198,9 @@ void ramd_launch_sigmoid_outputs(ramd_stream_t st, const RamdShape *sh, const Ra
                                  int nrows, int n);
 /* rnn_opinion's device work for one stream of a small net in one launch; 0: not its kind of shape */
 int ramd_launch_forward_small(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int r);
+/* The next ramd_launch_calc_deltas calls may run the weight-delta GEMM in two row halves and call `hook`
+ * (ctx, half 0 / 1, first float from ih_delta, floats) after each half's deltas are complete; NULL: off. */
+void ramd_set_delta_half_hook(void (*hook)(void *ctx, int half, size_t first_float, size_t n_floats), void *ctx);
 /* whether the last ramd_launch_calc_deltas also rebuilt the h_error / i_error images (reads and clears) */
 int ramd_calc_wrote_images(void);
 /* up to 12 word-wise copies (nwords[g] 32-bit words from src[g] to dst[g]) in one launch */

@@ -2414,17 +2414,52 @@ void rnn_amd_set_char_step_deltas(RnnAmdSet *set, int i) { char_step_deltas(set,
 static void apply_learning(RecurNN *net, int learning_method, float momentum,
                            const RamdPendingDelta *pend);
 
+/* The exchange step overlapped with the weight-delta GEMM: the GEMM runs as two
+ * row halves (kernels.hip: g_delta_half_hook); as soon as a half's deltas are complete its sum over the
+ * ranks starts on a stream of its own, so the first half's all-reduce (2.2 of the 4.6 MB at the north
+ * star) travels over xGMI while the second half is still being multiplied.  The update waits for both.
+ * Every rank reduces the same two ranges in the same order, so the replicas stay bit-identical. */
+static hipStream_t g_comm_stream = NULL;
+static hipEvent_t g_half_ready[2], g_half_summed[2];
+static int g_halves_seen = 0;
+
+static void delta_half_ready(void *ctx, int half, size_t first_float, size_t n_floats) {
+  RamdEngine *e = ctx;
+  if (!g_comm_stream) {
+    HIP_OK(hipStreamCreateWithFlags(&g_comm_stream, hipStreamNonBlocking));
+    for (int h = 0; h < 2; h++) {
+      HIP_OK(hipEventCreateWithFlags(&g_half_ready[h], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&g_half_summed[h], hipEventDisableTiming));
+    }
+  }
+  HIP_OK(hipEventRecord(g_half_ready[half], g_stream));
+  HIP_OK(hipStreamWaitEvent(g_comm_stream, g_half_ready[half], 0));
+  ramd_dist_all_reduce_on(e->b.ih_delta + first_float, n_floats, g_comm_stream);
+  HIP_OK(hipEventRecord(g_half_summed[half], g_comm_stream));
+  g_halves_seen |= 1 << half;
+}
+
 void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float momentum) {
   /* the deltas go straight from the GEMM's K slabs into the update (and into ih_delta) when
    * nothing can look at them in between: library-owned storage, no log on the prototype */
   RamdPendingDelta pend = {0};
   const int dist = ramd_dist_active();
   int fuse = !set->eng->delta_external && !set->nets[0]->log && !dist;
+  if (dist) {
+    g_halves_seen = 0;
+    ramd_set_delta_half_hook(delta_half_ready, set->eng);
+  }
   char_step_deltas(set, i, fuse ? &pend : NULL);
   if (dist) {
     /* the one exchange step of the path: this rank's deltas become the sum over all ranks'
      * streams (recur-nn.c:724-739 distributed), then the identical update everywhere */
-    rnn_amd_dist_all_reduce(set->eng->b.ih_delta, set->eng->ih_size + set->eng->ho_size);
+    ramd_set_delta_half_hook(NULL, NULL);
+    if (g_halves_seen == 3) { /* both halves are on their way: the update waits for them */
+      HIP_OK(hipStreamWaitEvent(g_stream, g_half_summed[0], 0));
+      HIP_OK(hipStreamWaitEvent(g_stream, g_half_summed[1], 0));
+    } else { /* a shape the two-halves form does not take: one all-reduce behind the deltas */
+      rnn_amd_dist_all_reduce(set->eng->b.ih_delta, set->eng->ih_size + set->eng->ho_size);
+    }
   }
   apply_learning(set->nets[0], learning_style, momentum, (pend.slab || pend.ho_slab) ? &pend : NULL);
 }

@@ -107,6 +107,7 @@ void ramd_rng_from_host(RecurNN *net);
 /* dist.c */
 int ramd_dist_active(void);
 void ramd_dist_bcast(void *host, size_t bytes, int root);
+void ramd_dist_all_reduce_on(void *device_buffer, size_t n_floats, void *stream);
 rand_ctx *ramd_shared_rng(RecurNN *net, rand_ctx *tmp);
 
 /* rnn_init.c: Jenkins PRNG (recur-rng.h) */

@@ -202,6 +202,26 @@ def test_library_exchange_step_through_rccl_with_one_rank():
         assert joined < 1e-6 and after == 0.0, (k, joined, after)
 
 
+def test_two_halves_exchange_equals_the_one_launch_form():
+    """RECUR_AMD_DIST_OVERLAP=1 (off by default: DESIGN.md section 6): the weight-delta GEMM as two row halves,
+    each half's all-reduce on the library's second stream as soon as its deltas are complete, the update
+    behind both.  Hidden 1024 (eight row tiles, rest rows riding with the upper half), one rank: the sum is
+    the identity, so weights, momentum and deltas must equal the plain path's to the summation order of
+    the K slabs."""
+    env = dict(os.environ, RECUR_AMD_DIST_OVERLAP="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    script = RCCL_SCRIPT.replace("hidden_size=128, output_size=42, S=32, D=6, learn_rate=2e-3",
+                                 "hidden_size=1024, output_size=42, S=64, D=5, learn_rate=1e-4")
+    r = subprocess.run([sys.executable, "-c", script % {"tests": os.path.dirname(os.path.abspath(__file__))}],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    import json
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert res.pop("rng")
+    for k, (joined, after) in res.items():
+        assert joined < 2e-6 and after == 0.0, (k, joined, after)
+
+
 def test_c_driver_with_G_1_goes_through_the_library_exchange_step():
     """tools/text_predict_amd -G 1: one forked-process-per-GPU launcher in plain C, the RCCL id
     handed over in shared memory, rnn_amd_dist_init, the shard constructor, the all-reduce
