@@ -20,6 +20,9 @@ float *ramd_feed_symbol(RecurNN *net, int hot, float presynaptic_noise);
  * (kept in step with the device).  `work` holds n floats. */
 int ramd_next_symbol(RecurNN *net, int hot, float bias, int head, int n, int greedy, float *work);
 
+/* ---- charmodel_meta.c ---- */
+uint32_t ramd_hash32(const char *s); /* recur-common.h:207-216: the signature in net file names */
+
 /* ---- rnn_dump.c ---- */
 void ramd_temporal_row(TemporalPPM *ppm, const float *row);
 /* the two image rows a caller may have asked for (model->images / the multi-text arguments) */

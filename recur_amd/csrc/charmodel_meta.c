@@ -232,7 +232,7 @@ void rnn_char_copy_metadata_items(struct RnnCharMetadata *src, struct RnnCharMet
 }
 
 /* recur-common.h:207-216 */
-static uint32_t hash32(const char *s) {
+uint32_t ramd_hash32(const char *s) {
   uint32_t sig = 0;
   size_t len = strlen(s);
   for (size_t i = 0; i < len; i++) {
@@ -249,7 +249,7 @@ char *rnn_char_construct_net_filename(struct RnnCharMetadata *m, const char *bas
                                       int output_size) {
   char s[260];
   char *metadata = rnn_char_construct_metadata(m);
-  uint32_t sig = hash32(metadata);
+  uint32_t sig = ramd_hash32(metadata);
   free(metadata);
   if (bottom_size) {
     snprintf(s, sizeof(s), "%s-s%0" PRIx32 "-i%d-b%d-h%d-o%d.net", basename, sig, input_size,

@@ -551,6 +551,40 @@ CHAR_API = {
     "rnn_char_load_new_encoded_text": (c_u8_p, [C.c_char_p, AlphaP, c_int_p, C.c_int]),
     "rnn_char_alloc_file_contents": (C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), c_int_p]),
 }
+
+
+class ClassifyMetadata(C.Structure):  # gstclassify.h:57-72 / include/recur_amd_classify.h
+    _fields_ = [("classes", C.c_char_p), ("min_freq", C.c_float), ("max_freq", C.c_float), ("knee_freq", C.c_float),
+                ("mfccs", C.c_int), ("window_size", C.c_int), ("basename", C.c_char_p), ("delta_features", C.c_int),
+                ("focus_freq", C.c_float), ("lag", C.c_float), ("intensity_feature", C.c_int),
+                ("confirmation_lag", C.c_float), ("features_offset", C.c_char_p), ("features_scale", C.c_char_p)]
+
+
+class BalancedTraining(C.Structure):
+    _fields_ = [("n_outputs", C.c_int), ("bias", C.c_float), ("seen", C.POINTER(C.c_uint32)),
+                ("used", C.POINTER(C.c_uint32)), ("train_p", c_float_p)]
+
+
+CLASSIFY_API = {
+    "rnn_amd_classify_construct_metadata": (C.c_void_p, [C.POINTER(ClassifyMetadata)]),
+    "rnn_amd_classify_load_metadata": (C.c_int, [C.c_char_p, C.POINTER(ClassifyMetadata)]),
+    "rnn_amd_classify_free_metadata_items": (None, [C.POINTER(ClassifyMetadata)]),
+    "rnn_amd_classify_net_filename": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                   C.c_int]),
+    "rnn_amd_classify_parse_classes": (C.c_int, [C.c_char_p, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p]),
+    "rnn_amd_classify_check_net": (C.c_int, [NetP, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rnn_amd_balanced_new": (C.POINTER(BalancedTraining), [C.c_int, C.c_float]),
+    "rnn_amd_balanced_free": (None, [C.POINTER(BalancedTraining)]),
+    "rnn_amd_balanced_begin": (None, [C.POINTER(BalancedTraining)]),
+    "rnn_amd_classify_generation": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p,
+                                              c_float_p, C.POINTER(BalancedTraining), C.c_int, C.c_float, C.c_int]),
+}
+
+
+def bind_classify(lib):
+    return _bind(lib, CLASSIFY_API)
+
+
 CHAR_CASE_INSENSITIVE, CHAR_UTF8, CHAR_COLLAPSE_SPACE = 1, 2, 4
 # text-predict's default character set (text-predict.c:44-45)
 DEFAULT_CHARSET = b"8 etaonihsrdlucmwfygpb,v.k-;x\"qj'?:z)(_!*&"

@@ -20,6 +20,7 @@ import pytest
 import recur_ctypes as rc
 import replay
 import scenarios as sc
+from test_gpu_parity import _load_state
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
@@ -336,4 +337,70 @@ def test_config4_rnnca_frame_fill_13824_cells(amd):
     for k in range(F):
         lib.rnn_delete_net(cells[k])
     lib.rnn_delete_net(net)
+    o.close()
+
+
+def test_config2_classify_generations_with_balanced_training(amd):
+    """BASELINE.json configs[2] (gstclassify: 512 hidden, 128 channels, 2 classes, Nesterov) through
+    rnn_amd_classify_generation -- maybe_learn's body (gstclassify.c:2196-2257) with the balanced-training
+    draws (2190-2215, 2096-2104) from the prototype's generator -- against the same loop written out over the
+    oracle's per-stream calls.  The sample of windows that train, the seen / used counts and the generator
+    must be identical; the nets to 1e-4 on the generations without a hidden unit within rounding of zero."""
+    lib = rc.bind_classify(amd)
+    S, D, NIN = 128, 12, 32
+    kw = dict(input_size=NIN, hidden_size=512, output_size=2, S=S, D=D, learn_rate=3e-4, seed=9, momentum=0.9)
+    g = sc.AmdBatchedSet(lib, **kw)
+    o = sc.OracleSet(**kw)
+    goff, gsize = np.array([0], np.int32), np.array([2], np.int32)
+    bal = lib.rnn_amd_balanced_new(2, 1.5)
+    seen, used = np.zeros(2, np.uint32), np.zeros(2, np.uint32)
+    to_unit = np.float32(1.0) / np.float32(float(0xfffffffffffffffe))
+    rs = np.random.default_rng(17)
+    flags = g.net.contents.flags
+    compared = 0
+    for gen in range(8):
+        x = (rs.standard_normal((S, NIN)) * 0.5).astype(np.float32)
+        tg = rs.choice([0, 0, 0, 1, -1], size=(S, 1)).astype(np.int32)  # class 0 three times as common; some unlabelled
+        n = lib.rnn_amd_classify_generation(g.handle, rc.fptr(x), NIN, 1, rc.iptr(goff), rc.iptr(gsize), rc.iptr(tg), None,
+                                            bal, rc.NESTEROV, 2000.0, 1)
+        # ---- the reference's loop on the oracle
+        o.orc.orc_clear_deltas(o.z)
+        share = np.float32(1.0) / np.float32(np.float32(seen.sum()) + np.float32(1.0))
+        train_p = np.power(np.float32(1.0) - seen.astype(np.float32) * share, np.float32(1.5)).astype(np.float32)
+        wins, wrong, trained_groups = C.c_int(0), C.c_float(0), 0
+        for j in range(S):
+            o.orc.orc_opinion(o.z, j, rc.fptr(np.ascontiguousarray(x[j])), 0.0)
+            t = int(tg[j, 0])
+            eff = np.array([-1], np.int32)
+            if 0 <= t < 2:
+                seen[t] += 1
+                draw = np.float32(np.float32(o.orc.orc_rand64(C.byref(o.z.contents.rng[0]))) * to_unit)
+                if train_p[t] > draw:
+                    used[t] += 1
+                    eff[0] = t
+            k = o.orc.orc_grouped_softmax_error(o.z, j, 1, rc.iptr(goff), rc.iptr(gsize), rc.iptr(eff), None,
+                                                C.byref(wins), C.byref(wrong))
+            if k:
+                o.orc.orc_calc_deltas(o.z, j, 1, None)
+            trained_groups += k
+            o.orc.orc_advance(o.z, j)
+        if wrong.value:
+            gen0 = float(o.arrays()["generation"][0])
+            o.orc.orc_apply_learning(o.z, rc.NESTEROV, o.orc.orc_momentum_soft_start(gen0, 0.9, 2000.0))
+        o.orc.orc_condition(o.z, flags)
+        # ---- the sample, the counts, the generator: exactly
+        assert n == trained_groups
+        assert list(bal.contents.seen[:2]) == list(seen) and list(bal.contents.used[:2]) == list(used)
+        sg, so = g.snapshot(), o.snapshot()
+        assert np.array_equal(sg["rng"][0], so["rng"][0])
+        flips = np.argwhere((sg["hidden"] != 0) != (so["hidden"] != 0))
+        if len(flips) == 0:
+            replay.check(sg, so, RTOL, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "output",
+                                             "hist"], exact=("index", "generation"))
+            compared += 1
+        _load_state(amd, g, so)
+    assert compared >= 4 and 0 < used.sum() < seen.sum()  # the draw did leave windows out
+    assert used[0] / max(seen[0], 1) < used[1] / max(seen[1], 1)  # ... more of the common class
+    lib.rnn_amd_balanced_free(bal)
+    g.close()
     o.close()

@@ -6,7 +6,7 @@ set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 cd "$root" && make -C recur_amd/csrc > /dev/null
 mkdir -p build/asan
-for f in rnn_core dist rnn_init rnn_io rnn_dump cdb charmodel char_sampling char_epoch char_multitext charmodel_meta; do
+for f in rnn_core dist rnn_init rnn_io rnn_dump cdb charmodel char_sampling char_epoch char_multitext charmodel_meta classify_host; do
   gcc -std=gnu11 -O1 -g -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -D_GNU_SOURCE -Irecur_amd/csrc -Iinclude \
       -I/opt/rocm/include -c recur_amd/csrc/$f.c -o build/asan/$f.o
 done
