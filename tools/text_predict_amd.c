@@ -12,6 +12,13 @@
  *   text_predict_amd [-f text] [-H hidden] [-t streams] [-d depth] [-l learn_rate]
  *                    [-m momentum] [-s stop_generation] [-r report_interval]
  *                    [-V validate_chars] [-S seed] [-n net_file] [-G gpus]
+ *                    [-a activation] [-L learning_style] [-N presynaptic_noise] [-B ballast]
+ *
+ * -a / -L take the reference's numbers (text-predict's --activation and --learning-style,
+ * text-predict.c:249-262; recur-nn.h:109-131): activation 1 ReLU (default), 2 ReSQRT, 5 ReCLIP20;
+ * learning style 0 weighted momentum (default), 1 Nesterov, 2 simplified Nesterov, 3 classical
+ * momentum, 4 adagrad, 5 adadelta, 6 rprop (4-6 get the auxiliary arrays; -B is adagrad's / adadelta's
+ * starting accumulator, text-predict.c:546-557).
  *
  * -G n shards the t streams over n GPUs, one PROCESS per GPU (forked here before anything
  * touches a device): rank 0 makes the RCCL id and hands it over in shared memory, every
@@ -48,10 +55,11 @@ static double cross_entropy(RecurNN *net, RnnCharAlphabet *alphabet, const u8 *t
 int main(int argc, char **argv) {
   const char *file = "tests/golden/erewhon.txt", *save = NULL;
   int hidden = 199, streams = 64, depth = 30, stop = 2000, report = 200, validate = 4000, gpus = 0;
-  float lr = 1e-4f, momentum = 0.95f;
+  int activation = RNN_RELU, style = RNN_MOMENTUM_WEIGHTED;
+  float lr = 1e-4f, momentum = 0.95f, noise = 0.0f, ballast = -1.0f;
   unsigned long long seed = 1;
   int opt;
-  while ((opt = getopt(argc, argv, "f:H:t:d:l:m:s:r:V:S:n:G:")) != -1) {
+  while ((opt = getopt(argc, argv, "f:H:t:d:l:m:s:r:V:S:n:G:a:L:N:B:")) != -1) {
     switch (opt) {
     case 'f': file = optarg; break;
     case 'H': hidden = atoi(optarg); break;
@@ -65,6 +73,10 @@ int main(int argc, char **argv) {
     case 'S': seed = strtoull(optarg, NULL, 10); break;
     case 'n': save = optarg; break;
     case 'G': gpus = atoi(optarg); break;
+    case 'a': activation = atoi(optarg); break;
+    case 'L': style = atoi(optarg); break;
+    case 'N': noise = atof(optarg); break;
+    case 'B': ballast = atof(optarg); break;
     default:
       fprintf(stderr, "see the comment at the top of %s\n", __FILE__);
       return 2;
@@ -87,15 +99,28 @@ int main(int argc, char **argv) {
   len -= validate;
 
   /* net (text-predict.c:414-437, 360-395) and its training set */
+  if ((activation != RNN_RELU && activation != RNN_RESQRT && activation != RNN_RECLIP20) || style < 0 ||
+      style >= RNN_LAST_LEARNING_METHOD) {
+    fprintf(stderr, "-a %d / -L %d: see the comment at the top of %s\n", activation, style, __FILE__);
+    return 2;
+  }
   u32 flags = RNN_NET_FLAG_STANDARD | RNN_NET_FLAG_BPTT_ADAPTIVE_MIN_ERROR;
+  if (style == RNN_ADADELTA || style == RNN_RPROP) {
+    flags |= RNN_NET_FLAG_AUX_ARRAYS; /* text-predict.c:418-421 */
+  }
   RecurNN *net = rnn_new(alphabet->len, hidden, alphabet->len, flags, seed, NULL, depth, lr,
-                         momentum, 0.0f, RNN_RELU);
+                         momentum, noise, activation);
   struct RecurInitialisationParameters p;
   rnn_init_default_weight_parameters(net, &p);
   p.method = RNN_INIT_FLAT;
   p.flat_shape = RNN_INIT_DIST_SEMICIRCLE;
   p.flat_perforation = 0;
   rnn_randomise_weights_clever(net, &p);
+  if (style == RNN_ADAGRAD || style == RNN_ADADELTA) { /* the accumulators' starting value (text-predict.c:546-557) */
+    rnn_set_momentum_values(net, ballast >= 0 ? ballast : style == RNN_ADAGRAD ? 200.0f : 0.0f); /* text-predict.c:106-107 */
+  } else if (style == RNN_RPROP) {
+    rnn_set_aux_values(net, 1); /* text-predict.c:558-560 */
+  }
   /* -G: one process per GPU, started before any device call */
   int rank = 0, world = gpus > 0 ? gpus : 1;
   pid_t kids[64];
@@ -148,7 +173,7 @@ int main(int argc, char **argv) {
   clock_gettime(CLOCK_MONOTONIC, &t0);
   for (int i = 0; i < len - 1 && (int)net->generation < stop; i++) {
     float m = rnn_calculate_momentum_soft_start(net->generation, momentum, 0);
-    rnn_amd_set_char_step(set, i, RNN_MOMENTUM_WEIGHTED, m);
+    rnn_amd_set_char_step(set, i, style, m);
     if (net->generation % report == 0 && rank == 0) {
       RnnAmdStats st;
       rnn_amd_set_read_stats(set, &st, 1);
