@@ -42,7 +42,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
 # HBM-side bytes per launch come from the PMC passes of THIS round's kernels, summarised by
 # tools/pmc_summary.py into this file (rocprofv3 cannot run inside the timed process)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 
 def parse():
@@ -442,6 +442,13 @@ def main():
         traffic, traffic_src = None, None
         if (Hd, S, D) == (HIDDEN, STREAMS, DEPTH) and os.path.exists(TRAFFIC_FILE):
             t = json.load(open(TRAFFIC_FILE)).get(dom)
+            # the counters come from a committed profile of this command, not from this run: refuse them when
+            # the kernel timed here is no longer the kernel that was profiled (its duration moved by > 20 %)
+            was = (t or {}).get("avg_us_when_profiled")
+            if t and was and abs(avg_us - was) > 0.2 * was:
+                traffic_src = "profiles/%s is stale (kernel %.1f us when profiled, %.1f us now): not reported" % (
+                    os.path.basename(TRAFFIC_FILE), was, avg_us)
+                t = None
             if t:
                 traffic = t["bytes_per_launch"] * t.get("launches_per_generation", launches_per_gen) / launches_per_gen
                 traffic_src = "profiles/%s (rocprofv3 --pmc passes of this bench command, 2 x FETCH_SIZE + " \

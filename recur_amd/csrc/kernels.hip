@@ -2802,7 +2802,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wreg[u][3][1], acc1, 0, 0, 0);
         /* a short pause of the MFMA stream (64 cycles asleep = the last MFMA's 32 + 32 with the vector ALU
          * free): the fetching wave's one v_cmp per poll gets through here and nowhere else */
-        if (((K == 1024 ? PC_GAPS : K == 512 ? PC_GAPS_512 : PC_GAPS_256) >> u) & 1) {
+        if (!ONE && (((K == 1024 ? PC_GAPS : K == 512 ? PC_GAPS_512 : PC_GAPS_256) >> u) & 1)) { /* (ONE: nobody polls beside a burst) */
           __builtin_amdgcn_sched_barrier(0);
 #if PC_GAP_NOPS
           asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");

@@ -14,9 +14,23 @@ from pmc_summary import per_kernel
 CLASSES = {"bptt_chain_gemm": ("k_chain_persist", "k_chain_main"), "delta_gemm": ("k_delta_dma",)}
 
 
+def durations(d):
+    """average kernel duration (us) by kernel name from the pass's kernel trace"""
+    import csv
+    import glob
+    acc = {}
+    for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            a = acc.setdefault(r["Kernel_Name"], [0, 0.0])
+            a[0] += 1
+            a[1] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
+    return {k: v[1] / max(v[0], 1) for k, v in acc.items()}
+
+
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    dur = durations(sys.argv[1])
     out = {}
     for cls, names in CLASSES.items():
         for k in fetch:
@@ -25,7 +39,10 @@ def main():
                 wn, ws = write.get(k, (0, 0.0))
                 f, w = s / max(n, 1), ws / max(wn, 1)
                 out[cls] = {"kernel": k.split("(")[0], "launches_profiled": n, "fetch_kb": f, "write_kb": w,
-                            "bytes_per_launch": (2 * f + w) * 1024.0}
+                            "bytes_per_launch": (2 * f + w) * 1024.0,
+                            # what the kernel took in the counter pass: bench.py refuses the figure when the
+                            # kernel it times has since changed by more than a fifth (a stale file)
+                            "avg_us_when_profiled": dur.get(k)}
                 break
     json.dump(out, sys.stdout, indent=1)
     print()
