@@ -2494,6 +2494,9 @@ constexpr unsigned PC_EPOCH = 64;           /* flag values per launch (depth <= 
 #ifndef PC_GAPS_256
 #define PC_GAPS_256 (PC_POLL_SCALAR ? 0x0 : 0xe)
 #endif
+#ifndef PC_FILL_MFMAS
+#define PC_FILL_MFMAS 0
+#endif
 #ifndef PC_FETCH_PRIO
 #define PC_FETCH_PRIO 0
 #endif
@@ -2771,6 +2774,16 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
          * later 135 / 136 / 147 us per chain against 135; the finished tile handed through LDS to
          * the fetching waves 150-155 us; wave groups of their own per sub-chain 195 us): beside a
          * wave that issues f32 MFMAs back to back a store's acknowledgement comes 1-4 us late. */
+#if PC_FILL_MFMAS
+        /* experiment (profiles/r03_fused_delta_negative.txt): how much foreign matrix work fits into the
+         * drain window?  PC_FILL_MFMAS MFMAs on a scratch accumulator between the stores and the wait. */
+        {
+          f32x4 junk = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int f = 0; f < PC_FILL_MFMAS; f++) junk = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[0], wreg[f % KB][f & 3][0], junk, 0, 0, 0);
+          asm volatile("" : : "v"(junk));
+        }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) g_store_saddr(0u, __uint_as_float(epoch0 + (unsigned)t + 1u), &sy->flags[g][xf][wv][j]);
         PC_STAMP(0, k, 3);
