@@ -5426,7 +5426,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
           else
             RAMD_LAUNCH(k_delta_dma<128>, dim3(blocks2), dim3(512), shm_rest, st, v, row0, nrows, oh, dr);
           timing_end(st, evh);
-          launch_gemm<true, true, ProbHoDelta>(st, ho_p, b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, T_DELTA);
+          launch_gemm<true, true, ProbHoDelta>(st, ho_p, b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, T_OTHER);
           const size_t up_floats = n - half_floats, n4u = up_floats / 4, ho_n = (size_t)sh->H * sh->O;
           const unsigned fin_blocks = (unsigned)((n4u + 255) / 256) + (unsigned)((ho_n / 4 + 255) / 256);
           RAMD_LAUNCH(k_delta_finalize, dim3(fin_blocks), dim3(256), 0, st, b->ih_delta + half_floats, b->slab + half_floats,
@@ -5458,7 +5458,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
         rest_base = b->slab + (size_t)kd * n;
         rest_stride = rest_plane;
         if (ho_paired) { /* the top layer's delta GEMM had been waiting for the pair launch */
-          launch_gemm<true, true, ProbHoDelta>(st, ho_p, b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, T_DELTA);
+          launch_gemm<true, true, ProbHoDelta>(st, ho_p, b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, T_OTHER);
           ho_paired = false;
           if (ho_finalize_after && !ranges) {
             ho_in_final = true; /* summed by the k_delta_finalize launch below */

@@ -12,6 +12,7 @@ Tolerance: 1e-4 relative (2-norm) on fp32 activations, gradients and weights
 are bit-exact.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1193,3 +1194,35 @@ def test_random_shapes_match_oracle(amd, shape):
     g.close()
     o.close()
     assert compared >= (shape["D"] + 3 + 1) // 2, "only %d generations were compared" % compared
+
+
+GIVEUP_SCRIPT = r"""
+import sys
+sys.path.insert(0, %(tests)r)
+import recur_ctypes as rc, scenarios as sc
+amd = rc.load_amd()
+text = sc.synthetic_text(4000)
+kw = dict(input_size=42, hidden_size=256, output_size=42, S=32, D=6, learn_rate=1e-3, seed=5)
+g, o = sc.AmdBatchedSet(amd, **kw), sc.OracleSet(**kw)
+for i in range(4):
+    g.char_step(text, i, rc.WEIGHTED, 0.9)
+    o.char_step(text, i, rc.WEIGHTED, 0.9)
+bad = sc.compare(g.snapshot(), o.snapshot(), 1e-4)
+print("RESULT", "ok" if not bad else "; ".join(bad))
+"""
+
+
+def test_a_chain_that_gives_up_on_its_first_launch_falls_back_for_that_call():
+    """The one-launch chain needs its 256 workgroups resident together; where they are not (a CU-masked queue, a
+    partition mode, a co-tenant) its first launch of the process raises the abort word.  The launcher then resets
+    it, stops using the kernel and runs the launch-per-step chain FOR THE SAME CALL (kernels.hip:
+    g_chain_validated).  RECUR_AMD_CHAIN_TEST_GIVEUP=1 takes that branch on a healthy device: the run must say so
+    and its results must be the oracle's."""
+    import subprocess
+    import sys as _sys
+    env = dict(os.environ, RECUR_AMD_CHAIN_TEST_GIVEUP="1")
+    r = subprocess.run([_sys.executable, "-c", GIVEUP_SCRIPT % {"tests": os.path.dirname(os.path.abspath(__file__))}],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "using the launch-per-step chain from here on" in r.stderr
+    assert [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1] == "RESULT ok"
