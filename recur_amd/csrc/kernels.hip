@@ -2508,6 +2508,12 @@ typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
 // one LDS-DMA piece (64 lanes x 16 bytes, L1 bypassed) with a wave-uniform global base, a
 // per-lane byte offset and a wave-uniform LDS destination: no vector-ALU instruction at all
 // (the builtin form computes a 64-bit per-lane address first)
+/* a pointer the compiler cannot prove wave-uniform (it went through a lambda's captures), for an "s" asm operand */
+__device__ __forceinline__ const char *uniform_ptr(const void *p) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return (const char *)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ void lds_dma16_sc1(const void *sbase, unsigned voff, uint32_t lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1"
                :
@@ -2871,6 +2877,9 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     voff[i] = (unsigned)(((size_t)r * s.I + 1 + 4 * c) * sizeof(float));
   }
   const float *sub_base = v.b.ehi + (size_t)(row0 + m0) * s.I; /* plane 0, sub-chain a, row 0 */
+  /* (Round 3, measured and removed: every workgroup of a row tile starting its fetch at another row and
+   * piece, so that the NT CUs do not all ask the L2 for the same line at the same moment: 102.2 against
+   * 100.8 us per chain, and the sixteen instructions still took 1.1-1.25 us to issue beside the burst.) */
   auto fetch = [&](int x, int plane) {
     const char *base = reinterpret_cast<const char *>(sub_base + (size_t)plane * plane_stride +
                                                       (size_t)x * PC_SUB * s.I);
