@@ -3285,13 +3285,23 @@ __device__ __forceinline__ void extras_load(const View &v, int t, int r, int nx,
   const float *erow = v.b.ehi + (t * s.Scap + r) * s.I;
   const float *x = input_row_auto(v, r, t);
   const int nq = (s.H / 4 + 63) / 64;
+  /* Every load is UNCONDITIONAL from a clamped (always valid) address, the select comes after: as
+   * `cond ? load : 0` hipcc branched around each load and waited for it at the join, so that the five loads of a
+   * row (and the ten of the two weight rows below) went out one L2 round trip after another -- most of this
+   * kernel's time until round 3. */
+  const int last4 = s.H / 4 - 1;
 #pragma unroll
   for (int i = 0; i < MAXQ; i++) {
-    int k4 = lane + 64 * i;
-    in.ev[i] = (i < nq && 4 * k4 < s.H) ? ld4(erow + 4 * k4) : zero4();
+    const int k4 = lane + 64 * i;
+    const float4 e = ld4(erow + 4 * min(k4, last4));
+    in.ev[i] = (i < nq && k4 <= last4) ? e : zero4();
   }
-  in.xi = (lane < nx) ? x[lane == 0 ? 0 : s.hidden_size + lane] : 0.0f;
-  in.pv = (lane < tn) ? v.b.esum_part[((size_t)t * (tn + 1) + lane) * s.Scap + r] : 0.0f;
+  {
+    const float xv = x[(lane == 0 || lane >= nx) ? 0 : s.hidden_size + lane];
+    in.xi = (lane < nx) ? xv : 0.0f;
+    const float pv = v.b.esum_part[((size_t)t * (tn + 1) + (lane < tn ? lane : 0)) * s.Scap + r];
+    in.pv = (lane < tn) ? pv : 0.0f;
+  }
 }
 /* sum of squares of the error row an item holds (column 0 and the padding are zero): the same in every lane */
 template <int MAXQ> __device__ __forceinline__ float row_sumsq(const ExtrasIn<MAXQ> &in) {
@@ -3343,12 +3353,14 @@ __device__ __forceinline__ float extras_compute(const View &v, int t, int r, int
       const float *wa = v.b.ih_w + na * s.H;
       const float *wb = v.b.ih_w + nb * s.H;
       float4 wva[MAXQ], wvb[MAXQ];
+      const int last4 = s.H / 4 - 1;
 #pragma unroll
-      for (int i = 0; i < MAXQ; i++) {
-        int k4 = lane + 64 * i;
-        bool inb = i < nq && 4 * k4 < s.H;
-        wva[i] = inb ? ld4(wa + 4 * k4) : zero4();
-        wvb[i] = inb ? ld4(wb + 4 * k4) : zero4();
+      for (int i = 0; i < MAXQ; i++) { /* unconditional, clamped: all ten in flight together (see extras_load) */
+        const int k4 = lane + 64 * i, k4c = min(k4, last4);
+        const float4 ta = ld4(wa + 4 * k4c), tb = ld4(wb + 4 * k4c);
+        const bool inb = i < nq && k4 <= last4;
+        wva[i] = inb ? ta : zero4();
+        wvb[i] = inb ? tb : zero4();
       }
       float acca = 0.0f, accb = 0.0f;
 #pragma unroll
