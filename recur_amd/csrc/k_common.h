@@ -1,0 +1,309 @@
+// k_common.h -- what the kernel translation units (kernels_*.hip) share: the launch-check macros,
+// the View of a training set that every kernel takes, small device helpers (input rows, soft clip,
+// block sums, the generator, LDS / LDS-DMA / inline-asm memory helpers) and the declarations of the
+// launch-side support functions (kernels_support.hip).  CDNA4 (gfx950), wave64 only; there is no
+// other backend.
+//
+// Heavy lifting is three fp32 MFMA GEMMs, all with M = "streams of the synchronic mini-batch":
+//   forward   Hpre[S x H] = X[S x I] . W_ih[I x H]              (recur-nn.c:18-48, 117)
+//   chain     E_i[S x I]  = E_h[S x H] . W_ih^T   per BPTT step (recur-nn.c:338-376)
+//   delta     dW[I x H]   = sum_t X_t^T . diag(c_t) . E_h,t      (recur-nn.c:344-356, 738)
+// kernels_forward.hip holds the first, kernels_chain.hip the second, kernels_bptt.hip the third with
+// the rest of rnn_bptt_calc_deltas, kernels_loss.hip the callers' loss functions on the device,
+// kernels_apply.hip rnn_apply_learning and the conditioning helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <utility>
+#include <type_traits>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include "ramd_internal.h"
+
+#define HIP_CHECK(x)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "librecur_amd: HIP error %s at %s:%d\n", hipGetErrorString(e_), \
+              __FILE__, __LINE__);                                                \
+      abort();                                                                    \
+    }                                                                             \
+  } while (0)
+
+// Every launch is followed by hipGetLastError(): a bad launch configuration at an untested
+// shape is reported where it happens, not at the next synchronisation.
+static inline void ramd_check_launch(const char *file, int line) {
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) {
+    fprintf(stderr, "librecur_amd: kernel launch failed: %s at %s:%d\n", hipGetErrorString(e_), file,
+            line);
+    abort();
+  }
+}
+#define RAMD_LAUNCH(...)                       \
+  do {                                         \
+    hipLaunchKernelGGL(__VA_ARGS__);           \
+    ramd_check_launch(__FILE__, __LINE__);     \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// constants of the algorithm (recur-nn.h:28-47)
+#define INPUT_MEAN_SOFT_TOP_F 16.0f
+#define MAX_TOP_ERROR_FACTOR_F 2.0f
+#define MAX_ERROR_GAIN_F 2.0f
+#define ERROR_GAIN_CEILING_F 1.0f
+#define MIN_ERROR_GAIN_F 1e-8f
+#define MAX_MIN_ERROR_FACTOR_F 1e-2f
+#define ABS_MIN_ERROR_FACTOR_F 1e-20f
+
+// ----------------------------------------------------------------- helpers --
+
+struct View {
+  RamdShape sh;
+  RamdBuffers b;
+};
+
+// input row (history slot or forward-only input row) of state row r, `back`
+// steps into the past (back = 0: the slot rnn_bptt_advance points at)
+//
+// When every stream of the call sits at the same ring position (the normal case:
+// the set advances in lock step) the host passes it in b.uniform_idx and no
+// index has to be fetched; a load here would sit on the address path of the
+// GEMM operand loads and drain their pipeline.
+template <bool UNI = false>
+__device__ __forceinline__ float *input_row(const View &v, int r, int back) {
+  const RamdShape &s = v.sh;
+  if (r < s.Scap) {
+    int slot = (UNI ? v.b.uniform_idx : v.b.idx[r]) - back;
+    if (slot < 0) slot += s.D;
+    return v.b.arena + (slot * s.Scap + r) * s.I; /* 32-bit element offsets: checked on the host */
+  }
+  return v.b.arena + (s.D * s.Scap + (r - s.Scap)) * s.I;
+}
+
+/* the same with the choice made at run time (b.uniform_idx >= 0: no index load in front of the row's) */
+__device__ __forceinline__ float *input_row_auto(const View &v, int r, int back) {
+  return v.b.uniform_idx >= 0 ? input_row<true>(v, r, back) : input_row<false>(v, r, back);
+}
+
+// recur-nn-helpers.h:104-113
+__device__ __forceinline__ float soft_clip_dev(float sum, float halfmax) {
+  if (halfmax == 0) return sum;
+  float x = sum / halfmax;
+  float fudge = (float)(0.99 + (double)(x * x) / 100);
+  return 2.0f * x / (1 + x * x * fudge);
+}
+
+// deterministic block-wide sum (fixed tree), blockDim.x == 256
+__device__ __forceinline__ float block_sum_256(float v, float *red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) {
+  return *reinterpret_cast<const float4 *>(p);
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// recur-rng.h:22-31 (Jenkins small fast PRNG, 64 bit) and 179-200 (the sum of twelve
+// 16-bit fields), bit for bit: the noise a stream gets must be the one the reference
+// would draw from that stream's generator.
+struct DevRng {
+  unsigned long long a, b, c, d;
+};
+/* k is a compile-time constant at every call site: two v_alignbit_b32 (full rate) instead of two
+ * 64-bit shifts and an or (the 64-bit shifts are quarter rate, and the generator's recurrence is
+ * a single lane's dependent instruction stream) */
+__device__ __forceinline__ unsigned long long rotl64(unsigned long long x, int k) {
+  unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+  if (k >= 32) {
+    unsigned t = lo;
+    lo = hi;
+    hi = t;
+    k -= 32;
+  }
+  if (k == 0) return ((unsigned long long)hi << 32) | lo;
+  const unsigned nh = __builtin_amdgcn_alignbit(hi, lo, 32 - k), nl = __builtin_amdgcn_alignbit(lo, hi, 32 - k);
+  return ((unsigned long long)nh << 32) | nl;
+}
+__device__ __forceinline__ unsigned long long dev_rand64(DevRng &x) {
+  unsigned long long e = x.a - rotl64(x.b, 7);
+  x.a = x.b ^ rotl64(x.c, 13);
+  x.b = x.c + rotl64(x.d, 37);
+  x.c = x.d + e;
+  x.d = e + x.a;
+  return x.d;
+}
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+/* recur-rng.h:179-201: the sum of the twelve 16-bit fields of three draws.  The sum fits 20
+ * bits, so it is kept in 32 bits and each draw's four fields are two v_dot2_u32_u16 with (1, 1)
+ * -- this lane is alone on its SIMD's issue slot, every instruction saved is time saved */
+__device__ __forceinline__ float dev_cheap_gaussian(DevRng &x) {
+  unsigned a = 0;
+  const u16x2_t ones = {1, 1};
+#pragma unroll
+  for (int w = 0; w < 3; w++) {
+    unsigned long long bits = dev_rand64(x);
+    a = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, (unsigned)bits), ones, a, false);
+    a = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, (unsigned)(bits >> 32)), ones, a, false);
+  }
+  return (float)((int)a - 0xffff * 6) / (0xffff);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+constexpr int CM = 32, CN = 32, CK = 128;
+constexpr int C_STAGES = 3;                    /* LDS ring: 2 stages in flight + 1 being read (a 4th buys nothing) */
+constexpr int C_STAGE_FLOATS = (CM + CN) * CK; /* 32 KB */
+
+__device__ __forceinline__ uint32_t lds_byte_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(lds_void_t *)p;
+}
+__device__ __forceinline__ f32x4 lds_read_b128(uint32_t addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+/* [k][col] and [k + 1][col] of a 64-column K-major stage; _hi: k + 2, k + 3 (offsets in dwords) */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 lds_read2_b32_w64(uint32_t addr) {
+  f32x2 v;
+  asm volatile("ds_read2_b32 %0, %1 offset1:64" : "=v"(v) : "v"(addr));
+  return v;
+}
+__device__ __forceinline__ f32x2 lds_read2_b32_w64_hi(uint32_t addr) {
+  f32x2 v;
+  asm volatile("ds_read2_b32 %0, %1 offset0:128 offset1:192" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+// one LDS-DMA piece (64 lanes x 16 bytes, L1 bypassed) with a wave-uniform global base, a
+// per-lane byte offset and a wave-uniform LDS destination: no vector-ALU instruction at all
+// (the builtin form computes a 64-bit per-lane address first)
+/* a pointer the compiler cannot prove wave-uniform (it went through a lambda's captures), for an "s" asm operand */
+__device__ __forceinline__ const char *uniform_ptr(const void *p) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return (const char *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void lds_dma16_sc1(const void *sbase, unsigned voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+
+__device__ __forceinline__ void lds_dma16(const void *sbase, unsigned voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void *sbase, unsigned voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+
+// --- inline-asm memory helpers of the one-launch chain.  hipcc neither sees nor waits for these
+// accesses: every use is followed by an explicit s_waitcnt that names the registers it protects.
+__device__ __forceinline__ void g_store_saddr(unsigned voff, float val, const void *sbase) {
+  asm volatile("global_store_dword %0, %1, %2" : : "v"(voff), "v"(val), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ float g_load_saddr(unsigned voff, const void *sbase) {
+  float r;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  return r;
+}
+template <int OFF> __device__ __forceinline__ f32x4 lds_read_b128_off(uint32_t addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF> __device__ __forceinline__ float lds_read_b32_off(uint32_t addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+/* wait until at most N LDS operations issued after `v`'s read are outstanding (they return in order) */
+template <int N> __device__ __forceinline__ void lgkm_wait(f32x4 &v) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
+/* two floats 64 * O0 and 64 * O1 floats from `addr` (bytes) */
+template <int O0, int O1> __device__ __forceinline__ f32x2 lds_read2st64(uint32_t addr) {
+  static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "ds_read2st64_b32 offsets are 8 bits");
+  f32x2 v;
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
+  return v;
+}
+/* wait until at most N LDS instructions issued after a fragment's reads are outstanding */
+template <int N> __device__ __forceinline__ void frag_wait(f32x4 &cf, f32x2 (&a)[2][2], f32x2 (&e)[2][2]) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+  asm volatile("s_waitcnt lgkmcnt(%9)"
+               : "+v"(cf), "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(e[0][0]), "+v"(e[0][1]),
+                 "+v"(e[1][0]), "+v"(e[1][1])
+               : "n"(N));
+}
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+// the sum of ks planes in plane order, eight loads in flight at a time
+__device__ __forceinline__ float4 sum_planes(const float *src, size_t stride, int ks) {
+  float4 sum = zero4();
+  for (int z0 = 0; z0 < ks; z0 += 8) {
+    float4 t[8];
+#pragma unroll
+    for (int z = 0; z < 8; z++) t[z] = ld4(src + (size_t)(z0 + z < ks ? z0 + z : z0) * stride);
+#pragma unroll
+    for (int z = 0; z < 8; z++)
+      if (z0 + z < ks) { sum.x += t[z].x; sum.y += t[z].y; sum.z += t[z].z; sum.w += t[z].w; }
+  }
+  return sum;
+}
+
+static inline View make_view(const RamdShape *sh, const RamdBuffers *b) {
+  View v;
+  v.sh = *sh;
+  v.b = *b;
+  return v;
+}
+
+// segments of the hidden row in the output-layer kernels (k_out_layer, k_text_top)
+constexpr int OUT_SEGS = 16;
+// 64 x 64 tiles of the wide chain step and the wide forward GEMM (k_chain_wide, k_fwd_wide)
+constexpr int WM = 64, WN = 64, WK = 64, W_STAGES = 4;
+constexpr int W_STAGE_FLOATS = (WM + WN) * WK; /* 32 KB */
+
+// ---- launch-side support (kernels_support.hip) ----
+// HIP-event timing of the kernel classes (bench.py's roofline leg)
+enum { T_CHAIN = 0, T_DELTA = 1, T_FWD = 2, T_APPLY = 3, T_OTHER = 4, T_CLASSES = 5 };
+#define RAMD_LOCAL __attribute__((visibility("hidden"))) /* shared by the kernel files, not exported */
+RAMD_LOCAL int timing_begin(hipStream_t st, int cls, int count = 1);
+RAMD_LOCAL void timing_end(hipStream_t st, int i);
+// Tuning knobs (RECUR_AMD_*): read from the environment once, then frozen
+RAMD_LOCAL int env_int(const char *name, int dflt);
+
+// ---- the BPTT chain (kernels_chain.hip) ----
+// the device copy of the View for the kernels that take it by pointer
+RAMD_LOCAL const View *device_view(hipStream_t st, const View &v);
+// All D steps of the chain for streams [row0, row0 + nrows): the one-launch chain where it applies,
+// otherwise a launch per step.  Returns the number of partial sums of squares per (step, stream) it
+// left for the extras kernels (0: the extras sum the rows themselves).
+RAMD_LOCAL int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const RamdBuffers *b,
+                                int row0, int nrows);

@@ -1,0 +1,1648 @@
+// kernels_bptt.hip -- the rest of rnn_bptt_calc_deltas: top-layer backprop, extras + control, the weight-delta GEMM,
+// the one-workgroup small-net form, finalizes, and ramd_launch_calc_deltas which strings them together.
+#include "k_common.h"
+#include "k_gemm.h"
+
+// cumulative_input_error of one stream (recur-nn.c:377-382): the input columns of
+// every executed step's error, summed in step order.  One workgroup per stream.
+__global__ __launch_bounds__(64) void k_bottom_error(View v, int row0, int nxp,
+                                                     const unsigned char *active) {
+  const RamdShape &s = v.sh;
+  int j = blockIdx.x, r = row0 + j;
+  int n = (active && !active[j]) ? 0 : v.b.n_exec[r];
+  for (int y = threadIdx.x; y < s.bO; y += 64) {
+    float sum = 0.0f;
+    if (y < s.input_size)
+      for (int k = 0; k < n; k++) sum += v.b.ex[((size_t)(k + 1) * s.Scap + r) * nxp + y + 1];
+    v.b.berr[(size_t)r * s.bO + y] = sum;
+  }
+}
+
+// single_layer_sgd on the bottom layer (recur-nn.c:750-757, 256-273) for the streams in
+// the reference's order.  bottom->o_error is shared by all the clones and only
+// rnn_bptt_clear_deltas ever zeroes it, so stream j's update uses the running total of
+// every stream before it (and of every earlier generation): carry_in + the prefix sum.
+// One thread per weight; the stream loop is sequential, as the reference's calls are.
+__global__ __launch_bounds__(256) void k_bottom_delta(View v, int row0, int nrows, int accumulate,
+                                                      const unsigned char *active,
+                                                      const float *carry_in, float *carry_out) {
+  const RamdShape &s = v.sh;
+  int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= s.bI * s.bO) return;
+  int yi = e / s.bO, x = e - yi * s.bO;
+  float cum = carry_in[x];
+  float acc = accumulate ? v.b.bdelta[e] : 0.0f;
+  for (int j = 0; j < nrows; j++) {
+    if (active && !active[j]) continue;
+    int r = row0 + j;
+    cum += v.b.berr[(size_t)r * s.bO + x];
+    /* a stream whose error gain was clipped shrinks the accumulator -- all of it, it is the layer's
+     * one o_error -- by ih_scale twice (recur-nn.c:391-399); an unclipped stream has ih_scale 1 */
+    const float sc = v.b.ih_scale[r];
+    if (sc != 1.0f && x < s.input_size) cum *= sc * sc;
+    float xi = v.b.binp[(size_t)r * s.bI + yi];
+    if (xi != 0.0f) acc += xi * cum;
+  }
+  v.b.bdelta[e] = acc;
+  if (yi == 0) carry_out[x] = cum;
+}
+
+// ---------------------------------------------------- K5/K6: top backprop --
+
+// backprop_single_layer / _sparse + softclip_scale (recur-nn.c:156-228,
+// 719-721).  One workgroup per stream.  Writes the (scaled) error both to
+// ehi[0] (what the BPTT chain reads) and leaves err_a for the lazy write-back.
+__global__ __launch_bounds__(256) void k_top_backprop(View v, int row0, const int *ranges,
+                                                      int range_stride,
+                                                      const unsigned char *active) {
+  extern __shared__ float sh[];
+  __shared__ float red[4];
+  const RamdShape &s = v.sh;
+  int j = blockIdx.x, r = row0 + j;
+  if (active && !active[j]) return;
+  if (ranges) ranges += (size_t)j * range_stride; /* 0: one list for every stream */
+  float *oerr = sh;          /* [O] */
+  float *herr = sh + s.O;    /* [H] */
+  for (int i = threadIdx.x; i < s.O; i += 256) oerr[i] = v.b.o_error[(size_t)r * s.O + i];
+  __syncthreads();
+  const float *hid = v.b.hidden + (size_t)r * s.H;
+  const float *old = v.b.err_a + (size_t)r * s.I;
+  float sum = 0.0f;
+  for (int y = threadIdx.x; y < s.H; y += 256) {
+    float e;
+    if (y == 0) {
+      e = 0.0f; /* the reference's loop starts at 1; step 1 of the BPTT zeroes it */
+    } else if (hid[y] != 0.0f) {
+      const float *row = v.b.ho_w + (size_t)y * s.O;
+      e = 0.0f;
+      if (ranges) {
+        for (int i = 0; ranges[2 * i] >= 0; i++) {
+          int start = ranges[2 * i] & ~3, len = (ranges[2 * i + 1] + 3) & ~3;
+          for (int x = 0; x < len; x++) e += row[start + x] * oerr[start + x];
+          sum += fabsf(e); /* once per range, e keeps running: recur-nn.c:178-191 */
+        }
+      } else {
+        /* a row is O contiguous floats (O % 4 == 0): whole rows as float4, same order */
+        for (int x = 0; x < s.O; x += 4) {
+          float4 w = ld4(row + x);
+          e += w.x * oerr[x];
+          e += w.y * oerr[x + 1];
+          e += w.z * oerr[x + 2];
+          e += w.w * oerr[x + 3];
+        }
+        sum += fabsf(e);
+      }
+    } else {
+      e = ranges ? old[y] : 0.0f; /* sparse path leaves the stale value */
+    }
+    herr[y] = e;
+  }
+  sum = block_sum_256(sum, red);
+  float halfmax = s.H * MAX_TOP_ERROR_FACTOR_F;
+  float scaled = sum, scale = 1.0f;
+  if (sum > halfmax) {
+    scale = soft_clip_dev(sum, halfmax);
+    scaled = scale * sum;
+  }
+  float *dst = v.b.ehi + (size_t)r * s.I; /* step 0 plane */
+  for (int y = threadIdx.x; y < s.H; y += 256) /* ehi keeps column 0 and the pad at zero */
+    dst[y] = (y == 0 || y > s.hidden_size) ? 0.0f : (sum > halfmax) ? herr[y] * scale : herr[y];
+  if (threadIdx.x == 0) {
+    v.b.top_raw[r] = sum;
+    v.b.top_scaled[r] = scaled;
+  }
+}
+
+// backprop_single_layer_sparse (recur-nn.c:156-196) with half a wave per hidden row: k_top_backprop
+// gives every thread a row of W_ho of its own and walks the ranges' columns one by one -- 64
+// lanes on 64 different cache lines per load -- which at o_size 3652 (the multi-head nets) took
+// 486 us for 256 streams.  Here 32 lanes read a row's range as float4 (a head of 73 symbols is 19
+// of them: one instruction per row and range), a wave works on eight rows at a time (four
+// instructions, each covering two rows) so that the loads and the shuffle chains of the rows
+// overlap, the products are reduced over the 32 lanes with xor shuffles (a fixed tree per range),
+// and the range's sum joins the row's running value and |running value| the error sum, range by
+// range as the reference does (recur-nn.c:178-191).  Rows whose hidden value is zero keep the
+// stale entry of the last BPTT run.  One workgroup of 16 waves per stream; with
+// few streams (a GPU's share of a sharded set, the one-net trainer) the rows of a stream are
+// shared out over gridDim.y workgroups -- a row is a chain of memory round trips per range, and
+// 32 busy CUs of 256 leave most of the latency exposed -- which leave the unscaled values and
+// their partial sums of |e| (part) for k_top_backprop_scale.
+__global__ __launch_bounds__(1024) void k_top_backprop_ranged(View v, int row0, const int *ranges,
+                                                              int range_stride, const unsigned char *active,
+                                                              float *part) {
+  extern __shared__ __attribute__((aligned(16))) float rsh[];
+  __shared__ float red[16];
+  __shared__ int rlist[2 * 65];
+  const RamdShape &s = v.sh;
+  const int j = blockIdx.x, r = row0 + j;
+  if (active && !active[j]) return;
+  ranges += (size_t)j * range_stride; /* 0: one list for every stream */
+  float *oerr = rsh;       /* [O] */
+  float *herr = rsh + s.O; /* [H] */
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int half = lane >> 5, l32 = lane & 31;
+  for (int i = threadIdx.x; i < s.O; i += 1024) oerr[i] = v.b.o_error[(size_t)r * s.O + i];
+  if (threadIdx.x == 0) {
+    int n = 0;
+    while (n < 64 && ranges[2 * n] >= 0) {
+      rlist[2 * n] = ranges[2 * n] & ~3;                 /* start, aligned as k_top_backprop does */
+      rlist[2 * n + 1] = (ranges[2 * n + 1] + 3) & ~3;   /* length */
+      n++;
+    }
+    rlist[2 * n] = -1;
+  }
+  __syncthreads();
+  const float *hid = v.b.hidden + (size_t)r * s.H;
+  const float *old = v.b.err_a + (size_t)r * s.I;
+  float sum = 0.0f; /* this half-wave's rows */
+  constexpr int PAIRS = 8; /* sixteen rows at a time */
+  /* this workgroup's rows: [ylo, yhi), whole groups of sixteen */
+  const int nb = gridDim.y, groups = (s.H + 2 * PAIRS - 1) / (2 * PAIRS);
+  const int ylo = (int)(((long)groups * blockIdx.y) / nb) * 2 * PAIRS;
+  const int yhi = min(s.H, (int)(((long)groups * (blockIdx.y + 1)) / nb) * 2 * PAIRS);
+  for (int y0 = ylo + 2 * PAIRS * wave; y0 < yhi; y0 += 2 * PAIRS * 16) {
+    float e[PAIRS];
+    bool act[PAIRS];
+    const float *rowp[PAIRS];
+#pragma unroll
+    for (int q = 0; q < PAIRS; q++) {
+      const int y = y0 + 2 * q + half; /* this half-wave's row of pair q */
+      act[q] = y > 0 && y < yhi && hid[y < s.H ? y : 0] != 0.0f;
+      rowp[q] = v.b.ho_w + (size_t)(act[q] ? y : 0) * s.O;
+      e[q] = 0.0f;
+    }
+    for (int i = 0; rlist[2 * i] >= 0; i++) {
+      const int start = rlist[2 * i], len4 = rlist[2 * i + 1] >> 2;
+      float p[PAIRS];
+#pragma unroll
+      for (int q = 0; q < PAIRS; q++) p[q] = 0.0f;
+      for (int x4 = l32; x4 < len4; x4 += 32) {
+        const float4 o4 = ld4(oerr + start + 4 * x4);
+#pragma unroll
+        for (int q = 0; q < PAIRS; q++) {
+          const float4 w4 = ld4(rowp[q] + start + 4 * x4);
+          p[q] += (w4.x * o4.x + w4.y * o4.y) + (w4.z * o4.z + w4.w * o4.w);
+        }
+      }
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1)
+#pragma unroll
+        for (int q = 0; q < PAIRS; q++) p[q] += __shfl_xor(p[q], off, 64);
+#pragma unroll
+      for (int q = 0; q < PAIRS; q++)
+        if (act[q]) {
+          e[q] += p[q];
+          sum += fabsf(e[q]); /* once per range, e keeps running: recur-nn.c:178-191 */
+        }
+    }
+    if (l32 == 0) {
+#pragma unroll
+      for (int q = 0; q < PAIRS; q++) {
+        const int y = y0 + 2 * q + half;
+        if (y < yhi) herr[y] = (y == 0) ? 0.0f : act[q] ? e[q] : old[y]; /* stale value where the row is skipped */
+      }
+    }
+  }
+  sum += __shfl_xor(sum, 32, 64); /* the two half-waves' rows */
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+  sum += ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
+  if (nb > 1) { /* unscaled values and this workgroup's share of the sum: k_top_backprop_scale goes on */
+    float *dst = v.b.ehi + (size_t)r * s.I;
+    for (int y = ylo + threadIdx.x; y < yhi; y += 1024) dst[y] = (y == 0 || y > s.hidden_size) ? 0.0f : herr[y];
+    if (threadIdx.x == 0) part[(size_t)j * nb + blockIdx.y] = sum;
+    return;
+  }
+  float halfmax = s.H * MAX_TOP_ERROR_FACTOR_F;
+  float scaled = sum, scale = 1.0f;
+  if (sum > halfmax) {
+    scale = soft_clip_dev(sum, halfmax);
+    scaled = scale * sum;
+  }
+  float *dst = v.b.ehi + (size_t)r * s.I; /* step 0 plane */
+  for (int y = threadIdx.x; y < s.H; y += 1024) /* ehi keeps column 0 and the pad at zero */
+    dst[y] = (y == 0 || y > s.hidden_size) ? 0.0f : (sum > halfmax) ? herr[y] * scale : herr[y];
+  if (threadIdx.x == 0) {
+    v.b.top_raw[r] = sum;
+    v.b.top_scaled[r] = scaled;
+  }
+}
+
+/* the end of backprop_single_layer_sparse + the soft clip (recur-nn.c:719-721) for streams whose
+ * rows were shared out over nb workgroups: the partial sums in order, the scale, the row */
+__global__ __launch_bounds__(256) void k_top_backprop_scale(View v, int row0, const unsigned char *active,
+                                                            const float *part, int nb) {
+  const RamdShape &s = v.sh;
+  const int j = blockIdx.x, r = row0 + j;
+  if (active && !active[j]) return;
+  float sum = 0.0f;
+  for (int k = 0; k < nb; k++) sum += part[(size_t)j * nb + k];
+  const float halfmax = s.H * MAX_TOP_ERROR_FACTOR_F;
+  float scaled = sum;
+  if (sum > halfmax) {
+    const float scale = soft_clip_dev(sum, halfmax);
+    scaled = scale * sum;
+    float *dst = v.b.ehi + (size_t)r * s.I;
+    for (int y = threadIdx.x; y < s.H; y += 256) dst[y] *= scale; /* (0 stays 0) */
+  }
+  if (threadIdx.x == 0) {
+    v.b.top_raw[r] = sum;
+    v.b.top_scaled[r] = scaled;
+  }
+}
+
+__global__ void k_live_mask(float *dst, const unsigned char *active, int n) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) dst[j] = (!active || active[j]) ? 1.0f : 0.0f;
+}
+
+// single_layer_sgd / _sparse for all streams at once (recur-nn.c:256-301):
+// hidden^T . o_error comes from the MFMA GEMM (ProbHoDelta); this sums its K
+// slabs into ho_delta.  With error ranges only the columns inside a range
+// receive anything.
+__global__ void k_ho_delta_finalize(View v, const float *slab, int ks, int accumulate,
+                                    const int *ranges) {
+  const RamdShape &s = v.sh;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  int n = s.H * s.O;
+  if (e >= n) return;
+  int x = e % s.O;
+  float acc = accumulate ? v.b.ho_delta[e] : 0.0f;
+  bool live = true;
+  if (ranges) {
+    live = false;
+    for (int i = 0; ranges[2 * i] >= 0; i++) {
+      int start = ranges[2 * i] & ~3, len = (ranges[2 * i + 1] + 3) & ~3;
+      if (x >= start && x < start + len) live = true;
+    }
+  }
+  if (live) {
+    for (int z = 0; z < ks; z++) acc += slab[(size_t)z * n + e];
+  }
+  v.b.ho_delta[e] = acc;
+}
+
+// Chain "extras" without a GEMM: for every (step, stream) the error of the bias
+// row (column 0) and of the real-input rows, i.e. e = W_ih[y][:] . E_h[t][s][:] for
+// the rows y whose input value is non-zero -- the reference's zero-row skip
+// (recur-nn.c:338-341) is what makes this cheap: a one-hot text stream has two
+// such rows per step, a dense audio frame a few dozen.  One wave per (step,
+// stream): the error row sits in registers (5 float4 per lane at h_size 1028),
+// the wave walks the non-zero columns (ballot), each dot product is reduced with
+// xor shuffles in a fixed order.  It also closes the step's sum of squares:
+// the column-tile partials of k_chain_main in index order, then the extras.
+// what one (step, stream) item reads before anything depends on anything: its error row,
+// this lane's input value of the first 64 extra columns, this lane's column-tile partial
+template <int MAXQ> struct ExtrasIn {
+  float4 ev[MAXQ];
+  float xi, pv;
+};
+template <int MAXQ> /* float4 per lane: 5 covers h_size <= 1280, 8 h_size <= 2048, 9 h_size <= 2304 */
+__device__ __forceinline__ void extras_load(const View &v, int t, int r, int nx, int tn, int lane,
+                                            ExtrasIn<MAXQ> &in) {
+  const RamdShape &s = v.sh;
+  const float *erow = v.b.ehi + (t * s.Scap + r) * s.I;
+  const float *x = input_row_auto(v, r, t);
+  const int nq = (s.H / 4 + 63) / 64;
+  /* Every load is UNCONDITIONAL from a clamped (always valid) address, the select comes after: as
+   * `cond ? load : 0` hipcc branched around each load and waited for it at the join, so that the five loads of a
+   * row (and the ten of the two weight rows below) went out one L2 round trip after another -- most of this
+   * kernel's time until round 3. */
+  const int last4 = s.H / 4 - 1;
+#pragma unroll
+  for (int i = 0; i < MAXQ; i++) {
+    const int k4 = lane + 64 * i;
+    const float4 e = ld4(erow + 4 * min(k4, last4));
+    in.ev[i] = (i < nq && k4 <= last4) ? e : zero4();
+  }
+  {
+    const float xv = x[(lane == 0 || lane >= nx) ? 0 : s.hidden_size + lane];
+    in.xi = (lane < nx) ? xv : 0.0f;
+    const float pv = v.b.esum_part[((size_t)t * (tn + 1) + (lane < tn ? lane : 0)) * s.Scap + r];
+    in.pv = (lane < tn) ? pv : 0.0f;
+  }
+}
+/* sum of squares of the error row an item holds (column 0 and the padding are zero): the same in every lane */
+template <int MAXQ> __device__ __forceinline__ float row_sumsq(const ExtrasIn<MAXQ> &in) {
+  float a = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXQ; i++)
+    a += (in.ev[i].x * in.ev[i].x + in.ev[i].y * in.ev[i].y) + (in.ev[i].z * in.ev[i].z + in.ev[i].w * in.ev[i].w);
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+  return a;
+}
+/* the same for row r of error plane `plane`, fetched here */
+__device__ __forceinline__ float row_sumsq_load(const View &v, int plane, int r, int lane) {
+  const RamdShape &s = v.sh;
+  const float *erow = v.b.ehi + ((size_t)plane * s.Scap + r) * s.I;
+  float a = 0.0f;
+  for (int k4 = lane; 4 * k4 < s.H; k4 += 64) {
+    const float4 e = ld4(erow + 4 * k4);
+    a += (e.x * e.x + e.y * e.y) + (e.z * e.z + e.w * e.w);
+  }
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+  return a;
+}
+template <int MAXQ>
+__device__ __forceinline__ float extras_compute(const View &v, int t, int r, int nx, int nxp, int tn,
+                                                int lane, const ExtrasIn<MAXQ> &in) {
+  const RamdShape &s = v.sh;
+  const float *x = input_row_auto(v, r, t);
+  float *dst = v.b.ex + ((size_t)(t + 1) * s.Scap + r) * nxp;
+  const int nq = (s.H / 4 + 63) / 64;
+  float sq = 0.0f;
+  for (int c0 = 0; c0 < nx; c0 += 64) {
+    int c = c0 + lane;
+    int n = (c == 0) ? 0 : s.hidden_size + c;
+    float xi = (c0 == 0) ? in.xi : ((c < nx) ? x[n] : 0.0f);
+    bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
+    if (c < nx) dst[c] = 0.0f;
+    unsigned long long live = __ballot(on);
+    /* two live columns per round, so that both weight rows are in flight together (a
+     * one-hot text stream has exactly two: the bias row and the symbol's row) */
+    while (live) {
+      int la = __ffsll((long long)live) - 1;
+      live &= live - 1;
+      int lb = live ? __ffsll((long long)live) - 1 : -1;
+      if (lb >= 0) live &= live - 1;
+      int ca = c0 + la, cb = c0 + (lb >= 0 ? lb : la);
+      int na = (ca == 0) ? 0 : s.hidden_size + ca;
+      int nb = (cb == 0) ? 0 : s.hidden_size + cb;
+      float xa = __shfl(xi, la, 64), xb = __shfl(xi, lb >= 0 ? lb : la, 64);
+      const float *wa = v.b.ih_w + na * s.H;
+      const float *wb = v.b.ih_w + nb * s.H;
+      float4 wva[MAXQ], wvb[MAXQ];
+      const int last4 = s.H / 4 - 1;
+#pragma unroll
+      for (int i = 0; i < MAXQ; i++) { /* unconditional, clamped: all ten in flight together (see extras_load) */
+        const int k4 = lane + 64 * i, k4c = min(k4, last4);
+        const float4 ta = ld4(wa + 4 * k4c), tb = ld4(wb + 4 * k4c);
+        const bool inb = i < nq && k4 <= last4;
+        wva[i] = inb ? ta : zero4();
+        wvb[i] = inb ? tb : zero4();
+      }
+      float acca = 0.0f, accb = 0.0f;
+#pragma unroll
+      for (int i = 0; i < MAXQ; i++) {
+        acca += in.ev[i].x * wva[i].x + in.ev[i].y * wva[i].y + in.ev[i].z * wva[i].z + in.ev[i].w * wva[i].w;
+        accb += in.ev[i].x * wvb[i].x + in.ev[i].y * wvb[i].y + in.ev[i].z * wvb[i].z + in.ev[i].w * wvb[i].w;
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        acca += __shfl_xor(acca, off, 64);
+        accb += __shfl_xor(accb, off, 64);
+      }
+      if (s.activation == 2) {
+        acca /= 2 * (xa + 1.0f);
+        accb /= 2 * (xb + 1.0f);
+      }
+      if (lane == 0) {
+        dst[ca] = acca;
+        if (lb >= 0) dst[cb] = accb;
+      }
+      sq += acca * acca; /* identical in every lane */
+      if (lb >= 0) sq += accb * accb;
+    }
+  }
+  // the step's total: the column-tile partials of k_chain_main in index order (each lane
+  // fetches one, every lane adds them in order), then the extras.  tn == 0 (the one-launch
+  // chain leaves no partials): the caller adds the hidden columns' part (row_sumsq of the
+  // step's OUTPUT row, error plane t + 1) itself.
+  float sum = 0.0f;
+  for (int p0 = 0; p0 < tn; p0 += 64) {
+    int p = p0 + lane;
+    float pv = (p0 == 0) ? in.pv
+                         : ((p < tn) ? v.b.esum_part[((size_t)t * (tn + 1) + p) * s.Scap + r] : 0.0f);
+    int cnt = min(64, tn - p0);
+    for (int i = 0; i < cnt; i++) sum += __shfl(pv, i, 64);
+  }
+  return sum + sq; /* the same in every lane */
+}
+
+template <int MAXQ>
+__global__ __launch_bounds__(256) void k_extras_gather(View v, int row0, int nrows, int nx, int nxp,
+                                                       int tn) {
+  const RamdShape &s = v.sh;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= s.D * nrows) return;
+  const int t = m / nrows, r = row0 + (m - t * nrows);
+  ExtrasIn<MAXQ> in;
+  extras_load<MAXQ>(v, t, r, nx, tn, lane, in);
+  float es = extras_compute<MAXQ>(v, t, r, nx, nxp, tn, lane, in);
+  if (tn == 0) es += row_sumsq_load(v, t + 1, r, lane);
+  if (lane == 0) v.b.esum[(size_t)t * s.Scap + r] = es;
+}
+
+// Finalize of the extras GEMM: applies the row rule to column 0 and the input
+// columns, keeps the raw values in ex[t+1][s][c] (for the h_error / i_error
+// images) and adds their squares as the last partial sum.  One wave per (t, s).
+__global__ __launch_bounds__(64) void k_extras_finalize(View v, int row0, int nrows, int nx, int nxp,
+                                                        int ks, int tn) {
+  const RamdShape &s = v.sh;
+  int m = blockIdx.x;
+  int t = m / nrows, j = m - t * nrows, r = row0 + j;
+  int M = s.D * nrows;
+  const float *x = input_row<false>(v, r, t);
+  float *dst = v.b.ex + ((size_t)(t + 1) * s.Scap + r) * nxp;
+  float sq = 0.0f;
+  for (int c = threadIdx.x; c < nx; c += 64) {
+    float e = 0.0f;
+    for (int z = 0; z < ks; z++) e += v.b.slab[((size_t)z * M + m) * nxp + c];
+    int n = c == 0 ? 0 : s.hidden_size + c;
+    float xi = x[n];
+    bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
+    e = on ? e : 0.0f;
+    if (on && s.activation == 2) e /= 2 * (xi + 1.0f);
+    dst[c] = e;
+    sq += e * e;
+  }
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+  /* the step's total: the column-tile partials of k_chain_main in index order, then
+   * the extras (a fixed order, so the break decisions are reproducible); tn == 0: the one-launch
+   * chain left no partials, the hidden columns' part is summed from the row */
+  const float hsq = tn == 0 ? row_sumsq_load(v, t + 1, r, threadIdx.x) : 0.0f;
+  if (threadIdx.x == 0) {
+    float sum = hsq;
+    for (int p = 0; p < tn; p++) sum += v.b.esum_part[((size_t)t * (tn + 1) + p) * s.Scap + r];
+    v.b.esum[(size_t)t * s.Scap + r] = sum + sq;
+  }
+}
+
+// ------------------------------------------------ weight-delta GEMM by LDS-DMA --
+//
+// ih_delta[m][n] = sum over (step t, stream r) of X_t[r][m] * coef[t][r] * E_t[r][n]
+// (recur-nn.c:343-358 for every executed step of every stream, with the stream's
+// ih_scale folded in).  Both operands are K-major: a K tile is 32 streams of one step, a
+// row of it 128 consecutive floats of a history slot (A) or of an error plane (B).
+//
+// Workgroup = 8 waves on one CU: waves 0-3 own a 64 x 64 quadrant of the 128 x 128 tile
+// each (2 x 2 accumulators, 64 MFMAs per K tile and wave); waves 4-7 only move data:
+// each K tile is 32 + 1 LDS-DMA wave instructions (16 KB of A, 16 KB of B, the tile's 32
+// coefficients) into a four-deep ring, three tiles in flight.  One raw s_barrier per K
+// tile; nothing else couples the two groups.  A K tile costs a compute wave 64 MFMAs
+// (4096 cycles), so the barrier and the LDS read latency between tiles are a few per cent.
+// The per-row coefficient is applied to the B fragments after the LDS read (select on
+// zero: rows of steps a stream did not execute may hold anything).
+//
+// Preconditions (checked by the launcher, which otherwise uses k_gemm2): every stream at
+// the same ring position, nrows % 32 == 0, hidden_size % 128 == 0, not RECLIP20.  Only
+// whole 128-row tiles are computed here; the remaining rows (bias row 0 is in tile 0; the
+// input rows above the last whole tile) go through the generic k_gemm with a row offset.
+constexpr int DD_STAGES = 4;
+constexpr int DD_STAGE_FLOATS = 2 * BK * 128 + 64; /* A, B, 32 coefficients (+ pad) */
+
+/* The rows above the last whole 128-row tile (the input rows of a text net: 44 at the north
+ * star) ride along: the tm workgroups that share a column tile and a K slice (mt = 0..tm-1;
+ * eight at hidden 1024) each take every tm-th K tile of the slice, fetch the 32 x 64 piece of the history rows'
+ * tail for it (columns rows_core .. rows_core + 63: past i_size they run into the next row,
+ * which only feeds output rows nobody stores), and multiply it with the error fragments they
+ * have in registers anyway: 8 more MFMAs per 16 in one K tile of tm, no second pass over
+ * the error planes.  Their partial sums are plane z * tm + mt of `planes`. */
+struct DeltaRest {
+  float *planes;  /* [ks * tm][rows][ldc] */
+  size_t stride;  /* floats between planes */
+  int rows;       /* i_size - rows_core, <= RR */
+  int col;        /* rows_core */
+};
+constexpr int DD_REST_FLOATS = BK * 128; /* the rest ring: two tiles of 32 k x 64 rows or one of 32 k x 128 */
+
+#ifdef PC_STAMPS /* development builds only (tools/mkabl.sh -DPC_STAMPS, tools/gpu_delta_stamps.py) */
+__device__ unsigned long long g_dd_stamps[64][8];
+extern "C" void ramd_delta_stamps(unsigned long long *out) {
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dd_stamps), sizeof(unsigned long long) * 64 * 8));
+}
+#endif
+/* RR: rows of the rest tile: 0 (none), 64 or 128 (a wave then has 32 or 64 rest rows x its 64 columns) */
+template <int RR>
+__global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, GemmOut o, DeltaRest dr) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  const RamdShape &s = v.sh;
+  const int L = blockIdx.x;
+  // K slice z lives on 8 / ks XCDs (ks divides 8), so each XCD's L2 sees one slice of X
+  // and E only; within a slice consecutive tiles alternate between its XCDs
+  const int xcd = L & 7, q = L >> 3;
+  const int per = 8 / o.ks;
+  const int z = xcd / per, tile = q * per + (xcd % per);
+  if (tile >= o.tm * o.tn) return;
+  const int mt = tile / o.tn, nt = tile % o.tn;
+  const int m0 = o.row0m + mt * 128, n0 = o.col0 + nt * 128; /* (row0m: a launch over the upper row tiles only) */
+  const int kt0 = (int)(((long)o.nkt * z) / o.ks), kt1 = (int)(((long)o.nkt * (z + 1)) / o.ks);
+  const int nst = kt1 - kt0;
+  const int wave8 = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rtiles = nrows / BK;
+  /* stage st carries rest work when st % tm == mt; its tile sits in slot (st / tm) % 2 behind the
+   * ring (tm >= 4, so a slot's previous tile was consumed long before the next one is fetched) */
+  constexpr bool REST = RR > 0;
+  constexpr int RI = RR / 64; /* 32-row groups of rest rows per wave */
+  auto is_rest = [&](int st) { return REST && st < nst && st % o.tm == mt; };
+  /* byte-free float offset of a stage's rest tile in the rest ring: two slots of 64 rows, one of 128 */
+  auto rest_slot = [&](int st) { return RR == 64 ? ((st / o.tm) & 1) * (BK * 64) : 0; };
+  float *const rest_ring = dsm + DD_STAGES * DD_STAGE_FLOATS;
+
+  if (wave8 >= 4) {
+    // ---------------------------------------------------------------- loaders
+    const int w = wave8 - 4;
+    // instruction i (0..31): rows 2 (i & 15), +1 of A (i < 16) or B; wave w issues i = 8 w + j
+    /* Every DMA is (wave-uniform base, per-lane byte offset that never changes, wave-uniform
+     * LDS address): issued as saddr + voffset by inline asm, a fetch costs the loader wave no
+     * vector-ALU instruction -- beside a wave that issues f32 MFMAs back to back (they run on
+     * the SIMD's vector ALU) such instructions wait for a gap in the MFMA stream. */
+    const int ws = __builtin_amdgcn_readfirstlane(w);
+    const unsigned voff = (unsigned)(((size_t)(lane >> 5) * s.I + (lane & 31) * 4) * sizeof(float));
+    const unsigned voff_c = (unsigned)((lane & 31) * sizeof(float));
+    const unsigned voff_r = RR == 128 ? voff : (unsigned)(((size_t)(lane >> 4) * s.I + (lane & 15) * 4) * sizeof(float));
+    const uint32_t dsm_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(dsm));
+    auto issue = [&](int st) {
+      const int kt = kt0 + st;
+      const int t = kt / rtiles, sb = (kt - t * rtiles) * BK;
+      int slot = v.b.uniform_idx - t;
+      if (slot < 0) slot += s.D;
+      /* waves 0, 1 fetch the history rows (A), waves 2, 3 the error rows (B): rows 2 (i & 15), + 1 */
+      const float *base = ws < 2 ? v.b.arena + ((size_t)slot * s.Scap + row0 + sb) * s.I + m0
+                                 : v.b.ehi + ((size_t)t * s.Scap + row0 + sb) * s.I + n0;
+      const uint32_t dst = dsm_lds + (uint32_t)(((st % DD_STAGES) * DD_STAGE_FLOATS + (ws < 2 ? 0 : BK * 128)) * sizeof(float));
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int i15 = (ws & 1) * 8 + j; /* = (w * 8 + j) & 15 */
+        lds_dma16(base + (size_t)(2 * i15) * s.I, voff, dst + (uint32_t)(i15 * 256 * sizeof(float)));
+      }
+      if (ws == 0) { /* the 32 coefficients of the tile: lanes 32-63 repeat them */
+        lds_dma4(v.b.coef + (size_t)t * s.Scap + row0 + sb, voff_c,
+                 dsm_lds + (uint32_t)(((st % DD_STAGES) * DD_STAGE_FLOATS + 2 * BK * 128) * sizeof(float)));
+      }
+      if (REST && ws == 3 && is_rest(st)) { /* the tail of the 32 history rows: four rows per instruction */
+        const float *rb = v.b.arena + ((size_t)slot * s.Scap + row0 + sb) * s.I + dr.col;
+        const uint32_t rdst = dsm_lds + (uint32_t)((DD_STAGES * DD_STAGE_FLOATS + rest_slot(st)) * sizeof(float));
+        /* an instruction moves 1 KB: four rows of 64 floats or two of 128 */
+#pragma unroll
+        for (int j = 0; j < 8 * (RI ? RI : 1); j++)
+          lds_dma16(rb + (size_t)((RR == 128 ? 2 : 4) * j) * s.I, voff_r, rdst + (uint32_t)(j * 256 * sizeof(float)));
+      }
+    };
+#pragma unroll
+    for (int p = 0; p < DD_STAGES - 1; p++)
+      if (p < nst) issue(p);
+    for (int st = 0; st < nst; st++) {
+      // stages st+1 .. st+DD_STAGES-2 may stay in flight (8 or 9 DMAs per stage)
+      const int ahead = min(DD_STAGES - 2, nst - 1 - st);
+      if (w == 0) {
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (REST && w == 3) {
+        /* 8 (RR 64) or 16 (RR 128) more in flight for a rest stage among the ones ahead (at most one:
+         * they are tm >= 4 apart) */
+        const bool more = (ahead >= 1 && is_rest(st + 1)) || (ahead >= 2 && is_rest(st + 2));
+        if (ahead >= 2) {
+          if (more && RR == 128) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+          else if (more) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else if (ahead == 1) {
+          if (more && RR == 128) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+          else if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      } else {
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier(); /* stage st has landed; stage st-1's buffer is free */
+      if (st + DD_STAGES - 1 < nst) issue(st + DD_STAGES - 1);
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ compute
+  const int wm = wave8 >> 1, wn = wave8 & 1;
+  const int lm = lane & 31, kh = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
+  // The fragments of K group u + 1 (8 k: four MFMA steps of two k each) are read from LDS
+  // before the 16 MFMAs of group u are issued and used after them, so the LDS latency
+  // and, at a stage boundary, the barrier sit in the shadow of the matrix pipe.
+  // Round 3: the reads are inline asm with COUNTED waits.  As plain loads hipcc put an
+  // `s_waitcnt lgkmcnt(0)` behind the reads of every second group, in front of the CURRENT group's
+  // multiplies -- the read-ahead it was meant to be waited for its own reads twice per K tile -- and
+  // spent five vector-ALU instructions per group on LDS addresses.  Now: `ds_read2st64_b32` (two k
+  // rows, 128 floats apart, per instruction; immediate offsets in units of 64 floats reach every k of
+  // a stage), four address registers per STAGE, and each group waits only for what was issued before
+  // the reads of the group after it (lgkmcnt(n), n = that group's instruction count <= 13).
+  struct Frag {
+    f32x2 a[2][2], e[2][2]; /* [i or jn][k pair]: k = 8 g + 4 kh + 2 pair, + 1 */
+    f32x4 cf;
+    f32x2 ar[RI ? RI : 1][2]; /* rest rows (REST stages only) */
+  };
+  f32x16 racc[RI ? RI : 1][2];
+#pragma unroll
+  for (int i = 0; i < (RI ? RI : 1); i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) racc[i][j][g] = 0.0f;
+  /* per-lane byte addresses within a stage: A rows i = 0, 1; E columns jn = 0, 1; the coefficients; the rest rows */
+  const uint32_t dsm0 = lds_byte_addr(dsm);
+  const uint32_t la_lane = dsm0 + 4u * (uint32_t)(4 * kh * 128 + wm * 64 + lm);
+  const uint32_t le_lane = dsm0 + 4u * (uint32_t)(BK * 128 + 4 * kh * 128 + wn * 64 + lm);
+  const uint32_t lc_lane = dsm0 + 4u * (uint32_t)(2 * BK * 128 + 4 * kh);
+  const uint32_t lr_lane = lds_byte_addr(rest_ring) + 4u * (uint32_t)(4 * kh * RR + wm * (RR / 2) + lm);
+  uint32_t ad_a0 = 0, ad_a1 = 0, ad_e0 = 0, ad_e1 = 0, ad_c = 0, ad_r = 0; /* of the stage being READ */
+  auto stage_addr = [&](int st, bool rest) {
+    const uint32_t sb = (uint32_t)((st % DD_STAGES) * DD_STAGE_FLOATS * (int)sizeof(float));
+    ad_a0 = la_lane + sb;
+    ad_a1 = ad_a0 + 128u;
+    ad_e0 = le_lane + sb;
+    ad_e1 = ad_e0 + 128u;
+    ad_c = lc_lane + sb;
+    if (REST && rest) ad_r = lr_lane + (uint32_t)(rest_slot(st) * (int)sizeof(float));
+  };
+  /* group G of the stage whose addresses are set: 9 LDS instructions (+ 2 RI for a rest stage) */
+  auto rd = [&](auto GC, Frag &f, bool rest) {
+    constexpr int G = decltype(GC)::value;
+    constexpr int RU = RR ? RR / 64 : 1; /* k rows of the rest tile are RR floats apart: RR / 64 offset units */
+    if (REST && rest) { /* wave-uniform */
+#pragma unroll
+      for (int i = 0; i < RI; i++) {
+        f.ar[i][0] = lds_read2st64<(8 * G + 0) * RU, (8 * G + 1) * RU>(ad_r + 128u * (uint32_t)i);
+        f.ar[i][1] = lds_read2st64<(8 * G + 2) * RU, (8 * G + 3) * RU>(ad_r + 128u * (uint32_t)i);
+      }
+    }
+    f.cf = lds_read_b128_off<32 * G>(ad_c);
+    f.a[0][0] = lds_read2st64<2 * (8 * G + 0), 2 * (8 * G + 1)>(ad_a0);
+    f.e[0][0] = lds_read2st64<2 * (8 * G + 0), 2 * (8 * G + 1)>(ad_e0);
+    f.a[1][0] = lds_read2st64<2 * (8 * G + 0), 2 * (8 * G + 1)>(ad_a1);
+    f.e[1][0] = lds_read2st64<2 * (8 * G + 0), 2 * (8 * G + 1)>(ad_e1);
+    f.a[0][1] = lds_read2st64<2 * (8 * G + 2), 2 * (8 * G + 3)>(ad_a0);
+    f.e[0][1] = lds_read2st64<2 * (8 * G + 2), 2 * (8 * G + 3)>(ad_e0);
+    f.a[1][1] = lds_read2st64<2 * (8 * G + 2), 2 * (8 * G + 3)>(ad_a1);
+    f.e[1][1] = lds_read2st64<2 * (8 * G + 2), 2 * (8 * G + 3)>(ad_e1);
+  };
+  /* Every group waits for "at most nine LDS instructions behind my reads": the next group's nine (a
+   * rest stage issues its 2 RI extra reads FIRST, so there the wait also covers those: a few dozen
+   * cycles once per tm stages).  A count chosen at run time would put the wait into branches, and
+   * hipcc then copies the whole fragment (ten v_mov_b64) in front of the multiplies in each of them. */
+  auto mm = [&](Frag &f, bool rest) {
+    frag_wait<9>(f.cf, f.a, f.e);
+    float b[2][4];
+    /* v_mul_legacy_f32: 0 * x is 0 for ANY x (a step past the break may hold inf), otherwise the
+     * IEEE product: select and multiply in one instruction of the MFMAs' own ALU.  All eight in
+     * ONE statement with early-clobber outputs: eight distinct registers that nothing rewrites
+     * while the sixteen MFMAs that read them are being issued (as separate statements hipcc
+     * recycled two registers between the MFMAs, and results went wrong). */
+    asm volatile("v_mul_legacy_f32 %0, %8, %12\n\tv_mul_legacy_f32 %1, %9, %13\n\t"
+                 "v_mul_legacy_f32 %2, %10, %14\n\tv_mul_legacy_f32 %3, %11, %15\n\t"
+                 "v_mul_legacy_f32 %4, %8, %16\n\tv_mul_legacy_f32 %5, %9, %17\n\t"
+                 "v_mul_legacy_f32 %6, %10, %18\n\tv_mul_legacy_f32 %7, %11, %19\n\ts_nop 1"
+                 : "=&v"(b[0][0]), "=&v"(b[0][1]), "=&v"(b[0][2]), "=&v"(b[0][3]), "=&v"(b[1][0]),
+                   "=&v"(b[1][1]), "=&v"(b[1][2]), "=&v"(b[1][3])
+                 : "v"(f.cf[0]), "v"(f.cf[1]), "v"(f.cf[2]), "v"(f.cf[3]), "v"(f.e[0][0][0]), "v"(f.e[0][0][1]),
+                   "v"(f.e[0][1][0]), "v"(f.e[0][1][1]), "v"(f.e[1][0][0]), "v"(f.e[1][0][1]), "v"(f.e[1][1][0]),
+                   "v"(f.e[1][1][1]));
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][jj >> 1][jj & 1], b[jn][jj], acc[i][jn], 0, 0, 0);
+    if (REST && rest) { /* wave-uniform: this wave's 32 or 64 rest rows x its 64 columns (their reads are older
+                         * than the nine waited for above) */
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+        for (int i = 0; i < RI; i++)
+#pragma unroll
+          for (int jn = 0; jn < 2; jn++)
+            racc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.ar[i][jj >> 1][jj & 1], b[jn][jj], racc[i][jn], 0, 0, 0);
+    }
+  };
+  /* groups 0-2 of a stage: read the next group of the same stage, multiply this one */
+  auto step = [&](auto GC, Frag &cur, Frag &nxt, bool rest) {
+    constexpr int g = decltype(GC)::value;
+    rd(std::integral_constant<int, g + 1>{}, nxt, rest);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(cur, rest);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  /* group 3: across the stage boundary.  After the last stage group 0 of the same stage is read once more
+   * (into the idle fragment), so that "nine instructions behind" holds for every group of the launch. */
+  auto step3 = [&](int st, Frag &cur, Frag &nxt, bool rest, bool rest_next) {
+    if (st + 1 < nst) {
+#ifdef PC_STAMPS
+      if (blockIdx.x == 0 && threadIdx.x == 0 && st < 63) g_dd_stamps[st + 1][4] = __builtin_amdgcn_s_memrealtime();
+#endif
+      __builtin_amdgcn_s_barrier(); /* stage st + 1 has landed; stage st - 1's buffer is free */
+      asm volatile("" ::: "memory");
+#ifdef PC_STAMPS
+      if (blockIdx.x == 0 && threadIdx.x == 0 && st < 63) g_dd_stamps[st + 1][5] = __builtin_amdgcn_s_memrealtime();
+#endif
+      stage_addr(st + 1, rest_next);
+    } else {
+      rest_next = false;
+    }
+    rd(std::integral_constant<int, 0>{}, nxt, rest_next);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(cur, rest);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  Frag f0, f1;
+#ifdef PC_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_dd_stamps[0][4] = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (nst > 0) {
+    __builtin_amdgcn_s_barrier(); /* stage 0 has landed */
+    asm volatile("" ::: "memory");
+    stage_addr(0, is_rest(0));
+    rd(std::integral_constant<int, 0>{}, f0, is_rest(0));
+  }
+  for (int st = 0; st < nst; st++) {
+    const bool r = is_rest(st), rn = is_rest(st + 1);
+    step(std::integral_constant<int, 0>{}, f0, f1, r);
+    step(std::integral_constant<int, 1>{}, f1, f0, r);
+    step(std::integral_constant<int, 2>{}, f0, f1, r);
+    step3(st, f1, f0, r, rn);
+  }
+#ifdef PC_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_dd_stamps[0][6] = __builtin_amdgcn_s_memrealtime();
+#endif
+  float *c = o.slab + (size_t)z * o.zs;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int jn = 0; jn < 2; jn++) {
+      const int col = n0 + wn * 64 + jn * 32 + lm;
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+        int row = m0 + wm * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
+        c[(size_t)row * o.ldc + col] = acc[i][jn][g];
+      }
+    }
+  if (REST) {
+    float *rp = dr.planes + (size_t)(z * o.tm + mt) * dr.stride;
+#pragma unroll
+    for (int i = 0; i < RI; i++)
+#pragma unroll
+      for (int jn = 0; jn < 2; jn++) {
+        const int col = n0 + wn * 64 + jn * 32 + lm;
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+          int row = wm * (RR / 2) + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
+          if (row < dr.rows) rp[(size_t)row * o.ldc + col] = racc[i][jn][g];
+        }
+      }
+  }
+}
+
+// ----------------------------------------------------- K9: BPTT control --
+
+// The data-dependent part of bptt_and_accumulate_error (recur-nn.c:317-330,
+// 383-413), one wave per stream: lane k holds the error sum of step k, a ballot finds
+// the step at which the reference's loop would have stopped, lane 0 derives ih_scale
+// and the adaptive min_error_factor, and the lanes publish coef[t][r] = ih_scale while
+// the step counts, 0 afterwards.
+/* es: the stream's error sums by step, es[k * stride] */
+__device__ __forceinline__ void bptt_control_wave(const View &v, int r, int j, int lane,
+                                                  const unsigned char *active, unsigned flags,
+                                                  const float *es_src, size_t es_stride) {
+  const RamdShape &s = v.sh;
+  const int D = s.D;
+  if (active && !active[j]) {
+    for (int k = lane; k < D; k += 64) v.b.coef[(size_t)k * s.Scap + r] = 0.0f;
+    if (lane == 0) v.b.n_exec[r] = 0; /* no step ran: k_err_writeback leaves its images alone */
+    return;
+  }
+  float top = v.b.top_scaled[r];
+  float max_error_sum = MAX_ERROR_GAIN_F * top + 1;
+  float error_sum_ceiling = ERROR_GAIN_CEILING_F * top;
+  float min_error_gain = MIN_ERROR_GAIN_F * top;
+  float mef = v.b.mef[r];
+  /* MIN(a, b) of the reference is (a < b) ? a : b: keep NaN behaviour aligned */
+  float mef_rate = mef / v.b.lr[r];
+  float min_error_sum = (mef_rate < min_error_gain) ? mef_rate : min_error_gain;
+  /* the first step whose sum leaves [min, max] ends the loop (recur-nn.c:387-389) */
+  int n_exec = D;
+  float error_sum = 0.0f;
+  for (int k0 = 0; k0 < D; k0 += 64) {
+    int k = k0 + lane;
+    float es = (k < D) ? es_src[(size_t)k * es_stride] : 0.0f;
+    bool stop = k < D && (es <= min_error_sum || es > max_error_sum);
+    unsigned long long hit = __ballot(stop);
+    int last = hit ? __ffsll((long long)hit) - 1 : min(63, D - 1 - k0);
+    error_sum = __shfl(es, last, 64);
+    if (hit) {
+      n_exec = k0 + last + 1;
+      break;
+    }
+  }
+  /* the reference's t counts down from D and is not decremented on a break */
+  bool broke = n_exec < D || (error_sum <= min_error_sum || error_sum > max_error_sum);
+  int t = broke ? D - n_exec + 1 : 0;
+  float scale;
+  if (error_sum > error_sum_ceiling) {
+    scale = soft_clip_dev(error_sum, max_error_sum);
+  } else {
+    scale = 1.0f;
+    if (flags & 64u) { /* RNN_NET_FLAG_BPTT_ADAPTIVE_MIN_ERROR */
+      int depth_error = D / 4 - t;
+      if (mef < MAX_MIN_ERROR_FACTOR_F && (min_error_gain != min_error_sum || depth_error < 0)) {
+        mef *= (float)(1.0f + depth_error * 1e-3);
+      }
+      mef = (mef >= ABS_MIN_ERROR_FACTOR_F) ? mef : ABS_MIN_ERROR_FACTOR_F;
+    }
+  }
+  if (lane == 0) {
+    v.b.mef[r] = mef;
+    v.b.ih_scale[r] = scale;
+    v.b.bptt_err[r] = error_sum;
+    v.b.n_exec[r] = n_exec;
+    v.b.depth_log[r] = D - t;
+    v.b.stat_depth[r] += (double)(D - t);
+  }
+  /* 0x20000000: rnn_bptt_calculate without batching leaves the UNSCALED sum in ih_delta and puts
+   * ih_scale into the rate (recur-nn.c:966-975) */
+  const float cf = (flags & 0x20000000u) ? 1.0f : scale;
+  for (int k = lane; k < D; k += 64) v.b.coef[(size_t)k * s.Scap + r] = (k < n_exec) ? cf : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_bptt_control(View v, int row0, int nrows,
+                                                      const unsigned char *active, unsigned flags,
+                                                      int tn) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= nrows) return;
+  const int r = row0 + j;
+  bptt_control_wave(v, r, j, lane, active, flags, v.b.esum + r, (size_t)v.sh.Scap);
+}
+
+// k_extras_gather and k_bptt_control in one launch, one workgroup per stream: the waves
+// share out the stream's steps, leave each step's error sum in LDS, and wave 0 then runs
+// the control logic on them (nothing else needs the sums of other streams).
+template <int MAXQ, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, int nrows, int nx,
+                                                            int nxp, int tn,
+                                                            const unsigned char *active,
+                                                            unsigned flags) {
+  extern __shared__ float es_sh[]; /* [D] the steps' totals; tn == 0: then [D + 1] the rows' own sums of squares */
+  const RamdShape &s = v.sh;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.x, r = row0 + j;
+  /* tn == 0 (after the one-launch chain, which leaves no per-tile partial sums): the hidden columns'
+   * part of step t's sum of squares (recur-nn.c:371) is the sum over the step's OUTPUT row, error
+   * plane t + 1 -- the row that the item of step t + 1 holds in registers for its dot products.  So
+   * every item also sums its own row, one more item (t = D) does only that, and the totals are put
+   * together after the barrier. */
+  const int items = tn == 0 ? s.D + 1 : s.D;
+  float *hs_sh = es_sh + s.D;
+  /* the next item's reads are requested before the current one is worked on */
+  ExtrasIn<MAXQ> cur, nxt;
+  if (wave < items) extras_load<MAXQ>(v, wave, r, nx, tn, lane, cur);
+  for (int t = wave; t < items; t += THREADS / 64) {
+    const int tnext = t + THREADS / 64;
+    if (tnext < items) extras_load<MAXQ>(v, tnext, r, nx, tn, lane, nxt);
+    if (tn == 0) {
+      const float hs = row_sumsq<MAXQ>(cur);
+      if (lane == 0) hs_sh[t] = hs;
+    }
+    if (t < s.D) {
+      float es = extras_compute<MAXQ>(v, t, r, nx, nxp, tn, lane, cur);
+      if (lane == 0) {
+        if (tn != 0) v.b.esum[(size_t)t * s.Scap + r] = es;
+        es_sh[t] = es;
+      }
+    }
+    cur = nxt;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    if (tn == 0) {
+      for (int k = lane; k < s.D; k += 64) {
+        const float es = hs_sh[k + 1] + es_sh[k];
+        es_sh[k] = es;
+        v.b.esum[(size_t)k * s.Scap + r] = es;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the wave's own LDS writes before it reads them back */
+    }
+    bptt_control_wave(v, r, j, lane, active, flags, es_sh, 1);
+  }
+}
+
+// ------------------------------------------ one stream, small net: one launch --
+//
+// bptt_and_accumulate_error (recur-nn.c:303-450) for ONE stream of a small net as one
+// workgroup -- what the per-net calls of an unchanged caller need (text-predict's default net
+// has 99 hidden units: D launches of a 100 x 142 matrix-vector product are all launch latency).
+// The workgroup walks the steps in the reference's own order.  Thread (y = tid / 8,
+// chunk = tid % 8) owns 16 columns of rows y and y + 128 of the recurrent matrix: their
+// weights AND their weight-delta sums live in its registers for the whole launch, so a step
+// costs it four float4 of the incoming error row and two input values from LDS, 32 + 32
+// multiply-adds, and three xor shuffles per row to close the dot products (LDS bandwidth is what
+// a single CU runs out of first: an earlier version that fetched the weights from LDS took
+// 2.1 us per step, all of it LDS reads).  The input rows of all D steps are brought into LDS
+// up front and the barriers inside the loop wait for LDS only: vmcnt counts stores too on this
+// architecture, so a global load inside the loop would make every step wait for the previous
+// step's plane stores.  The sum of squares closes the step and the loop ends where the
+// reference's would (recur-nn.c:387-389).  The planes the other kernels read afterwards
+// (error rows, extras, sums: k_err_writeback, k_bottom_error, the log) are written as the
+// chain kernels write them, the control logic is the shared bptt_control_wave, and
+// ih_delta (+)= ih_scale * the accumulated matrix at the end.
+// Preconditions (launcher): h_size <= 128, i_size <= 256, D * i_size floats fit in LDS.
+__global__ __launch_bounds__(1024) void k_bptt_small(View v, int r, int accumulate, unsigned flags,
+                                                     int nx, int nxp) {
+  extern __shared__ __attribute__((aligned(16))) float bsm[];
+  const RamdShape &s = v.sh;
+  const int I = s.I, H = s.H, hs = s.hidden_size, D = s.D;
+  float *h = bsm;             /* [128] error into the step, 0 at column 0 and past hidden_size */
+  float *xon = h + 128;       /* [256] the step's input row, 0 where the row is skipped or absent */
+  float *en = xon + 256;      /* [256] error out of the step, by row                           */
+  float *red = en + 256;      /* [16] + [1]                                                    */
+  float *es_sh = red + 20;    /* [D]  sums of squares by step                                  */
+  float *xall = es_sh + ((D + 3) & ~3); /* [D][I] the input rows of all the steps              */
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int y0 = tid >> 3, n0 = (tid & 7) * 16; /* rows y0, y0 + 128; columns n0 .. n0 + 15 */
+  const float *W = v.b.ih_w;
+  const int idx0 = v.b.idx[r];
+  /* weights: rows past I and columns past H are zero */
+  float w[2][16], acc[2][16];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int y = y0 + 128 * q;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      float4 t = (y < I && n0 + 4 * k < H) ? ld4(W + (size_t)y * H + n0 + 4 * k) : zero4();
+      w[q][4 * k] = t.x; w[q][4 * k + 1] = t.y; w[q][4 * k + 2] = t.z; w[q][4 * k + 3] = t.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc[q][k] = 0.0f;
+  }
+  {
+    const int I4 = I / 4;
+    for (int e = tid; e < D * I4; e += 1024) {
+      const int t = e / I4, i = e - t * I4;
+      int slot = idx0 - t;
+      if (slot < 0) slot += D;
+      *reinterpret_cast<float4 *>(xall + t * I + 4 * i) = ld4(v.b.arena + ((size_t)slot * s.Scap + r) * I + 4 * i);
+    }
+    const float *e0 = v.b.ehi + (size_t)r * I; /* plane 0: the top layer's error */
+    if (tid < 128) h[tid] = (tid == 0 || tid > hs || tid >= H) ? 0.0f : e0[tid];
+    if (tid < 256) xon[tid] = 0.0f;
+    for (int i = tid; i < D; i += 1024) es_sh[i] = 0.0f;
+  }
+  /* thresholds exactly as bptt_control_wave derives them */
+  const float top = v.b.top_scaled[r];
+  const float max_error_sum = MAX_ERROR_GAIN_F * top + 1;
+  const float min_error_gain = MIN_ERROR_GAIN_F * top;
+  const float mef_rate = v.b.mef[r] / v.b.lr[r];
+  const float min_error_sum = (mef_rate < min_error_gain) ? mef_rate : min_error_gain;
+  const size_t plane = (size_t)s.Scap * I;
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  /* sum over the eight lanes of a row without LDS: two quad permutes and a half-row mirror */
+#define DPP_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
+  const bool two_rows = (wave * 8 + 128) < I; /* this wave's second rows exist */
+  __syncthreads();
+  if (tid < I) { /* step 0's input row */
+    const float xi = xall[tid];
+    bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
+    xon[tid] = on ? xi : 0.0f;
+  }
+  LDS_BARRIER();
+  for (int t = 0; t < D; t++) {
+    float sq = 0.0f;
+    {
+      float hv[16];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float4 t4 = ld4(h + n0 + 4 * k);
+        hv[4 * k] = t4.x; hv[4 * k + 1] = t4.y; hv[4 * k + 2] = t4.z; hv[4 * k + 3] = t4.w;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        if (q == 1 && !two_rows) break; /* wave-uniform */
+        const float xi = xon[y0 + 128 * q];
+        /* weight deltas of the step (recur-nn.c:343-358) and the error that leaves it
+         * (359-376); a skipped row has xi == 0: nothing is added and its error is 0 */
+        float e = 0.0f, e1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+          acc[q][k] += xi * hv[k];
+          acc[q][k + 1] += xi * hv[k + 1];
+          e += w[q][k] * hv[k];
+          e1 += w[q][k + 1] * hv[k + 1];
+        }
+        e += e1;
+        DPP_ADD(e, 0xB1);  /* quad_perm [1,0,3,2] */
+        DPP_ADD(e, 0x4E);  /* quad_perm [2,3,0,1] */
+        DPP_ADD(e, 0x141); /* row_half_mirror: the other quad of the eight */
+        if (s.activation == 2) e /= 2 * (xi + 1.0f);
+        e = (xi != 0.0f) ? e : 0.0f;
+        if ((tid & 7) == 0) {
+          en[y0 + 128 * q] = e;
+          sq += e * e;
+        }
+      }
+    }
+    /* the wave's share of the sum of squares: its row leaders sit in lanes 0, 8, .., 56 */
+    DPP_ADD(sq, 0x128); /* row_ror 8: lanes 0 and 8 of every row of sixteen */
+    {
+      const int sqi = __builtin_bit_cast(int, sq);
+      float ws = __builtin_bit_cast(float, __builtin_amdgcn_readlane(sqi, 0)) +
+                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(sqi, 16));
+      ws += __builtin_bit_cast(float, __builtin_amdgcn_readlane(sqi, 32)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(sqi, 48));
+      if (lane == 0) red[wave] = ws;
+    }
+    LDS_BARRIER();
+    float es = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    es += ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
+    /* the planes, laid out as the chain and extras kernels leave them; the next step's rows */
+    {
+      float *eo = v.b.ehi + (size_t)(t + 1) * plane + (size_t)r * I;
+      if (tid >= 1 && tid <= hs) eo[tid] = en[tid];
+      float *xo = v.b.ex + ((size_t)(t + 1) * s.Scap + r) * nxp;
+      if (tid < nxp) xo[tid] = (tid == 0) ? en[0] : (tid < nx) ? en[hs + tid] : 0.0f;
+    }
+    if (tid < 128) h[tid] = (tid == 0 || tid > hs) ? 0.0f : en[tid];
+    if (tid < I && t + 1 < D) {
+      const float xi = xall[(t + 1) * I + tid];
+      bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
+      xon[tid] = on ? xi : 0.0f;
+    }
+    if (tid == 0) {
+      es_sh[t] = es;
+      v.b.esum[(size_t)t * s.Scap + r] = es;
+    }
+    LDS_BARRIER();
+    if (es <= min_error_sum || es > max_error_sum) break; /* the same for every thread */
+  }
+#undef DPP_ADD
+#undef LDS_BARRIER
+  if (wave == 0) {
+    /* the steps that did not run left zeros, which end the scan of bptt_control_wave too */
+    bptt_control_wave(v, r, 0, lane, nullptr, flags, es_sh, 1);
+    if (lane == 0) {
+      red[16] = v.b.ih_scale[r]; /* lane 0 wrote it */
+      red[17] = __int_as_float(v.b.n_exec[r]);
+    }
+  }
+  __syncthreads(); /* (also: every plane store of this workgroup has been performed) */
+  const float scale = (flags & 0x20000000u) ? 1.0f : red[16]; /* see bptt_control_wave */
+  {
+    /* bptt->h_error / i_error as the reference leaves them: k_err_writeback's job, from the planes
+     * this workgroup has just written (nothing of them was read before: no stale lines) */
+    const int nex = __float_as_int(red[17]);
+    if (nex > 0 && tid < I) {
+      float *A = v.b.err_a + (size_t)r * I, *B = v.b.err_b + (size_t)r * I;
+      float *last_written = (nex & 1) ? B : A, *last_read = (nex & 1) ? A : B;
+      const float *enp = v.b.ehi + (size_t)nex * plane + (size_t)r * I;
+      const float *epp = v.b.ehi + (size_t)(nex - 1) * plane + (size_t)r * I;
+      const float *xn = v.b.ex + ((size_t)nex * s.Scap + r) * nxp;
+      const float *xp = v.b.ex + ((size_t)(nex - 1) * s.Scap + r) * nxp;
+      const int i = tid;
+      last_written[i] = (i == 0) ? xn[0] : (i <= hs) ? enp[i] : xn[i - hs];
+      if (i < H) {
+        last_read[i] = (i == 0 || i > hs) ? 0.0f : epp[i];
+      } else if (nex > 1) { /* the top error (nex == 1) only covers h_size entries */
+        last_read[i] = xp[i - hs];
+      }
+    }
+  }
+  float *d = v.b.ih_delta;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int y = y0 + 128 * q;
+    if (y < I) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (n0 + 4 * k < H) {
+          float4 *dp = reinterpret_cast<float4 *>(d + (size_t)y * H + n0 + 4 * k);
+          float4 a = make_float4(acc[q][4 * k] * scale, acc[q][4 * k + 1] * scale, acc[q][4 * k + 2] * scale,
+                                 acc[q][4 * k + 3] * scale);
+          if (accumulate) {
+            float4 o = *dp;
+            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+          }
+          *dp = a;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------- finalize: delta --
+
+// ih_delta (+)= sum of the K slabs (recur-nn.c:735-748 folded: the per-stream
+// ih_scale already multiplies the error rows that went into the GEMM)
+__global__ __launch_bounds__(256) void k_delta_finalize(float *delta, const float *slab,
+                                                        size_t n4, size_t n, int ks,
+                                                        int accumulate, int H, int hidden_size,
+                                                        int rows_core, int ks_rest,
+                                                        const float *rest, size_t rest_stride,
+                                                        float *ho_delta, const float *ho_slab,
+                                                        size_t ho_n, int ho_ks) {
+  size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t ih_threads = ((n4 + 255) / 256) * 256;
+  if (q >= ih_threads) {
+    /* the blocks past ih_delta: ho_delta (+)= its K slabs, when the caller has them pending
+     * (k_ho_delta_finalize without error ranges) */
+    size_t e = q - ih_threads;
+    if (ho_slab && 4 * e < ho_n) {
+      float4 a = accumulate ? ld4(ho_delta + 4 * e) : zero4();
+      for (int z = 0; z < ho_ks; z++) {
+        float4 t = ld4(ho_slab + (size_t)z * ho_n + 4 * e);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
+      *reinterpret_cast<float4 *>(ho_delta + 4 * e) = a;
+    }
+    return;
+  }
+  if (q >= n4) return;
+  /* rows below rows_core were produced with ks K slices, the others with ks_rest (their own planes) */
+  const float *src = slab + 4 * q;
+  size_t stride = n;
+  if ((int)((4 * q) / (size_t)H) >= rows_core) {
+    ks = ks_rest;
+    src = rest + (4 * q - (size_t)rows_core * H);
+    stride = rest_stride;
+  }
+  float4 a = accumulate ? ld4(delta + 4 * q) : zero4();
+  float4 sum = sum_planes(src, stride, ks);
+  /* the GEMM only produced columns 1..hidden_size; the others are exactly zero */
+  int c = (int)((4 * q) % (size_t)H);
+  a.x += (c + 0 >= 1 && c + 0 <= hidden_size) ? sum.x : 0.0f;
+  a.y += (c + 1 >= 1 && c + 1 <= hidden_size) ? sum.y : 0.0f;
+  a.z += (c + 2 >= 1 && c + 2 <= hidden_size) ? sum.z : 0.0f;
+  a.w += (c + 3 >= 1 && c + 3 <= hidden_size) ? sum.w : 0.0f;
+  *reinterpret_cast<float4 *>(delta + 4 * q) = a;
+}
+
+// Rebuilds bptt->h_error (err_a) and bptt->i_error (err_b) as the reference
+// leaves them: the loop ping-pongs between the two buffers (recur-nn.c:384-386),
+// zeroing element 0 and the pad of whichever one it reads (334-337).  Columns
+// 1..hidden_size of a step's error live in ehi, column 0 and the input columns
+// in ex.
+__global__ __launch_bounds__(256) void k_err_writeback(View v, int row0, int nxp) {
+  const RamdShape &s = v.sh;
+  int r = row0 + blockIdx.x;
+  int n = v.b.n_exec[r];
+  if (n <= 0) return;
+  float *A = v.b.err_a + (size_t)r * s.I, *B = v.b.err_b + (size_t)r * s.I;
+  float *last_written = (n & 1) ? B : A; /* step n wrote it in full        */
+  float *last_read = (n & 1) ? A : B;    /* step n read it (and zeroed bits) */
+  const float *en = v.b.ehi + ((size_t)n * s.Scap + r) * s.I;
+  const float *ep = v.b.ehi + ((size_t)(n - 1) * s.Scap + r) * s.I;
+  const float *xn = v.b.ex + ((size_t)n * s.Scap + r) * nxp;
+  const float *xp = v.b.ex + ((size_t)(n - 1) * s.Scap + r) * nxp;
+  int hs = s.hidden_size;
+  for (int i = threadIdx.x; i < s.I; i += 256) {
+    last_written[i] = (i == 0) ? xn[0] : (i <= hs) ? en[i] : xn[i - hs];
+    if (i < s.H) {
+      last_read[i] = (i == 0 || i > hs) ? 0.0f : ep[i];
+    } else if (n > 1) { /* the top error (n == 1) only covers h_size entries */
+      last_read[i] = xp[i - hs];
+    }
+  }
+}
+
+__global__ void k_zero_f4(float *a, size_t n4) {
+  size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n4) *reinterpret_cast<float4 *>(a + 4 * q) = zero4();
+}
+
+extern "C" void ramd_launch_bottom_deltas(ramd_stream_t st_, const RamdShape *sh, RamdBuffers *b,
+                                          int row0, int nrows, int accumulate,
+                                          const unsigned char *active) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  int nxp = (sh->I - sh->hidden_size + 3) & ~3;
+  RAMD_LAUNCH(k_bottom_error, dim3(nrows), dim3(64), 0, st, v, row0, nxp, active);
+  int n = sh->bI * sh->bO;
+  const float *cin = b->bcarry + (size_t)b->bcarry_cur * sh->bO;
+  float *cout = b->bcarry + (size_t)(b->bcarry_cur ^ 1) * sh->bO;
+  RAMD_LAUNCH(k_bottom_delta, dim3((n + 255) / 256), dim3(256), 0, st, v, row0, nrows,
+                     accumulate, active, cin, cout);
+  b->bcarry_cur ^= 1;
+}
+
+extern "C" void ramd_launch_clear_deltas(ramd_stream_t st_, const RamdShape *sh,
+                                         const RamdBuffers *b) {
+  hipStream_t st = (hipStream_t)st_;
+  size_t ih4 = (size_t)sh->I * sh->H / 4, ho4 = (size_t)sh->H * sh->O / 4;
+  RAMD_LAUNCH(k_zero_f4, dim3((unsigned)((ih4 + 255) / 256)), dim3(256), 0, st, b->ih_delta, ih4);
+  RAMD_LAUNCH(k_zero_f4, dim3((unsigned)((ho4 + 255) / 256)), dim3(256), 0, st, b->ho_delta, ho4);
+  if (sh->bI) { /* recur-nn.c:687-692 */
+    size_t b4 = (size_t)sh->bI * sh->bO / 4, c4 = (size_t)2 * sh->bO / 4;
+    RAMD_LAUNCH(k_zero_f4, dim3((unsigned)((b4 + 255) / 256)), dim3(256), 0, st, b->bdelta, b4);
+    RAMD_LAUNCH(k_zero_f4, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, st, b->bcarry, c4);
+  }
+}
+
+static int g_calc_wrote_images = 0;
+/* Multi-GPU: the weight-delta GEMM in two row halves, so that the sum over the ranks of the first half
+ * can travel while the second half is still being multiplied (rnn_core.c sets the hook for the call it
+ * wants split; the launcher calls it after each half's deltas are complete in ih_delta || ho_delta,
+ * with the half's range in floats from ih_delta). */
+static void (*g_delta_half_hook)(void *ctx, int half, size_t first_float, size_t n_floats) = nullptr;
+static void *g_delta_half_ctx = nullptr;
+extern "C" void ramd_set_delta_half_hook(void (*hook)(void *, int, size_t, size_t), void *ctx) {
+  g_delta_half_hook = hook;
+  g_delta_half_ctx = ctx;
+}
+/* whether the last ramd_launch_calc_deltas also rebuilt bptt->h_error / i_error (reads and clears) */
+extern "C" int ramd_calc_wrote_images(void) {
+  int w = g_calc_wrote_images;
+  g_calc_wrote_images = 0;
+  return w;
+}
+
+extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
+                                        const RamdBuffers *b, int row0, int nrows, int accumulate,
+                                        const int *ranges, int range_stride,
+                                        const unsigned char *active, unsigned flags,
+                                        RamdPendingDelta *defer) {
+  g_calc_wrote_images = 0;
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  // top layer
+  size_t shm = (size_t)(sh->O + sh->H) * sizeof(float);
+  if (!(flags & 0x40000000u)) { /* ramd_launch_text_top has already done the top backprop */
+    if (ranges && env_int("RECUR_AMD_TOP_RANGED", 1)) {
+      /* up to 16 workgroups per stream (their partial sums sit in the split-K workspace, which
+       * nothing uses at this point) */
+      /* (measured: 256 streams with 1 / 2 / 4 / 8 / 16 workgroups per stream = 552 / 548 / 538 /
+       * 550 / 629 us per generation; 64 streams with 4 / 16: 347 / 358; 32 streams with 8 / 16: 306 / 312) */
+      int nb = 256 / nrows;
+      if (nb < 4) nb = nrows > 1024 ? 1 : 4;
+      if (nb > 16) nb = 16;
+      if ((size_t)nrows * nb > b->slab_floats) nb = 1;
+      RAMD_LAUNCH(k_top_backprop_ranged, dim3(nrows, nb), dim3(1024), shm, st, v, row0, ranges, range_stride,
+                  active, b->slab);
+      if (nb > 1)
+        RAMD_LAUNCH(k_top_backprop_scale, dim3(nrows), dim3(256), 0, st, v, row0, active, b->slab, nb);
+    } else
+      RAMD_LAUNCH(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges, range_stride, active);
+  }
+  /* the weight-delta GEMM's path is decided here already: when it ends with the small GEMM
+   * over the rows above the last whole 128-row tile, the top layer's equally small delta
+   * GEMM can share that launch (nothing before the optimiser needs its result) */
+  const bool dma = b->uniform_idx >= 0 && nrows % BK == 0 && sh->hidden_size % 128 == 0 &&
+                   sh->I >= 128 && sh->activation != 5 && env_int("RECUR_AMD_DELTA_DMA", 1);
+  const bool has_rest = dma && (sh->I / 128) * 128 < sh->I;
+  bool ho_paired = false, ho_finalize_after = false, ho_in_final = false;
+  ProbHoDelta ho_p = {};
+  int ho_nkt = 0, ho_ks = 0;
+  if (!(flags & 0x80000000u)) { /* the fused single-net path updates W_ho directly */
+    int tm = (sh->H + BM - 1) / BM, tn = (sh->O + BN - 1) / BN;
+    int nkt = (nrows + BK - 1) / BK;
+    int ho = sh->H * sh->O;
+    int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_HO", b->slab_floats, (size_t)ho);
+    /* per-stream 1.0 / 0.0 participation flags as floats (b->coef plane 0 is free here:
+     * k_bptt_control rewrites it later in this call) */
+    const float *live = b->ones + row0;
+    if (active) {
+      RAMD_LAUNCH(k_live_mask, dim3((nrows + 255) / 256), dim3(256), 0, st, b->coef + row0,
+                         active, nrows);
+      live = b->coef + row0;
+    }
+    ProbHoDelta p = {v, row0, nrows, live};
+    if (defer) defer->ho_slab = nullptr;
+    if (defer && !accumulate && !ranges && b->ho_slab) {
+      /* the optimiser launch that follows sums these slabs itself (and stores ho_delta) */
+      if (ks > 8) ks = 8;
+      if (has_rest && !active && env_int("RECUR_AMD_PAIR_HO", 1)) {
+        ho_paired = true; /* launched together with the rest rows of the weight-delta GEMM */
+        ho_p = p;
+        ho_nkt = nkt;
+        ho_ks = ks;
+      } else {
+        launch_gemm<true, true, ProbHoDelta>(st, p, b->ho_slab, sh->H, sh->O, nkt, ks, T_OTHER);
+      }
+      defer->ho_slab = b->ho_slab;
+      defer->ho_n = (size_t)ho;
+      defer->ho_ks = ks;
+      defer->ho_delta_out = b->ho_delta;
+    } else if (has_rest && !active && b->ho_slab && env_int("RECUR_AMD_PAIR_HO", 1)) {
+      /* not deferred (the deltas are wanted as such: accumulation, an all-reduce between the
+       * ranks): still one launch with the rest rows, summed right after it */
+      if (ks > 8) ks = 8;
+      ho_paired = true;
+      ho_finalize_after = true;
+      ho_p = p;
+      ho_nkt = nkt;
+      ho_ks = ks;
+    } else {
+      launch_gemm<true, true, ProbHoDelta>(st, p, b->slab, sh->H, sh->O, nkt, ks, T_OTHER);
+      /* with one range list per stream the set of touched columns differs per stream; the
+       * error is zero outside a stream's own ranges, so every column may take its sum */
+      RAMD_LAUNCH(k_ho_delta_finalize, dim3((ho + 255) / 256), dim3(256), 0, st, v, b->slab,
+                         ks, accumulate, range_stride ? nullptr : ranges);
+    }
+  }
+  // BPTT chain: D dependent steps, one launch each, then the extras of all steps
+  bool control_done = false;
+  const int tn = (sh->hidden_size + CN - 1) / CN;
+  int tn_parts = tn; /* partial sums of squares per (step, stream): one per column tile of the chain kernel used */
+  const int nx = sh->I - sh->hidden_size; /* column 0 + the input columns */
+  const int nxp = (nx + 3) & ~3;
+  if (nrows == 1 && !active && row0 < sh->Scap && sh->H <= 256 &&
+      env_int("RECUR_AMD_BPTT_SMALL", 1)) {
+    /* one stream of a small net (the per-net calls): chain, extras, control and weight deltas
+     * in one workgroup */
+    /* h_size <= 128 and i_size <= 256 (text-predict's default 99 hidden units: 100 x 142):
+     * the matrix lives in the workgroup's registers; larger nets take the launch-per-step route */
+    const size_t shm = (size_t)(128 + 256 + 256 + 20 + ((sh->D + 3) & ~3) + (size_t)sh->D * sh->I) * sizeof(float);
+    if (sh->H <= 128 && sh->I <= 256 && shm <= 150 * 1024) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_bptt_small,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+      }
+      if (defer) defer->slab = nullptr; /* ih_delta is written here: nothing left for the optimiser to sum */
+      int ev = timing_begin(st, T_CHAIN, 1);
+      RAMD_LAUNCH(k_bptt_small, dim3(1), dim3(1024), shm, st, v, row0, accumulate, flags, nx, nxp);
+      timing_end(st, ev);
+      g_calc_wrote_images = 1; /* the error images are done: no k_err_writeback for this call */
+      return;
+    }
+  }
+  {
+    tn_parts = ramd_chain_steps(st, v, sh, b, row0, nrows);
+    int M = sh->D * nrows;
+    int etm = (M + BM - 1) / BM, etn = (nx + BN - 1) / BN, nkt = (sh->H + BK - 1) / BK;
+    int ks = pick_ks(etm * etn, nkt, "RECUR_AMD_KS_EXTRAS", b->slab_floats, (size_t)M * nxp);
+    /* the gather over the non-zero input rows (one-hot symbols: two rows per step and stream) or,
+     * for dense inputs with more than a handful of columns, the GEMM over all of them */
+    if (sh->H <= 2304 && !env_int("RECUR_AMD_EXTRAS_GEMM", 0) && !(b->dense_inputs && nx > 8)) {
+      const int nq = (sh->H / 4 + 63) / 64;
+      if (env_int("RECUR_AMD_EXTRAS_SPLIT", 0)) {
+        if (nq <= 5)
+          RAMD_LAUNCH(k_extras_gather<5>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
+                             nxp, tn_parts);
+        else if (nq <= 8)
+          RAMD_LAUNCH(k_extras_gather<8>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
+                             nxp, tn_parts);
+        else /* h_size 2052: hidden 2048 */
+          RAMD_LAUNCH(k_extras_gather<9>, dim3((M + 3) / 4), dim3(256), 0, st, v, row0, nrows, nx,
+                             nxp, tn_parts);
+      } else {
+        /* extras and control in one launch, one workgroup per stream */
+        const size_t shm = (size_t)(2 * sh->D + 1) * sizeof(float);
+        if (nq <= 5)
+          RAMD_LAUNCH((k_extras_control<5, 1024>), dim3(nrows), dim3(1024), shm, st, v, row0, nrows,
+                             nx, nxp, tn_parts, active, flags);
+        else if (nq <= 8)
+          RAMD_LAUNCH((k_extras_control<8, 512>), dim3(nrows), dim3(512), shm, st, v, row0, nrows,
+                             nx, nxp, tn_parts, active, flags);
+        else /* h_size 2052: hidden 2048 */
+          RAMD_LAUNCH((k_extras_control<9, 512>), dim3(nrows), dim3(512), shm, st, v, row0, nrows,
+                             nx, nxp, tn_parts, active, flags);
+        control_done = true;
+      }
+    } else { /* very wide nets: the dense GEMM over all extra columns */
+      ProbExtras p = {v, row0, nrows, nx};
+      launch_gemm<false, false, ProbExtras>(st, p, b->slab, M, nxp, nkt, ks, T_OTHER);
+      RAMD_LAUNCH(k_extras_finalize, dim3(M), dim3(64), 0, st, v, row0, nrows, nx, nxp, ks, tn_parts);
+    }
+  }
+  if (!control_done)
+    RAMD_LAUNCH(k_bptt_control, dim3((nrows + 3) / 4), dim3(256), 0, st, v, row0, nrows,
+                       active, flags, tn);
+  // weight deltas: one GEMM over (step, stream)
+  {
+    /* only columns 1..hidden_size of the delta can be non-zero (h_error[0] and the pad are
+     * zero, recur-nn.c:334-337), so the column tiles start at 1: at hidden 1024 that is 16
+     * exact tiles instead of 17 */
+    const int ncol = sh->hidden_size + 1;
+    int tm = (sh->I + BM - 1) / BM, tn = (ncol - 1 + BN - 1) / BN;
+    int rtiles = (nrows + BK - 1) / BK;
+    int nkt = sh->D * rtiles;
+    size_t n = (size_t)sh->I * sh->H;
+    int ks = pick_ks(tm * tn, nkt, "RECUR_AMD_KS_DELTA", b->slab_floats, n);
+    const bool big = env_int("RECUR_AMD_DELTA_TILE", sh->I >= 256 && nkt >= 16 ? 128 : 64) == 128;
+    if (big) {
+      int tm2 = (sh->I + BM2 - 1) / BM2, tn2 = (ncol - 1 + BN2 - 1) / BN2;
+      ks = pick_ks(tm2 * tn2, nkt, "RECUR_AMD_KS_DELTA", b->slab_floats, n);
+    }
+    int rows_core = sh->I, ks_rest = ks;
+    float *rest_base = b->slab; /* planes of the rows from rows_core on: rest_base + z * rest_stride */
+    size_t rest_stride = n;
+    if (dma) {
+      /* whole 128-row tiles by LDS-DMA, one workgroup per CU; the rows above them (the
+       * input rows of a text net) by the generic kernel with its own K split */
+      static bool attr_set = false;
+      size_t shm = (size_t)DD_STAGES * DD_STAGE_FLOATS * sizeof(float);
+      const size_t shm_rest = shm + (size_t)DD_REST_FLOATS * sizeof(float);
+      if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_delta_dma<0>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_delta_dma<64>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_rest));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_delta_dma<128>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_rest));
+        attr_set = true;
+      }
+      rows_core = (sh->I / 128) * 128;
+      GemmOut o;
+      o.slab = b->slab;
+      o.M = sh->I;
+      o.N = ncol;
+      o.ldc = sh->H;
+      o.zs = n;
+      o.nkt = nkt;
+      o.tm = rows_core / 128;
+      o.tn = sh->hidden_size / 128;
+      o.col0 = 1;
+      o.row0m = 0;
+      int tiles = o.tm * o.tn;
+      int kd = env_int("RECUR_AMD_KS_DELTA", 0);
+      if (kd != 1 && kd != 2 && kd != 4 && kd != 8) {
+        kd = 8;
+        while (kd > 1 && tiles * kd > 256) kd >>= 1;
+      }
+      while (kd > 1 && (kd > nkt || (size_t)kd * n > b->slab_floats)) kd >>= 1;
+      o.ks = ks = kd;
+      const int per = 8 / kd;
+      int blocks = ((tiles + per - 1) / per) * 8;
+      /* the rows above the last whole tile inside the same launch (see DeltaRest) when there are at
+       * most 128 of them, at least four row tiles to share them out, and room for ks * tm planes */
+      const int rest_rows = sh->I - rows_core;
+      const size_t rest_plane = (size_t)rest_rows * sh->H;
+      const bool rest_in = rest_rows > 0 && rest_rows <= 128 && o.tm >= 4 && kd * o.tm <= RAMD_MAX_REST_PLANES &&
+                           (size_t)kd * n + (size_t)kd * o.tm * rest_plane <= b->slab_floats &&
+                           env_int("RECUR_AMD_DELTA_REST_IN", 1);
+      /* ---- the two-halves form (see g_delta_half_hook): rows [0, tm / 2 tiles) with twice the K split
+       * (the same number of workgroups and of slab bytes), summed into ih_delta, hook; then the upper
+       * tiles with the rest rows riding along, the top layer's deltas, summed, hook */
+      if (g_delta_half_hook && !defer && rest_in && o.tm >= 8 && o.tm % 2 == 0 && ho_paired && ho_finalize_after &&
+          !ranges && env_int("RECUR_AMD_DIST_OVERLAP", 0)) {
+        /* OFF by default -- measured with ONE rank (bench.py --dist, round 3): 305 against 255 us per
+         * generation.  Two launches of half the rows with twice the K split cost the GEMM class +24 us
+         * (each workgroup's prologue, epilogue and ring fill amortise over 20 instead of 40 K tiles, the
+         * finalize sums 8 planes twice), the two event hand-overs and RCCL calls another ~25 us: more
+         * than the ~2.2 MB all-reduce it could hide is expected to take over xGMI.  And while a half's
+         * GEMM holds every CU with 148 KB of LDS, RCCL's own workgroups can only become resident as that
+         * launch drains.  Kept for the day a multi-GPU node says otherwise (RECUR_AMD_DIST_OVERLAP=1;
+         * results equal the one-launch form: tests/test_gpu_dist.py). */
+        const int tmh = o.tm / 2;
+        int kd2 = 8;
+        while (kd2 > 1 && (tmh * o.tn * kd2 > 256 || kd2 > nkt ||
+                           (size_t)kd2 * n + (size_t)kd2 * tmh * rest_plane > b->slab_floats))
+          kd2 >>= 1;
+        const int per2 = 8 / kd2;
+        const int blocks2 = ((tmh * o.tn + per2 - 1) / per2) * 8;
+        const size_t half_floats = (size_t)tmh * 128 * sh->H, n4h = half_floats / 4;
+        GemmOut oh = o;
+        oh.tm = tmh;
+        oh.ks = kd2;
+        int evh = timing_begin(st, T_DELTA, 2);
+        { /* lower half: no rest rows */
+          DeltaRest none = {};
+          oh.row0m = 0;
+          RAMD_LAUNCH(k_delta_dma<0>, dim3(blocks2), dim3(512), shm, st, v, row0, nrows, oh, none);
+          RAMD_LAUNCH(k_delta_finalize, dim3((unsigned)((n4h + 255) / 256)), dim3(256), 0, st, b->ih_delta, b->slab, n4h, n,
+                      kd2, accumulate, sh->H, sh->hidden_size, tmh * 128, 0, b->slab, (size_t)0, b->ho_delta,
+                      (const float *)nullptr, (size_t)0, 0);
+          g_delta_half_hook(g_delta_half_ctx, 0, 0, half_floats);
+        }
+        { /* upper half + rest rows + the top layer */
+          DeltaRest dr;
+          dr.planes = b->slab + (size_t)kd2 * n;
+          dr.stride = rest_plane;
+          dr.rows = rest_rows;
+          dr.col = rows_core;
+          oh.row0m = tmh * 128;
+          if (rest_rows <= 64)
+            RAMD_LAUNCH(k_delta_dma<64>, dim3(blocks2), dim3(512), shm_rest, st, v, row0, nrows, oh, dr);
+          else
+            RAMD_LAUNCH(k_delta_dma<128>, dim3(blocks2), dim3(512), shm_rest, st, v, row0, nrows, oh, dr);
+          timing_end(st, evh);
+          launch_gemm<true, true, ProbHoDelta>(st, ho_p, b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, T_OTHER);
+          const size_t up_floats = n - half_floats, n4u = up_floats / 4, ho_n = (size_t)sh->H * sh->O;
+          const unsigned fin_blocks = (unsigned)((n4u + 255) / 256) + (unsigned)((ho_n / 4 + 255) / 256);
+          RAMD_LAUNCH(k_delta_finalize, dim3(fin_blocks), dim3(256), 0, st, b->ih_delta + half_floats, b->slab + half_floats,
+                      n4u, n, kd2, accumulate, sh->H, sh->hidden_size, rows_core - tmh * 128, kd2 * tmh, dr.planes,
+                      rest_plane, b->ho_delta, b->ho_slab, ho_n, ho_ks);
+          g_delta_half_hook(g_delta_half_ctx, 1, half_floats, up_floats + ho_n);
+        }
+        return;
+      }
+      int ev = timing_begin(st, T_DELTA);
+      if (rest_in) {
+        DeltaRest dr;
+        dr.planes = b->slab + (size_t)kd * n;
+        dr.stride = rest_plane;
+        dr.rows = rest_rows;
+        dr.col = rows_core;
+        if (rest_rows <= 64)
+          RAMD_LAUNCH(k_delta_dma<64>, dim3(blocks), dim3(512), shm_rest, st, v, row0, nrows, o, dr);
+        else
+          RAMD_LAUNCH(k_delta_dma<128>, dim3(blocks), dim3(512), shm_rest, st, v, row0, nrows, o, dr);
+      } else {
+        DeltaRest dr = {};
+        RAMD_LAUNCH(k_delta_dma<0>, dim3(blocks), dim3(512), shm, st, v, row0, nrows, o, dr);
+      }
+      timing_end(st, ev);
+      ks_rest = 0;
+      if (rest_in) {
+        ks_rest = kd * o.tm;
+        rest_base = b->slab + (size_t)kd * n;
+        rest_stride = rest_plane;
+        if (ho_paired) { /* the top layer's delta GEMM had been waiting for the pair launch */
+          launch_gemm<true, true, ProbHoDelta>(st, ho_p, b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, T_OTHER);
+          ho_paired = false;
+          if (ho_finalize_after && !ranges) {
+            ho_in_final = true; /* summed by the k_delta_finalize launch below */
+          } else if (ho_finalize_after) {
+            RAMD_LAUNCH(k_ho_delta_finalize, dim3((sh->H * sh->O + 255) / 256), dim3(256), 0, st, v,
+                               b->ho_slab, ho_ks, accumulate, range_stride ? nullptr : ranges);
+          }
+        }
+      } else if (rows_core < sh->I) {
+        /* The rest rows' planes are compact ([ks_rest][I - rows_core][H], behind the core planes).
+         * This GEMM is a few rows tall and K = S * D deep; measured at the north star its time does
+         * not fall below 17 us for any K split from 16 to 48 (one workgroup per CU and ten K tiles
+         * each, or three per CU and three tiles each: 0.87 us per 64 x 64 x 32 tile step and CU
+         * either way), while every further plane costs the optimiser's sum: 16 it is. */
+        int tmr = (rest_rows + BM - 1) / BM, tnr = (ncol - 1 + BN - 1) / BN;
+        ks_rest = pick_ks(tmr * tnr, nkt, "RECUR_AMD_KS_DELTA_REST", (size_t)RAMD_MAX_REST_PLANES, 1);
+        if (ks_rest > RAMD_MAX_REST_PLANES) ks_rest = RAMD_MAX_REST_PLANES;
+        if (ks_rest > nkt) ks_rest = nkt;
+        while (ks_rest > 1 && (size_t)ks * n + (size_t)ks_rest * rest_plane > b->slab_floats) ks_rest--;
+        if (ks_rest < 1) ks_rest = 1;
+        rest_base = b->slab + (size_t)ks * n;
+        rest_stride = rest_plane;
+        ProbDelta<true> p = {v, row0, nrows, rtiles};
+        if (ho_paired) {
+          int blocks_a, blocks_b;
+          GemmOut oa = make_gemm_out(b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, 0, 0, 0, &blocks_a);
+          GemmOut ob = make_gemm_out(rest_base - (size_t)rows_core * sh->H, sh->I, ncol, nkt, ks_rest, 1,
+                                     sh->H, rows_core, &blocks_b);
+          ob.zs = rest_stride;
+          int ev2 = timing_begin(st, T_DELTA);
+          RAMD_LAUNCH((k_gemm_pair<ProbHoDelta, ProbDelta<true>>), dim3(blocks_a + blocks_b),
+                             dim3(256), 0, st, ho_p, oa, blocks_a, p, ob);
+          timing_end(st, ev2);
+          ho_paired = false;
+          if (ho_finalize_after && !ranges) {
+            ho_in_final = true; /* summed by the k_delta_finalize launch below */
+          } else if (ho_finalize_after) {
+            RAMD_LAUNCH(k_ho_delta_finalize, dim3((sh->H * sh->O + 255) / 256), dim3(256), 0, st, v,
+                               b->ho_slab, ho_ks, accumulate, range_stride ? nullptr : ranges);
+          }
+        } else {
+          launch_gemm<true, true, ProbDelta<true>>(st, p, rest_base - (size_t)rows_core * sh->H, sh->I, ncol,
+                                                   nkt, ks_rest, T_DELTA, 1, sh->H, rows_core, rest_stride);
+        }
+      }
+    } else if (big && b->uniform_idx >= 0) {
+      ProbDelta<true> p = {v, row0, nrows, rtiles};
+      launch_gemm2<ProbDelta<true>>(st, p, b->slab, sh->I, ncol, nkt, ks, T_DELTA, 1, sh->H);
+    } else if (big) {
+      ProbDelta<false> p = {v, row0, nrows, rtiles};
+      launch_gemm2<ProbDelta<false>>(st, p, b->slab, sh->I, ncol, nkt, ks, T_DELTA, 1, sh->H);
+    } else if (b->uniform_idx >= 0) {
+      ProbDelta<true> p = {v, row0, nrows, rtiles};
+      launch_gemm<true, true, ProbDelta<true>>(st, p, b->slab, sh->I, ncol, nkt, ks, T_DELTA, 1, sh->H);
+    } else {
+      ProbDelta<false> p = {v, row0, nrows, rtiles};
+      launch_gemm<true, true, ProbDelta<false>>(st, p, b->slab, sh->I, ncol, nkt, ks, T_DELTA, 1, sh->H);
+    }
+    size_t n4 = n / 4;
+    if (defer && !accumulate) { /* the optimiser launch that follows sums the slabs itself */
+      defer->slab = b->slab;
+      defer->n = n;
+      defer->ks = ks;
+      defer->H = sh->H;
+      defer->hidden_size = sh->hidden_size;
+      defer->rows_core = rows_core;
+      defer->ks_rest = ks_rest;
+      defer->rest = rest_base == b->slab ? b->slab + (size_t)rows_core * sh->H : rest_base;
+      defer->rest_stride = rest_stride;
+      defer->delta_out = b->ih_delta;
+      return;
+    }
+    if (defer) defer->slab = nullptr;
+    const size_t ho_n = (size_t)sh->H * sh->O;
+    const unsigned fin_blocks = (unsigned)((n4 + 255) / 256) + (ho_in_final ? (unsigned)((ho_n / 4 + 255) / 256) : 0u);
+    RAMD_LAUNCH(k_delta_finalize, dim3(fin_blocks), dim3(256), 0, st, b->ih_delta, b->slab, n4, n, ks,
+                       accumulate, sh->H, sh->hidden_size, rows_core, ks_rest,
+                       rest_base == b->slab ? b->slab + (size_t)rows_core * sh->H : rest_base, rest_stride, b->ho_delta,
+                       ho_in_final ? b->ho_slab : nullptr, ho_n, ho_ks);
+  }
+}
+
+extern "C" void ramd_launch_err_writeback(ramd_stream_t st_, const RamdShape *sh,
+                                          const RamdBuffers *b, int row0, int nrows) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  int nxp = (sh->I - sh->hidden_size + 3) & ~3;
+  RAMD_LAUNCH(k_err_writeback, dim3(nrows), dim3(256), 0, st, v, row0, nxp);
+}

@@ -1,0 +1,666 @@
+// kernels_loss.hip -- the callers' loss functions on the device (text, multi-text, classify, rnnca) and their launchers.
+#include "k_common.h"
+
+// -------------------------------------------------------- loss on device --
+
+#pragma clang fp contract(off)
+// badmaths.h:14-29, kept operation for operation
+__device__ float fast_expf_dev(float x) {
+  int count = 0;
+  while (fabsf(x) > 0.2) {
+    x *= 0.125;
+    count++;
+  }
+  float a = ((x + 3) * (x + 3) + 3) / ((x - 3) * (x - 3) + 3);
+  while (count) {
+    a *= a;
+    a *= a;
+    a *= a;
+    count--;
+  }
+  return a;
+}
+
+// net_error_bptt's loss (charmodel-predict.c:18-27): softmax (badmaths.h:71-111),
+// best guess and negation (badmaths.h:113-141), +1 on the target; plus the
+// running statistics of the epoch loop (charmodel-predict.c:302-304).  One
+// thread per stream walks its row in the reference's order, so the sums round
+// the same way.
+__global__ __launch_bounds__(64) void k_softmax_error(View v, int row0, int nrows) {
+  extern __shared__ float ex[]; /* [output_size] exponentials */
+  int j = blockIdx.x;
+  if (j >= nrows) return;
+  const RamdShape &s = v.sh;
+  int r = row0 + j;
+  // zero fraction of the hidden row (recur-nn.c:438-442), counted by the wave
+  const float *hid = v.b.hidden + (size_t)r * s.H;
+  int zeros = 0;
+  for (int i = threadIdx.x; i < s.H; i += 64) zeros += (hid[i] == 0.0f);
+  for (int off = 32; off > 0; off >>= 1) zeros += __shfl_down(zeros, off, 64);
+  const float *src = v.b.out + (size_t)r * s.O;
+  float *err = v.b.o_error + (size_t)r * s.O;
+  int len = s.output_size;
+  // max and min are order independent: one pass over the lanes
+  float lo = src[0], hi = src[0];
+  for (int i = threadIdx.x; i < len; i += 64) {
+    hi = fmaxf(hi, src[i]);
+    lo = fminf(lo, src[i]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    lo = fminf(lo, __shfl_xor(lo, off, 64));
+  }
+  float adj = 0.0f;
+  if (hi > 50.0f) adj = 50.0f - hi;
+  else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+  // the exponentials in parallel, their sum in the reference's order (lane 0)
+  for (int i = threadIdx.x; i < len; i += 64) ex[i] = fast_expf_dev(src[i] + adj);
+  __syncthreads();
+  // every lane adds the exponentials in the reference's order (the same value in all of
+  // them); the divisions and the arg max (first of equal maxima, badmaths.h:126-139) are
+  // spread over the lanes
+  float sum = 0.0f;
+  for (int i = 0; i < len; i++) sum += ex[i];
+  float best_e = -1.0f;
+  int best_i = 0x7fffffff;
+  const int target = v.b.target[r];
+  for (int i = threadIdx.x; i < len; i += 64) {
+    float e = ex[i] / sum;
+    err[i] = (i == target) ? -e + 1.0f : -e; /* error[next] += 1.0f, charmodel-predict.c:25 */
+    if (e > best_e) {
+      best_e = e;
+      best_i = i;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    float oe = __shfl_xor(best_e, off, 64);
+    int oi = __shfl_xor(best_i, off, 64);
+    if (oe > best_e || (oe == best_e && oi < best_i)) {
+      best_e = oe;
+      best_i = oi;
+    }
+  }
+  if (threadIdx.x != 0) return;
+  float e = -(ex[target] / sum) + 1.0f;
+  float l = 1.0f - e;
+  v.b.stat_err[r] += e;
+  v.b.stat_ent[r] += (l < 1e-30f) ? -100.0f : log2f(l); /* charmodel-helpers.h:11-13 */
+  v.b.stat_correct[r] += (best_i == target);
+  v.b.stat_count[r] += 1;
+  v.b.stat_zero[r] += zeros / (double)s.hidden_size;
+}
+// The top of a text generation in one launch, one workgroup (16 waves) per stream: the
+// output layer (k_out_layer), the softmax loss against the stream's target
+// (k_softmax_error) and the top-layer backprop with its soft clip (k_top_backprop, dense
+// form), each exactly as in the separate kernels -- same operation order per value -- with
+// the hidden row, the outputs and the output error passed through LDS instead of HBM.
+__global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, int fwd_ks) {
+  extern __shared__ float tsh[];
+  __shared__ float tred[16];
+  const RamdShape &s = v.sh;
+  const int r = row0 + blockIdx.x;
+  float *shid = tsh;                   /* [H] hidden row                    */
+  float *part = shid + s.H;            /* [OUT_SEGS][64] output partial sums */
+  float *sout = part + OUT_SEGS * 64;  /* [O] outputs                        */
+  float *sex = sout + s.O;             /* [O] exponentials                   */
+  float *serr = sex + s.O;             /* [O] output error                   */
+  float *hid = v.b.hidden + (size_t)r * s.H;
+  if (fwd_ks != 0) {
+    // the forward GEMM's K slabs are still in the workspace: sum them, apply the
+    // activation and write the hidden row here (what k_fwd_finalize does, recur-nn.c:123-148).
+    // fwd_ks < 0: k_fwd_fused left one plane of sums and, for the h_size padding columns,
+    // -fwd_ks per-tile partial sums in plane 1.
+    const float *p = v.b.slab + (size_t)blockIdx.x * s.H;
+    const int npart = fwd_ks < 0 ? -fwd_ks : 0;
+    if (fwd_ks < 0) fwd_ks = 1;
+    for (int i = threadIdx.x; i < s.H; i += 1024) {
+      /* all the slabs' loads in flight at once (a loop with a run-time trip count issues
+       * them one L2 latency after another) */
+      const size_t plane = (size_t)nrows * s.H;
+      float xs[8];
+#pragma unroll
+      for (int z = 0; z < 8; z++) xs[z] = (z < fwd_ks) ? p[z * plane + i] : 0.0f;
+      float x = xs[0];
+#pragma unroll
+      for (int z = 1; z < 8; z++)
+        if (z < fwd_ks) x += xs[z];
+      for (int z = 8; z < fwd_ks; z++) x += p[z * plane + i];
+      if (npart && i >= s.H - 4) continue; /* the tail columns: below */
+      if (s.activation == 2) {
+        x = (x > 0.0f) ? sqrtf(x + 1.0f) - 1.0f : 0.0f;
+      } else if (s.activation == 5) {
+        x = x < 20.0f ? x : 20.0f;
+        x = (x > 0.0f) ? x : 0.0f;
+      } else {
+        x = (x > 0.0f) ? x : 0.0f;
+      }
+      if (i == 0) x = 1.0f; /* the bias node, recur-nn.c:148 */
+      hid[i] = x;
+      shid[i] = x;
+    }
+    if (npart && threadIdx.x < 256) {
+      /* k_fwd_fused's four tail columns (hidden value hidden_size and the padding of h_size):
+       * wave p adds column p's per-tile partial sums */
+      const int p4 = threadIdx.x >> 6, ln = threadIdx.x & 63;
+      const float *pd = v.b.slab + (size_t)nrows * s.H + (size_t)blockIdx.x * 4 + p4;
+      float x = 0.0f;
+      for (int t = ln; t < npart; t += 64) x += pd[(size_t)t * nrows * 4];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      if (s.activation == 2) {
+        x = (x > 0.0f) ? sqrtf(x + 1.0f) - 1.0f : 0.0f;
+      } else if (s.activation == 5) {
+        x = x < 20.0f ? x : 20.0f;
+        x = (x > 0.0f) ? x : 0.0f;
+      } else {
+        x = (x > 0.0f) ? x : 0.0f;
+      }
+      if (ln == 0) {
+        hid[s.H - 4 + p4] = x;
+        shid[s.H - 4 + p4] = x;
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < s.H; i += 1024) shid[i] = hid[i];
+  }
+  __syncthreads();
+  const int seg = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // ---- output layer (recur-nn.c:150-151)
+  {
+    const int per = (s.H + OUT_SEGS - 1) / OUT_SEGS;
+    const int y0 = seg * per, y1 = min(s.H, y0 + per);
+    float *out = v.b.out + (size_t)r * s.O;
+    for (int c0 = 0; c0 < s.O; c0 += 64) {
+      int col = c0 + lane;
+      float acc0 = 0.0f, acc1 = 0.0f;
+      if (col < s.O) {
+        const float *w = v.b.ho_w + col;
+        int y = y0;
+        /* 32 rows' weights in flight per batch; the sums keep the order of the plain loop */
+        for (; y + 31 < y1; y += 32) {
+          float wv[32];
+#pragma unroll
+          for (int k = 0; k < 32; k++) wv[k] = w[(size_t)(y + k) * s.O];
+#pragma unroll
+          for (int k = 0; k < 32; k += 2) {
+            acc0 += shid[y + k] * wv[k];
+            acc1 += shid[y + k + 1] * wv[k + 1];
+          }
+        }
+#pragma unroll 4
+        for (; y + 1 < y1; y += 2) {
+          acc0 += shid[y] * w[(size_t)y * s.O];
+          acc1 += shid[y + 1] * w[(size_t)(y + 1) * s.O];
+        }
+        if (y < y1) acc0 += shid[y] * w[(size_t)y * s.O];
+      }
+      part[seg * 64 + lane] = acc0 + acc1;
+      __syncthreads();
+      if (seg == 0 && col < s.O) {
+        float sum = part[lane];
+        for (int g = 1; g < OUT_SEGS; g++) sum += part[g * 64 + lane];
+        out[col] = sum;
+        sout[col] = sum;
+      }
+      __syncthreads();
+    }
+  }
+  // the backprop below needs this thread's row of W_ho: request it now (narrow output layers),
+  // so that it arrives while wave 0 works out the softmax
+  constexpr int TOP_PF = 12; /* float4 per row: o_size <= 48 */
+  float4 wrow[TOP_PF];
+  const bool top_pf = s.O <= 4 * TOP_PF;
+  if (top_pf) {
+    const int y = threadIdx.x;
+    const bool need = y != 0 && y < s.H && shid[y] != 0.0f;
+    const float *rowp = v.b.ho_w + (size_t)(need ? y : 0) * s.O;
+#pragma unroll
+    for (int k = 0; k < TOP_PF; k++) wrow[k] = (need && 4 * k < s.O) ? ld4(rowp + 4 * k) : zero4();
+  }
+  // ---- softmax loss (charmodel-predict.c:18-27, badmaths.h:71-141): wave 0
+  if (seg == 0) {
+    const int len = s.output_size;
+    float *err = v.b.o_error + (size_t)r * s.O;
+    int zeros = 0;
+    for (int i = lane; i < s.H; i += 64) zeros += (shid[i] == 0.0f);
+    for (int off = 32; off > 0; off >>= 1) zeros += __shfl_down(zeros, off, 64);
+    float lo = sout[0], hi = sout[0];
+    for (int i = lane; i < len; i += 64) {
+      hi = fmaxf(hi, sout[i]);
+      lo = fminf(lo, sout[i]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+      lo = fminf(lo, __shfl_xor(lo, off, 64));
+    }
+    float adj = 0.0f;
+    if (hi > 50.0f) adj = 50.0f - hi;
+    else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+    for (int i = lane; i < len; i += 64) sex[i] = fast_expf_dev(sout[i] + adj);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* one wave: its LDS writes are ordered */
+    float sum = 0.0f;
+    for (int i = 0; i < len; i++) sum += sex[i];
+    float best_e = -1.0f;
+    int best_i = 0x7fffffff;
+    const int target = v.b.target[r];
+    for (int i = lane; i < s.O; i += 64) {
+      float oe;
+      if (i < len) {
+        float e = sex[i] / sum;
+        oe = (i == target) ? -e + 1.0f : -e;
+        err[i] = oe;
+        if (e > best_e) {
+          best_e = e;
+          best_i = i;
+        }
+      } else {
+        oe = err[i]; /* the pad of o_error stays what it was (zero) */
+      }
+      serr[i] = oe;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      float oe = __shfl_xor(best_e, off, 64);
+      int oi = __shfl_xor(best_i, off, 64);
+      if (oe > best_e || (oe == best_e && oi < best_i)) {
+        best_e = oe;
+        best_i = oi;
+      }
+    }
+    if (lane == 0) {
+      float e = -(sex[target] / sum) + 1.0f;
+      float l = 1.0f - e;
+      v.b.stat_err[r] += e;
+      v.b.stat_ent[r] += (l < 1e-30f) ? -100.0f : log2f(l);
+      v.b.stat_correct[r] += (best_i == target);
+      v.b.stat_count[r] += 1;
+      v.b.stat_zero[r] += zeros / (double)s.hidden_size;
+    }
+  }
+  __syncthreads();
+  // ---- top-layer backprop + soft clip (recur-nn.c:199-228, 719-721)
+  float sum = 0.0f;
+  float ev[3] = {0.0f, 0.0f, 0.0f}; /* h_size <= 3072 per launch condition */
+  for (int q = 0, y = threadIdx.x; y < s.H; y += 1024, q++) {
+    float e = 0.0f;
+    if (y != 0 && shid[y] != 0.0f) {
+      if (top_pf && q == 0) {
+#pragma unroll
+        for (int k = 0; k < TOP_PF; k++) {
+          if (4 * k < s.O) {
+            e += wrow[k].x * serr[4 * k];
+            e += wrow[k].y * serr[4 * k + 1];
+            e += wrow[k].z * serr[4 * k + 2];
+            e += wrow[k].w * serr[4 * k + 3];
+          }
+        }
+      } else {
+        const float *row = v.b.ho_w + (size_t)y * s.O;
+        for (int x = 0; x < s.O; x += 4) {
+          float4 w = ld4(row + x);
+          e += w.x * serr[x];
+          e += w.y * serr[x + 1];
+          e += w.z * serr[x + 2];
+          e += w.w * serr[x + 3];
+        }
+      }
+      sum += fabsf(e);
+    }
+    ev[q] = e;
+  }
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if (lane == 0) tred[seg] = sum;
+  __syncthreads();
+  /* the same tree as block_sum_256 within each group of four waves, then the four groups */
+  float g0 = (tred[0] + tred[1]) + (tred[2] + tred[3]), g1 = (tred[4] + tred[5]) + (tred[6] + tred[7]);
+  float g2 = (tred[8] + tred[9]) + (tred[10] + tred[11]), g3 = (tred[12] + tred[13]) + (tred[14] + tred[15]);
+  sum = (g0 + g1) + (g2 + g3);
+  float halfmax = s.H * MAX_TOP_ERROR_FACTOR_F;
+  float scaled = sum, scale = 1.0f;
+  if (sum > halfmax) {
+    scale = soft_clip_dev(sum, halfmax);
+    scaled = scale * sum;
+  }
+  float *dst = v.b.ehi + (size_t)r * s.I; /* step 0 plane */
+  for (int q = 0, y = threadIdx.x; y < s.H; y += 1024, q++)
+    dst[y] = (y == 0 || y > s.hidden_size) ? 0.0f : (sum > halfmax) ? ev[q] * scale : ev[q];
+  if (threadIdx.x == 0) {
+    v.b.top_raw[r] = sum;
+    v.b.top_scaled[r] = scaled;
+  }
+}
+
+// multi_softmax_error (charmodel-multi-predict.c:17-58) after the opinion: the output row is
+// n_classes heads of alphabet_len symbols.  The head of the stream's own class is always
+// trained; every other head with probability `leakage`, decided by a draw from the
+// stream's generator (none for the own head: the || short-circuits).  A trained head gets
+// -softmax with +1 on the next symbol; the others stay zero.  The (start, len) ranges
+// the reference builds for rnn_bptt_calc_deltas -- aligned, merged when they touch -- are
+// left in ranges[j].  One wave per stream; every lane runs the generator redundantly so
+// that the decisions are uniform.
+// Four waves per stream: wave 0 makes the leak decisions (the generator is sequential) and the
+// range list while all four clear the error row; then the trained heads are shared out over the
+// waves, each head's softmax exactly as before (the sum of the exponentials in index order).
+// (As one wave per stream this was 35 us for 256 streams of 50 heads.)
+constexpr int MS_WAVES = 4, MS_MAXCLS = 256;
+__global__ __launch_bounds__(64 * MS_WAVES) void k_multi_softmax_error(View v, int row0, int alen, int ncls,
+                                                                       unsigned long long threshold,
+                                                                       const int *tclass, int *ranges,
+                                                                       int range_stride) {
+  extern __shared__ float exs[]; /* [MS_WAVES][alen] */
+  __shared__ short trained[MS_MAXCLS];
+  __shared__ int ntrained;
+  __shared__ float own_err_sh;
+  const RamdShape &s = v.sh;
+  const int j = blockIdx.x, r = row0 + j, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float *src = v.b.out + (size_t)r * s.O;
+  float *err = v.b.o_error + (size_t)r * s.O;
+  const int next = v.b.target[r], own = tclass[j];
+  for (int i = threadIdx.x; i < s.output_size; i += 64 * MS_WAVES) err[i] = 0.0f;
+  if (wave == 0) {
+    /* every lane runs the generator redundantly, so that the decisions are wave-uniform */
+    int *rg = ranges + (size_t)j * range_stride;
+    DevRng g = reinterpret_cast<DevRng *>(v.b.rng)[r];
+    int nt = 0, nr = 0, prev_start = 0, prev_len = 0;
+    for (int c = 0; c < ncls; c++) {
+      bool train = (c == own);
+      if (!train) train = dev_rand64(g) < threshold;
+      if (!train) continue;
+      if (lane == 0) trained[nt] = (short)c;
+      nt++;
+      const int offset = c * alen;
+      int start = offset & ~3, end = (offset + alen + 3) & ~3;
+      if (nr && prev_start + prev_len >= start) {
+        prev_len = end - prev_start;
+        if (lane == 0) rg[2 * (nr - 1) + 1] = prev_len;
+      } else {
+        prev_start = start;
+        prev_len = end - start;
+        if (lane == 0) {
+          rg[2 * nr] = prev_start;
+          rg[2 * nr + 1] = prev_len;
+        }
+        nr++;
+      }
+    }
+    if (lane == 0) {
+      rg[2 * nr] = -1;
+      rg[2 * nr + 1] = 0;
+      reinterpret_cast<DevRng *>(v.b.rng)[r] = g;
+      ntrained = nt;
+    }
+  }
+  __syncthreads(); /* the row is clear, the list is there */
+  float *ex = exs + wave * alen;
+  const int nt = ntrained;
+  for (int k = wave; k < nt; k += MS_WAVES) {
+    const int c = trained[k], offset = c * alen;
+    const float *gs = src + offset;
+    float lo = gs[0], hi = gs[0];
+    for (int i = lane; i < alen; i += 64) {
+      hi = fmaxf(hi, gs[i]);
+      lo = fminf(lo, gs[i]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+      lo = fminf(lo, __shfl_xor(lo, off, 64));
+    }
+    float adj = 0.0f;
+    if (hi > 50.0f) adj = 50.0f - hi;
+    else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+    for (int i = lane; i < alen; i += 64) ex[i] = fast_expf_dev(gs[i] + adj);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* one wave: its LDS writes are ordered */
+    float sum = 0.0f;
+    for (int i = 0; i < alen; i++) sum += ex[i];
+    for (int i = lane; i < alen; i += 64) {
+      float e = ex[i] / sum;
+      err[offset + i] = (i == next) ? -e + 1.0f : -e;
+    }
+    if (c == own && lane == 0) own_err_sh = -(ex[next] / sum) + 1.0f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* before this wave's next head rewrites ex */
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float own_err = own_err_sh;
+    float l = 1.0f - own_err;
+    v.b.stat_err[r] += own_err;
+    v.b.stat_ent[r] += (l < 1e-30f) ? -100.0f : log2f(l);
+    v.b.stat_count[r] += 1;
+  }
+}
+
+// train_channel's loss (gstclassify.c:2070-2119) for every stream: the output row is a
+// few class groups; a group whose target is valid gets -softmax with +1 on the target,
+// the others zeros; if any group was trained the whole error row is multiplied by the
+// per-output error weights.  One wave per stream.  gt[j * ngroups + i] < 0 (or out of
+// range) = "no training for this group" -- the caller decides that (target unknown,
+// ignored windows, the balanced-sampling draw), as the reference's caller does.
+__global__ __launch_bounds__(64) void k_grouped_softmax_error(View v, int row0, int ngroups,
+                                                              const int *goff, const int *gsize,
+                                                              const int *gt, const float *weight) {
+  extern __shared__ float ex[]; /* [largest group] */
+  const RamdShape &s = v.sh;
+  const int j = blockIdx.x, r = row0 + j, lane = threadIdx.x;
+  const float *src = v.b.out + (size_t)r * s.O;
+  float *err = v.b.o_error + (size_t)r * s.O;
+  int trained = 0, wins = 0;
+  float wrong = 0.0f;
+  for (int i = 0; i < ngroups; i++) {
+    const int o = goff[i], n = gsize[i], target = gt[(size_t)j * ngroups + i];
+    if (target < 0 || target >= n) {
+      for (int q = lane; q < n; q += 64) err[o + q] = 0.0f;
+      continue;
+    }
+    const float *gs = src + o;
+    float lo = gs[0], hi = gs[0];
+    for (int q = lane; q < n; q += 64) {
+      hi = fmaxf(hi, gs[q]);
+      lo = fminf(lo, gs[q]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+      lo = fminf(lo, __shfl_xor(lo, off, 64));
+    }
+    float adj = 0.0f;
+    if (hi > 50.0f) adj = 50.0f - hi;
+    else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+    __syncthreads();
+    for (int q = lane; q < n; q += 64) ex[q] = fast_expf_dev(gs[q] + adj);
+    __syncthreads();
+    float sum = 0.0f;
+    for (int q = 0; q < n; q++) sum += ex[q];
+    float best_e = -1.0f;
+    int best_i = 0x7fffffff;
+    for (int q = lane; q < n; q += 64) {
+      float e = ex[q] / sum;
+      err[o + q] = (q == target) ? -e + 1.0f : -e;
+      if (e > best_e) {
+        best_e = e;
+        best_i = q;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      float oe = __shfl_xor(best_e, off, 64);
+      int oi = __shfl_xor(best_i, off, 64);
+      if (oe > best_e || (oe == best_e && oi < best_i)) {
+        best_e = oe;
+        best_i = oi;
+      }
+    }
+    wins += (best_i == target);
+    wrong += -(ex[target] / sum) + 1.0f;
+    trained++;
+  }
+  if (trained && weight) {
+    __syncthreads(); /* one wave: its own stores are ordered; this keeps the compiler honest */
+    for (int q = lane; q < s.output_size; q += 64) err[q] *= weight[q];
+  }
+  if (lane == 0 && trained) {
+    v.b.stat_err[r] += wrong;
+    v.b.stat_correct[r] += wins;
+    v.b.stat_count[r] += trained;
+  }
+}
+
+// get_cross_entropy's inner step (charmodel-predict.c:71-76): softmax of one state
+// row's outputs (badmaths.h:71-111, sums in the reference's order), the probability of
+// the row's target symbol, capped_log2f of it added to the row's running total.
+__global__ __launch_bounds__(64) void k_xent_accumulate(View v, int r, int count_it) {
+  extern __shared__ float ex[];
+  const RamdShape &s = v.sh;
+  const float *src = v.b.out + (size_t)r * s.O;
+  int len = s.output_size;
+  float lo = src[0], hi = src[0];
+  for (int i = threadIdx.x; i < len; i += 64) {
+    hi = fmaxf(hi, src[i]);
+    lo = fminf(lo, src[i]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    lo = fminf(lo, __shfl_xor(lo, off, 64));
+  }
+  float adj = 0.0f;
+  if (hi > 50.0f) adj = 50.0f - hi;
+  else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+  for (int i = threadIdx.x; i < len; i += 64) ex[i] = fast_expf_dev(src[i] + adj);
+  __syncthreads();
+  if (threadIdx.x != 0 || !count_it) return;
+  float sum = 0.0f;
+  for (int i = 0; i < len; i++) sum += ex[i];
+  float e = ex[v.b.target[r]] / sum;
+  v.b.xent[r] += (double)((e < 1e-30f) ? -100.0f : log2f(e));
+}
+
+// rnn_char_multi_cross_entropy's inner step (charmodel-multi-predict.c:395-403): block c
+// takes head c of the output row -- softmax over that head alone (badmaths.h:71-111), the
+// probability of the row's target symbol, capped log2 added to acc[c].
+__global__ __launch_bounds__(64) void k_multi_xent_accumulate(View v, int r, int alen, double *acc,
+                                                              int count_it) {
+  extern __shared__ float ex[];
+  const RamdShape &s = v.sh;
+  const int c = blockIdx.x;
+  const float *src = v.b.out + (size_t)r * s.O + (size_t)c * alen;
+  float lo = src[0], hi = src[0];
+  for (int i = threadIdx.x; i < alen; i += 64) {
+    hi = fmaxf(hi, src[i]);
+    lo = fminf(lo, src[i]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    lo = fminf(lo, __shfl_xor(lo, off, 64));
+  }
+  float adj = 0.0f;
+  if (hi > 50.0f) adj = 50.0f - hi;
+  else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+  for (int i = threadIdx.x; i < alen; i += 64) ex[i] = fast_expf_dev(src[i] + adj);
+  __syncthreads();
+  if (threadIdx.x != 0 || !count_it) return;
+  float sum = 0.0f;
+  for (int i = 0; i < alen; i++) sum += ex[i];
+  float e = ex[v.b.target[r]] / sum;
+  acc[c] += (double)((e < 1e-30f) ? -100.0f : log2f(e));
+}
+
+// rnnca's loss (gstrnnca.c:701-714, train_net): fast_sigmoid_array(answer, answer, n) IN
+// PLACE on the first n outputs (badmaths.h:33-44), then o_error[i] = a (1 - a) (target - a).
+// One thread per (stream, output); the rest of the error row stays as it was (zero).
+__global__ void k_sigmoid_mse_error(View v, int row0, int nrows, int n, const float *targets,
+                                    int ld) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nrows * n) return;
+  int j = q / n, i = q - j * n, r = row0 + j;
+  float *out = v.b.out + (size_t)r * v.sh.O;
+  float a = 1.0f / (1.0f + fast_expf_dev(-out[i] * 1.0f));
+  out[i] = a;
+  float slope = a * (1.0f - a);
+  v.b.o_error[(size_t)r * v.sh.O + i] = slope * (targets[(size_t)j * ld + i] - a);
+}
+
+// fill_frame's fast_sigmoid_array(answer, answer, 3) (gstrnnca.c:813-814) for state rows
+__global__ void k_sigmoid_outputs(View v, int r0, int nrows, int n) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nrows * n) return;
+  int j = q / n, i = q - j * n;
+  float *out = v.b.out + (size_t)(r0 + j) * v.sh.O;
+  out[i] = 1.0f / (1.0f + fast_expf_dev(-out[i] * 1.0f));
+}
+
+#pragma clang fp contract(fast)
+
+extern "C" int ramd_text_top_ok(const RamdShape *sh) {
+  return sh->O <= 256 && sh->H <= 3072 && !env_int("RECUR_AMD_NO_TEXT_TOP", 0);
+}
+
+extern "C" void ramd_launch_text_top(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
+                                     int row0, int nrows, int fwd_ks) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  size_t shm = (size_t)(sh->H + OUT_SEGS * 64 + 3 * sh->O) * sizeof(float);
+  RAMD_LAUNCH(k_text_top, dim3(nrows), dim3(1024), shm, st, v, row0, nrows, fwd_ks);
+}
+
+extern "C" void ramd_launch_softmax_error(ramd_stream_t st_, const RamdShape *sh,
+                                          const RamdBuffers *b, int row0, int nrows) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  RAMD_LAUNCH(k_softmax_error, dim3(nrows), dim3(64), (size_t)sh->output_size * sizeof(float), st, v,
+                     row0, nrows);
+}
+
+extern "C" void ramd_launch_xent_accumulate(ramd_stream_t st_, const RamdShape *sh,
+                                            const RamdBuffers *b, int row, int count_it) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  RAMD_LAUNCH(k_xent_accumulate, dim3(1), dim3(64), (size_t)sh->output_size * sizeof(float),
+                     st, v, row, count_it);
+}
+
+extern "C" void ramd_launch_multi_xent_accumulate(ramd_stream_t st_, const RamdShape *sh,
+                                                  const RamdBuffers *b, int row, int alphabet_len,
+                                                  int n_classes, double *acc, int count_it) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  RAMD_LAUNCH(k_multi_xent_accumulate, dim3(n_classes), dim3(64), (size_t)alphabet_len * sizeof(float), st,
+              v, row, alphabet_len, acc, count_it);
+}
+
+extern "C" void ramd_launch_sigmoid_mse_error(ramd_stream_t st_, const RamdShape *sh,
+                                              const RamdBuffers *b, int row0, int nrows, int n,
+                                              const float *targets, int ld) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  RAMD_LAUNCH(k_sigmoid_mse_error, dim3((nrows * n + 255) / 256), dim3(256), 0, st, v, row0, nrows, n,
+              targets, ld);
+}
+
+extern "C" void ramd_launch_sigmoid_outputs(ramd_stream_t st_, const RamdShape *sh,
+                                            const RamdBuffers *b, int r0, int nrows, int n) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  RAMD_LAUNCH(k_sigmoid_outputs, dim3((nrows * n + 255) / 256), dim3(256), 0, st, v, r0, nrows, n);
+}
+
+extern "C" void ramd_launch_multi_softmax_error(ramd_stream_t st_, const RamdShape *sh,
+                                                const RamdBuffers *b, int row0, int nrows,
+                                                int alphabet_len, int n_classes,
+                                                unsigned long long threshold, const int *tclass,
+                                                int *ranges, int range_stride) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  if (n_classes > MS_MAXCLS) {
+    fprintf(stderr, "librecur_amd: more than %d class heads\n", MS_MAXCLS);
+    abort();
+  }
+  RAMD_LAUNCH(k_multi_softmax_error, dim3(nrows), dim3(64 * MS_WAVES),
+                     (size_t)MS_WAVES * alphabet_len * sizeof(float), st, v, row0, alphabet_len, n_classes,
+                     threshold, tclass, ranges, range_stride);
+}
+
+extern "C" void ramd_launch_grouped_softmax_error(ramd_stream_t st_, const RamdShape *sh,
+                                                  const RamdBuffers *b, int row0, int nrows,
+                                                  int ngroups, int largest, const int *goff,
+                                                  const int *gsize, const int *gt,
+                                                  const float *weight) {
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  RAMD_LAUNCH(k_grouped_softmax_error, dim3(nrows), dim3(64), (size_t)largest * sizeof(float), st,
+                     v, row0, ngroups, goff, gsize, gt, weight);
+}

@@ -1,5 +1,5 @@
 /* ramd_internal.h -- private interface between the gnu11 C host code
- * (rnn_core.c, rnn_init.c, rnn_io.c) and the HIP kernels (kernels.hip).
+ * (rnn_core.c, rnn_init.c, rnn_io.c) and the HIP kernels (kernels_*.hip).
  *
  * The HIP side is a thin shim: every ramd_launch_* function enqueues one
  * kernel (or a fixed short sequence) on the given stream and returns.  All

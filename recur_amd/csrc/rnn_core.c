@@ -1,7 +1,7 @@
 /* rnn_core.c -- host side of the RNN core (gnu11 C).
  *
  * Implements the reference's RecurNN API (recur-nn.h:269-334; behaviour of
- * recur-nn.c and recur-nn-init.c) on top of the HIP kernels in kernels.hip.
+ * recur-nn.c and recur-nn-init.c) on top of the HIP kernels in kernels_*.hip.
  * The structs the caller sees are host memory, as the ABI demands; the device
  * holds the authoritative copy of anything that has been computed on, and this
  * file is the coherence protocol between the two plus the order of launches.
@@ -2415,7 +2415,7 @@ static void apply_learning(RecurNN *net, int learning_method, float momentum,
                            const RamdPendingDelta *pend);
 
 /* The exchange step overlapped with the weight-delta GEMM: the GEMM runs as two
- * row halves (kernels.hip: g_delta_half_hook); as soon as a half's deltas are complete its sum over the
+ * row halves (kernels_bptt.hip: g_delta_half_hook); as soon as a half's deltas are complete its sum over the
  * ranks starts on a stream of its own, so the first half's all-reduce (2.2 of the 4.6 MB at the north
  * star) travels over xGMI while the second half is still being multiplied.  The update waits for both.
  * Every rank reduces the same two ranges in the same order, so the replicas stay bit-identical. */

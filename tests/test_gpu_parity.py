@@ -1215,7 +1215,7 @@ print("RESULT", "ok" if not bad else "; ".join(bad))
 def test_a_chain_that_gives_up_on_its_first_launch_falls_back_for_that_call():
     """The one-launch chain needs its 256 workgroups resident together; where they are not (a CU-masked queue, a
     partition mode, a co-tenant) its first launch of the process raises the abort word.  The launcher then resets
-    it, stops using the kernel and runs the launch-per-step chain FOR THE SAME CALL (kernels.hip:
+    it, stops using the kernel and runs the launch-per-step chain FOR THE SAME CALL (kernels_chain.hip:
     g_chain_validated).  RECUR_AMD_CHAIN_TEST_GIVEUP=1 takes that branch on a healthy device: the run must say so
     and its results must be the oracle's."""
     import subprocess

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build container: the library's host code (gnu11 C) under AddressSanitizer + UBSan, the CPU test suite against it.
-# (GPU AddressSanitizer is not available on the pool; the kernels object is the ordinary one.)
+# (GPU AddressSanitizer is not available on the pool; the kernel objects are the ordinary ones.)
 #   tools/asan_cpu_suite.sh        -> prints the sanitizers' reports, if any, and the suite's verdict
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -11,7 +11,7 @@ for f in rnn_core dist rnn_init rnn_io rnn_dump cdb charmodel char_sampling char
       -I/opt/rocm/include -c recur_amd/csrc/$f.c -o build/asan/$f.o
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -o build/asan/librecur_amd.so build/asan/*.o \
-    build/obj/kernels.o -Wl,-rpath,/opt/rocm/lib -lm -ldl
+    build/obj/kernels_*.o -Wl,-rpath,/opt/rocm/lib -lm -ldl
 export RECUR_AMD_LIB=$root/build/asan/librecur_amd.so
 export LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 UBSAN_OPTIONS=print_stacktrace=1

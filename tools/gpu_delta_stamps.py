@@ -8,8 +8,8 @@ g = sc.AmdBatchedSet(amd, input_size=42, hidden_size=1024, output_size=42, S=256
 g.load_text(text)
 for i in range(30):
     amd.rnn_amd_set_char_step(g.handle, i, rc.WEIGHTED, 0.95)
-buf = np.zeros((2, 64, 8), np.uint64)
-amd.ramd_chain_stamps(C.c_void_p(buf.ctypes.data))
+buf = np.zeros((1, 64, 8), np.uint64)
+amd.ramd_delta_stamps(C.c_void_p(buf.ctypes.data))
 t0 = int(buf[0, 0, 4])
 us = lambda x: (int(x) - t0) / 100.0
 print("start->first barrier release: see stage 1; end of loop at %.2f us" % us(buf[0,0,6]))
