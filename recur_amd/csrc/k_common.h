@@ -263,15 +263,16 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
   static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-// the sum of ks planes in plane order, eight loads in flight at a time
+// the sum of ks planes in plane order, B loads in flight at a time
+template <int B = 8>
 __device__ __forceinline__ float4 sum_planes(const float *src, size_t stride, int ks) {
   float4 sum = zero4();
-  for (int z0 = 0; z0 < ks; z0 += 8) {
-    float4 t[8];
+  for (int z0 = 0; z0 < ks; z0 += B) {
+    float4 t[B];
 #pragma unroll
-    for (int z = 0; z < 8; z++) t[z] = ld4(src + (size_t)(z0 + z < ks ? z0 + z : z0) * stride);
+    for (int z = 0; z < B; z++) t[z] = ld4(src + (size_t)(z0 + z < ks ? z0 + z : z0) * stride);
 #pragma unroll
-    for (int z = 0; z < 8; z++)
+    for (int z = 0; z < B; z++)
       if (z0 + z < ks) { sum.x += t[z].x; sum.y += t[z].y; sum.z += t[z].z; sum.w += t[z].w; }
   }
   return sum;

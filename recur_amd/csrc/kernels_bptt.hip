@@ -627,16 +627,17 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
-  // The fragments of K group u + 1 (8 k: four MFMA steps of two k each) are read from LDS
-  // before the 16 MFMAs of group u are issued and used after them, so the LDS latency
-  // and, at a stage boundary, the barrier sit in the shadow of the matrix pipe.
-  // Round 3: the reads are inline asm with COUNTED waits.  As plain loads hipcc put an
-  // `s_waitcnt lgkmcnt(0)` behind the reads of every second group, in front of the CURRENT group's
-  // multiplies -- the read-ahead it was meant to be waited for its own reads twice per K tile -- and
-  // spent five vector-ALU instructions per group on LDS addresses.  Now: `ds_read2st64_b32` (two k
-  // rows, 128 floats apart, per instruction; immediate offsets in units of 64 floats reach every k of
-  // a stage), four address registers per STAGE, and each group waits only for what was issued before
-  // the reads of the group after it (lgkmcnt(n), n = that group's instruction count <= 13).
+  // The fragments of K group u + 1 (8 k: four MFMA steps of two k each) are read from LDS while the 16
+  // MFMAs of group u are issued, ONE READ BEHIND EACH OF THE FIRST NINE MFMAs, and used after them.
+  // This wave is the only one that feeds its SIMD's matrix pipe, and it issues in order: whatever stands
+  // between the last MFMA of a group and the first of the next beyond the ~60 cycles of that MFMA's own
+  // shadow is time the pipe idles.  Measured (round 3, ablation builds): the nine reads bunched in front of
+  // a group cost 3.8 us of a 100 us launch, the eight coefficient multiplies 4.4 us, and a run-time test
+  // that skipped the multiplies cost what they did.  So: reads spread one per MFMA shadow; inline asm
+  // (`ds_read2st64_b32`: two k rows, 128 floats apart, per instruction; immediate offsets in units of 64
+  // floats reach every k of a stage; four address registers per STAGE) because as plain loads hipcc waited
+  // for them twice per K tile; the multiplies only for a stage whose coefficients are not all exactly 1.0
+  // (out of line); the stage's rest-row bookkeeping as two counters instead of a division per stage.
   struct Frag {
     f32x2 a[2][2], e[2][2]; /* [i or jn][k pair]: k = 8 g + 4 kh + 2 pair, + 1 */
     f32x4 cf;
@@ -649,94 +650,131 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int g = 0; g < 16; g++) racc[i][j][g] = 0.0f;
-  /* per-lane byte addresses within a stage: A rows i = 0, 1; E columns jn = 0, 1; the coefficients; the rest rows */
+  /* per-lane byte addresses within a stage: A rows i = 0, 1; E columns jn = 0, 1; the coefficients (four of the
+   * group for the multiplies; the lane's one of the stage's 32 for the all-ones test); the rest rows */
   const uint32_t dsm0 = lds_byte_addr(dsm);
   const uint32_t la_lane = dsm0 + 4u * (uint32_t)(4 * kh * 128 + wm * 64 + lm);
   const uint32_t le_lane = dsm0 + 4u * (uint32_t)(BK * 128 + 4 * kh * 128 + wn * 64 + lm);
   const uint32_t lc_lane = dsm0 + 4u * (uint32_t)(2 * BK * 128 + 4 * kh);
+  const uint32_t lf_lane = dsm0 + 4u * (uint32_t)(2 * BK * 128 + (lane & 31));
   const uint32_t lr_lane = lds_byte_addr(rest_ring) + 4u * (uint32_t)(4 * kh * RR + wm * (RR / 2) + lm);
   uint32_t ad_a0 = 0, ad_a1 = 0, ad_e0 = 0, ad_e1 = 0, ad_c = 0, ad_r = 0; /* of the stage being READ */
-  auto stage_addr = [&](int st, bool rest) {
-    const uint32_t sb = (uint32_t)((st % DD_STAGES) * DD_STAGE_FLOATS * (int)sizeof(float));
+  float cfl = 0.0f; /* the lane's coefficient of that stage */
+  /* `slot`: the stage's ring buffer (st % DD_STAGES); `par`: which half of the rest ring ((st / tm) & 1) */
+  auto stage_addr = [&](int slot, bool rest, int par) {
+    const uint32_t sb = (uint32_t)(slot * DD_STAGE_FLOATS * (int)sizeof(float));
     ad_a0 = la_lane + sb;
     ad_a1 = ad_a0 + 128u;
     ad_e0 = le_lane + sb;
     ad_e1 = ad_e0 + 128u;
     ad_c = lc_lane + sb;
-    if (REST && rest) ad_r = lr_lane + (uint32_t)(rest_slot(st) * (int)sizeof(float));
+    if (REST && rest) ad_r = lr_lane + (uint32_t)((RR == 64 ? par * (BK * 64) : 0) * (int)sizeof(float));
+    cfl = lds_read_b32_off<0>(lf_lane + sb);
   };
-  /* group G of the stage whose addresses are set: 9 LDS instructions (+ 2 RI for a rest stage) */
-  auto rd = [&](auto GC, Frag &f, bool rest) {
+  /* read k (0 .. 8) of group G of the stage whose addresses are set */
+  auto rd1 = [&](auto GC, auto KC, Frag &f) {
+    constexpr int G = decltype(GC)::value, k = decltype(KC)::value;
+    if constexpr (k == 0) {
+      f.cf = lds_read_b128_off<32 * G>(ad_c);
+    } else {
+      constexpr int pair = (k - 1) >> 2, which = (k - 1) & 3;
+      constexpr int o0 = 2 * (8 * G + 2 * pair), o1 = o0 + 2;
+      if constexpr (which == 0) f.a[0][pair] = lds_read2st64<o0, o1>(ad_a0);
+      if constexpr (which == 1) f.e[0][pair] = lds_read2st64<o0, o1>(ad_e0);
+      if constexpr (which == 2) f.a[1][pair] = lds_read2st64<o0, o1>(ad_a1);
+      if constexpr (which == 3) f.e[1][pair] = lds_read2st64<o0, o1>(ad_e1);
+    }
+  };
+  /* ... and the rest rows' 2 RI reads of that group (rest stages only) */
+  auto rd_rest = [&](auto GC, Frag &f) {
     constexpr int G = decltype(GC)::value;
     constexpr int RU = RR ? RR / 64 : 1; /* k rows of the rest tile are RR floats apart: RR / 64 offset units */
-    if (REST && rest) { /* wave-uniform */
 #pragma unroll
-      for (int i = 0; i < RI; i++) {
-        f.ar[i][0] = lds_read2st64<(8 * G + 0) * RU, (8 * G + 1) * RU>(ad_r + 128u * (uint32_t)i);
-        f.ar[i][1] = lds_read2st64<(8 * G + 2) * RU, (8 * G + 3) * RU>(ad_r + 128u * (uint32_t)i);
-      }
+    for (int i = 0; i < RI; i++) {
+      f.ar[i][0] = lds_read2st64<(8 * G + 0) * RU, (8 * G + 1) * RU>(ad_r + 128u * (uint32_t)i);
+      f.ar[i][1] = lds_read2st64<(8 * G + 2) * RU, (8 * G + 3) * RU>(ad_r + 128u * (uint32_t)i);
     }
-    f.cf = lds_read_b128_off<32 * G>(ad_c);
-    f.a[0][0] = lds_read2st64<2 * (8 * G + 0), 2 * (8 * G + 1)>(ad_a0);
-    f.e[0][0] = lds_read2st64<2 * (8 * G + 0), 2 * (8 * G + 1)>(ad_e0);
-    f.a[1][0] = lds_read2st64<2 * (8 * G + 0), 2 * (8 * G + 1)>(ad_a1);
-    f.e[1][0] = lds_read2st64<2 * (8 * G + 0), 2 * (8 * G + 1)>(ad_e1);
-    f.a[0][1] = lds_read2st64<2 * (8 * G + 2), 2 * (8 * G + 3)>(ad_a0);
-    f.e[0][1] = lds_read2st64<2 * (8 * G + 2), 2 * (8 * G + 3)>(ad_e0);
-    f.a[1][1] = lds_read2st64<2 * (8 * G + 2), 2 * (8 * G + 3)>(ad_a1);
-    f.e[1][1] = lds_read2st64<2 * (8 * G + 2), 2 * (8 * G + 3)>(ad_e1);
   };
-  /* Every group waits for "at most nine LDS instructions behind my reads": the next group's nine (a
-   * rest stage issues its 2 RI extra reads FIRST, so there the wait also covers those: a few dozen
-   * cycles once per tm stages).  A count chosen at run time would put the wait into branches, and
-   * hipcc then copies the whole fragment (ten v_mov_b64) in front of the multiplies in each of them. */
-  auto mm = [&](Frag &f, bool rest) {
-    frag_wait<9>(f.cf, f.a, f.e);
-    float b[2][4];
+  /* One group: the MFMAs on `cur` (whose reads were issued during the group before: all landed), the reads
+   * of group GN into `nxt` behind the first nine of them.
+   * `ones`: every coefficient of the stage is exactly 1.0 (the usual case: no stream was soft-clipped, none
+   * broke off early) -- the error fragments go into the MFMAs as they are. */
+  /* (the flags are ints in scalar registers: as bools that live across blocks hipcc keeps them as vector
+   * masks and rebuilds each with two vector-ALU instructions per use) */
+  auto group = [&](auto GN, Frag &cur, Frag &nxt, int rest, int rest_next, int ones) {
+    frag_wait<0>(cur.cf, cur.a, cur.e);
     /* v_mul_legacy_f32: 0 * x is 0 for ANY x (a step past the break may hold inf), otherwise the
-     * IEEE product: select and multiply in one instruction of the MFMAs' own ALU.  All eight in
-     * ONE statement with early-clobber outputs: eight distinct registers that nothing rewrites
-     * while the sixteen MFMAs that read them are being issued (as separate statements hipcc
-     * recycled two registers between the MFMAs, and results went wrong). */
-    asm volatile("v_mul_legacy_f32 %0, %8, %12\n\tv_mul_legacy_f32 %1, %9, %13\n\t"
-                 "v_mul_legacy_f32 %2, %10, %14\n\tv_mul_legacy_f32 %3, %11, %15\n\t"
-                 "v_mul_legacy_f32 %4, %8, %16\n\tv_mul_legacy_f32 %5, %9, %17\n\t"
-                 "v_mul_legacy_f32 %6, %10, %18\n\tv_mul_legacy_f32 %7, %11, %19\n\ts_nop 1"
-                 : "=&v"(b[0][0]), "=&v"(b[0][1]), "=&v"(b[0][2]), "=&v"(b[0][3]), "=&v"(b[1][0]),
-                   "=&v"(b[1][1]), "=&v"(b[1][2]), "=&v"(b[1][3])
-                 : "v"(f.cf[0]), "v"(f.cf[1]), "v"(f.cf[2]), "v"(f.cf[3]), "v"(f.e[0][0][0]), "v"(f.e[0][0][1]),
-                   "v"(f.e[0][1][0]), "v"(f.e[0][1][1]), "v"(f.e[1][0][0]), "v"(f.e[1][0][1]), "v"(f.e[1][1][0]),
-                   "v"(f.e[1][1][1]));
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++)
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int jn = 0; jn < 2; jn++)
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][jj >> 1][jj & 1], b[jn][jj], acc[i][jn], 0, 0, 0);
-    if (REST && rest) { /* wave-uniform: this wave's 32 or 64 rest rows x its 64 columns (their reads are older
-                         * than the nine waited for above) */
+     * IEEE product: select and multiply in one instruction of the MFMAs' own ALU.  In place, all eight
+     * in ONE statement: as separate statements with outputs of their own hipcc recycled two registers
+     * between the MFMAs, and results went wrong.  (One MFMA sequence behind a conditional multiply, not
+     * two sequences: with the MFMAs in both arms hipcc copies accumulators at the join.) */
+    if (__builtin_expect(ones == 0, 0))
+      asm volatile("v_mul_legacy_f32 %0, %8, %0\n\tv_mul_legacy_f32 %1, %9, %1\n\t"
+                   "v_mul_legacy_f32 %2, %10, %2\n\tv_mul_legacy_f32 %3, %11, %3\n\t"
+                   "v_mul_legacy_f32 %4, %8, %4\n\tv_mul_legacy_f32 %5, %9, %5\n\t"
+                   "v_mul_legacy_f32 %6, %10, %6\n\tv_mul_legacy_f32 %7, %11, %7\n\ts_nop 1"
+                   : "+v"(cur.e[0][0][0]), "+v"(cur.e[0][0][1]), "+v"(cur.e[0][1][0]), "+v"(cur.e[0][1][1]),
+                     "+v"(cur.e[1][0][0]), "+v"(cur.e[1][0][1]), "+v"(cur.e[1][1][0]), "+v"(cur.e[1][1][1])
+                   : "v"(cur.cf[0]), "v"(cur.cf[1]), "v"(cur.cf[2]), "v"(cur.cf[3]));
+    if (REST && __builtin_expect(rest_next != 0, 0)) rd_rest(GN, nxt); /* wave-uniform */
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<16>([&](auto MC) {
+      constexpr int m = decltype(MC)::value, jj = m >> 2, i = (m >> 1) & 1, jn = m & 1;
+      acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[i][jj >> 1][jj & 1], cur.e[jn][jj >> 1][jj & 1], acc[i][jn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (m < 9) {
+        rd1(GN, std::integral_constant<int, m>{}, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+    if (REST && __builtin_expect(rest != 0, 0)) { /* wave-uniform: this wave's 32 or 64 rest rows x its 64 columns */
 #pragma unroll
       for (int jj = 0; jj < 4; jj++)
 #pragma unroll
         for (int i = 0; i < RI; i++)
 #pragma unroll
           for (int jn = 0; jn < 2; jn++)
-            racc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.ar[i][jj >> 1][jj & 1], b[jn][jj], racc[i][jn], 0, 0, 0);
+            racc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.ar[i][jj >> 1][jj & 1], cur.e[jn][jj >> 1][jj & 1], racc[i][jn], 0, 0, 0);
     }
-  };
-  /* groups 0-2 of a stage: read the next group of the same stage, multiply this one */
-  auto step = [&](auto GC, Frag &cur, Frag &nxt, bool rest) {
-    constexpr int g = decltype(GC)::value;
-    rd(std::integral_constant<int, g + 1>{}, nxt, rest);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(cur, rest);
     __builtin_amdgcn_sched_barrier(0);
   };
-  /* group 3: across the stage boundary.  After the last stage group 0 of the same stage is read once more
-   * (into the idle fragment), so that "nine instructions behind" holds for every group of the launch. */
-  auto step3 = [&](int st, Frag &cur, Frag &nxt, bool rest, bool rest_next) {
-    if (st + 1 < nst) {
+  /* (the lane's coefficient was requested before the nine reads of the stage's group 0) */
+  auto all_ones = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(cfl));
+    return __builtin_amdgcn_readfirstlane(__ballot(cfl == 1.0f) == ~0ull ? 1 : 0);
+  };
+  Frag f0, f1;
+  /* stage st carries rest work when st % tm == mt (ph), in half (st / tm) & 1 of the rest ring (par) */
+  int ph = 0, par = 0;
+#ifdef PC_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_dd_stamps[0][4] = __builtin_amdgcn_s_memrealtime();
+    g_dd_stamps[0][7] = __builtin_readcyclecounter(); /* shader clocks: with [1][7], the clock the loop ran at */
+  }
+#endif
+  if (nst > 0) {
+    __builtin_amdgcn_s_barrier(); /* stage 0 has landed */
+    asm volatile("" ::: "memory");
+    stage_addr(0, REST && mt == 0, 0);
+    if (REST && mt == 0) rd_rest(std::integral_constant<int, 0>{}, f0);
+    static_for<9>([&](auto KC) { rd1(std::integral_constant<int, 0>{}, KC, f0); });
+  }
+  int ones = all_ones();
+  for (int st = 0; st < nst; st++) {
+    const int r = __builtin_amdgcn_readfirstlane(REST && ph == mt ? 1 : 0);
+    int phn = ph + 1, parn = par;
+    if (phn == o.tm) {
+      phn = 0;
+      parn ^= 1;
+    }
+    const bool more = st + 1 < nst;
+    const int rn = __builtin_amdgcn_readfirstlane(REST && more && phn == mt ? 1 : 0);
+    group(std::integral_constant<int, 1>{}, f0, f1, r, r, ones);
+    group(std::integral_constant<int, 2>{}, f1, f0, r, r, ones);
+    group(std::integral_constant<int, 3>{}, f0, f1, r, r, ones);
+    /* group 3 runs across the stage boundary: its reads are group 0 of stage st + 1 (after the last stage
+     * group 0 of the same stage once more, into the idle fragment: every group then looks the same) */
+    if (more) {
 #ifdef PC_STAMPS
       if (blockIdx.x == 0 && threadIdx.x == 0 && st < 63) g_dd_stamps[st + 1][4] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -745,34 +783,21 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
 #ifdef PC_STAMPS
       if (blockIdx.x == 0 && threadIdx.x == 0 && st < 63) g_dd_stamps[st + 1][5] = __builtin_amdgcn_s_memrealtime();
 #endif
-      stage_addr(st + 1, rest_next);
-    } else {
-      rest_next = false;
+      stage_addr((st + 1) % DD_STAGES, rn != 0, parn);
     }
-    rd(std::integral_constant<int, 0>{}, nxt, rest_next);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(cur, rest);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  Frag f0, f1;
+    group(std::integral_constant<int, 0>{}, f1, f0, r, rn, ones);
 #ifdef PC_STAMPS
-  if (blockIdx.x == 0 && threadIdx.x == 0) g_dd_stamps[0][4] = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && st < 63) g_dd_stamps[st][3] = ones ? 1ull : 0ull;
 #endif
-  if (nst > 0) {
-    __builtin_amdgcn_s_barrier(); /* stage 0 has landed */
-    asm volatile("" ::: "memory");
-    stage_addr(0, is_rest(0));
-    rd(std::integral_constant<int, 0>{}, f0, is_rest(0));
-  }
-  for (int st = 0; st < nst; st++) {
-    const bool r = is_rest(st), rn = is_rest(st + 1);
-    step(std::integral_constant<int, 0>{}, f0, f1, r);
-    step(std::integral_constant<int, 1>{}, f1, f0, r);
-    step(std::integral_constant<int, 2>{}, f0, f1, r);
-    step3(st, f1, f0, r, rn);
+    if (more) ones = all_ones();
+    ph = phn;
+    par = parn;
   }
 #ifdef PC_STAMPS
-  if (blockIdx.x == 0 && threadIdx.x == 0) g_dd_stamps[0][6] = __builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_dd_stamps[0][6] = __builtin_amdgcn_s_memrealtime();
+    g_dd_stamps[1][7] = __builtin_readcyclecounter();
+  }
 #endif
   float *c = o.slab + (size_t)z * o.zs;
 #pragma unroll
