@@ -835,23 +835,38 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
 // and the adaptive min_error_factor, and the lanes publish coef[t][r] = ih_scale while
 // the step counts, 0 afterwards.
 /* es: the stream's error sums by step, es[k * stride] */
-__device__ __forceinline__ void bptt_control_wave(const View &v, int r, int j, int lane,
-                                                  const unsigned char *active, unsigned flags,
-                                                  const float *es_src, size_t es_stride) {
+/* what the control logic reads about its stream besides the error sums: requested by the caller before it
+ * starts the work whose results the logic waits for (one memory round trip less behind the barrier) */
+struct ControlIn {
+  float top, mef, lr;
+  double depth_total; /* stat_depth so far */
+  bool live;
+};
+__device__ __forceinline__ ControlIn bptt_control_load(const View &v, int r, int j, const unsigned char *active) {
+  ControlIn ci;
+  ci.top = v.b.top_scaled[r];
+  ci.mef = v.b.mef[r];
+  ci.lr = v.b.lr[r];
+  ci.depth_total = v.b.stat_depth[r];
+  ci.live = !active || active[j];
+  return ci;
+}
+__device__ __forceinline__ void bptt_control_wave(const View &v, int r, int j, int lane, const ControlIn &ci,
+                                                  unsigned flags, const float *es_src, size_t es_stride) {
   const RamdShape &s = v.sh;
   const int D = s.D;
-  if (active && !active[j]) {
+  if (!ci.live) {
     for (int k = lane; k < D; k += 64) v.b.coef[(size_t)k * s.Scap + r] = 0.0f;
     if (lane == 0) v.b.n_exec[r] = 0; /* no step ran: k_err_writeback leaves its images alone */
     return;
   }
-  float top = v.b.top_scaled[r];
+  float top = ci.top;
   float max_error_sum = MAX_ERROR_GAIN_F * top + 1;
   float error_sum_ceiling = ERROR_GAIN_CEILING_F * top;
   float min_error_gain = MIN_ERROR_GAIN_F * top;
-  float mef = v.b.mef[r];
+  float mef = ci.mef;
   /* MIN(a, b) of the reference is (a < b) ? a : b: keep NaN behaviour aligned */
-  float mef_rate = mef / v.b.lr[r];
+  float mef_rate = mef / ci.lr;
   float min_error_sum = (mef_rate < min_error_gain) ? mef_rate : min_error_gain;
   /* the first step whose sum leaves [min, max] ends the loop (recur-nn.c:387-389) */
   int n_exec = D;
@@ -890,7 +905,7 @@ __device__ __forceinline__ void bptt_control_wave(const View &v, int r, int j, i
     v.b.bptt_err[r] = error_sum;
     v.b.n_exec[r] = n_exec;
     v.b.depth_log[r] = D - t;
-    v.b.stat_depth[r] += (double)(D - t);
+    v.b.stat_depth[r] = ci.depth_total + (double)(D - t);
   }
   /* 0x20000000: rnn_bptt_calculate without batching leaves the UNSCALED sum in ih_delta and puts
    * ih_scale into the rate (recur-nn.c:966-975) */
@@ -905,7 +920,7 @@ __global__ __launch_bounds__(256) void k_bptt_control(View v, int row0, int nrow
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= nrows) return;
   const int r = row0 + j;
-  bptt_control_wave(v, r, j, lane, active, flags, v.b.esum + r, (size_t)v.sh.Scap);
+  bptt_control_wave(v, r, j, lane, bptt_control_load(v, r, j, active), flags, v.b.esum + r, (size_t)v.sh.Scap);
 }
 
 // k_extras_gather and k_bptt_control in one launch, one workgroup per stream: the waves
@@ -929,6 +944,8 @@ __global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, in
   float *hs_sh = es_sh + s.D;
   /* the next item's reads are requested before the current one is worked on */
   ExtrasIn<MAXQ> cur, nxt;
+  ControlIn ci = {0.0f, 0.0f, 1.0f, 0.0, true};
+  if (wave == 0) ci = bptt_control_load(v, r, j, active);
   if (wave < items) extras_load<MAXQ>(v, wave, r, nx, tn, lane, cur);
   for (int t = wave; t < items; t += THREADS / 64) {
     const int tnext = t + THREADS / 64;
@@ -956,7 +973,7 @@ __global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, in
       }
       __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the wave's own LDS writes before it reads them back */
     }
-    bptt_control_wave(v, r, j, lane, active, flags, es_sh, 1);
+    bptt_control_wave(v, r, j, lane, ci, flags, es_sh, 1);
   }
 }
 
@@ -1111,7 +1128,7 @@ __global__ __launch_bounds__(1024) void k_bptt_small(View v, int r, int accumula
 #undef LDS_BARRIER
   if (wave == 0) {
     /* the steps that did not run left zeros, which end the scan of bptt_control_wave too */
-    bptt_control_wave(v, r, 0, lane, nullptr, flags, es_sh, 1);
+    bptt_control_wave(v, r, 0, lane, bptt_control_load(v, r, 0, nullptr), flags, es_sh, 1);
     if (lane == 0) {
       red[16] = v.b.ih_scale[r]; /* lane 0 wrote it */
       red[17] = __int_as_float(v.b.n_exec[r]);
