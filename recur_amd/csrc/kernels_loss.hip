@@ -94,17 +94,50 @@ __global__ __launch_bounds__(64) void k_softmax_error(View v, int row0, int nrow
 // (k_softmax_error) and the top-layer backprop with its soft clip (k_top_backprop, dense
 // form), each exactly as in the separate kernels -- same operation order per value -- with
 // the hidden row, the outputs and the output error passed through LDS instead of HBM.
+#ifdef PC_STAMPS /* development builds only (tools/mkabl.sh -DPC_STAMPS, tools/gpu_top_stamps.py) */
+__device__ unsigned long long g_tt_stamps[8];
+extern "C" void ramd_top_stamps(unsigned long long *out) {
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tt_stamps), sizeof(unsigned long long) * 8));
+}
+#define TT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tt_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TT_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, int fwd_ks) {
   extern __shared__ float tsh[];
   __shared__ float tred[16];
+  __shared__ float tstat[4];
   const RamdShape &s = v.sh;
   const int r = row0 + blockIdx.x;
   float *shid = tsh;                   /* [H] hidden row                    */
-  float *part = shid + s.H;            /* [OUT_SEGS][64] output partial sums */
-  float *sout = part + OUT_SEGS * 64;  /* [O] outputs                        */
+  float *part = shid + s.H;            /* [OUT_SEGS][64] float4 of partial sums (16-byte aligned: h_size % 4 == 0) */
+  float *sout = part + OUT_SEGS * 64 * 4 + OUT_SEGS * s.O; /* [O] outputs (behind the waves' column sums [OUT_SEGS][O]) */
   float *sex = sout + s.O;             /* [O] exponentials                   */
   float *serr = sex + s.O;             /* [O] output error                   */
   float *hid = v.b.hidden + (size_t)r * s.H;
+  const int seg = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  TT_STAMP(0);
+  /* What does not depend on anything computed here is requested FIRST (round 3, from stamps of the 12.2 us
+   * between the first and the last instruction: the target, the pad of o_error and the statistics'
+   * read-modify-writes were three memory round trips inside the one-wave softmax): wave 0 asks for the
+   * stream's target and the o_error pad here; the statistics are added to by wave 1 behind the softmax's
+   * barrier, beside the backprop.  (The output layer's weights too would be wanted here -- 2 us behind the
+   * first barrier -- but 14 float4 per lane beside the hidden row's sums do not fit 128 registers, and a
+   * spilled prefetch waits for its data on the spot: 258 against 246 us per generation.) */
+  const bool wide = (s.O >> 2) <= 64;
+  const int OQ = s.O >> 2, RPW = wide ? min(64 / OQ, 8) : 1, rsub = lane / (wide ? OQ : 64), c4 = lane - rsub * OQ;
+  const bool rows_mine = wide && rsub < RPW;
+  const int per = (s.H + OUT_SEGS - 1) / OUT_SEGS;
+  const int y0 = seg * per, y1 = min(s.H, y0 + per);
+  constexpr int NB = 14; /* float4 in flight per lane and batch: 66 rows of a wave at 5 rows per instruction */
+  int target = 0;
+  float pad_oe = 0.0f;
+  if (seg == 0) {
+    target = v.b.target[r];
+    const int pi = lane < s.O ? lane : 0; /* (o_size > 64: the later columns are read where they are used) */
+    pad_oe = v.b.o_error[(size_t)r * s.O + pi];
+  }
   if (fwd_ks != 0) {
     // the forward GEMM's K slabs are still in the workspace: sum them, apply the
     // activation and write the hidden row here (what k_fwd_finalize does, recur-nn.c:123-148).
@@ -163,9 +196,62 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
     for (int i = threadIdx.x; i < s.H; i += 1024) shid[i] = hid[i];
   }
   __syncthreads();
-  const int seg = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  TT_STAMP(1);
   // ---- output layer (recur-nn.c:150-151)
-  {
+  if (wide) {
+    /* Rows of W_ho as float4: a wave instruction fetches RPW whole rows (11 lanes x 16 bytes each at o_size 44)
+     * instead of one float per lane of one row -- the texture path takes a wave instruction at a time, and
+     * 1056 of them per workgroup for 180 KB were 5 us of this kernel.  Lane (rsub, c4) sums rows y0 + rsub,
+     * + RPW, ... of its four columns; the RPW x 16 partial sums of a column are added in a fixed order. */
+    float4 acc = zero4();
+    for (int yb = y0; yb < y1; yb += NB * RPW) {
+      float4 wv[NB];
+#pragma unroll
+      for (int i = 0; i < NB; i++) {
+        const int y = yb + rsub + RPW * i;
+        wv[i] = ld4(v.b.ho_w + (size_t)((rows_mine && y < y1) ? y : y0) * s.O + 4 * c4);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; i++) {
+        const int y = yb + rsub + RPW * i;
+        if (rows_mine && y < y1) {
+          const float hv = shid[y];
+          acc.x += hv * wv[i].x;
+          acc.y += hv * wv[i].y;
+          acc.z += hv * wv[i].z;
+          acc.w += hv * wv[i].w;
+        }
+      }
+    }
+    *reinterpret_cast<float4 *>(part + 4 * (seg * 64 + lane)) = acc;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* one wave: its own LDS writes are ordered */
+    /* the wave's RPW partial sums of a column, rows ascending; then (behind the barrier) the sixteen waves' */
+    float *wsum = part + 4 * OUT_SEGS * 64; /* [OUT_SEGS][o_size] */
+    for (int col = lane; col < s.O; col += 64) {
+      const float *p = part + 4 * (seg * 64 + (col >> 2)) + (col & 3);
+      float t[8];
+#pragma unroll
+      for (int rs = 0; rs < 8; rs++) t[rs] = p[4 * ((rs < RPW ? rs : 0) * OQ)];
+      float sum = t[0];
+#pragma unroll
+      for (int rs = 1; rs < 8; rs++)
+        if (rs < RPW) sum += t[rs];
+      wsum[seg * s.O + col] = sum;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < s.O) {
+      const int col = threadIdx.x;
+      float t[OUT_SEGS];
+#pragma unroll
+      for (int g = 0; g < OUT_SEGS; g++) t[g] = wsum[g * s.O + col];
+      float sum = t[0];
+#pragma unroll
+      for (int g = 1; g < OUT_SEGS; g++) sum += t[g];
+      v.b.out[(size_t)r * s.O + col] = sum;
+      sout[col] = sum;
+    }
+    __syncthreads();
+  } else {
     const int per = (s.H + OUT_SEGS - 1) / OUT_SEGS;
     const int y0 = seg * per, y1 = min(s.H, y0 + per);
     float *out = v.b.out + (size_t)r * s.O;
@@ -204,6 +290,7 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
       __syncthreads();
     }
   }
+  TT_STAMP(2);
   // the backprop below needs this thread's row of W_ho: request it now (narrow output layers),
   // so that it arrives while wave 0 works out the softmax
   constexpr int TOP_PF = 12; /* float4 per row: o_size <= 48 */
@@ -238,10 +325,24 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
     for (int i = lane; i < len; i += 64) sex[i] = fast_expf_dev(sout[i] + adj);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* one wave: its LDS writes are ordered */
     float sum = 0.0f;
-    for (int i = 0; i < len; i++) sum += sex[i];
+    if (s.O <= 64) { /* the exponentials in order, four float4 reads in flight instead of a read per addition */
+      for (int i0 = 0; 4 * i0 < len; i0 += 4) {
+        float4 q[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[i] = *reinterpret_cast<const float4 *>(sex + 4 * (4 * (i0 + i) < s.O ? i0 + i : 0));
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          if (4 * (i0 + i) + 0 < len) sum += q[i].x;
+          if (4 * (i0 + i) + 1 < len) sum += q[i].y;
+          if (4 * (i0 + i) + 2 < len) sum += q[i].z;
+          if (4 * (i0 + i) + 3 < len) sum += q[i].w;
+        }
+      }
+    } else {
+      for (int i = 0; i < len; i++) sum += sex[i];
+    }
     float best_e = -1.0f;
     int best_i = 0x7fffffff;
-    const int target = v.b.target[r];
     for (int i = lane; i < s.O; i += 64) {
       float oe;
       if (i < len) {
@@ -253,7 +354,7 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
           best_i = i;
         }
       } else {
-        oe = err[i]; /* the pad of o_error stays what it was (zero) */
+        oe = i < 64 ? pad_oe : err[i]; /* the pad of o_error stays what it was (zero) */
       }
       serr[i] = oe;
     }
@@ -268,14 +369,21 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
     if (lane == 0) {
       float e = -(sex[target] / sum) + 1.0f;
       float l = 1.0f - e;
-      v.b.stat_err[r] += e;
-      v.b.stat_ent[r] += (l < 1e-30f) ? -100.0f : log2f(l);
-      v.b.stat_correct[r] += (best_i == target);
-      v.b.stat_count[r] += 1;
-      v.b.stat_zero[r] += zeros / (double)s.hidden_size;
+      tstat[0] = e;
+      tstat[1] = (l < 1e-30f) ? -100.0f : log2f(l);
+      tstat[2] = (best_i == target) ? 1.0f : 0.0f;
+      tstat[3] = (float)zeros; /* exact: h_size < 2^24 */
     }
   }
   __syncthreads();
+  if (threadIdx.x == 64) { /* (its loads return before the wave's backprop loads, which are issued behind them) */
+    v.b.stat_err[r] += tstat[0];
+    v.b.stat_ent[r] += tstat[1];
+    v.b.stat_correct[r] += (tstat[2] != 0.0f);
+    v.b.stat_count[r] += 1;
+    v.b.stat_zero[r] += (int)tstat[3] / (double)s.hidden_size;
+  }
+  TT_STAMP(3);
   // ---- top-layer backprop + soft clip (recur-nn.c:199-228, 719-721)
   float sum = 0.0f;
   float ev[3] = {0.0f, 0.0f, 0.0f}; /* h_size <= 3072 per launch condition */
@@ -309,6 +417,7 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
   if (lane == 0) tred[seg] = sum;
   __syncthreads();
+  TT_STAMP(4);
   /* the same tree as block_sum_256 within each group of four waves, then the four groups */
   float g0 = (tred[0] + tred[1]) + (tred[2] + tred[3]), g1 = (tred[4] + tred[5]) + (tred[6] + tred[7]);
   float g2 = (tred[8] + tred[9]) + (tred[10] + tred[11]), g3 = (tred[12] + tred[13]) + (tred[14] + tred[15]);
@@ -326,6 +435,7 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
     v.b.top_raw[r] = sum;
     v.b.top_scaled[r] = scaled;
   }
+  TT_STAMP(5);
 }
 
 // multi_softmax_error (charmodel-multi-predict.c:17-58) after the opinion: the output row is
@@ -593,7 +703,7 @@ extern "C" void ramd_launch_text_top(ramd_stream_t st_, const RamdShape *sh, con
                                      int row0, int nrows, int fwd_ks) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  size_t shm = (size_t)(sh->H + OUT_SEGS * 64 + 3 * sh->O) * sizeof(float);
+  size_t shm = (size_t)(sh->H + OUT_SEGS * 64 * 4 + (OUT_SEGS + 3) * sh->O) * sizeof(float);
   RAMD_LAUNCH(k_text_top, dim3(nrows), dim3(1024), shm, st, v, row0, nrows, fwd_ks);
 }
 
