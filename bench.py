@@ -462,7 +462,20 @@ def main():
             "flop_per_launch": flop_launch,
             "classes_ms_per_step": {k: v[0] / n_roof for k, v in cls.items()},
             "steps": n_roof,
+            # both MFMA-bound kernels, not only the longer one
+            "per_kernel": {
+                k: {"avg_launch_us": 1e3 * cls[k][0] / max(cls[k][1], 1),
+                    "achieved": per_gen_flops[k] / (max(cls[k][1], 1) / n_roof) / (1e3 * cls[k][0] / max(cls[k][1], 1) * 1e-6) / 1e12
+                    if cls[k][1] else 0.0}
+                for k in per_gen_flops},
+            # `peak` is the data-sheet figure at 2.4 GHz.  Measured on this part (tools/mfma_clock_microbench.hip,
+            # profiles/r03_mfma_clock_microbench.txt): a dense v_mfma_f32_32x32x2_f32 stream on all 256 CUs holds
+            # 2.12 GHz (2.40 GHz with one CU busy), i.e. 139 TFLOP/s is what a launch that keeps every matrix pipe
+            # busy can reach.
+            "peak_at_sustained_clock": PEAK_FP32_MFMA_TFLOPS * 2.12 / 2.40,
         }
+        for k, d in roofline["per_kernel"].items():
+            d["frac"] = d["achieved"] / PEAK_FP32_MFMA_TFLOPS
 
     out = {
         "metric": "BPTT timesteps*streams/sec at 1024-hidden/256-stream",
