@@ -306,5 +306,15 @@ RAMD_LOCAL const View *device_view(hipStream_t st, const View &v);
 // All D steps of the chain for streams [row0, row0 + nrows): the one-launch chain where it applies,
 // otherwise a launch per step.  Returns the number of partial sums of squares per (step, stream) it
 // left for the extras kernels (0: the extras sum the rows themselves).
+/* The top layer's weight delta (single_layer_sgd, recur-nn.c:256-301, for all streams at once: dst[h][o] =
+ * sum over streams [row0, row0 + nrows) of hidden[s][h] * o_error[s][o], streams with active[s - row0] == 0
+ * left out) as a request to whoever has idle vector ALUs before the weight deltas are needed: the one-launch
+ * chain forms it while its weight panels are on their way (chain_ho_delta) and sets `done`. */
+struct HoWork {
+  float *dst; /* [H][O], overwritten: a slab plane for the optimiser to take, or ho_delta itself */
+  const unsigned char *active;
+  int row0, nrows;
+  int done;
+};
 RAMD_LOCAL int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const RamdBuffers *b,
-                                int row0, int nrows);
+                                int row0, int nrows, HoWork *ho);

@@ -1340,7 +1340,16 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   bool ho_paired = false, ho_finalize_after = false, ho_in_final = false;
   ProbHoDelta ho_p = {};
   int ho_nkt = 0, ho_ks = 0;
-  if (!(flags & 0x80000000u)) { /* the fused single-net path updates W_ho directly */
+  /* The top layer's delta.  Where the one-launch chain will run it is handed to that launch as a request
+   * (HoWork: formed while the chain's weight panels are on their way, no launch of its own); otherwise, and
+   * when the chain declines, the GEMM below. */
+  HoWork ho_req = {};
+  /* (up to 256 streams: the request costs the chain launch 0.014 us per stream -- 3.6 us at 256 against the GEMM's
+   * 6.2 us launch -- and nothing where the set leaves workgroups of that launch without chain work: 32 streams
+   * 145.3 -> 141.0 us per generation, 64: 155.7 -> 151.2, 256: 244.8 -> 242.4) */
+  const bool ho_asked = !(flags & 0x80000000u) && !ranges && !accumulate && nrows >= 16 && nrows <= 256 && sh->O <= 48 &&
+                        env_int("RECUR_AMD_HO_IN_CHAIN", 1);
+  auto ho_classic = [&]() { /* (the fused single-net path, flag 0x80000000, updates W_ho directly) */
     int tm = (sh->H + BM - 1) / BM, tn = (sh->O + BN - 1) / BN;
     int nkt = (nrows + BK - 1) / BK;
     int ho = sh->H * sh->O;
@@ -1386,6 +1395,14 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       RAMD_LAUNCH(k_ho_delta_finalize, dim3((ho + 255) / 256), dim3(256), 0, st, v, b->slab,
                          ks, accumulate, range_stride ? nullptr : ranges);
     }
+  };
+  if (ho_asked) {
+    ho_req.dst = (defer && b->ho_slab) ? b->ho_slab : b->ho_delta;
+    ho_req.active = active;
+    ho_req.row0 = row0;
+    ho_req.nrows = nrows;
+  } else if (!(flags & 0x80000000u)) {
+    ho_classic();
   }
   // BPTT chain: D dependent steps, one launch each, then the extras of all steps
   bool control_done = false;
@@ -1416,7 +1433,17 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     }
   }
   {
-    tn_parts = ramd_chain_steps(st, v, sh, b, row0, nrows);
+    tn_parts = ramd_chain_steps(st, v, sh, b, row0, nrows, ho_asked ? &ho_req : nullptr);
+    if (ho_asked && ho_req.done) {
+      if (defer) { /* one plane for the optimiser launch to take (or ho_delta is complete already) */
+        defer->ho_slab = ho_req.dst == b->ho_slab ? b->ho_slab : nullptr;
+        defer->ho_n = (size_t)sh->H * sh->O;
+        defer->ho_ks = 1;
+        defer->ho_delta_out = b->ho_delta;
+      }
+    } else if (ho_asked) {
+      ho_classic();
+    }
     int M = sh->D * nrows;
     int etm = (M + BM - 1) / BM, etn = (nx + BN - 1) / BN, nkt = (sh->H + BK - 1) / BK;
     int ks = pick_ks(etm * etn, nkt, "RECUR_AMD_KS_EXTRAS", b->slab_floats, (size_t)M * nxp);
@@ -1523,8 +1550,9 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       /* ---- the two-halves form (see g_delta_half_hook): rows [0, tm / 2 tiles) with twice the K split
        * (the same number of workgroups and of slab bytes), summed into ih_delta, hook; then the upper
        * tiles with the rest rows riding along, the top layer's deltas, summed, hook */
-      if (g_delta_half_hook && !defer && rest_in && o.tm >= 8 && o.tm % 2 == 0 && ho_paired && ho_finalize_after &&
-          !ranges && env_int("RECUR_AMD_DIST_OVERLAP", 0)) {
+      const bool ho_direct = ho_asked && ho_req.done && ho_req.dst == b->ho_delta; /* complete since the chain launch */
+      if (g_delta_half_hook && !defer && rest_in && o.tm >= 8 && o.tm % 2 == 0 &&
+          ((ho_paired && ho_finalize_after) || ho_direct) && !ranges && env_int("RECUR_AMD_DIST_OVERLAP", 0)) {
         /* OFF by default -- measured with ONE rank (bench.py --dist, round 3): 305 against 255 us per
          * generation.  Two launches of half the rows with twice the K split cost the GEMM class +24 us
          * (each workgroup's prologue, epilogue and ring fill amortise over 20 instead of 40 K tiles, the
@@ -1566,12 +1594,13 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
           else
             RAMD_LAUNCH(k_delta_dma<128>, dim3(blocks2), dim3(512), shm_rest, st, v, row0, nrows, oh, dr);
           timing_end(st, evh);
-          launch_gemm<true, true, ProbHoDelta>(st, ho_p, b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, T_OTHER);
+          if (!ho_direct) launch_gemm<true, true, ProbHoDelta>(st, ho_p, b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, T_OTHER);
           const size_t up_floats = n - half_floats, n4u = up_floats / 4, ho_n = (size_t)sh->H * sh->O;
-          const unsigned fin_blocks = (unsigned)((n4u + 255) / 256) + (unsigned)((ho_n / 4 + 255) / 256);
+          const unsigned fin_blocks = (unsigned)((n4u + 255) / 256) + (ho_direct ? 0u : (unsigned)((ho_n / 4 + 255) / 256));
           RAMD_LAUNCH(k_delta_finalize, dim3(fin_blocks), dim3(256), 0, st, b->ih_delta + half_floats, b->slab + half_floats,
                       n4u, n, kd2, accumulate, sh->H, sh->hidden_size, rows_core - tmh * 128, kd2 * tmh, dr.planes,
-                      rest_plane, b->ho_delta, b->ho_slab, ho_n, ho_ks);
+                      rest_plane, b->ho_delta, ho_direct ? (const float *)nullptr : b->ho_slab, ho_direct ? (size_t)0 : ho_n,
+                      ho_direct ? 0 : ho_ks);
           g_delta_half_hook(g_delta_half_ctx, 1, half_floats, up_floats + ho_n);
         }
         return;

@@ -499,6 +499,64 @@ __device__ unsigned long long g_pc_stamps[2][64][8];
 #define PC_STAMP(role, k, slot) do { } while (0)
 #endif
 
+/* The top layer's weight delta in the chain launch's first microseconds (HoWork, k_common.h): 22 MFLOP that as
+ * a launch of their own (k_gemm<ProbHoDelta>) cost 6 us of launch, ramp and three dependent memory round trips
+ * on the generation's critical path.  Here every workgroup of the launch -- also those without a seat in the
+ * chain -- takes ceil(H / workgroups) rows of the delta while its weight panel / its first operand rows are in
+ * flight: thread (row, output quad, group g) sums streams g, g + NG, ... straight from global memory (eight
+ * streams' loads in flight), the NG groups are added in order through LDS (`lds`: 2048 floats, the partial-tile
+ * area, unused until the first multiply has finished).  All 512 threads call it exactly once (two barriers). */
+template <bool MASK>
+__device__ __forceinline__ float4 chain_ho_sum(const View &v, const HoWork &hw, int h, int q4, int g, int NG) {
+  const RamdShape &s = v.sh;
+  const float *hp = v.b.hidden + (size_t)hw.row0 * s.H + h;
+  const float *ep = v.b.o_error + (size_t)hw.row0 * s.O + 4 * q4;
+  float4 acc = zero4();
+  for (int s0 = g; s0 < hw.nrows; s0 += 8 * NG) {
+    float hv[8];
+    float4 e4[8];
+    unsigned char am[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { /* clamped addresses, values selected afterwards: every load of the batch in flight */
+      const int ss = s0 + i * NG, sc = ss < hw.nrows ? ss : s0;
+      hv[i] = hp[(size_t)sc * s.H];
+      e4[i] = ld4(ep + (size_t)sc * s.O);
+      am[i] = MASK ? hw.active[sc] : (unsigned char)1;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float x = (s0 + i * NG < hw.nrows && am[i] != 0) ? hv[i] : 0.0f;
+      acc.x += x * e4[i].x;
+      acc.y += x * e4[i].y;
+      acc.z += x * e4[i].z;
+      acc.w += x * e4[i].w;
+    }
+  }
+  return acc;
+}
+__device__ __forceinline__ void chain_ho_delta(const View &v, const HoWork &hw, float *lds) {
+  if (!hw.dst) return; /* (a kernel argument: the same for every thread) */
+  const RamdShape &s = v.sh;
+  const int H = s.H, O = s.O, OQ = O >> 2;
+  const int HR = (H + (int)gridDim.x - 1) / (int)gridDim.x; /* rows per workgroup */
+  const int cells = HR * OQ, NG = 512 / cells;             /* (row, quad) cells; stream groups */
+  const int tid = threadIdx.x, g = tid / cells, cell = tid - g * cells, rr = cell / OQ, q4 = cell - rr * OQ;
+  const int h = (int)blockIdx.x * HR + rr;
+  float4 acc = zero4();
+  if (g < NG && h < H) acc = hw.active ? chain_ho_sum<true>(v, hw, h, q4, g, NG) : chain_ho_sum<false>(v, hw, h, q4, g, NG);
+  if (g < NG) *reinterpret_cast<float4 *>(lds + 4 * (g * cells + cell)) = acc;
+  __syncthreads();
+  if (g == 0 && h < H) {
+    float4 sum = *reinterpret_cast<const float4 *>(lds + 4 * cell);
+    for (int k = 1; k < NG; k++) {
+      const float4 t = *reinterpret_cast<const float4 *>(lds + 4 * (k * cells + cell));
+      sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+    }
+    *reinterpret_cast<float4 *>(hw.dst + (size_t)h * O + 4 * q4) = sum;
+  }
+  __syncthreads(); /* `lds` is the chain's again */
+}
+
 /* ONE: row tiles of 16 streams, i.e. only sub-chain a exists and every other half-step is empty
  * (the workgroup multiplies, then finishes and publishes, then waits for the 32 producers of its
  * next operand): 4.5 instead of 6.4 us per step for HALF the streams per workgroup -- worse per
@@ -510,7 +568,8 @@ __device__ unsigned long long g_pc_stamps[2][64][8];
 template <int ACT, int K, bool ONE = false, bool PAD = false> /* rnn_activation; hidden size: 1024, 512 or 256 */
 __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ vp, int uniform_idx,
                                                        int row0, int nrows, int depth, unsigned seq,
-                                                       ChainSync *sy, unsigned *host_abort, int nvalid, int vlo) {
+                                                       ChainSync *sy, unsigned *host_abort, int nvalid, int vlo,
+                                                       HoWork hw) {
   extern __shared__ __attribute__((aligned(16))) float psm[];
   constexpr int BUF = PC_SUB * K;             /* one sub-chain's operand (64 KB at K = 1024) */
   constexpr int NT = K / 32;                  /* column tiles of a row tile            */
@@ -545,9 +604,12 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
       __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(host_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    return; /* (the launcher repeats the call's work another way, the top layer's delta included) */
+  }
+  if (g >= mtiles) { /* fewer row tiles than seats: no chain work here, only a share of the top layer's delta */
+    chain_ho_delta(v, hw, red);
     return;
   }
-  if (g >= mtiles) return; /* fewer row tiles than seats: nothing to do here */
   const int j = (int)(seat % NT);
   const int m0 = TR * g, n0 = 1 + 32 * j;     /* output columns start at 1 */
   const unsigned epoch0 = seq * PC_EPOCH;
@@ -593,6 +655,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
         for (int i = 0; i < 4; i++)
 #pragma unroll
           for (int h = 0; h < 2; h++) wreg[u][i][h] = wb[(size_t)16 * h * s.H + 16 * u + i];
+      chain_ho_delta(v, hw, red); /* while the panel is on its way */
       /* The panel has to have LANDED before the loop, as far as hipcc can tell: otherwise it puts the
        * `s_waitcnt vmcnt(0)` for these loads in front of the loop's first MFMA, where it waits in EVERY
        * half-step for the gate loads issued just before (inline asm, not on its scoreboard).  An empty
@@ -837,6 +900,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
 
   fetch(0, 0);
   if (halfsteps > 1 && !ONE) fetch(1, 0);
+  chain_ho_delta(v, hw, red); /* while the first operand rows are on their way */
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads(); /* barrier 0 */
   for (int k = 0; k < halfsteps; k++) {
@@ -920,7 +984,7 @@ static bool chain_persist_ok(const RamdShape *sh, const RamdBuffers *b, int nrow
 template <int ACT, int K>
 static void launch_chain_persist_k(hipStream_t st, const View *d_view, const RamdShape *sh,
                                    const RamdBuffers *b, int row0, int nrows, unsigned seq, bool one, int nvalid,
-                                   int vlo) {
+                                   int vlo, const HoWork &hw) {
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<ACT, K, false>,
@@ -933,13 +997,13 @@ static void launch_chain_persist_k(hipStream_t st, const View *d_view, const Ram
   }
   if (one && (nvalid < nrows || vlo > 0))
     RAMD_LAUNCH((k_chain_persist<ACT, K, true, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
-                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nvalid, vlo);
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nvalid, vlo, hw);
   else if (one)
     RAMD_LAUNCH((k_chain_persist<ACT, K, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
-                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0);
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw);
   else
     RAMD_LAUNCH((k_chain_persist<ACT, K, false>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
-                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0);
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw);
 }
 
 /* row tiles per launch: 8 XCDs x (32 seats / column tiles) */
@@ -954,8 +1018,11 @@ static bool chain_persist_one(const RamdShape *sh, int nrows) {
 }
 static int chain_persist_rows(const RamdShape *sh, bool one) { return chain_persist_seats(sh) * (one ? 16 : 32); }
 
+/* `ho`: a pending request for the top layer's delta rides in this launch (and is marked done when the launch stands) */
 static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdShape *sh,
-                                 const RamdBuffers *b, int row0, int nrows, bool one, int nvalid, int vlo = 0) {
+                                 const RamdBuffers *b, int row0, int nrows, bool one, int nvalid, int vlo, HoWork *ho) {
+  HoWork hw = {};
+  if (ho && !ho->done) hw = *ho;
   if (!g_chain_sync) {
     HIP_CHECK(hipMalloc(&g_chain_sync, sizeof(ChainSync)));
     HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
@@ -972,9 +1039,9 @@ static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
   int ev = timing_begin(st, T_CHAIN, 1);
 #define CHAIN_PERSIST(ACT)                                                                  \
   do {                                                                                      \
-    if (sh->hidden_size == 1024) launch_chain_persist_k<ACT, 1024>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo); \
-    else if (sh->hidden_size == 512) launch_chain_persist_k<ACT, 512>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo); \
-    else launch_chain_persist_k<ACT, 256>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo);             \
+    if (sh->hidden_size == 1024) launch_chain_persist_k<ACT, 1024>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo, hw); \
+    else if (sh->hidden_size == 512) launch_chain_persist_k<ACT, 512>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo, hw); \
+    else launch_chain_persist_k<ACT, 256>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo, hw);         \
   } while (0)
   if (sh->activation == 2) CHAIN_PERSIST(2);
   else if (sh->activation == 5) CHAIN_PERSIST(5);
@@ -996,6 +1063,7 @@ static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
     }
     g_chain_validated = true;
   }
+  if (ho && hw.dst) ho->done = 1;
   return true;
 }
 
@@ -1003,7 +1071,7 @@ static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
  * top layer's backprop and the extras): the one-launch chain where it applies, otherwise a launch per
  * step with 64 x 64 or 32 x 32 tiles.  Returns the partial sums of squares per (step, stream) it left. */
 int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const RamdBuffers *b, int row0,
-                     int nrows) {
+                     int nrows, HoWork *ho) {
   const int tn = (sh->hidden_size + CN - 1) / CN;
   int tn_parts = tn; /* one per column tile of the chain kernel used */
   int tm = (nrows + CM - 1) / CM;
@@ -1024,7 +1092,7 @@ int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const R
                         span / 16 <= chain_persist_seats(sh);
   bool windowed_done = false;
   if (windowed) {
-    windowed_done = launch_chain_persist(st, d_view, sh, b, span_base, span, true, row0 - span_base + nrows, row0 - span_base);
+    windowed_done = launch_chain_persist(st, d_view, sh, b, span_base, span, true, row0 - span_base + nrows, row0 - span_base, ho);
   }
   bool persist = windowed_done || chain_persist_ok(sh, b, chain_rows);
   if (persist && !windowed_done) { /* as many row tiles per launch as there are seats; more streams: more launches */
@@ -1042,7 +1110,7 @@ int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const R
         n = chain_persist_rows(sh, true);
         if (n > left) n = left;
       }
-      if (!launch_chain_persist(st, d_view, sh, b, row0 + r, n, one, real_left < n ? real_left : n)) {
+      if (!launch_chain_persist(st, d_view, sh, b, row0 + r, n, one, real_left < n ? real_left : n, 0, ho)) {
         persist = false; /* (only a process's first launch can fail here: r == 0, nothing done yet) */
         break;
       }

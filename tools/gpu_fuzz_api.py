@@ -419,6 +419,11 @@ for trial in range(trials):
                 print("      b_o_error reference", sr["b_o_error"])
                 print("      b_delta rows differing:", np.argwhere(np.abs(sg["b_delta"] - sr["b_delta"]).max(axis=1) > 1e-4 * np.abs(sr["b_delta"]).max()).ravel())
                 print("      input rows (hist, current slot) max:", np.abs(sr["hist"]).max(), " ih_scale", sr["ih_scale"], sg["ih_scale"])
+            if os.environ.get("FUZZ_DEBUG"):  # which streams' hidden (x) o_error are in each side's ho_delta, by least squares
+                E = np.stack([np.outer(sr["hidden"][j], sr["o_error"][j]).ravel() for j in range(S)], axis=1)
+                for name, snap in (("product", sg), ("reference", sr)):
+                    c, *_ = np.linalg.lstsq(E, snap["ho_delta"].ravel(), rcond=None)
+                    print("      ho_delta of the %s = sum_j c_j hidden_j (x) o_error_j with c =" % name, np.round(c, 3))
             for k in ("ih_delta", "ho_delta"):
                 print("      %s: product norm %.6g, reference norm %.6g, difference %.6g" % (
                     k, np.linalg.norm(sg[k]), np.linalg.norm(sr[k]), np.linalg.norm(sg[k] - sr[k])))
