@@ -502,57 +502,88 @@ __device__ unsigned long long g_pc_stamps[2][64][8];
 /* The top layer's weight delta in the chain launch's first microseconds (HoWork, k_common.h): 22 MFLOP that as
  * a launch of their own (k_gemm<ProbHoDelta>) cost 6 us of launch, ramp and three dependent memory round trips
  * on the generation's critical path.  Here every workgroup of the launch -- also those without a seat in the
- * chain -- takes ceil(H / workgroups) rows of the delta while its weight panel / its first operand rows are in
- * flight: thread (row, output quad, group g) sums streams g, g + NG, ... straight from global memory (eight
- * streams' loads in flight), the NG groups are added in order through LDS (`lds`: 2048 floats, the partial-tile
- * area, unused until the first multiply has finished).  All 512 threads call it exactly once (two barriers). */
+ * chain -- takes HR = ceil(H / workgroups) rows of the delta while its weight panel / its first operand rows are
+ * in flight.  Lane (output quad q4, group gl) of wave w sums streams g = 4 w + gl, g + 32, ... for ALL HR rows:
+ * one float4 of o_error and HR hidden values per stream (a thread per row instead had five lanes load every
+ * float4 again, and the texture path is paid by the lane: 3.6 us, now 1.x).  The four groups of a wave are
+ * added by shuffles, the eight waves in order through LDS (`lds`: 2560 floats of the partial-tile area, which is
+ * unused until the first multiply has finished).  All 512 threads call it exactly once (two barriers). */
+#ifndef HO_BATCH
+#define HO_BATCH 8 /* streams whose loads are in flight together, per thread: all of a 256-stream set's */
+#endif
+constexpr int HO_HR = 5; /* rows per workgroup at most: h_size <= 1280 with 256 workgroups */
 template <bool MASK>
-__device__ __forceinline__ float4 chain_ho_sum(const View &v, const HoWork &hw, int h, int q4, int g, int NG) {
+__device__ __forceinline__ void chain_ho_sum(const View &v, const HoWork &hw, int h0, int HR, int q4, int g,
+                                             float4 (&acc)[HO_HR]) {
   const RamdShape &s = v.sh;
-  const float *hp = v.b.hidden + (size_t)hw.row0 * s.H + h;
+  const float *hp = v.b.hidden + (size_t)hw.row0 * s.H;
   const float *ep = v.b.o_error + (size_t)hw.row0 * s.O + 4 * q4;
-  float4 acc = zero4();
-  for (int s0 = g; s0 < hw.nrows; s0 += 8 * NG) {
-    float hv[8];
-    float4 e4[8];
-    unsigned char am[8];
+  int hc[HO_HR]; /* clamped row indices: every load from a valid address, the value selected afterwards */
 #pragma unroll
-    for (int i = 0; i < 8; i++) { /* clamped addresses, values selected afterwards: every load of the batch in flight */
-      const int ss = s0 + i * NG, sc = ss < hw.nrows ? ss : s0;
-      hv[i] = hp[(size_t)sc * s.H];
+  for (int rr = 0; rr < HO_HR; rr++) hc[rr] = (rr < HR && h0 + rr < s.H) ? h0 + rr : 0;
+  for (int s0 = g; s0 < hw.nrows; s0 += HO_BATCH * 32) {
+    float hv[HO_BATCH][HO_HR];
+    float4 e4[HO_BATCH];
+    unsigned char am[HO_BATCH];
+#pragma unroll
+    for (int i = 0; i < HO_BATCH; i++) {
+      const int ss = s0 + i * 32, sc = ss < hw.nrows ? ss : s0;
       e4[i] = ld4(ep + (size_t)sc * s.O);
+#pragma unroll
+      for (int rr = 0; rr < HO_HR; rr++) hv[i][rr] = hp[(size_t)sc * s.H + hc[rr]];
       am[i] = MASK ? hw.active[sc] : (unsigned char)1;
     }
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const float x = (s0 + i * NG < hw.nrows && am[i] != 0) ? hv[i] : 0.0f;
-      acc.x += x * e4[i].x;
-      acc.y += x * e4[i].y;
-      acc.z += x * e4[i].z;
-      acc.w += x * e4[i].w;
+    for (int i = 0; i < HO_BATCH; i++) {
+      const bool keep = s0 + i * 32 < hw.nrows && am[i] != 0;
+#pragma unroll
+      for (int rr = 0; rr < HO_HR; rr++) {
+        const float x = keep ? hv[i][rr] : 0.0f;
+        acc[rr].x += x * e4[i].x;
+        acc[rr].y += x * e4[i].y;
+        acc[rr].z += x * e4[i].z;
+        acc[rr].w += x * e4[i].w;
+      }
     }
   }
-  return acc;
 }
 __device__ __forceinline__ void chain_ho_delta(const View &v, const HoWork &hw, float *lds) {
   if (!hw.dst) return; /* (a kernel argument: the same for every thread) */
   const RamdShape &s = v.sh;
-  const int H = s.H, O = s.O, OQ = O >> 2;
-  const int HR = (H + (int)gridDim.x - 1) / (int)gridDim.x; /* rows per workgroup */
-  const int cells = HR * OQ, NG = 512 / cells;             /* (row, quad) cells; stream groups */
-  const int tid = threadIdx.x, g = tid / cells, cell = tid - g * cells, rr = cell / OQ, q4 = cell - rr * OQ;
-  const int h = (int)blockIdx.x * HR + rr;
-  float4 acc = zero4();
-  if (g < NG && h < H) acc = hw.active ? chain_ho_sum<true>(v, hw, h, q4, g, NG) : chain_ho_sum<false>(v, hw, h, q4, g, NG);
-  if (g < NG) *reinterpret_cast<float4 *>(lds + 4 * (g * cells + cell)) = acc;
-  __syncthreads();
-  if (g == 0 && h < H) {
-    float4 sum = *reinterpret_cast<const float4 *>(lds + 4 * cell);
-    for (int k = 1; k < NG; k++) {
-      const float4 t = *reinterpret_cast<const float4 *>(lds + 4 * (k * cells + cell));
-      sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+  const int H = s.H, O = s.O, OQ = O >> 2; /* OQ <= 12 (launcher) */
+  const int HR = (H + (int)gridDim.x - 1) / (int)gridDim.x; /* rows per workgroup, <= HO_HR (launcher) */
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane & 15, gl = lane >> 4;
+  const int h0 = (int)blockIdx.x * HR;
+  float4 acc[HO_HR];
+#pragma unroll
+  for (int rr = 0; rr < HO_HR; rr++) acc[rr] = zero4();
+  if (h0 < H) { /* (the whole workgroup) */
+    const int q4c = q4 < OQ ? q4 : 0; /* lanes 12-15 of a group repeat quad 0 and are not stored */
+    if (hw.active) chain_ho_sum<true>(v, hw, h0, HR, q4c, 4 * wave + gl, acc);
+    else chain_ho_sum<false>(v, hw, h0, HR, q4c, 4 * wave + gl, acc);
+#pragma unroll
+    for (int rr = 0; rr < HO_HR; rr++) {
+      acc[rr].x += __shfl_xor(acc[rr].x, 16, 64); acc[rr].x += __shfl_xor(acc[rr].x, 32, 64);
+      acc[rr].y += __shfl_xor(acc[rr].y, 16, 64); acc[rr].y += __shfl_xor(acc[rr].y, 32, 64);
+      acc[rr].z += __shfl_xor(acc[rr].z, 16, 64); acc[rr].z += __shfl_xor(acc[rr].z, 32, 64);
+      acc[rr].w += __shfl_xor(acc[rr].w, 16, 64); acc[rr].w += __shfl_xor(acc[rr].w, 32, 64);
     }
-    *reinterpret_cast<float4 *>(hw.dst + (size_t)h * O + 4 * q4) = sum;
+    if (gl == 0) {
+#pragma unroll
+      for (int rr = 0; rr < HO_HR; rr++) *reinterpret_cast<float4 *>(lds + 4 * ((wave * HO_HR + rr) * 16 + q4)) = acc[rr];
+    }
+  }
+  __syncthreads();
+  if (tid < HO_HR * 16) {
+    const int rr = tid >> 4, q = tid & 15;
+    if (rr < HR && h0 + rr < H && q < OQ) {
+      float4 sum = *reinterpret_cast<const float4 *>(lds + 4 * (rr * 16 + q));
+      for (int w = 1; w < 8; w++) {
+        const float4 t = *reinterpret_cast<const float4 *>(lds + 4 * ((w * HO_HR + rr) * 16 + q));
+        sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+      }
+      *reinterpret_cast<float4 *>(hw.dst + (size_t)(h0 + rr) * O + 4 * q) = sum;
+    }
   }
   __syncthreads(); /* `lds` is the chain's again */
 }
@@ -646,6 +677,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     //     each), the first three before the finish, whose drain covers their latency.
     const int wv = __builtin_amdgcn_readfirstlane(wave8) - 4, m = lane & 15, kq = lane >> 4;
     const int col = lane & 31, rh = lane >> 5;
+    chain_ho_delta(v, hw, red); /* before the panel's loads: its own loads need the registers, and return first */
     float wreg[KB][4][2];
     {
       const float *wb = v.b.ih_w + (size_t)(n0 + m) * s.H + 1 + (K / 4) * wv + 4 * kq;
@@ -655,7 +687,6 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
         for (int i = 0; i < 4; i++)
 #pragma unroll
           for (int h = 0; h < 2; h++) wreg[u][i][h] = wb[(size_t)16 * h * s.H + 16 * u + i];
-      chain_ho_delta(v, hw, red); /* while the panel is on its way */
       /* The panel has to have LANDED before the loop, as far as hipcc can tell: otherwise it puts the
        * `s_waitcnt vmcnt(0)` for these loads in front of the loop's first MFMA, where it waits in EVERY
        * half-step for the gate loads issued just before (inline asm, not on its scoreboard).  An empty
