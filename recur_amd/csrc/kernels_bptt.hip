@@ -926,6 +926,16 @@ __global__ __launch_bounds__(256) void k_bptt_control(View v, int row0, int nrow
 // k_extras_gather and k_bptt_control in one launch, one workgroup per stream: the waves
 // share out the stream's steps, leave each step's error sum in LDS, and wave 0 then runs
 // the control logic on them (nothing else needs the sums of other streams).
+#ifdef PC_STAMPS /* development builds only (tools/mkabl.sh -DPC_STAMPS, tools/gpu_extras_stamps.py) */
+__device__ unsigned long long g_ex_stamps[8];
+extern "C" void ramd_extras_stamps(unsigned long long *out) {
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ex_stamps), sizeof(unsigned long long) * 8));
+}
+#define EX_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ex_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define EX_STAMP(i) do { } while (0)
+#endif
 template <int MAXQ, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, int nrows, int nx,
                                                             int nxp, int tn,
@@ -944,6 +954,7 @@ __global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, in
   float *hs_sh = es_sh + s.D;
   /* the next item's reads are requested before the current one is worked on */
   ExtrasIn<MAXQ> cur, nxt;
+  EX_STAMP(0);
   ControlIn ci = {0.0f, 0.0f, 1.0f, 0.0, true};
   if (wave == 0) ci = bptt_control_load(v, r, j, active);
   if (wave < items) extras_load<MAXQ>(v, wave, r, nx, tn, lane, cur);
@@ -955,7 +966,10 @@ __global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, in
       if (lane == 0) hs_sh[t] = hs;
     }
     if (t < s.D) {
+      if (t == 0) EX_STAMP(1);
       float es = extras_compute<MAXQ>(v, t, r, nx, nxp, tn, lane, cur);
+      if (t == 0) EX_STAMP(2);
+      if (t == THREADS / 64) EX_STAMP(3);
       if (lane == 0) {
         if (tn != 0) v.b.esum[(size_t)t * s.Scap + r] = es;
         es_sh[t] = es;
@@ -964,6 +978,7 @@ __global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, in
     cur = nxt;
   }
   __syncthreads();
+  EX_STAMP(4);
   if (wave == 0) {
     if (tn == 0) {
       for (int k = lane; k < s.D; k += 64) {
@@ -974,6 +989,7 @@ __global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, in
       __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the wave's own LDS writes before it reads them back */
     }
     bptt_control_wave(v, r, j, lane, ci, flags, es_sh, 1);
+    EX_STAMP(5);
   }
 }
 
