@@ -457,11 +457,22 @@ __device__ __forceinline__ f32x2 lds_read2_b32_hi(uint32_t addr) {
   return v;
 }
 
+#ifdef PC_STAMPS /* development builds only (tools/mkabl.sh -DPC_STAMPS, tools/gpu_fwd_stamps.py) */
+__device__ unsigned long long g_ff_stamps[8];
+extern "C" void ramd_fwd_stamps(unsigned long long *out) {
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ff_stamps), sizeof(unsigned long long) * 8));
+}
+#define FF_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ff_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FF_STAMP(i) do { } while (0)
+#endif
 template <int NS = 0>
 __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, int new_idx, int row0,
                                                    int nrows, int tm, int tn, int nstages_arg,
                                                    int mode, int text_i, int global_first,
                                                    int n_set) {
+  FF_STAMP(0);
   View v = *vp;
   const int nstages = NS > 0 ? NS : nstages_arg;
   __shared__ __attribute__((aligned(16))) float smem[C_STAGES * C_STAGE_FLOATS];
@@ -540,6 +551,13 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
   // weights under its four columns, and the tail columns of W in the rows of its four inputs
   int hot = -1, text_o = 0;
   float4 a4 = zero4(), wb = zero4(), ws = zero4(), wt_mine = zero4();
+  /* column tile 0 also covers what no tile does (one row in eight lanes): the hidden values from `tail` on and the
+   * one-hot input, times their W rows' tail columns -- requested with the rest, not in the epilogue (round 3: those
+   * eight workgroups' two extra round trips were the launch's last microsecond) */
+  constexpr int TAILK = 4; /* hidden values tail .. hidden_size: at most h_size - tail */
+  float xt[TAILK] = {0.f, 0.f, 0.f, 0.f};
+  float4 wtl[TAILK] = {zero4(), zero4(), zero4(), zero4()}, wth = zero4();
+  const bool tail_row = nt == 0 && (etid & 7) == 0;
   if (!loader) {
     if (mode == RAMD_IN_TEXT) { /* charmodel-predict.c:273, 295-298 */
       int len = v.b.text_len;
@@ -550,14 +568,25 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
     } else {
       hot = v.b.hot[grow];
     }
-    if (hot < 0 || hot >= s.input_size) hot = -1;
     a4 = ld4(hid0 + (size_t)er * s.H + n0 + ec4);
-    if (n0 + ec4 == 0) a4.x = 1.0f;
     wb = ld4(v.b.ih_w + n0 + ec4);
-    ws = ld4(v.b.ih_w + (size_t)(hot >= 0 ? s.hidden_size + 1 + hot : 0) * s.H + n0 + ec4);
     /* the tail columns of W in this tile's 32 input rows: one row per thread of the first half
      * wave, shared through LDS at the end */
     if (etid < CN) wt_mine = ld4(v.b.ih_w + (size_t)(n0 + etid) * s.H + tail);
+    if (tail_row) {
+#pragma unroll
+      for (int i = 0; i < TAILK; i++) {
+        const int k = tail + i <= s.hidden_size ? tail + i : tail;
+        xt[i] = hid0[(size_t)er * s.H + k];
+        wtl[i] = ld4(v.b.ih_w + (size_t)k * s.H + tail);
+      }
+    }
+  }
+  if (!loader) { /* ... and what depends on the symbol (a load behind a load) */
+    if (hot < 0 || hot >= s.input_size) hot = -1;
+    if (n0 + ec4 == 0) a4.x = 1.0f;
+    ws = ld4(v.b.ih_w + (size_t)(hot >= 0 ? s.hidden_size + 1 + hot : 0) * s.H + n0 + ec4);
+    if (tail_row) wth = ld4(v.b.ih_w + (size_t)(hot >= 0 ? s.hidden_size + 1 + hot : 0) * s.H + tail);
   }
   const uint32_t lds0 = lds_byte_addr(smem);
   const uint32_t rowoff = (uint32_t)lm * (CK * 4u);
@@ -608,7 +637,9 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
     if constexpr (NS > 0) {
       f32x4 a0[4], a1[4];
       BFrag b0, b1;
+      FF_STAMP(1);
       __builtin_amdgcn_s_barrier();
+      FF_STAMP(2);
       rd(0, a0, b0);
 #pragma unroll
       for (int st = 0; st < NS; st += 2) {
@@ -638,6 +669,7 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
     }
   }
   float *red = smem + (nstages % C_STAGES) * C_STAGE_FLOATS; /* [4][32][32] */
+  if (!loader) FF_STAMP(3);
   if (!loader) {
 #pragma unroll
     for (int g = 0; g < 16; g++) {
@@ -650,6 +682,7 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
   }
   __syncthreads();
   if (loader) return;
+  FF_STAMP(4);
   const int row = erow, c4 = ec4;
   float4 wt[4];
 #pragma unroll
@@ -698,15 +731,17 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
     if (nt == 0) {
       /* once per row: the inputs the tiles do not cover -- hidden values tail .. hidden_size and
        * the one-hot input -- times their W rows */
-      for (int k = tail; k <= s.hidden_size; k++) {
-        float x = hid0[(size_t)er * s.H + k];
-        float4 w = ld4(v.b.ih_w + (size_t)k * s.H + tail);
-        pp.x += x * w.x; pp.y += x * w.y; pp.z += x * w.z; pp.w += x * w.w;
-        slot[k] = x * scale;
+#pragma unroll
+      for (int i = 0; i < TAILK; i++) {
+        if (tail + i <= s.hidden_size) {
+          const float x = xt[i];
+          const float4 w = wtl[i];
+          pp.x += x * w.x; pp.y += x * w.y; pp.z += x * w.z; pp.w += x * w.w;
+          slot[tail + i] = x * scale;
+        }
       }
       if (hot >= 0) {
-        float4 w = ld4(v.b.ih_w + (size_t)(s.hidden_size + 1 + hot) * s.H + tail);
-        pp.x += w.x; pp.y += w.y; pp.z += w.z; pp.w += w.w;
+        pp.x += wth.x; pp.y += wth.y; pp.z += wth.z; pp.w += wth.w;
       }
     }
     float *pd = v.b.slab + (size_t)nrows * s.H + ((size_t)nt * nrows + er) * 4;
@@ -720,6 +755,7 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
     }
     for (int k = sub; k < s.input_size; k += 8) slot[s.hidden_size + 1 + k] = (k == hot) ? scale : 0.0f;
   }
+  FF_STAMP(5);
 }
 
 // ------------------------------------ one stream, small net: forward in one launch --
