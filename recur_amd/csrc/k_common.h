@@ -315,6 +315,7 @@ struct HoWork {
   const unsigned char *active;
   int row0, nrows;
   int done;
+  int workers, idle_only; /* (the launch's own: how many of its workgroups share the rows; only those without other work) */
 };
 RAMD_LOCAL int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const RamdBuffers *b,
                                 int row0, int nrows, HoWork *ho);

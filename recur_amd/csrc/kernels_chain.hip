@@ -511,8 +511,9 @@ __device__ unsigned long long g_pc_stamps[2][64][8];
 #ifndef HO_BATCH
 #define HO_BATCH 8 /* streams whose loads are in flight together, per thread: all of a 256-stream set's */
 #endif
-constexpr int HO_HR = 5; /* rows per workgroup at most: h_size <= 1280 with 256 workgroups */
-template <bool MASK>
+/* HO_HR: rows per workgroup at most (5: h_size <= 1280 over 256 workgroups; 9: h_size <= 1152 over the 128 or more
+ * that have no chain work when the set is small) */
+template <bool MASK, int HO_HR, int BATCH>
 __device__ __forceinline__ void chain_ho_sum(const View &v, const HoWork &hw, int h0, int HR, int q4, int g,
                                              float4 (&acc)[HO_HR]) {
   const RamdShape &s = v.sh;
@@ -521,12 +522,12 @@ __device__ __forceinline__ void chain_ho_sum(const View &v, const HoWork &hw, in
   int hc[HO_HR]; /* clamped row indices: every load from a valid address, the value selected afterwards */
 #pragma unroll
   for (int rr = 0; rr < HO_HR; rr++) hc[rr] = (rr < HR && h0 + rr < s.H) ? h0 + rr : 0;
-  for (int s0 = g; s0 < hw.nrows; s0 += HO_BATCH * 32) {
-    float hv[HO_BATCH][HO_HR];
-    float4 e4[HO_BATCH];
-    unsigned char am[HO_BATCH];
+  for (int s0 = g; s0 < hw.nrows; s0 += BATCH * 32) {
+    float hv[BATCH][HO_HR];
+    float4 e4[BATCH];
+    unsigned char am[BATCH];
 #pragma unroll
-    for (int i = 0; i < HO_BATCH; i++) {
+    for (int i = 0; i < BATCH; i++) {
       const int ss = s0 + i * 32, sc = ss < hw.nrows ? ss : s0;
       e4[i] = ld4(ep + (size_t)sc * s.O);
 #pragma unroll
@@ -534,7 +535,7 @@ __device__ __forceinline__ void chain_ho_sum(const View &v, const HoWork &hw, in
       am[i] = MASK ? hw.active[sc] : (unsigned char)1;
     }
 #pragma unroll
-    for (int i = 0; i < HO_BATCH; i++) {
+    for (int i = 0; i < BATCH; i++) {
       const bool keep = s0 + i * 32 < hw.nrows && am[i] != 0;
 #pragma unroll
       for (int rr = 0; rr < HO_HR; rr++) {
@@ -547,20 +548,21 @@ __device__ __forceinline__ void chain_ho_sum(const View &v, const HoWork &hw, in
     }
   }
 }
-__device__ __forceinline__ void chain_ho_delta(const View &v, const HoWork &hw, float *lds) {
-  if (!hw.dst) return; /* (a kernel argument: the same for every thread) */
+/* `rank`: this workgroup's number among the hw.workers that share the rows */
+template <int HO_HR, int BATCH>
+__device__ __forceinline__ void chain_ho_delta(const View &v, const HoWork &hw, float *lds, int rank) {
   const RamdShape &s = v.sh;
   const int H = s.H, O = s.O, OQ = O >> 2; /* OQ <= 12 (launcher) */
-  const int HR = (H + (int)gridDim.x - 1) / (int)gridDim.x; /* rows per workgroup, <= HO_HR (launcher) */
+  const int HR = (H + hw.workers - 1) / hw.workers; /* rows per workgroup, <= HO_HR (launcher) */
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane & 15, gl = lane >> 4;
-  const int h0 = (int)blockIdx.x * HR;
+  const int h0 = rank * HR;
   float4 acc[HO_HR];
 #pragma unroll
   for (int rr = 0; rr < HO_HR; rr++) acc[rr] = zero4();
   if (h0 < H) { /* (the whole workgroup) */
     const int q4c = q4 < OQ ? q4 : 0; /* lanes 12-15 of a group repeat quad 0 and are not stored */
-    if (hw.active) chain_ho_sum<true>(v, hw, h0, HR, q4c, 4 * wave + gl, acc);
-    else chain_ho_sum<false>(v, hw, h0, HR, q4c, 4 * wave + gl, acc);
+    if (hw.active) chain_ho_sum<true, HO_HR, BATCH>(v, hw, h0, HR, q4c, 4 * wave + gl, acc);
+    else chain_ho_sum<false, HO_HR, BATCH>(v, hw, h0, HR, q4c, 4 * wave + gl, acc);
 #pragma unroll
     for (int rr = 0; rr < HO_HR; rr++) {
       acc[rr].x += __shfl_xor(acc[rr].x, 16, 64); acc[rr].x += __shfl_xor(acc[rr].x, 32, 64);
@@ -638,9 +640,21 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     return; /* (the launcher repeats the call's work another way, the top layer's delta included) */
   }
   if (g >= mtiles) { /* fewer row tiles than seats: no chain work here, only a share of the top layer's delta */
-    chain_ho_delta(v, hw, red);
+    if (hw.dst && hw.idle_only) {
+      /* a small set: the workgroups without chain work share the rows among themselves (the others start their
+       * chain at once).  Rank among them from (XCD, seat): XCD x' has its row-tile slots r0(x') .. SP - 1 idle. */
+      constexpr int SP = 32 / NT; /* row-tile slots of an XCD */
+      const int x = (int)wg_info[0];
+      auto r0 = [&](int xx) { const int r = (mtiles - xx + 7) / 8; return r < 0 ? 0 : r > SP ? SP : r; };
+      int rank = (int)seat - r0(x) * NT;
+      for (int xx = 0; xx < x; xx++) rank += (SP - r0(xx)) * NT;
+      chain_ho_delta<9, 4>(v, hw, psm, rank);
+    } else if (hw.dst) {
+      chain_ho_delta<5, HO_BATCH>(v, hw, red, (int)blockIdx.x);
+    }
     return;
   }
+  const bool ho_here = hw.dst && !hw.idle_only; /* (kernel arguments: the same for every thread) */
   const int j = (int)(seat % NT);
   const int m0 = TR * g, n0 = 1 + 32 * j;     /* output columns start at 1 */
   const unsigned epoch0 = seq * PC_EPOCH;
@@ -677,7 +691,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     //     each), the first three before the finish, whose drain covers their latency.
     const int wv = __builtin_amdgcn_readfirstlane(wave8) - 4, m = lane & 15, kq = lane >> 4;
     const int col = lane & 31, rh = lane >> 5;
-    chain_ho_delta(v, hw, red); /* before the panel's loads: its own loads need the registers, and return first */
+    if (ho_here) chain_ho_delta<5, HO_BATCH>(v, hw, red, (int)blockIdx.x); /* before the panel's loads: its own loads need the registers, and return first */
     float wreg[KB][4][2];
     {
       const float *wb = v.b.ih_w + (size_t)(n0 + m) * s.H + 1 + (K / 4) * wv + 4 * kq;
@@ -931,7 +945,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
 
   fetch(0, 0);
   if (halfsteps > 1 && !ONE) fetch(1, 0);
-  chain_ho_delta(v, hw, red); /* while the first operand rows are on their way */
+  if (ho_here) chain_ho_delta<5, HO_BATCH>(v, hw, red, (int)blockIdx.x); /* while the first operand rows are on their way */
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads(); /* barrier 0 */
   for (int k = 0; k < halfsteps; k++) {
@@ -1053,7 +1067,13 @@ static int chain_persist_rows(const RamdShape *sh, bool one) { return chain_pers
 static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdShape *sh,
                                  const RamdBuffers *b, int row0, int nrows, bool one, int nvalid, int vlo, HoWork *ho) {
   HoWork hw = {};
-  if (ho && !ho->done) hw = *ho;
+  if (ho && !ho->done) {
+    hw = *ho;
+    /* the launch's workgroups without chain work, if they are at least half of it, else all 256 */
+    const int busy = (nrows / (one ? 16 : 32)) * (sh->hidden_size / 32);
+    hw.idle_only = 256 - busy >= 128;
+    hw.workers = hw.idle_only ? 256 - busy : 256;
+  }
   if (!g_chain_sync) {
     HIP_CHECK(hipMalloc(&g_chain_sync, sizeof(ChainSync)));
     HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
