@@ -501,13 +501,16 @@ __device__ unsigned long long g_pc_stamps[2][64][8];
 
 /* The top layer's weight delta in the chain launch's first microseconds (HoWork, k_common.h): 22 MFLOP that as
  * a launch of their own (k_gemm<ProbHoDelta>) cost 6 us of launch, ramp and three dependent memory round trips
- * on the generation's critical path.  Here every workgroup of the launch -- also those without a seat in the
- * chain -- takes HR = ceil(H / workgroups) rows of the delta while its weight panel / its first operand rows are
- * in flight.  Lane (output quad q4, group gl) of wave w sums streams g = 4 w + gl, g + 32, ... for ALL HR rows:
- * one float4 of o_error and HR hidden values per stream (a thread per row instead had five lanes load every
- * float4 again, and the texture path is paid by the lane: 3.6 us, now 1.x).  The four groups of a wave are
- * added by shuffles, the eight waves in order through LDS (`lds`: 2560 floats of the partial-tile area, which is
- * unused until the first multiply has finished).  All 512 threads call it exactly once (two barriers). */
+ * on the generation's critical path.  Here the launch's workgroups share the rows of the delta, HR =
+ * ceil(H / workers) each: all 256 of them before they request their weight panel / while their first operand
+ * rows are in flight, or -- when at least half of the launch has no chain work, a small set -- only those
+ * (hw.idle_only; the others start their chain at once).  Lane (output quad q4, group gl) of wave w sums
+ * streams g = 4 w + gl, g + 32, ... for ALL HR rows: one float4 of o_error and HR hidden values per stream (a
+ * thread per row instead had five lanes load every float4 again, and the texture path is paid by the lane:
+ * 3.6 us, now 2.5).  The four groups of a wave are added by shuffles, the eight waves in order through LDS
+ * (`lds`: 8 x HO_HR x 64 floats the caller does not need yet: the partial-tile area, which is unused until the
+ * first multiply has finished, or the operand buffers of a workgroup without chain work).  A workgroup's 512
+ * threads all call it, once (two barriers). */
 #ifndef HO_BATCH
 #define HO_BATCH 8 /* streams whose loads are in flight together, per thread: all of a 256-stream set's */
 #endif
