@@ -511,6 +511,9 @@ __device__ unsigned long long g_pc_stamps[2][64][8];
  * (`lds`: 8 x HO_HR x 64 floats the caller does not need yet: the partial-tile area, which is unused until the
  * first multiply has finished, or the operand buffers of a workgroup without chain work).  A workgroup's 512
  * threads all call it, once (two barriers). */
+#ifndef PC_ONE_SHARED_FETCH
+#define PC_ONE_SHARED_FETCH 1
+#endif
 #ifndef HO_BATCH
 #define HO_BATCH 8 /* streams whose loads are in flight together, per thread: all of a 256-stream set's */
 #endif
@@ -728,6 +731,18 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
       }
     }
     const float *ehi_sub = v.b.ehi + (size_t)(row0 + m0) * s.I; /* plane 0, sub-chain a, row 0 */
+    /* ONE: in the half-step that multiplies nothing this wave fetches the second half of its row group's
+     * pieces of the next operand itself (rows 4 wv + 2, + 3 at K = 1024), the fetching wave the first half:
+     * sixteen LDS-DMA instructions per wave took 0.4 us to issue, on the critical path of every step */
+    unsigned hvoff[ONE ? 2 * PPR : 1];
+    if constexpr (ONE) {
+#pragma unroll
+      for (int i = 0; i < 2 * PPR; i++) {
+        const int ii = 2 * PPR + i, r = 4 * wv + ii / PPR;
+        const int c = (64 * (ii % PPR) + lane) ^ r;
+        hvoff[i] = (unsigned)(((size_t)r * s.I + 1 + 4 * c) * sizeof(float));
+      }
+    }
     // LDS addresses.  A fragment of K block u: chunk ((K / 16) wv + 4 u + kq) ^ m of row m; the
     // xor only touches the low four bits, i.e. (4 (u & 3) + kq) ^ m: four per-lane addresses per
     // sub-chain, the rest of u is an immediate offset.
@@ -740,6 +755,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     const uint32_t red_rd = lds_byte_addr(red) + 4u * (uint32_t)((4 * wv + rh) * 32 + col);
     float xg0 = 0.f, xg1 = 0.f;
     f32x4 af[4];
+    bool mdead = false; /* somebody gave up: no more polling, only the barriers */
     __syncthreads(); /* barrier 0: both operands of the first two half-steps have landed */
 
     // one half-step; XC: which sub-chain it MULTIPLIES (it finishes the other one's previous half-step)
@@ -805,6 +821,32 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
       }
       if (k == halfsteps) return false; /* nothing left to multiply (nobody polls the last flag) */
       if (!multiplies) {                /* ONE: sub-chain b does not exist, an empty half-step */
+        if constexpr (ONE) {
+          if (k >= 1 && k + 1 < halfsteps && PC_ONE_SHARED_FETCH) {
+            /* the flags of this wave's row group (the same ones its fetching wave polls), then its pieces */
+            const unsigned want = epoch0 + (unsigned)((k - 1) >> 1) + 1u;
+            const char *fbase = uniform_ptr(&sy->flags[g][0][wv][0]);
+            const unsigned poff = (unsigned)((lane % NT) * sizeof(unsigned));
+            for (unsigned spins = 0; !mdead; spins++) { /* (the fetching waves raise the alarm; this wave only heeds it) */
+              unsigned got;
+              asm volatile("global_load_dword %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(got) : "v"(poff), "s"(fbase) : "memory");
+              if (__all(got >= want)) break;
+              if ((spins & 1023u) == 1023u) {
+                const unsigned ab = __hip_atomic_load((gu32 *)&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__any(ab != 0u) || spins > (1u << 21)) mdead = true;
+              }
+              __builtin_amdgcn_s_sleep(PC_SLEEP1);
+            }
+            const char *base = uniform_ptr(ehi_sub + (size_t)((k + 1) >> 1) * plane_stride);
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr(abuf + 4 * wv * K));
+#pragma unroll
+            for (int i = 0; i < 2 * PPR; i++) {
+              const int ii = 2 * PPR + i;
+              lds_dma16_sc1(base, hvoff[i], dst + (uint32_t)(((ii / PPR) * K + 256 * (ii % PPR)) * sizeof(float)));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+        }
         __syncthreads();
         return true;
       }
@@ -889,13 +931,14 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   /* (Round 3, measured and removed: every workgroup of a row tile starting its fetch at another row and
    * piece, so that the NT CUs do not all ask the L2 for the same line at the same moment: 102.2 against
    * 100.8 us per chain, and the sixteen instructions still took 1.1-1.25 us to issue beside the burst.) */
-  auto fetch = [&](int x, int plane) {
+  auto fetch = [&](int x, int plane, bool first_half_only = false) {
     const char *base = reinterpret_cast<const char *>(sub_base + (size_t)plane * plane_stride +
                                                       (size_t)x * PC_SUB * s.I);
     const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr(abuf + x * BUF + 4 * lw * K));
 #pragma unroll
     for (int i = 0; i < 4 * PPR; i++)
-      lds_dma16_sc1(base, voff[i], dst + (uint32_t)(((i / PPR) * K + 256 * (i % PPR)) * sizeof(float)));
+      if (i < 2 * PPR || !first_half_only) /* (ONE: the multiplying wave of the row group fetches the other half) */
+        lds_dma16_sc1(base, voff[i], dst + (uint32_t)(((i / PPR) * K + 256 * (i % PPR)) * sizeof(float)));
   };
   // wait until all NT column tiles have published step t of sub-chain x (rows of this wave).
   // Beside a wave that issues f32 MFMAs back to back this wave gets NO vector-ALU instruction through
@@ -961,7 +1004,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
 #if PC_FETCH_PRIO
       __builtin_amdgcn_s_setprio(3);
 #endif
-      if (!dead) fetch((k + 1) & 1, (k + 1) >> 1);
+      if (!dead) fetch((k + 1) & 1, (k + 1) >> 1, ONE && PC_ONE_SHARED_FETCH);
 #if PC_FETCH_PRIO
       __builtin_amdgcn_s_setprio(0);
 #endif
