@@ -187,6 +187,20 @@ __device__ __forceinline__ f32x2 lds_read2_b32_w64_hi(uint32_t addr) {
   return v;
 }
 
+// Loads through pointers that hipcc cannot prove global (the View read from device memory instead of coming as a
+// kernel argument): as generic pointers they become FLAT loads, which count on vmcnt AND lgkmcnt and may return out of
+// order with other memory instructions -- every wait behind one is a wait for everything.  Say that they are global.
+template <class T> __device__ __forceinline__ const __attribute__((address_space(1))) T *as_global(const T *p) {
+  return (const __attribute__((address_space(1))) T *)p;
+}
+template <class T> __device__ __forceinline__ __attribute__((address_space(1))) T *as_global(T *p) {
+  return (__attribute__((address_space(1))) T *)p;
+}
+__device__ __forceinline__ float4 ld4g(const void *p) {
+  const f32x4 q = *(const __attribute__((address_space(1))) f32x4 *)p;
+  return make_float4(q.x, q.y, q.z, q.w);
+}
+
 // one LDS-DMA piece (64 lanes x 16 bytes, L1 bypassed) with a wave-uniform global base, a
 // per-lane byte offset and a wave-uniform LDS destination: no vector-ALU instruction at all
 // (the builtin form computes a 64-bit per-lane address first)
@@ -317,5 +331,18 @@ struct HoWork {
   int done;
   int workers, idle_only; /* (the launch's own: how many of its workgroups share the rows; only those without other work) */
 };
+/* The extras of every step (column 0 and the input columns of each step's error) and the per-stream control
+ * logic (k_extras_control's work, k_extras.h) as a request of the same kind: the one-launch chain runs them in
+ * its tail, each workgroup for the stream(s) of its row tile that its column tile number names, from error
+ * planes that are still in its XCD's L2 -- no launch and no second pass over HBM.  `done` is set when the
+ * launch stands. */
+struct XcWork {
+  int on;
+  int row0;   /* first row of the CALL (the launch may start lower: windowed) -- `active` is indexed from it */
+  int nx, nxp;
+  const unsigned char *active;
+  unsigned flags;
+  int done;
+};
 RAMD_LOCAL int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const RamdBuffers *b,
-                                int row0, int nrows, HoWork *ho);
+                                int row0, int nrows, HoWork *ho, XcWork *xc);

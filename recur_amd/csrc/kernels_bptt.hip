@@ -283,141 +283,8 @@ __global__ void k_ho_delta_finalize(View v, const float *slab, int ks, int accum
   v.b.ho_delta[e] = acc;
 }
 
-// Chain "extras" without a GEMM: for every (step, stream) the error of the bias
-// row (column 0) and of the real-input rows, i.e. e = W_ih[y][:] . E_h[t][s][:] for
-// the rows y whose input value is non-zero -- the reference's zero-row skip
-// (recur-nn.c:338-341) is what makes this cheap: a one-hot text stream has two
-// such rows per step, a dense audio frame a few dozen.  One wave per (step,
-// stream): the error row sits in registers (5 float4 per lane at h_size 1028),
-// the wave walks the non-zero columns (ballot), each dot product is reduced with
-// xor shuffles in a fixed order.  It also closes the step's sum of squares:
-// the column-tile partials of k_chain_main in index order, then the extras.
-// what one (step, stream) item reads before anything depends on anything: its error row,
-// this lane's input value of the first 64 extra columns, this lane's column-tile partial
-template <int MAXQ> struct ExtrasIn {
-  float4 ev[MAXQ];
-  float xi, pv;
-};
-template <int MAXQ> /* float4 per lane: 5 covers h_size <= 1280, 8 h_size <= 2048, 9 h_size <= 2304 */
-__device__ __forceinline__ void extras_load(const View &v, int t, int r, int nx, int tn, int lane,
-                                            ExtrasIn<MAXQ> &in) {
-  const RamdShape &s = v.sh;
-  const float *erow = v.b.ehi + (t * s.Scap + r) * s.I;
-  const float *x = input_row_auto(v, r, t);
-  const int nq = (s.H / 4 + 63) / 64;
-  /* Every load is UNCONDITIONAL from a clamped (always valid) address, the select comes after: as
-   * `cond ? load : 0` hipcc branched around each load and waited for it at the join, so that the five loads of a
-   * row (and the ten of the two weight rows below) went out one L2 round trip after another -- most of this
-   * kernel's time until round 3. */
-  const int last4 = s.H / 4 - 1;
-#pragma unroll
-  for (int i = 0; i < MAXQ; i++) {
-    const int k4 = lane + 64 * i;
-    const float4 e = ld4(erow + 4 * min(k4, last4));
-    in.ev[i] = (i < nq && k4 <= last4) ? e : zero4();
-  }
-  {
-    const float xv = x[(lane == 0 || lane >= nx) ? 0 : s.hidden_size + lane];
-    in.xi = (lane < nx) ? xv : 0.0f;
-    const float pv = v.b.esum_part[((size_t)t * (tn + 1) + (lane < tn ? lane : 0)) * s.Scap + r];
-    in.pv = (lane < tn) ? pv : 0.0f;
-  }
-}
-/* sum of squares of the error row an item holds (column 0 and the padding are zero): the same in every lane */
-template <int MAXQ> __device__ __forceinline__ float row_sumsq(const ExtrasIn<MAXQ> &in) {
-  float a = 0.0f;
-#pragma unroll
-  for (int i = 0; i < MAXQ; i++)
-    a += (in.ev[i].x * in.ev[i].x + in.ev[i].y * in.ev[i].y) + (in.ev[i].z * in.ev[i].z + in.ev[i].w * in.ev[i].w);
-  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
-  return a;
-}
-/* the same for row r of error plane `plane`, fetched here */
-__device__ __forceinline__ float row_sumsq_load(const View &v, int plane, int r, int lane) {
-  const RamdShape &s = v.sh;
-  const float *erow = v.b.ehi + ((size_t)plane * s.Scap + r) * s.I;
-  float a = 0.0f;
-  for (int k4 = lane; 4 * k4 < s.H; k4 += 64) {
-    const float4 e = ld4(erow + 4 * k4);
-    a += (e.x * e.x + e.y * e.y) + (e.z * e.z + e.w * e.w);
-  }
-  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
-  return a;
-}
-template <int MAXQ>
-__device__ __forceinline__ float extras_compute(const View &v, int t, int r, int nx, int nxp, int tn,
-                                                int lane, const ExtrasIn<MAXQ> &in) {
-  const RamdShape &s = v.sh;
-  const float *x = input_row_auto(v, r, t);
-  float *dst = v.b.ex + ((size_t)(t + 1) * s.Scap + r) * nxp;
-  const int nq = (s.H / 4 + 63) / 64;
-  float sq = 0.0f;
-  for (int c0 = 0; c0 < nx; c0 += 64) {
-    int c = c0 + lane;
-    int n = (c == 0) ? 0 : s.hidden_size + c;
-    float xi = (c0 == 0) ? in.xi : ((c < nx) ? x[n] : 0.0f);
-    bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
-    if (c < nx) dst[c] = 0.0f;
-    unsigned long long live = __ballot(on);
-    /* two live columns per round, so that both weight rows are in flight together (a
-     * one-hot text stream has exactly two: the bias row and the symbol's row) */
-    while (live) {
-      int la = __ffsll((long long)live) - 1;
-      live &= live - 1;
-      int lb = live ? __ffsll((long long)live) - 1 : -1;
-      if (lb >= 0) live &= live - 1;
-      int ca = c0 + la, cb = c0 + (lb >= 0 ? lb : la);
-      int na = (ca == 0) ? 0 : s.hidden_size + ca;
-      int nb = (cb == 0) ? 0 : s.hidden_size + cb;
-      float xa = __shfl(xi, la, 64), xb = __shfl(xi, lb >= 0 ? lb : la, 64);
-      const float *wa = v.b.ih_w + na * s.H;
-      const float *wb = v.b.ih_w + nb * s.H;
-      float4 wva[MAXQ], wvb[MAXQ];
-      const int last4 = s.H / 4 - 1;
-#pragma unroll
-      for (int i = 0; i < MAXQ; i++) { /* unconditional, clamped: all ten in flight together (see extras_load) */
-        const int k4 = lane + 64 * i, k4c = min(k4, last4);
-        const float4 ta = ld4(wa + 4 * k4c), tb = ld4(wb + 4 * k4c);
-        const bool inb = i < nq && k4 <= last4;
-        wva[i] = inb ? ta : zero4();
-        wvb[i] = inb ? tb : zero4();
-      }
-      float acca = 0.0f, accb = 0.0f;
-#pragma unroll
-      for (int i = 0; i < MAXQ; i++) {
-        acca += in.ev[i].x * wva[i].x + in.ev[i].y * wva[i].y + in.ev[i].z * wva[i].z + in.ev[i].w * wva[i].w;
-        accb += in.ev[i].x * wvb[i].x + in.ev[i].y * wvb[i].y + in.ev[i].z * wvb[i].z + in.ev[i].w * wvb[i].w;
-      }
-      for (int off = 32; off > 0; off >>= 1) {
-        acca += __shfl_xor(acca, off, 64);
-        accb += __shfl_xor(accb, off, 64);
-      }
-      if (s.activation == 2) {
-        acca /= 2 * (xa + 1.0f);
-        accb /= 2 * (xb + 1.0f);
-      }
-      if (lane == 0) {
-        dst[ca] = acca;
-        if (lb >= 0) dst[cb] = accb;
-      }
-      sq += acca * acca; /* identical in every lane */
-      if (lb >= 0) sq += accb * accb;
-    }
-  }
-  // the step's total: the column-tile partials of k_chain_main in index order (each lane
-  // fetches one, every lane adds them in order), then the extras.  tn == 0 (the one-launch
-  // chain leaves no partials): the caller adds the hidden columns' part (row_sumsq of the
-  // step's OUTPUT row, error plane t + 1) itself.
-  float sum = 0.0f;
-  for (int p0 = 0; p0 < tn; p0 += 64) {
-    int p = p0 + lane;
-    float pv = (p0 == 0) ? in.pv
-                         : ((p < tn) ? v.b.esum_part[((size_t)t * (tn + 1) + p) * s.Scap + r] : 0.0f);
-    int cnt = min(64, tn - p0);
-    for (int i = 0; i < cnt; i++) sum += __shfl(pv, i, 64);
-  }
-  return sum + sq; /* the same in every lane */
-}
+#include "k_extras.h"
+
 
 template <int MAXQ>
 __global__ __launch_bounds__(256) void k_extras_gather(View v, int row0, int nrows, int nx, int nxp,
@@ -827,91 +694,6 @@ __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, 
   }
 }
 
-// ----------------------------------------------------- K9: BPTT control --
-
-// The data-dependent part of bptt_and_accumulate_error (recur-nn.c:317-330,
-// 383-413), one wave per stream: lane k holds the error sum of step k, a ballot finds
-// the step at which the reference's loop would have stopped, lane 0 derives ih_scale
-// and the adaptive min_error_factor, and the lanes publish coef[t][r] = ih_scale while
-// the step counts, 0 afterwards.
-/* es: the stream's error sums by step, es[k * stride] */
-/* what the control logic reads about its stream besides the error sums: requested by the caller before it
- * starts the work whose results the logic waits for (one memory round trip less behind the barrier) */
-struct ControlIn {
-  float top, mef, lr;
-  double depth_total; /* stat_depth so far */
-  bool live;
-};
-__device__ __forceinline__ ControlIn bptt_control_load(const View &v, int r, int j, const unsigned char *active) {
-  ControlIn ci;
-  ci.top = v.b.top_scaled[r];
-  ci.mef = v.b.mef[r];
-  ci.lr = v.b.lr[r];
-  ci.depth_total = v.b.stat_depth[r];
-  ci.live = !active || active[j];
-  return ci;
-}
-__device__ __forceinline__ void bptt_control_wave(const View &v, int r, int j, int lane, const ControlIn &ci,
-                                                  unsigned flags, const float *es_src, size_t es_stride) {
-  const RamdShape &s = v.sh;
-  const int D = s.D;
-  if (!ci.live) {
-    for (int k = lane; k < D; k += 64) v.b.coef[(size_t)k * s.Scap + r] = 0.0f;
-    if (lane == 0) v.b.n_exec[r] = 0; /* no step ran: k_err_writeback leaves its images alone */
-    return;
-  }
-  float top = ci.top;
-  float max_error_sum = MAX_ERROR_GAIN_F * top + 1;
-  float error_sum_ceiling = ERROR_GAIN_CEILING_F * top;
-  float min_error_gain = MIN_ERROR_GAIN_F * top;
-  float mef = ci.mef;
-  /* MIN(a, b) of the reference is (a < b) ? a : b: keep NaN behaviour aligned */
-  float mef_rate = mef / ci.lr;
-  float min_error_sum = (mef_rate < min_error_gain) ? mef_rate : min_error_gain;
-  /* the first step whose sum leaves [min, max] ends the loop (recur-nn.c:387-389) */
-  int n_exec = D;
-  float error_sum = 0.0f;
-  for (int k0 = 0; k0 < D; k0 += 64) {
-    int k = k0 + lane;
-    float es = (k < D) ? es_src[(size_t)k * es_stride] : 0.0f;
-    bool stop = k < D && (es <= min_error_sum || es > max_error_sum);
-    unsigned long long hit = __ballot(stop);
-    int last = hit ? __ffsll((long long)hit) - 1 : min(63, D - 1 - k0);
-    error_sum = __shfl(es, last, 64);
-    if (hit) {
-      n_exec = k0 + last + 1;
-      break;
-    }
-  }
-  /* the reference's t counts down from D and is not decremented on a break */
-  bool broke = n_exec < D || (error_sum <= min_error_sum || error_sum > max_error_sum);
-  int t = broke ? D - n_exec + 1 : 0;
-  float scale;
-  if (error_sum > error_sum_ceiling) {
-    scale = soft_clip_dev(error_sum, max_error_sum);
-  } else {
-    scale = 1.0f;
-    if (flags & 64u) { /* RNN_NET_FLAG_BPTT_ADAPTIVE_MIN_ERROR */
-      int depth_error = D / 4 - t;
-      if (mef < MAX_MIN_ERROR_FACTOR_F && (min_error_gain != min_error_sum || depth_error < 0)) {
-        mef *= (float)(1.0f + depth_error * 1e-3);
-      }
-      mef = (mef >= ABS_MIN_ERROR_FACTOR_F) ? mef : ABS_MIN_ERROR_FACTOR_F;
-    }
-  }
-  if (lane == 0) {
-    v.b.mef[r] = mef;
-    v.b.ih_scale[r] = scale;
-    v.b.bptt_err[r] = error_sum;
-    v.b.n_exec[r] = n_exec;
-    v.b.depth_log[r] = D - t;
-    v.b.stat_depth[r] = ci.depth_total + (double)(D - t);
-  }
-  /* 0x20000000: rnn_bptt_calculate without batching leaves the UNSCALED sum in ih_delta and puts
-   * ih_scale into the rate (recur-nn.c:966-975) */
-  const float cf = (flags & 0x20000000u) ? 1.0f : scale;
-  for (int k = lane; k < D; k += 64) v.b.coef[(size_t)k * s.Scap + r] = (k < n_exec) ? cf : 0.0f;
-}
 
 __global__ __launch_bounds__(256) void k_bptt_control(View v, int row0, int nrows,
                                                       const unsigned char *active, unsigned flags,
@@ -925,72 +707,16 @@ __global__ __launch_bounds__(256) void k_bptt_control(View v, int row0, int nrow
 
 // k_extras_gather and k_bptt_control in one launch, one workgroup per stream: the waves
 // share out the stream's steps, leave each step's error sum in LDS, and wave 0 then runs
-// the control logic on them (nothing else needs the sums of other streams).
-#ifdef PC_STAMPS /* development builds only (tools/mkabl.sh -DPC_STAMPS, tools/gpu_extras_stamps.py) */
-__device__ unsigned long long g_ex_stamps[8];
-extern "C" void ramd_extras_stamps(unsigned long long *out) {
-  HIP_CHECK(hipDeviceSynchronize());
-  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ex_stamps), sizeof(unsigned long long) * 8));
-}
-#define EX_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ex_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define EX_STAMP(i) do { } while (0)
-#endif
+// the control logic on them (nothing else needs the sums of other streams).  The body is
+// extras_control_stream (k_extras.h), which the one-launch chain also runs in its tail.
 template <int MAXQ, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, int nrows, int nx,
                                                             int nxp, int tn,
                                                             const unsigned char *active,
                                                             unsigned flags) {
   extern __shared__ float es_sh[]; /* [D] the steps' totals; tn == 0: then [D + 1] the rows' own sums of squares */
-  const RamdShape &s = v.sh;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int j = blockIdx.x, r = row0 + j;
-  /* tn == 0 (after the one-launch chain, which leaves no per-tile partial sums): the hidden columns'
-   * part of step t's sum of squares (recur-nn.c:371) is the sum over the step's OUTPUT row, error
-   * plane t + 1 -- the row that the item of step t + 1 holds in registers for its dot products.  So
-   * every item also sums its own row, one more item (t = D) does only that, and the totals are put
-   * together after the barrier. */
-  const int items = tn == 0 ? s.D + 1 : s.D;
-  float *hs_sh = es_sh + s.D;
-  /* the next item's reads are requested before the current one is worked on */
-  ExtrasIn<MAXQ> cur, nxt;
-  EX_STAMP(0);
-  ControlIn ci = {0.0f, 0.0f, 1.0f, 0.0, true};
-  if (wave == 0) ci = bptt_control_load(v, r, j, active);
-  if (wave < items) extras_load<MAXQ>(v, wave, r, nx, tn, lane, cur);
-  for (int t = wave; t < items; t += THREADS / 64) {
-    const int tnext = t + THREADS / 64;
-    if (tnext < items) extras_load<MAXQ>(v, tnext, r, nx, tn, lane, nxt);
-    if (tn == 0) {
-      const float hs = row_sumsq<MAXQ>(cur);
-      if (lane == 0) hs_sh[t] = hs;
-    }
-    if (t < s.D) {
-      if (t == 0) EX_STAMP(1);
-      float es = extras_compute<MAXQ>(v, t, r, nx, nxp, tn, lane, cur);
-      if (t == 0) EX_STAMP(2);
-      if (t == THREADS / 64) EX_STAMP(3);
-      if (lane == 0) {
-        if (tn != 0) v.b.esum[(size_t)t * s.Scap + r] = es;
-        es_sh[t] = es;
-      }
-    }
-    cur = nxt;
-  }
-  __syncthreads();
-  EX_STAMP(4);
-  if (wave == 0) {
-    if (tn == 0) {
-      for (int k = lane; k < s.D; k += 64) {
-        const float es = hs_sh[k + 1] + es_sh[k];
-        es_sh[k] = es;
-        v.b.esum[(size_t)k * s.Scap + r] = es;
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the wave's own LDS writes before it reads them back */
-    }
-    bptt_control_wave(v, r, j, lane, ci, flags, es_sh, 1);
-    EX_STAMP(5);
-  }
+  const int j = blockIdx.x;
+  extras_control_stream<MAXQ, THREADS>(v, row0 + j, j, nx, nxp, tn, active, flags, es_sh);
 }
 
 // ------------------------------------------ one stream, small net: one launch --
@@ -1449,7 +1175,20 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     }
   }
   {
-    tn_parts = ramd_chain_steps(st, v, sh, b, row0, nrows, ho_asked ? &ho_req : nullptr);
+    /* the extras and the control logic ride in the one-launch chain's tail where they are the gather form
+     * (XcWork, k_common.h); where the chain declines, the launch below */
+    const bool extras_gather = sh->H <= 2304 && !env_int("RECUR_AMD_EXTRAS_GEMM", 0) && !(b->dense_inputs && nx > 8);
+    XcWork xc_req = {};
+    if (extras_gather && nx <= 64 && !env_int("RECUR_AMD_EXTRAS_SPLIT", 0) && env_int("RECUR_AMD_XC_IN_CHAIN", 1) &&
+        (size_t)(sh->D + 1) * sh->Scap * sh->I * sizeof(float) < ((size_t)1 << 31)) { /* (32-bit byte offsets into the planes) */
+      xc_req.on = 1;
+      xc_req.row0 = row0;
+      xc_req.nx = nx;
+      xc_req.nxp = nxp;
+      xc_req.active = active;
+      xc_req.flags = flags;
+    }
+    tn_parts = ramd_chain_steps(st, v, sh, b, row0, nrows, ho_asked ? &ho_req : nullptr, xc_req.on ? &xc_req : nullptr);
     if (ho_asked && ho_req.done) {
       if (defer) { /* one plane for the optimiser launch to take (or ho_delta is complete already) */
         defer->ho_slab = ho_req.dst == b->ho_slab ? b->ho_slab : nullptr;
@@ -1465,7 +1204,9 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int ks = pick_ks(etm * etn, nkt, "RECUR_AMD_KS_EXTRAS", b->slab_floats, (size_t)M * nxp);
     /* the gather over the non-zero input rows (one-hot symbols: two rows per step and stream) or,
      * for dense inputs with more than a handful of columns, the GEMM over all of them */
-    if (sh->H <= 2304 && !env_int("RECUR_AMD_EXTRAS_GEMM", 0) && !(b->dense_inputs && nx > 8)) {
+    if (xc_req.done) {
+      control_done = true; /* extras and control: done in the chain launch */
+    } else if (extras_gather) {
       const int nq = (sh->H / 4 + 63) / 64;
       if (env_int("RECUR_AMD_EXTRAS_SPLIT", 0)) {
         if (nq <= 5)

@@ -1,6 +1,11 @@
 // kernels_chain.hip -- the BPTT chain E_i = E_h . W_ih^T over the D steps (recur-nn.c:338-376): a launch per step
 // (k_chain_main, k_chain_wide) or all steps in one launch (k_chain_persist), and their launch logic.
 #include "k_common.h"
+#ifdef PC_STAMPS /* development builds only: stamps of the chain's tail (tools/gpu_chain_stamps.py) */
+__device__ unsigned long long g_xc_stamps[16];
+#define XC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == ((i) == 10 ? 256 : 0)) g_xc_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
+#include "k_extras.h"
 
 // ------------------------------------------------------ BPTT chain step --
 //
@@ -608,7 +613,7 @@ template <int ACT, int K, bool ONE = false, bool PAD = false> /* rnn_activation;
 __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ vp, int uniform_idx,
                                                        int row0, int nrows, int depth, unsigned seq,
                                                        ChainSync *sy, unsigned *host_abort, int nvalid, int vlo,
-                                                       HoWork hw) {
+                                                       HoWork hw, XcWork xc) {
   extern __shared__ __attribute__((aligned(16))) float psm[];
   constexpr int BUF = PC_SUB * K;             /* one sub-chain's operand (64 KB at K = 1024) */
   constexpr int NT = K / 32;                  /* column tiles of a row tile            */
@@ -617,6 +622,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   float *abuf = psm;                          /* [2][16][K], swizzled chunks           */
   float *red = psm + 2 * BUF;                 /* [2][4 waves][16 rows][32 cols]        */
   unsigned *wg_info = reinterpret_cast<unsigned *>(red + 2 * PC_RED_FLOATS);
+  XC_STAMP(0);
   View v = *vp;
   v.b.uniform_idx = uniform_idx;
   const RamdShape &s = v.sh;
@@ -667,6 +673,10 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   const int halfsteps = 2 * depth;
   const int tn = NT;
   const size_t plane_stride = (size_t)s.Scap * s.I;
+  /* the tail's first stream (row tile's stream j): what it can ask for now (extras_tail_prefetch) */
+  const bool xc_first = xc.on && j < TR && !(PAD && (m0 + j < vlo || m0 + j >= nvalid));
+  TailPre tpre;
+  if (xc_first) tpre = extras_tail_prefetch<512>(v, row0 + m0 + j, row0 + m0 + j - xc.row0, xc.nx, xc.active);
 
   if (wave8 >= 4) {
     // ============================================ multiply, finish, publish
@@ -902,9 +912,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
       if (!half(std::integral_constant<int, 0>{}, k)) break;
       if (!half(std::integral_constant<int, 1>{}, k + 1)) break;
     }
-    return;
-  }
-
+  } else {
   // ======================================================= poll and fetch
   // Waves 0-3: rows 4 lw .. 4 lw + 3 of each sub-chain's operand.  Almost no vector-ALU
   // work (one compare per poll), so the multiplying waves keep the ALU.
@@ -1014,6 +1022,53 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     PC_STAMP(1, k, 4);
     __syncthreads(); /* barrier k + 1 */
   }
+  }
+
+  // ================================================ tail: the extras and the control logic
+  // (XcWork, k_common.h.)  Stream i of the row tile belongs to column tile i % NT: at hidden 1024 with
+  // 32-stream tiles every workgroup has exactly one.  A stream's rows of ALL error planes must have been
+  // published by all NT column tiles: the flags of its row group at the last step (earlier ones were
+  // raised before it, in program order behind a drained store queue) -- and only the item of the last
+  // plane has to wait for them: every earlier plane was seen complete by this workgroup's own fetching
+  // waves before a barrier that all its waves have passed.  The rows are read past the L1 (sc1 loads) from
+  // this XCD's L2, where the row tile's planes were written.
+  if (!xc.on) return;
+  XC_STAMP(1);
+  XC_STAMP(10);
+  /* (the sums' scratch is the operand area: nobody reads it behind the loop's last barrier, while the
+   * multiplying waves' last finish still reads `red` -- no barrier in front of the tail) */
+  for (int i = j; i < TR; i += NT) {
+    const int sr = m0 + i; /* row within the launch */
+    if (PAD && (sr < vlo || sr >= nvalid)) continue; /* (kernel arguments and the seat: uniform over the workgroup) */
+    const int x = i / PC_SUB, rg = (i % PC_SUB) >> 2;
+    auto wait_last = [&]() {
+      const unsigned want = epoch0 + (unsigned)depth;
+      const char *fbase = uniform_ptr(&sy->flags[g][x][rg][0]);
+      const unsigned poff = (unsigned)((lane % NT) * sizeof(unsigned));
+      for (unsigned spins = 0;; spins++) {
+        unsigned got;
+        asm volatile("global_load_dword %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(got) : "v"(poff), "s"(fbase) : "memory");
+        if (__all(got >= want)) break;
+        if ((spins & 1023u) == 1023u) {
+          const unsigned ab = __hip_atomic_load((gu32 *)&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__any(ab != 0u) || spins > (1u << 21)) { /* (the launch's results are discarded: see dsync) */
+            if (lane == 0) {
+              __hip_atomic_store((gu32 *)&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(PC_SLEEP1);
+      }
+      XC_STAMP(2);
+    };
+    constexpr int XQ = (K / 4 + 1 + 63) / 64; /* float4 per lane of an error row (h_size = K + 4) */
+    const int r = row0 + sr;
+    extras_control_tail<XQ, 512>(v, r, r - xc.row0, xc.nx, xc.nxp, xc.active, xc.flags, abuf, (i == j && xc_first) ? &tpre : nullptr, wait_last);
+    XC_STAMP(9);
+    __syncthreads();
+  }
 }
 
 /* the device copy of the View for the kernels that take it by pointer, rewritten only when
@@ -1051,6 +1106,10 @@ extern "C" void ramd_chain_stamps(unsigned long long *out) {
   HIP_CHECK(hipDeviceSynchronize());
   HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pc_stamps), sizeof(unsigned long long) * 2 * 64 * 8));
 }
+extern "C" void ramd_chain_tail_stamps(unsigned long long *out) {
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xc_stamps), sizeof(unsigned long long) * 16));
+}
 #endif
 
 extern "C" unsigned ramd_chain_abort_word(void) {
@@ -1075,7 +1134,7 @@ static bool chain_persist_ok(const RamdShape *sh, const RamdBuffers *b, int nrow
 template <int ACT, int K>
 static void launch_chain_persist_k(hipStream_t st, const View *d_view, const RamdShape *sh,
                                    const RamdBuffers *b, int row0, int nrows, unsigned seq, bool one, int nvalid,
-                                   int vlo, const HoWork &hw) {
+                                   int vlo, const HoWork &hw, const XcWork &xc) {
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<ACT, K, false>,
@@ -1088,13 +1147,13 @@ static void launch_chain_persist_k(hipStream_t st, const View *d_view, const Ram
   }
   if (one && (nvalid < nrows || vlo > 0))
     RAMD_LAUNCH((k_chain_persist<ACT, K, true, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
-                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nvalid, vlo, hw);
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nvalid, vlo, hw, xc);
   else if (one)
     RAMD_LAUNCH((k_chain_persist<ACT, K, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
-                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw);
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw, xc);
   else
     RAMD_LAUNCH((k_chain_persist<ACT, K, false>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
-                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw);
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw, xc);
 }
 
 /* row tiles per launch: 8 XCDs x (32 seats / column tiles) */
@@ -1111,8 +1170,14 @@ static int chain_persist_rows(const RamdShape *sh, bool one) { return chain_pers
 
 /* `ho`: a pending request for the top layer's delta rides in this launch (and is marked done when the launch stands) */
 static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdShape *sh,
-                                 const RamdBuffers *b, int row0, int nrows, bool one, int nvalid, int vlo, HoWork *ho) {
+                                 const RamdBuffers *b, int row0, int nrows, bool one, int nvalid, int vlo, HoWork *ho,
+                                 XcWork *xcp) {
   HoWork hw = {};
+  /* (not in a process's first launch, which is checked and may be discarded: the control logic updates
+   * per-stream state -- min_error_factor, the depth statistics -- that a repeat would update twice) */
+  XcWork xc = {};
+  if (xcp && g_chain_validated) xc = *xcp;
+  if (xcp && !xc.on) xcp->on = 0; /* (the caller then runs the extras as a launch of their own) */
   if (ho && !ho->done) {
     hw = *ho;
     /* the launch's workgroups without chain work, if they are at least half of it, else all 256 */
@@ -1136,9 +1201,9 @@ static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
   int ev = timing_begin(st, T_CHAIN, 1);
 #define CHAIN_PERSIST(ACT)                                                                  \
   do {                                                                                      \
-    if (sh->hidden_size == 1024) launch_chain_persist_k<ACT, 1024>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo, hw); \
-    else if (sh->hidden_size == 512) launch_chain_persist_k<ACT, 512>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo, hw); \
-    else launch_chain_persist_k<ACT, 256>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo, hw);         \
+    if (sh->hidden_size == 1024) launch_chain_persist_k<ACT, 1024>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo, hw, xc); \
+    else if (sh->hidden_size == 512) launch_chain_persist_k<ACT, 512>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo, hw, xc); \
+    else launch_chain_persist_k<ACT, 256>(st, d_view, sh, b, row0, nrows, seq, one, nvalid, vlo, hw, xc);         \
   } while (0)
   if (sh->activation == 2) CHAIN_PERSIST(2);
   else if (sh->activation == 5) CHAIN_PERSIST(5);
@@ -1168,7 +1233,7 @@ static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
  * top layer's backprop and the extras): the one-launch chain where it applies, otherwise a launch per
  * step with 64 x 64 or 32 x 32 tiles.  Returns the partial sums of squares per (step, stream) it left. */
 int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const RamdBuffers *b, int row0,
-                     int nrows, HoWork *ho) {
+                     int nrows, HoWork *ho, XcWork *xc) {
   const int tn = (sh->hidden_size + CN - 1) / CN;
   int tn_parts = tn; /* one per column tile of the chain kernel used */
   int tm = (nrows + CM - 1) / CM;
@@ -1189,7 +1254,7 @@ int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const R
                         span / 16 <= chain_persist_seats(sh);
   bool windowed_done = false;
   if (windowed) {
-    windowed_done = launch_chain_persist(st, d_view, sh, b, span_base, span, true, row0 - span_base + nrows, row0 - span_base, ho);
+    windowed_done = launch_chain_persist(st, d_view, sh, b, span_base, span, true, row0 - span_base + nrows, row0 - span_base, ho, xc);
   }
   bool persist = windowed_done || chain_persist_ok(sh, b, chain_rows);
   if (persist && !windowed_done) { /* as many row tiles per launch as there are seats; more streams: more launches */
@@ -1207,7 +1272,7 @@ int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const R
         n = chain_persist_rows(sh, true);
         if (n > left) n = left;
       }
-      if (!launch_chain_persist(st, d_view, sh, b, row0 + r, n, one, real_left < n ? real_left : n, 0, ho)) {
+      if (!launch_chain_persist(st, d_view, sh, b, row0 + r, n, one, real_left < n ? real_left : n, 0, ho, xc)) {
         persist = false; /* (only a process's first launch can fail here: r == 0, nothing done yet) */
         break;
       }
@@ -1215,6 +1280,7 @@ int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const R
     }
   }
   if (persist) tn_parts = 0; /* the one-launch chain leaves no partial sums: the extras sum the rows themselves */
+  if (persist && xc && xc->on) xc->done = 1; /* every launch of the chain carried its rows' extras and control */
   /* big sets of a wide net: 64 x 64 tiles (k_chain_wide), one partial sum per 64 columns */
   const int wide_ns = sh->hidden_size / WK;
   const bool wide = !persist && b->uniform_idx >= 0 && nrows % WM == 0 && sh->hidden_size % WN == 0 &&
