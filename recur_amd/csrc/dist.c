@@ -136,6 +136,7 @@ int rnn_amd_dist_init(int rank, int world, const void *id) {
     return -1;
   }
   ramd_require_device("rnn_amd_dist_init");
+  ramd_note_side_stream(); /* RCCL's own queues and kernels run beside the library's from here on */
   if (bind_rccl()) {
     return -1;
   }

@@ -1,0 +1,101 @@
+// k_top.h -- the text model's loss on one stream as a device function: what k_text_top (kernels_loss.hip) and the
+// fused forward + top launch (k_fwd_fused<.., TOP>, kernels_forward.hip) share.
+#pragma once
+#include "k_common.h"
+
+// badmaths.h:14-29, kept operation for operation
+__device__ __forceinline__ float fast_expf_dev(float x) {
+#pragma clang fp contract(off)
+  int count = 0;
+  while (fabsf(x) > 0.2) {
+    x *= 0.125;
+    count++;
+  }
+  float a = ((x + 3) * (x + 3) + 3) / ((x - 3) * (x - 3) + 3);
+  while (count) {
+    a *= a;
+    a *= a;
+    a *= a;
+    count--;
+  }
+  return a;
+}
+
+// The softmax loss of one stream (charmodel-predict.c:18-27, badmaths.h:71-141) by ONE wave: sout[o_size] the
+// outputs (LDS), shid[h_size] the hidden row (LDS; its zeros are counted for the statistics), target the
+// stream's next symbol, pad_oe this lane's current o_error value (for the pad columns, which stay what they
+// were).  Leaves the exponentials in sex, the error row in serr (LDS) and in `err` (global), and in tstat[0..3]
+// the error on the target, its log2 likelihood, "best guess == target" and the zero count.
+__device__ __forceinline__ void text_softmax_wave(const RamdShape &s, int lane, const float *shid, const float *sout,
+                                                  float *sex, float *serr, float *err, int target, float pad_oe,
+                                                  float *tstat) {
+#pragma clang fp contract(off)
+  const int len = s.output_size;
+  int zeros = 0;
+  for (int i = lane; i < s.H; i += 64) zeros += (shid[i] == 0.0f);
+  for (int off = 32; off > 0; off >>= 1) zeros += __shfl_down(zeros, off, 64);
+  float lo = sout[0], hi = sout[0];
+  for (int i = lane; i < len; i += 64) {
+    hi = fmaxf(hi, sout[i]);
+    lo = fminf(lo, sout[i]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    lo = fminf(lo, __shfl_xor(lo, off, 64));
+  }
+  float adj = 0.0f;
+  if (hi > 50.0f) adj = 50.0f - hi;
+  else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+  for (int i = lane; i < len; i += 64) sex[i] = fast_expf_dev(sout[i] + adj);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* one wave: its LDS writes are ordered */
+  float sum = 0.0f;
+  if (s.O <= 64) { /* the exponentials in order, four float4 reads in flight instead of a read per addition */
+    for (int i0 = 0; 4 * i0 < len; i0 += 4) {
+      float4 q[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) q[i] = *reinterpret_cast<const float4 *>(sex + 4 * (4 * (i0 + i) < s.O ? i0 + i : 0));
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (4 * (i0 + i) + 0 < len) sum += q[i].x;
+        if (4 * (i0 + i) + 1 < len) sum += q[i].y;
+        if (4 * (i0 + i) + 2 < len) sum += q[i].z;
+        if (4 * (i0 + i) + 3 < len) sum += q[i].w;
+      }
+    }
+  } else {
+    for (int i = 0; i < len; i++) sum += sex[i];
+  }
+  float best_e = -1.0f;
+  int best_i = 0x7fffffff;
+  for (int i = lane; i < s.O; i += 64) {
+    float oe;
+    if (i < len) {
+      float e = sex[i] / sum;
+      oe = (i == target) ? -e + 1.0f : -e;
+      err[i] = oe;
+      if (e > best_e) {
+        best_e = e;
+        best_i = i;
+      }
+    } else {
+      oe = i < 64 ? pad_oe : err[i]; /* the pad of o_error stays what it was (zero) */
+    }
+    serr[i] = oe;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    float oe = __shfl_xor(best_e, off, 64);
+    int oi = __shfl_xor(best_i, off, 64);
+    if (oe > best_e || (oe == best_e && oi < best_i)) {
+      best_e = oe;
+      best_i = oi;
+    }
+  }
+  if (lane == 0) {
+    float e = -(sex[target] / sum) + 1.0f;
+    float l = 1.0f - e;
+    tstat[0] = e;
+    tstat[1] = (l < 1e-30f) ? -100.0f : log2f(l);
+    tstat[2] = (best_i == target) ? 1.0f : 0.0f;
+    tstat[3] = (float)zeros; /* exact: h_size < 2^24 */
+  }
+}

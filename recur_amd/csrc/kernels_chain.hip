@@ -613,7 +613,7 @@ template <int ACT, int K, bool ONE = false, bool PAD = false> /* rnn_activation;
 __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ vp, int uniform_idx,
                                                        int row0, int nrows, int depth, unsigned seq,
                                                        ChainSync *sy, unsigned *host_abort, int nvalid, int vlo,
-                                                       HoWork hw, XcWork xc) {
+                                                       HoWork hw, XcWork xc, int static_map, unsigned tseq) {
   extern __shared__ __attribute__((aligned(16))) float psm[];
   constexpr int BUF = PC_SUB * K;             /* one sub-chain's operand (64 KB at K = 1024) */
   constexpr int NT = K / 32;                  /* column tiles of a row tile            */
@@ -630,20 +630,32 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   constexpr int TR = ONE ? PC_SUB : 2 * PC_SUB; /* streams of a row tile */
   const int mtiles = nrows / TR;
 
-  // --- which XCD am I on, and which of its 32 seats do I get
-  if (threadIdx.x == 0) {
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; /* HW_REG_XCC_ID */
-    const unsigned t = __hip_atomic_fetch_add(&sy->tickets[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                       (seq - 1u) * 32u;
-    wg_info[0] = xcc;
-    wg_info[1] = t;
+  // --- which XCD am I on, and which of its 32 seats do I get.  static_map (the process's residency probe found the
+  // launch's workgroups dealt to the XCDs in turn, workgroup i on XCD i % 8: chain_validate): XCD and seat follow
+  // from the workgroup number, no ticket, no barrier -- each wave checks its XCD against the register, and a
+  // mismatch gives the launch up (never silently wrong).  Otherwise: a ticket on the XCD the workgroup finds itself on.
+  unsigned seat, my_xcc;
+  if (static_map) {
+    my_xcc = blockIdx.x & 7u;
+    seat = blockIdx.x >> 3;
+    const unsigned real = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; /* HW_REG_XCC_ID */
+    if (real != my_xcc) seat = 32u;
+  } else {
+    if (threadIdx.x == 0) {
+      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; /* HW_REG_XCC_ID */
+      const unsigned t = __hip_atomic_fetch_add(&sy->tickets[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                         (tseq - 1u) * 32u; /* (tseq: this launch's number among those that draw tickets) */
+      wg_info[0] = xcc;
+      wg_info[1] = t;
+    }
+    __syncthreads();
+    /* (wave-uniform by construction: say so, or every address built from them goes through the vector ALU) */
+    seat = __builtin_amdgcn_readfirstlane(wg_info[1]);
+    my_xcc = __builtin_amdgcn_readfirstlane(wg_info[0]);
   }
-  __syncthreads();
-  /* (wave-uniform by construction: say so, or every address built from them goes through the vector ALU) */
-  const unsigned seat = __builtin_amdgcn_readfirstlane(wg_info[1]);
   /* row tile = XCD + 8 x (seat / column tiles): the first 8 row tiles spread over the 8 XCDs
    * before any XCD takes a second one; column tile = seat % column tiles */
-  const int g = __builtin_amdgcn_readfirstlane((int)wg_info[0]) + 8 * (int)(seat / NT);
+  const int g = (int)my_xcc + 8 * (int)(seat / NT);
   if (seat >= 32u) { /* cannot happen with one workgroup per CU on a 256-CU part */
     if (threadIdx.x == 0) {
       __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -656,7 +668,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
       /* a small set: the workgroups without chain work share the rows among themselves (the others start their
        * chain at once).  Rank among them from (XCD, seat): XCD x' has its row-tile slots r0(x') .. SP - 1 idle. */
       constexpr int SP = 32 / NT; /* row-tile slots of an XCD */
-      const int x = (int)wg_info[0];
+      const int x = (int)my_xcc;
       auto r0 = [&](int xx) { const int r = (mtiles - xx + 7) / 8; return r < 0 ? 0 : r > SP ? SP : r; };
       int rank = (int)seat - r0(x) * NT;
       for (int xx = 0; xx < x; xx++) rank += (SP - r0(xx)) * NT;
@@ -1088,18 +1100,36 @@ const View *device_view(hipStream_t st, const View &v) {
   return d_view;
 }
 
-/* ---- the one-launch chain (k_chain_persist): its device state and the abort word ---- */
-static ChainSync *g_chain_sync = nullptr;
-static unsigned *g_chain_abort_host = nullptr, *g_chain_abort_dev = nullptr;
-static unsigned g_chain_seq = 0;
-static int g_chain_cus = -1;
-/* The first one-launch chain of a process is checked synchronously: where its 256 workgroups cannot all be
- * resident (a CU-masked queue, a partition mode that still reports 256 CUs, a co-tenant holding CUs) it
- * raises the abort word; the launcher then resets it, stops using the kernel for the rest of the process
- * and the caller runs the launch-per-step chain for that very call (the one-launch chain reads error plane
- * 0 and writes planes >= 1 only, so its input is intact).  Later give-ups -- a co-tenant that arrives in
- * mid-run -- are still caught at the next synchronisation (rnn_core.c: dsync), where nothing can be redone. */
-static bool g_chain_validated = false, g_chain_broken = false;
+/* ---- the one-launch chain (k_chain_persist): its device state and the abort word (above) ---- */
+/* A launch whose workgroups wait for one another (the one-launch chain) needs all 256 of them resident together,
+ * one per CU.  Whether this process's device and queue grant that -- no CU mask, no
+ * partition mode that still reports 256 CUs, no co-tenant holding CUs -- is found out ONCE, by a probe launch of the
+ * same footprint (512 threads and the chain's LDS per workgroup, so one per CU) whose workgroups count themselves
+ * and wait, bounded, for the count to reach 256 (chain_validate).  It also records the XCD each workgroup found
+ * itself on: where workgroup i sits on XCD i % 8 -- the dispatcher deals workgroups to the XCDs in turn -- the
+ * kernels take XCD and seat from the workgroup number (g_xcd_static; every wave still checks its XCD against the
+ * register) instead of drawing a ticket.  A probe that fails switches the kernel off for the process; the
+ * launch-per-step chain takes its place from the first call on.  A give-up in
+ * mid-run -- a co-tenant that arrives later -- is caught at the next synchronisation (rnn_core.c: dsync). */
+static bool g_chain_validated = false, g_chain_broken = false, g_xcd_static = false;
+
+struct ProbeOut {
+  unsigned arrived, fail;
+  unsigned xcc[256];
+};
+__global__ __launch_bounds__(512) void k_residency_probe(ProbeOut *p) {
+  extern __shared__ float probe_lds[]; /* (sized by the launch: what makes it one workgroup per CU) */
+  if (threadIdx.x != 0) return;
+  p->xcc[blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; /* HW_REG_XCC_ID */
+  __hip_atomic_fetch_add(&p->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (unsigned spins = 0; __hip_atomic_load(&p->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; spins++) {
+    if (spins > (1u << 20) || __hip_atomic_load(&p->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { /* ~0.5 s */
+      __hip_atomic_store(&p->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
 
 #ifdef PC_STAMPS
 extern "C" void ramd_chain_stamps(unsigned long long *out) {
@@ -1112,15 +1142,13 @@ extern "C" void ramd_chain_tail_stamps(unsigned long long *out) {
 }
 #endif
 
-extern "C" unsigned ramd_chain_abort_word(void) {
-  return g_chain_abort_host ? *(volatile unsigned *)g_chain_abort_host : 0u;
-}
-
-static bool chain_persist_ok(const RamdShape *sh, const RamdBuffers *b, int nrows) {
-  const int hs = sh->hidden_size;
-  if (b->uniform_idx < 0 || (hs != 1024 && hs != 512 && hs != 256) || nrows < 1 || nrows % 16 != 0 ||
-      sh->D > 60 || g_chain_broken || !env_int("RECUR_AMD_CHAIN_PERSIST", 1))
-    return false;
+static ChainSync *g_chain_sync = nullptr;
+static unsigned *g_chain_abort_host = nullptr, *g_chain_abort_dev = nullptr;
+static unsigned g_chain_seq = 0;
+static int g_chain_cus = -1;
+/* the probe (see above), once per process */
+static void chain_validate(hipStream_t st) {
+  if (g_chain_validated || g_chain_broken) return;
   if (g_chain_cus < 0) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -1128,13 +1156,66 @@ static bool chain_persist_ok(const RamdShape *sh, const RamdBuffers *b, int nrow
     HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     g_chain_cus = prop.multiProcessorCount;
   }
-  return g_chain_cus == 256; /* 8 XCDs x 32 CUs: one workgroup per CU, 32 seats per XCD */
+  if (g_chain_cus != 256) { /* 8 XCDs x 32 CUs: one workgroup per CU, 32 seats per XCD */
+    g_chain_broken = true;
+    return;
+  }
+  if (!g_chain_sync) {
+    HIP_CHECK(hipMalloc(&g_chain_sync, sizeof(ChainSync)));
+    HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
+    HIP_CHECK(hipHostMalloc((void **)&g_chain_abort_host, 64, hipHostMallocMapped));
+    *g_chain_abort_host = 0;
+    HIP_CHECK(hipHostGetDevicePointer((void **)&g_chain_abort_dev, g_chain_abort_host, 0));
+  }
+  ProbeOut *d_probe = nullptr, h_probe;
+  HIP_CHECK(hipMalloc(&d_probe, sizeof(ProbeOut)));
+  HIP_CHECK(hipMemsetAsync(d_probe, 0, sizeof(ProbeOut), st));
+  HIP_CHECK(hipFuncSetAttribute((const void *)k_residency_probe, hipFuncAttributeMaxDynamicSharedMemorySize, pc_lds_bytes(1024)));
+  RAMD_LAUNCH(k_residency_probe, dim3(256), dim3(512), pc_lds_bytes(1024), st, d_probe);
+  HIP_CHECK(hipMemcpyAsync(&h_probe, d_probe, sizeof(ProbeOut), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  HIP_CHECK(hipFree(d_probe));
+  /* (RECUR_AMD_CHAIN_TEST_GIVEUP=1: the tests' way of taking the failure branch on a healthy device) */
+  if (h_probe.fail || h_probe.arrived != 256u || env_int("RECUR_AMD_CHAIN_TEST_GIVEUP", 0) == 1) {
+    fprintf(stderr, "librecur_amd: the residency probe failed (%u of 256 workgroups resident together, one per CU); "
+                    "using the launch-per-step chain from here on\n", h_probe.arrived);
+    g_chain_broken = true;
+    return;
+  }
+  bool in_turn = true;
+  for (int i = 0; i < 256; i++) in_turn = in_turn && h_probe.xcc[i] == (unsigned)(i & 7);
+  g_xcd_static = in_turn && env_int("RECUR_AMD_XCD_STATIC", 1);
+  g_chain_validated = true;
+}
+
+/* Another queue of this process may have work on the device beside the chain (the noise generated ahead on a side
+ * stream, an exchange overlapped on a communication stream): the dispatcher then deals the workgroups of BOTH
+ * launches to the XCDs in turn, and workgroup i of the chain is not on XCD i % 8 (found by the configs[3] test, whose
+ * every wave's check raised the abort word).  rnn_core.c says so when it creates such a stream; from then on the
+ * chain draws tickets. */
+static bool g_side_streams = false;
+static unsigned g_ticket_launches = 0; /* launches that drew tickets: 32 per XCD each */
+extern "C" void ramd_note_side_stream(void) { g_side_streams = true; }
+
+extern "C" unsigned ramd_chain_abort_word(void) {
+  return g_chain_abort_host ? *(volatile unsigned *)g_chain_abort_host : 0u;
+}
+
+static bool chain_persist_ok(hipStream_t st, const RamdShape *sh, const RamdBuffers *b, int nrows) {
+  const int hs = sh->hidden_size;
+  if (b->uniform_idx < 0 || (hs != 1024 && hs != 512 && hs != 256) || nrows < 1 || nrows % 16 != 0 ||
+      sh->D > 60 || g_chain_broken || !env_int("RECUR_AMD_CHAIN_PERSIST", 1))
+    return false;
+  chain_validate(st);
+  return g_chain_validated;
 }
 
 template <int ACT, int K>
 static void launch_chain_persist_k(hipStream_t st, const View *d_view, const RamdShape *sh,
                                    const RamdBuffers *b, int row0, int nrows, unsigned seq, bool one, int nvalid,
                                    int vlo, const HoWork &hw, const XcWork &xc) {
+  const bool use_static = g_xcd_static && !g_side_streams;
+  const unsigned tseq = use_static ? 0u : ++g_ticket_launches;
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<ACT, K, false>,
@@ -1147,13 +1228,13 @@ static void launch_chain_persist_k(hipStream_t st, const View *d_view, const Ram
   }
   if (one && (nvalid < nrows || vlo > 0))
     RAMD_LAUNCH((k_chain_persist<ACT, K, true, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
-                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nvalid, vlo, hw, xc);
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nvalid, vlo, hw, xc, (int)use_static, tseq);
   else if (one)
     RAMD_LAUNCH((k_chain_persist<ACT, K, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
-                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw, xc);
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw, xc, (int)use_static, tseq);
   else
     RAMD_LAUNCH((k_chain_persist<ACT, K, false>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
-                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw, xc);
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw, xc, (int)use_static, tseq);
 }
 
 /* row tiles per launch: 8 XCDs x (32 seats / column tiles) */
@@ -1173,11 +1254,8 @@ static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
                                  const RamdBuffers *b, int row0, int nrows, bool one, int nvalid, int vlo, HoWork *ho,
                                  XcWork *xcp) {
   HoWork hw = {};
-  /* (not in a process's first launch, which is checked and may be discarded: the control logic updates
-   * per-stream state -- min_error_factor, the depth statistics -- that a repeat would update twice) */
   XcWork xc = {};
-  if (xcp && g_chain_validated) xc = *xcp;
-  if (xcp && !xc.on) xcp->on = 0; /* (the caller then runs the extras as a launch of their own) */
+  if (xcp) xc = *xcp;
   if (ho && !ho->done) {
     hw = *ho;
     /* the launch's workgroups without chain work, if they are at least half of it, else all 256 */
@@ -1185,17 +1263,11 @@ static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
     hw.idle_only = 256 - busy >= 128;
     hw.workers = hw.idle_only ? 256 - busy : 256;
   }
-  if (!g_chain_sync) {
-    HIP_CHECK(hipMalloc(&g_chain_sync, sizeof(ChainSync)));
-    HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
-    HIP_CHECK(hipHostMalloc((void **)&g_chain_abort_host, 64, hipHostMallocMapped));
-    *g_chain_abort_host = 0;
-    HIP_CHECK(hipHostGetDevicePointer((void **)&g_chain_abort_dev, g_chain_abort_host, 0));
-  }
   if (g_chain_seq >= (1u << 25)) { /* flags are seq * 64 + step and compare as unsigned numbers: start over */
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
     g_chain_seq = 0;
+    g_ticket_launches = 0;
   }
   const unsigned seq = ++g_chain_seq;
   int ev = timing_begin(st, T_CHAIN, 1);
@@ -1210,21 +1282,6 @@ static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
   else CHAIN_PERSIST(1);
 #undef CHAIN_PERSIST
   timing_end(st, ev);
-  if (!g_chain_validated) {
-    HIP_CHECK(hipStreamSynchronize(st));
-    /* (RECUR_AMD_CHAIN_TEST_GIVEUP=1: the tests' way of taking this branch on a healthy device) */
-    if (*(volatile unsigned *)g_chain_abort_host || env_int("RECUR_AMD_CHAIN_TEST_GIVEUP", 0)) {
-      fprintf(stderr, "librecur_amd: the one-launch BPTT chain gave up on its first launch (code %u: its 256 "
-                      "workgroups were not all resident, one per CU); using the launch-per-step chain from here on\n",
-              *(volatile unsigned *)g_chain_abort_host);
-      *(volatile unsigned *)g_chain_abort_host = 0;
-      HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
-      g_chain_seq = 0;
-      g_chain_broken = true;
-      return false;
-    }
-    g_chain_validated = true;
-  }
   if (ho && hw.dst) ho->done = 1;
   return true;
 }
@@ -1250,13 +1307,13 @@ int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const R
   /* ... and a small set that does not start on a tile boundary (a per-net call on stream j):
    * the tiles from the boundary below it, one launch */
   const int span_base = row0 & ~15, span = ((row0 + nrows + 15) & ~15) - span_base;
-  const bool windowed = span_base != row0 && span_base + span <= sh->Scap && chain_persist_ok(sh, b, span) &&
+  const bool windowed = span_base != row0 && span_base + span <= sh->Scap && chain_persist_ok(st, sh, b, span) &&
                         span / 16 <= chain_persist_seats(sh);
   bool windowed_done = false;
   if (windowed) {
     windowed_done = launch_chain_persist(st, d_view, sh, b, span_base, span, true, row0 - span_base + nrows, row0 - span_base, ho, xc);
   }
-  bool persist = windowed_done || chain_persist_ok(sh, b, chain_rows);
+  bool persist = windowed_done || chain_persist_ok(st, sh, b, chain_rows);
   if (persist && !windowed_done) { /* as many row tiles per launch as there are seats; more streams: more launches */
     /* (an odd number of 16-stream tiles beyond one launch: 32-stream tiles, the last 16 streams alone) */
     for (int r = 0; r < chain_rows;) {

@@ -238,6 +238,9 @@ void ramd_launch_fused_updates(ramd_stream_t st, const RamdShape *sh, const Ramd
 /* non-zero once the one-launch BPTT chain has given up (its workgroups were not all
  * resident, or a poll timed out): the results of that launch are not valid */
 unsigned ramd_chain_abort_word(void);
+/* the library has created a second stream with work that may run beside the BPTT chain: the chain then stops
+ * deriving its workgroups' XCDs from their numbers (kernels_chain.hip) */
+void ramd_note_side_stream(void);
 
 /* ---- timing hooks ---- */
 void ramd_timing_enable(int enable);

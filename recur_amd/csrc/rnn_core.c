@@ -2238,6 +2238,7 @@ static void noise_speculate(RnnAmdSet *set) {
   }
   if (!g_side) {
     HIP_OK(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+    ramd_note_side_stream();
   }
   if (!e->spec_go) {
     HIP_OK(hipEventCreateWithFlags((hipEvent_t *)&e->spec_go, hipEventDisableTiming));
@@ -2427,6 +2428,7 @@ static void delta_half_ready(void *ctx, int half, size_t first_float, size_t n_f
   RamdEngine *e = ctx;
   if (!g_comm_stream) {
     HIP_OK(hipStreamCreateWithFlags(&g_comm_stream, hipStreamNonBlocking));
+    ramd_note_side_stream();
     for (int h = 0; h < 2; h++) {
       HIP_OK(hipEventCreateWithFlags(&g_half_ready[h], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&g_half_summed[h], hipEventDisableTiming));
