@@ -34,7 +34,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+TESTS = os.path.join(ROOT, "tests")  # the checker's loaders (oracle, compiled reference): the cpu_baseline legs only
 
 HIDDEN, STREAMS, DEPTH, ALPHABET = 1024, 256, 20, 42
 LEARN_RATE, MOMENTUM = 1e-5, 0.95
@@ -42,7 +42,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
 # HBM-side bytes per launch come from the PMC passes of THIS round's kernels, summarised by
 # tools/pmc_summary.py into this file (rocprofv3 cannot run inside the timed process)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 
 
 def parse():
@@ -200,6 +200,7 @@ def _all_cores_worker(p, P, s_p, hidden, depth, text, n_floats, slabs_mm, result
     the weights, per generation the deltas of its streams -> slab p; everybody sums one
     1/P-th of the range over all slabs -> result; everybody applies the summed deltas."""
     import numpy as np
+    sys.path.insert(0, TESTS)
     import recur_ctypes as rc
     import scenarios as sc
     try:
@@ -328,9 +329,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import numpy as np
-    import golden_cases as gc
-    import recur_ctypes as rc
-    import scenarios as sc
+    from recur_amd import api as rc, drivers as sc  # the measured path's driver lives with the package
 
     if args.scaling == "strong":
         if args.streams_global % world or (args.streams_global // world) % 16:
@@ -343,7 +342,7 @@ def main():
     # right after 30 generations runs 2.4 % slower than after 300; sustained rate is the metric)
     prefill = max(D + 5, args.prefill)
     total_steps = prefill + args.warmup + args.steps + 260
-    text = gc.synthetic_text_np(max(20000, S * world * 40 + total_steps + 16), ALPHABET, 7)
+    text = sc.synthetic_text_np(max(20000, S * world * 40 + total_steps + 16), ALPHABET, 7)
 
     if args.all_cores_leg:
         # the all-core CPU figure in a process of its own (it forks its workers and never touches
@@ -419,6 +418,7 @@ def main():
         amd.rnn_amd_kernel_time_ms(0, None, 1)
         amd.rnn_amd_set_read_stats(gpu.handle, C.byref(st), 1)
         d_exec = st.bptt_depth_sum / max(st.count, 1)
+        gI, gH, gO = (Hd + ALPHABET + 1 + 3) // 4 * 4, (Hd + 1 + 3) // 4 * 4, (ALPHABET + 3) // 4 * 4  # padded sizes
         # the kernels' OWN work per generation: the chain multiplies the hidden x hidden block
         # (the extras' columns are another kernel's), the delta GEMM every row of W
         per_gen_flops = {
@@ -468,14 +468,17 @@ def main():
                     "achieved": per_gen_flops[k] / (max(cls[k][1], 1) / n_roof) / (1e3 * cls[k][0] / max(cls[k][1], 1) * 1e-6) / 1e12
                     if cls[k][1] else 0.0}
                 for k in per_gen_flops},
-            # `peak` is the data-sheet figure at 2.4 GHz.  Measured on this part (tools/mfma_clock_microbench.hip,
-            # profiles/r03_mfma_clock_microbench.txt): a dense v_mfma_f32_32x32x2_f32 stream on all 256 CUs holds
-            # 2.12 GHz (2.40 GHz with one CU busy), i.e. 139 TFLOP/s is what a launch that keeps every matrix pipe
-            # busy can reach.
-            "peak_at_sustained_clock": PEAK_FP32_MFMA_TFLOPS * 2.12 / 2.40,
+            # the whole generation by SURVEY.md section 8(d)'s count (forward + top layer + D_exec BPTT steps with their
+            # weight-delta accumulation), over the timed region's ms_per_step
+            "generation": {"flop": S * (2.0 * gI * gH + 2.0 * gH * gO + 2.0 * (2.0 * gH * gO) + d_exec * 4.0 * gI * gH),
+                           "note": "bptt_chain_gemm's launch includes the extras and the control logic of all steps "
+                                   "(its tail, ~6 us of the launch) since round 4"},
         }
         for k, d in roofline["per_kernel"].items():
             d["frac"] = d["achieved"] / PEAK_FP32_MFMA_TFLOPS
+        gen = roofline["generation"]
+        gen["achieved"] = gen["flop"] / (elapsed / args.steps) / 1e12
+        gen["frac"] = gen["achieved"] / PEAK_FP32_MFMA_TFLOPS
 
     out = {
         "metric": "BPTT timesteps*streams/sec at 1024-hidden/256-stream",

@@ -481,13 +481,18 @@ void rnn_amd_set_read_stats(RnnAmdSet *set, RnnAmdStats *stats, int clear);
  * library's stream between the deltas and the update; rnn_amd_set_open shards the text
  * offsets as rnn_amd_set_shard(rank * n_nets, world * n_nets) unless told otherwise.
  * COLLECTIVE BEHAVIOUR of host draws: on a net whose training set is sharded over the group
- * (made by rnn_amd_new_training_set_shard with n_local != global_count, opened as a training set
- * while the group is joined, or given a shard by rnn_amd_set_shard), rnn_weight_noise,
+ * (made by rnn_amd_new_training_set_shard with n_local != global_count, opened with rnn_amd_set_open
+ * as ALL of its engine's training streams while the group is joined -- until that set is closed or
+ * dropped --, or given a shard by rnn_amd_set_shard), rnn_weight_noise,
  * rnn_perforate_weights and the random damage of rnn_condition_net draw from RANK 0's generator
  * (a 32-byte broadcast) so that the replicas stay identical: EVERY rank must make that call on
  * its replica.  Nets that are not part of a sharded set (validation / confabulation clone
  * families of their own, side nets) are untouched by the group and draw locally.
- * All return 0 on success, -1 on failure (RCCL not loadable, bad arguments). */
+ * All return 0 on success, -1 on failure (RCCL not loadable, bad arguments), with two exceptions in
+ * rnn_amd_dist_init, which END THE PROCESS with _exit(86) after a message on stderr: a rank that has waited
+ * RECUR_AMD_RCCL_INIT_TIMEOUT seconds (default 180) for the others inside ncclCommInitRank -- the helper thread
+ * sitting in RCCL cannot be cancelled, and a process that has touched the GPU must not re-exec or retry --, and a
+ * communicator whose rank / size are not the ones asked for.  A launcher sees exit status 86 of that rank. */
 #define RNN_AMD_DIST_ID_BYTES 128
 int rnn_amd_dist_get_id(void *id);
 int rnn_amd_dist_init(int rank, int world, const void *id);

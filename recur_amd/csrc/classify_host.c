@@ -28,9 +28,10 @@ char *rnn_amd_classify_construct_metadata(const RnnAmdClassifyMetadata *m) {
   return text;
 }
 
-/* one "name value" item at *at: the value's text (up to white space) is copied to `value`; returns 1 and
- * moves *at past it when the name matched */
-static int take_item(const char **at, const char *name, char *value, size_t room) {
+/* one "name value" item at *at: returns the value's length (the text up to white space, which *value then
+ * points at, inside the string) and moves *at past it when the name matched; 0 otherwise.  No length limit: the
+ * reference reads text items with %ms (gstclassify.c:841-929) */
+static size_t take_item(const char **at, const char *name, const char **value) {
   const char *p = *at;
   while (*p == ' ' || *p == '\n' || *p == '\t') {
     p++;
@@ -43,13 +44,10 @@ static int take_item(const char **at, const char *name, char *value, size_t room
   while (*p == ' ') {
     p++;
   }
-  size_t k = 0;
-  while (*p && *p != ' ' && *p != '\n' && *p != '\t' && k + 1 < room) {
-    value[k++] = *p++;
-  }
-  value[k] = 0;
-  *at = p;
-  return k > 0;
+  const size_t k = strcspn(p, " \n\t");
+  *value = p;
+  *at = p + k;
+  return k;
 }
 
 int rnn_amd_classify_load_metadata(const char *metadata, RnnAmdClassifyMetadata *m) {
@@ -70,16 +68,16 @@ int rnn_amd_classify_load_metadata(const char *metadata, RnnAmdClassifyMetadata 
                {"focus-frequency", REAL, &m->focus_freq}, {"lag", REAL, &m->lag},
                {"intensity-feature", WHOLE, &m->intensity_feature}};
   const int wanted = (int)(sizeof(items) / sizeof(items[0]));
-  char value[512];
-  const char *at = metadata;
+  const char *at = metadata, *value;
   int found = 0;
   for (; found < wanted; found++) {
-    if (!take_item(&at, items[found].name, value, sizeof(value))) {
+    const size_t len = take_item(&at, items[found].name, &value);
+    if (!len) {
       break;
     }
     if (items[found].kind == TEXT) {
-      *(const char **)items[found].field = strdup(value);
-    } else if (items[found].kind == REAL) {
+      *(const char **)items[found].field = strndup(value, len);
+    } else if (items[found].kind == REAL) { /* (the number ends at the white space behind it) */
       *(float *)items[found].field = strtof(value, NULL);
     } else {
       *(int *)items[found].field = (int)strtol(value, NULL, 10);

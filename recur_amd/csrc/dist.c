@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 #include <pthread.h>
 #include <time.h>
+#include <unistd.h>
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 
@@ -150,7 +151,14 @@ int rnn_amd_dist_init(int rank, int world, const void *id) {
   job.world = world;
   HIP_OK(hipGetDevice(&job.device));
   const char *te = getenv("RECUR_AMD_RCCL_INIT_TIMEOUT");
-  long limit = (te && atol(te) > 0) ? atol(te) : 180;
+  long limit = 180;
+  if (te) {
+    limit = atol(te);
+    if (limit <= 0) {
+      fprintf(stderr, "librecur_amd: RECUR_AMD_RCCL_INIT_TIMEOUT=%s is not a number of seconds; using 180\n", te);
+      limit = 180;
+    }
+  }
   pthread_t th;
   if (pthread_create(&th, NULL, init_thread, &job) != 0) {
     fprintf(stderr, "librecur_amd: rnn_amd_dist_init cannot start its helper thread\n");
@@ -163,7 +171,11 @@ int rnn_amd_dist_init(int rank, int world, const void *id) {
     fprintf(stderr, "librecur_amd: rank %d of %d has waited %ld s in ncclCommInitRank: not every rank joined the "
                     "group (is each of the %d ranks running, with rank 0's id, on a GPU of its own, "
                     "HSA_ENABLE_IPC_MODE_LEGACY=0 set?).  Giving up.\n", rank, world, limit, world);
-    abort();
+    /* the helper thread sits inside RCCL and cannot be cancelled, and a process that has touched the GPU must
+     * not re-exec: leave at once, without a core dump, with a status the launcher can read (documented in
+     * include/recur_amd.h) */
+    fflush(stderr);
+    _exit(86);
   }
   if (job.result != 0) {
     fprintf(stderr, "librecur_amd: ncclCommInitRank failed: %s\n", rccl.GetErrorString(job.result));
@@ -176,7 +188,8 @@ int rnn_amd_dist_init(int rank, int world, const void *id) {
   if (g_world != world || g_rank != rank) {
     fprintf(stderr, "librecur_amd: the RCCL group has %d ranks and this is rank %d (asked for rank %d of %d)\n",
             g_world, g_rank, rank, world);
-    abort();
+    fflush(stderr);
+    _exit(86); /* (a group that is not the one asked for: nothing this rank computes would be right) */
   }
   HIP_OK(hipMalloc(&g_scratch, 256));
   return 0;

@@ -1851,7 +1851,12 @@ RnnAmdSet *rnn_amd_set_open(RecurNN **nets, int n_nets) {
   set->fwd_only = fwd_only;
   set->global_first = 0;
   set->global_count = n_nets;
-  if (ramd_dist_active() && !fwd_only) { /* rank r holds global streams [r n, (r + 1) n) */
+  set->sharded_before = e->sharded;
+  /* A set of ALL the engine's training streams opened inside a group is this rank's shard of the distributed
+   * training set: rank r holds global streams [r n, (r + 1) n).  A set of some of them -- the host layers' one-net
+   * passes, a validation or side net that one rank alone touches -- stays local: its host draws must not become
+   * collectives that the other ranks never enter. */
+  if (ramd_dist_active() && !fwd_only && n_nets == e->n_streams) {
     set->global_first = rnn_amd_dist_rank() * n_nets;
     set->global_count = rnn_amd_dist_world() * n_nets;
     e->sharded = 1;
@@ -1864,6 +1869,7 @@ void rnn_amd_set_close(RnnAmdSet *set) {
     return;
   }
   ramd_need_host(set->nets[0], RNN_AMD_EVERYTHING);
+  set->eng->sharded = set->sharded_before;
   free(set->nets);
   free(set);
 }
@@ -1873,6 +1879,7 @@ void rnn_amd_set_drop(RnnAmdSet *set) {
   if (!set) {
     return;
   }
+  set->eng->sharded = set->sharded_before;
   free(set->nets);
   free(set);
 }

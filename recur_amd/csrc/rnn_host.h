@@ -84,6 +84,7 @@ struct RnnAmdSet {
   int row0;     /* first training-stream row, or first forward-only index when fwd_only */
   int fwd_only; /* the set is made of forward-only clones (no bptt): opinion calls only */
   int global_first, global_count;
+  int sharded_before; /* the engine's `sharded` when the set was opened: put back when it is closed or dropped */
 };
 
 static inline RamdPriv *ramd_priv(const RecurNN *net) {

@@ -65,33 +65,7 @@ def case_kwargs(c):
     return kw
 
 
-def synthetic_text_np(n=TEXT_LEN, alphabet=42, seed=7):
-    """The seeded symbol stream of scenarios.synthetic_text, restated in numpy so
-    that fixtures do not depend on any C library (Jenkins PRNG, recur-rng.h)."""
-    M = (1 << 64) - 1
-
-    def rot(x, k):
-        return ((x << k) | (x >> (64 - k))) & M
-
-    a, b, c, d = 0xF1EA5EED, seed, seed, seed
-
-    def step():
-        nonlocal a, b, c, d
-        e = (a - rot(b, 7)) & M
-        a = b ^ rot(c, 13)
-        b = (c + rot(d, 37)) & M
-        c = (d + e) & M
-        d = (e + a) & M
-        return d
-
-    for _ in range(20):
-        step()
-    out = np.empty(n, np.uint8)
-    for i in range(n):
-        bits = (step() & 0x000FFFFFFFFFFFFF) | 0x3FF0000000000000
-        x = np.frombuffer(np.uint64(bits).tobytes(), dtype=np.float64)[0] - 1.0
-        out[i] = int(x * alphabet)
-    return out
+from recur_amd.drivers import synthetic_text_np  # noqa: E402,F401
 
 
 def prepare(driver, c, set_momentum_values, set_aux_values):

@@ -7,5 +7,5 @@ for f in recur_amd/csrc/kernels_*.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -Wno-unused-result -Wno-pass-failed "$@" -Irecur_amd/csrc -Iinclude -I/opt/rocm/include -c "$f" -o build/dev/abl_$n/"$(basename "$f" .hip)".o &
 done
 wait
-host=$(ls build/obj/*.o | grep -v "/kernels_")
+host=$(make -s -C recur_amd/csrc print-host-objs)  # (not `ls build/obj`: an incremental tree keeps objects of files that no longer exist)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/dev/abl_$n/librecur_amd.so $host build/dev/abl_$n/kernels_*.o -Wl,-rpath,/opt/rocm/lib -lm -ldl
