@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--prefill", type=int, default=300, help="untimed generations before the warm-up")
     ap.add_argument("--dist", action="store_true",
                     help="join an RCCL group even with one rank (exercises the exchange step)")
+    ap.add_argument("--exchange", choices=("rccl", "kernel"), default=os.environ.get("RECUR_AMD_DIST_EXCHANGE", "rccl"),
+                    help="the exchange step of a sharded run: one RCCL all-reduce per generation (default), or the "
+                         "library's kernel-issued reduce-scatter -> sharded update -> all-gather through peer pointers "
+                         "(rnn_amd_set_exchange_*; also with one rank)")
     ap.add_argument("--all-cores-leg", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -138,6 +142,39 @@ def exchange_id(amd, rank, world):
         raise SystemExit("bench.py: rnn_amd_dist_init failed on rank %d" % rank)
     if rank == 0:  # the init is collective: everybody has read the file
         os.unlink(path)
+
+
+def join_kernel_exchange(amd, handle, rank, world):
+    """--exchange kernel: every rank's 256-byte blob (IPC handles of its delta and weight arrays) and the 64 bytes of
+    arrival counters live in one file in /dev/shm that all ranks of the node map."""
+    B = 256
+    key = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("RECUR_BENCH_RUN_ID") or
+                     (os.getppid() if world > 1 else os.getpid()))
+    path = "/dev/shm/recur_amd_exchange_" + key
+    if rank == 0:
+        with open(path + ".tmp", "wb") as f:
+            f.write(b"\0" * 4096)
+        os.replace(path + ".tmp", path)
+    t0 = time.time()
+    while not (os.path.exists(path) and os.path.getmtime(path) > t0 - 300):
+        if time.time() - t0 > 300:
+            raise SystemExit("bench.py: rank %d never saw the exchange file" % rank)
+        time.sleep(0.02)
+    fd = os.open(path, os.O_RDWR)
+    mm = mmap.mmap(fd, 4096)  # [0, 64) counters; [256, 256 + 8 B) blobs; [3072 + r] "blob r is there"
+    blob = C.create_string_buffer(B)
+    amd.rnn_amd_set_exchange_export(handle, blob)
+    mm[256 + rank * B:256 + (rank + 1) * B] = blob.raw
+    mm[3072 + rank] = 1
+    while not all(mm[3072 + r] for r in range(world)):
+        if time.time() - t0 > 300:
+            raise SystemExit("bench.py: rank %d: not every rank exported its arrays" % rank)
+        time.sleep(0.01)
+    blobs = C.create_string_buffer(bytes(mm[256:256 + world * B]), world * B)
+    counters = (C.c_char * 64).from_buffer(mm, 0)
+    if amd.rnn_amd_set_exchange_join(handle, rank, world, blobs, counters, 0) != 0:
+        raise SystemExit("bench.py: rnn_amd_set_exchange_join failed on rank %d" % rank)
+    return path, mm, counters  # (kept alive by the caller; rank 0 unlinks the file at the end)
 
 
 # --------------------------------------------------------------- CPU baseline --
@@ -367,6 +404,9 @@ def main():
                            shard=(rank * S, world * S))
     gpu.load_text(text)
     amd.rnn_amd_set_shard(gpu.handle, rank * S, world * S)
+    xchg = None
+    if args.exchange == "kernel" and (dist or any(a.startswith("--exchange") for a in sys.argv)):
+        xchg = join_kernel_exchange(amd, gpu.handle, rank, world)
 
     def step(i):  # deltas -> (all-reduce over ranks, inside the library) -> update
         amd.rnn_amd_set_char_step(gpu.handle, i, rc.WEIGHTED, MOMENTUM)
@@ -497,7 +537,9 @@ def main():
             "workload": "text-predict multi-tap generation: hidden %d, %d streams/GPU, BPTT depth "
                         "%d, 42 symbols, RELU, weighted momentum, lr 1e-5" % (Hd, S, D),
             "streams_per_gpu": S, "global_streams": S * world, "scaling_mode": args.scaling,
-            "parallelism": ("streams sharded x%d, one RCCL all-reduce of the weight deltas per generation "
+            "parallelism": ("streams sharded x%d, kernel-issued reduce-scatter -> sharded update -> all-gather through "
+                            "peer pointers per generation (in librecur_amd)" % world) if xchg else
+                           ("streams sharded x%d, one RCCL all-reduce of the weight deltas per generation "
                             "(in librecur_amd)" % world) if dist else "single GPU",
             "rccl_ranks": amd.rnn_amd_dist_world() if dist else 0,
             "untimed_prefill_generations": prefill,
@@ -527,6 +569,14 @@ def main():
         base["cores_available"] = all_cores.get("cores_available") if all_cores else None
         base["all_cores"] = all_cores
         out["cpu_baseline"] = base
+    if xchg:
+        amd.rnn_amd_set_exchange_leave(gpu.handle)
+        if dist:
+            amd.rnn_amd_dist_barrier()  # (every rank has left: nobody maps the file any more)
+        path, mm, counters = xchg
+        del counters
+        if rank == 0 and os.path.exists(path):
+            os.unlink(path)
     if dist:
         amd.rnn_amd_dist_barrier()
         amd.rnn_amd_dist_finalize()

@@ -499,6 +499,36 @@ int rnn_amd_dist_init(int rank, int world, const void *id);
 void rnn_amd_dist_finalize(void);
 int rnn_amd_dist_rank(void);  /* 0 when no group is joined */
 int rnn_amd_dist_world(void); /* 1 when no group is joined */
+/* ---- the exchange step WITHOUT a collective library: reduce-scatter -> sharded optimiser -> all-gather as
+ * kernel-issued peer traffic (SURVEY.md section 8e's alternative; the sum it distributes is recur-nn.c:734-739,
+ * the update it shards recur-nn.c:601-678).  Every rank owns 1 / world of each weight array; ONE kernel per
+ * generation adds the ranks' local delta sums for its range in rank order through peer pointers (replicas stay
+ * bit-identical), updates its own weights and momentum there -- the optimiser state of a range lives on its owner
+ * only -- and stores the new weights into every rank's weight array; two arrival barriers (kernels on the
+ * library's stream that count in host memory all ranks have mapped) keep the ranks' generations apart.  No RCCL
+ * launch, no separate all-reduce pass.  Up to 8 ranks, no bottom layer, ranks on GPUs with peer access (or on one
+ * GPU: the tests' emulation).  OPT-IN: the RCCL all-reduce above stays the default until a multi-GPU node has
+ * measured both.
+ *   1. each rank: rnn_amd_set_exchange_export(set, blob)  -- 256 bytes naming its delta and weight arrays (IPC
+ *      handles; same-process peers are recognised and take the plain pointers);
+ *   2. the launcher hands every blob to every rank (a file, shared memory, a pipe) and provides `counters`: 64 bytes
+ *      of zeroed host memory that ALL ranks have mapped (MAP_SHARED memory made before fork, or a file in /dev/shm);
+ *   3. each rank: rnn_amd_set_exchange_join(set, rank, world, blobs, counters, 0); from then on
+ *      rnn_amd_set_char_step runs deltas -> barrier -> sharded update -> barrier.
+ * lockstep != 0: the ranks are sets of ONE process driven by one thread (counters may be NULL): no barriers are
+ * launched, the caller gives the order -- rnn_amd_set_char_step_deltas on every rank, then
+ * rnn_amd_set_apply_exchange on every rank.  After a step ih_delta || ho_delta hold the sum over the ranks in the
+ * rank's OWN range only, and momentum / aux arrays are current in the own range only (rnn_amd_set_exchange_range).
+ * Returns 0, or -1 with a message (a peer's arrays cannot be opened, bad arguments). */
+#define RNN_AMD_EXCHANGE_BLOB_BYTES 256
+void rnn_amd_set_exchange_export(RnnAmdSet *set, void *blob);
+int rnn_amd_set_exchange_join(RnnAmdSet *set, int rank, int world, const void *blobs, void *counters, int lockstep);
+void rnn_amd_set_exchange_leave(RnnAmdSet *set);
+/* the update of rnn_apply_learning through the exchange (the second half of rnn_amd_set_char_step) */
+void rnn_amd_set_apply_exchange(RnnAmdSet *set, int learning_style, float momentum);
+/* this rank's range of the recurrent (which = 0) or top-layer (1) arrays, in floats */
+void rnn_amd_set_exchange_range(const RnnAmdSet *set, int which, size_t *first, size_t *count);
+
 /* in-place sum over the ranks of a device buffer of floats, on the library's stream */
 void rnn_amd_dist_all_reduce(void *device_buffer, size_t n_floats);
 /* max over the ranks of a host value / a barrier (the timing bracket of a benchmark) */

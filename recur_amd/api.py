@@ -221,6 +221,11 @@ AMD_API = {
     "rnn_amd_set_calc_deltas": (None, [C.c_void_p, C.c_int, C.POINTER(ErrorRange), c_u8_p]),
     "rnn_amd_set_load_text": (None, [C.c_void_p, c_u8_p, C.c_int]),
     "rnn_amd_set_char_step": (None, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
+    "rnn_amd_set_exchange_export": (None, [C.c_void_p, C.c_void_p]),
+    "rnn_amd_set_exchange_join": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "rnn_amd_set_exchange_leave": (None, [C.c_void_p]),
+    "rnn_amd_set_apply_exchange": (None, [C.c_void_p, C.c_int, C.c_float]),
+    "rnn_amd_set_exchange_range": (None, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rnn_amd_set_char_step_fused": (None, [C.c_void_p, C.c_int, C.c_uint]),
     "rnn_amd_set_read_stats": (None, [C.c_void_p, C.POINTER(AmdStats), C.c_int]),
     "rnn_amd_set_external_delta": (None, [C.c_void_p, C.c_void_p]),
@@ -252,6 +257,7 @@ AMD_API = {
 }
 RNN_AMD_WEIGHTS, RNN_AMD_MOMENTUMS, RNN_AMD_DELTAS, RNN_AMD_STREAM, RNN_AMD_ALL_STREAMS = 1, 2, 4, 8, 16
 RNN_AMD_EVERYTHING = 31
+RNN_AMD_EXCHANGE_BLOB_BYTES = 256
 
 def _bind(lib, table, skip=()):
     for name, (res, args) in table.items():

@@ -22,6 +22,60 @@ struct ApplySegs {
    * k_delta_finalize would have (non-accumulating form) and stores them as well */
   RamdPendingDelta pend;
 };
+// one float4 of rnn_apply_learning's update (recur-nn.c:454-593): weights wv, deltas dv, momentum / accumulator mv
+// and, for ADADELTA and RPROP, the second accumulator av
+template <int METHOD>
+__device__ __forceinline__ void apply_update4(float (&wv)[4], float (&dv)[4], float (&mv)[4], float (&av)[4], float rate,
+                                              float momentum, float mw) {
+#pragma unroll
+for (int i = 0; i < 4; i++) {
+  if (METHOD == 0) { /* weighted / simplified nesterov / classical: 482-487 */
+    float t = dv[i] * rate;
+    float mm = mv[i];
+    wv[i] += t + mm * mw;
+    mv[i] = (mm + t) * momentum;
+  } else if (METHOD == 1) { /* nesterov: 501-508 */
+    float t = dv[i] * rate;
+    wv[i] += t;
+    float mm = (mv[i] + t) * momentum;
+    mv[i] = mm;
+    wv[i] += mm;
+  } else if (METHOD == 4) { /* adagrad: 518-524 */
+    float d = dv[i];
+    float a = mv[i] + d * d;
+    wv[i] += d * rate / sqrtf(a);
+    mv[i] = a;
+  } else if (METHOD == 5) { /* adadelta, abs-value branch: 537-557 */
+    const float renewal = 1.0f - momentum;
+    float d = dv[i];
+    float g = mv[i] * momentum;
+    float s = av[i] * momentum;
+    g += fabsf(d) * renewal + rate;
+    float step = s / g * d;
+    s += fabsf(step) * renewal + rate;
+    mv[i] = g;
+    av[i] = s;
+    wv[i] += step;
+  } else if (METHOD == 6) { /* rprop: 568-592 */
+    const float max_step = 1 * rate;
+    const float min_step = (float)(1e-6 * (double)rate);
+    float d = dv[i], p = mv[i], step = av[i];
+    if (d * p > 0.0f) {
+      float g = step * 1.2f;
+      step = (g < max_step) ? g : max_step;
+    } else if (d * p < 0.0f) {
+      float g = step * 0.5f;
+      step = (g >= min_step) ? g : min_step;
+      d = 0;
+    }
+    if (d > 0.0f) wv[i] += step;
+    else wv[i] -= step;
+    av[i] = step;
+    mv[i] = d;
+  }
+}
+}
+
 template <int METHOD>
 __global__ __launch_bounds__(256) void k_apply(ApplySegs sg, float momentum, float mw,
                                                const float *rs) {
@@ -71,57 +125,87 @@ __global__ __launch_bounds__(256) void k_apply(ApplySegs sg, float momentum, flo
   float4 A = (METHOD == 5 || METHOD == 6) ? ld4(aux + 4 * q) : zero4();
   float wv[4] = {W.x, W.y, W.z, W.w}, dv[4] = {Dl.x, Dl.y, Dl.z, Dl.w};
   float mv[4] = {M.x, M.y, M.z, M.w}, av[4] = {A.x, A.y, A.z, A.w};
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    if (METHOD == 0) { /* weighted / simplified nesterov / classical: 482-487 */
-      float t = dv[i] * rate;
-      float mm = mv[i];
-      wv[i] += t + mm * mw;
-      mv[i] = (mm + t) * momentum;
-    } else if (METHOD == 1) { /* nesterov: 501-508 */
-      float t = dv[i] * rate;
-      wv[i] += t;
-      float mm = (mv[i] + t) * momentum;
-      mv[i] = mm;
-      wv[i] += mm;
-    } else if (METHOD == 4) { /* adagrad: 518-524 */
-      float d = dv[i];
-      float a = mv[i] + d * d;
-      wv[i] += d * rate / sqrtf(a);
-      mv[i] = a;
-    } else if (METHOD == 5) { /* adadelta, abs-value branch: 537-557 */
-      const float renewal = 1.0f - momentum;
-      float d = dv[i];
-      float g = mv[i] * momentum;
-      float s = av[i] * momentum;
-      g += fabsf(d) * renewal + rate;
-      float step = s / g * d;
-      s += fabsf(step) * renewal + rate;
-      mv[i] = g;
-      av[i] = s;
-      wv[i] += step;
-    } else if (METHOD == 6) { /* rprop: 568-592 */
-      const float max_step = 1 * rate;
-      const float min_step = (float)(1e-6 * (double)rate);
-      float d = dv[i], p = mv[i], step = av[i];
-      if (d * p > 0.0f) {
-        float g = step * 1.2f;
-        step = (g < max_step) ? g : max_step;
-      } else if (d * p < 0.0f) {
-        float g = step * 0.5f;
-        step = (g >= min_step) ? g : min_step;
-        d = 0;
-      }
-      if (d > 0.0f) wv[i] += step;
-      else wv[i] -= step;
-      av[i] = step;
-      mv[i] = d;
-    }
-  }
+  apply_update4<METHOD>(wv, dv, mv, av, rate, momentum, mw);
   *reinterpret_cast<float4 *>(w + 4 * q) = make_float4(wv[0], wv[1], wv[2], wv[3]);
   *reinterpret_cast<float4 *>(m + 4 * q) = make_float4(mv[0], mv[1], mv[2], mv[3]);
   if (METHOD == 5 || METHOD == 6)
     *reinterpret_cast<float4 *>(aux + 4 * q) = make_float4(av[0], av[1], av[2], av[3]);
+}
+
+// --------------------------------- the exchange step as kernel-issued peer traffic --
+//
+// The sum of the weight deltas over the ranks (recur-nn.c:734-739 distributed) and the update (recur-nn.c:601-678) as
+// reduce-scatter -> sharded optimiser -> all-gather IN ONE KERNEL, with no collective library in between (SURVEY.md
+// section 8e's alternative to the all-reduce).  Every rank owns 1 / world of each weight array (a contiguous range of
+// float4): for its range it adds the `world` ranks' local delta sums in RANK ORDER through peer pointers (every replica
+// therefore sees bit-identical sums), applies the update rule to its own copy of weights and momentum -- the
+// momentum / accumulator arrays are only ever touched in the owned range: optimiser state and traffic / world --, and
+// writes the new weights into EVERY rank's weight array.  The summed deltas are left in the owner's delta array
+// (owned range only).  Ordering between ranks comes from k_xchg_barrier launches around it (or, for ranks that one
+// host thread drives in lock step -- the one-GPU emulation of the tests --, from that thread's own order).
+constexpr int XCHG_MAX = 8;
+struct XchgSeg {
+  float *w[XCHG_MAX];            /* every rank's weight array (own included, at index `rank`) */
+  const float *delta[XCHG_MAX];  /* every rank's local delta sums                              */
+  float *m, *aux, *delta_out;    /* own                                                       */
+  size_t lo4, hi4;               /* owned range in float4                                     */
+  float rate;
+};
+struct XchgArgs {
+  XchgSeg seg[2]; /* top layer, recurrent layer */
+  int world, rank;
+  unsigned first1; /* first block of segment 1 */
+};
+template <int METHOD>
+__global__ __launch_bounds__(256) void k_apply_xchg(XchgArgs xa, float momentum, float mw) {
+  const int g = blockIdx.x >= xa.first1 ? 1 : 0;
+  const XchgSeg &sg = xa.seg[g];
+  const size_t q = sg.lo4 + (size_t)(blockIdx.x - (g ? xa.first1 : 0u)) * 256 + threadIdx.x;
+  if (q >= sg.hi4) return;
+  float4 t[XCHG_MAX];
+#pragma unroll
+  for (int p = 0; p < XCHG_MAX; p++) t[p] = ld4(sg.delta[p < xa.world ? p : 0] + 4 * q); /* all in flight */
+  float4 Dl = t[0];
+#pragma unroll
+  for (int p = 1; p < XCHG_MAX; p++)
+    if (p < xa.world) { Dl.x += t[p].x; Dl.y += t[p].y; Dl.z += t[p].z; Dl.w += t[p].w; }
+  float *w = sg.w[xa.rank];
+  const float4 W = ld4(w + 4 * q), M = ld4(sg.m + 4 * q);
+  const float4 A = (METHOD == 5 || METHOD == 6) ? ld4(sg.aux + 4 * q) : zero4();
+  float wv[4] = {W.x, W.y, W.z, W.w}, dv[4] = {Dl.x, Dl.y, Dl.z, Dl.w};
+  float mv[4] = {M.x, M.y, M.z, M.w}, av[4] = {A.x, A.y, A.z, A.w};
+  apply_update4<METHOD>(wv, dv, mv, av, sg.rate, momentum, mw);
+  const float4 Wn = make_float4(wv[0], wv[1], wv[2], wv[3]);
+#pragma unroll
+  for (int p = 0; p < XCHG_MAX; p++)
+    if (p < xa.world) *reinterpret_cast<float4 *>(sg.w[p] + 4 * q) = Wn; /* the all-gather, by stores */
+  *reinterpret_cast<float4 *>(sg.m + 4 * q) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+  if (METHOD == 5 || METHOD == 6) *reinterpret_cast<float4 *>(sg.aux + 4 * q) = make_float4(av[0], av[1], av[2], av[3]);
+  *reinterpret_cast<float4 *>(sg.delta_out + 4 * q) = Dl;
+}
+
+// Arrival barrier between the ranks' streams: this rank's slot of the shared counter array (host memory that every
+// rank has mapped: visible across processes and GPUs inside a kernel) takes `seq`, then the launch waits until every
+// slot has reached it.  What the previous kernels of this stream wrote is visible to the peers' later kernels through
+// the kernel boundaries (release at the end of a launch, acquire at the start of the next, both at system scope).
+// Bounded: ~20 s of polling raise *abort_word (see dsync in rnn_core.c).
+__global__ void k_xchg_barrier(unsigned *flags, int rank, int world, unsigned seq, unsigned *abort_word) {
+  const int p = threadIdx.x;
+  if (p == 0) {
+    __threadfence_system();
+    __hip_atomic_store(&flags[rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (p < world) {
+    for (unsigned spins = 0;; spins++) {
+      /* (seq - got) as a signed number: counters that have wrapped still compare */
+      if ((int)(__hip_atomic_load(&flags[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) >= 0) break;
+      if (spins > (1u << 24)) {
+        if (abort_word) __hip_atomic_store(abort_word, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+  }
 }
 
 // rnn_bptt_calculate's two updates in ONE launch: workgroups below `top_blocks` do apply_sgd_top_layer's
@@ -289,6 +373,55 @@ extern "C" void ramd_launch_apply_multi(ramd_stream_t st_, int method, int nseg,
   case 5: RAMD_LAUNCH(k_apply<5>, gr, bl, 0, st, sg, momentum, mw, rs); break;
   case 6: RAMD_LAUNCH(k_apply<6>, gr, bl, 0, st, sg, momentum, mw, rs); break;
   default: RAMD_LAUNCH(k_apply<0>, gr, bl, 0, st, sg, momentum, mw, rs); break;
+  }
+  timing_end(st, ev);
+}
+
+extern "C" void ramd_launch_xchg_barrier(ramd_stream_t st, unsigned *flags_dev, int rank, int world, unsigned seq,
+                                         unsigned *abort_word_dev) {
+  RAMD_LAUNCH(k_xchg_barrier, dim3(1), dim3(64), 0, (hipStream_t)st, flags_dev, rank, world, seq, abort_word_dev);
+}
+
+/* the sharded update (k_apply_xchg): w / delta: [2][world] device pointers of every rank's top-layer (0) and recurrent
+ * (1) arrays; m, aux, delta_out: own arrays [2]; n: floats per array [2] */
+extern "C" void ramd_launch_apply_xchg(ramd_stream_t st_, int method, int rank, int world, float *const *w,
+                                       const float *const *delta, float *const *m, float *const *aux,
+                                       float *const *delta_out, const size_t *n, const float *rate, float momentum,
+                                       float mw) {
+  hipStream_t st = (hipStream_t)st_;
+  if (world < 1 || world > XCHG_MAX || rank < 0 || rank >= world) {
+    fprintf(stderr, "librecur_amd: the kernel-issued exchange takes 1..%d ranks (rank %d of %d)\n", XCHG_MAX, rank, world);
+    abort();
+  }
+  XchgArgs xa = {};
+  xa.world = world;
+  xa.rank = rank;
+  unsigned blocks = 0;
+  for (int g = 0; g < 2; g++) {
+    XchgSeg &sg = xa.seg[g];
+    for (int p = 0; p < world; p++) {
+      sg.w[p] = w[g * world + p];
+      sg.delta[p] = delta[g * world + p];
+    }
+    sg.m = m[g];
+    sg.aux = aux[g];
+    sg.delta_out = delta_out[g];
+    const size_t n4 = n[g] / 4;
+    sg.lo4 = n4 * (size_t)rank / world;
+    sg.hi4 = n4 * (size_t)(rank + 1) / world;
+    sg.rate = rate[g];
+    if (g == 1) xa.first1 = blocks;
+    blocks += (unsigned)((sg.hi4 - sg.lo4 + 255) / 256);
+  }
+  if (!blocks) return;
+  dim3 gr(blocks), bl(256);
+  int ev = timing_begin(st, T_APPLY);
+  switch (method) {
+  case 1: RAMD_LAUNCH(k_apply_xchg<1>, gr, bl, 0, st, xa, momentum, mw); break;
+  case 4: RAMD_LAUNCH(k_apply_xchg<4>, gr, bl, 0, st, xa, momentum, mw); break;
+  case 5: RAMD_LAUNCH(k_apply_xchg<5>, gr, bl, 0, st, xa, momentum, mw); break;
+  case 6: RAMD_LAUNCH(k_apply_xchg<6>, gr, bl, 0, st, xa, momentum, mw); break;
+  default: RAMD_LAUNCH(k_apply_xchg<0>, gr, bl, 0, st, xa, momentum, mw); break;
   }
   timing_end(st, ev);
 }

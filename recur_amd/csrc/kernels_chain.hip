@@ -1163,9 +1163,7 @@ static void chain_validate(hipStream_t st) {
   if (!g_chain_sync) {
     HIP_CHECK(hipMalloc(&g_chain_sync, sizeof(ChainSync)));
     HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
-    HIP_CHECK(hipHostMalloc((void **)&g_chain_abort_host, 64, hipHostMallocMapped));
-    *g_chain_abort_host = 0;
-    HIP_CHECK(hipHostGetDevicePointer((void **)&g_chain_abort_dev, g_chain_abort_host, 0));
+    ramd_abort_word_dev();
   }
   ProbeOut *d_probe = nullptr, h_probe;
   HIP_CHECK(hipMalloc(&d_probe, sizeof(ProbeOut)));
@@ -1196,6 +1194,16 @@ static void chain_validate(hipStream_t st) {
 static bool g_side_streams = false;
 static unsigned g_ticket_launches = 0; /* launches that drew tickets: 32 per XCD each */
 extern "C" void ramd_note_side_stream(void) { g_side_streams = true; }
+
+/* the host-mapped abort word's device address, for other bounded device-side waits (the exchange's barriers) */
+extern "C" unsigned *ramd_abort_word_dev(void) {
+  if (!g_chain_abort_host) {
+    HIP_CHECK(hipHostMalloc((void **)&g_chain_abort_host, 64, hipHostMallocMapped));
+    *g_chain_abort_host = 0;
+    HIP_CHECK(hipHostGetDevicePointer((void **)&g_chain_abort_dev, g_chain_abort_host, 0));
+  }
+  return g_chain_abort_dev;
+}
 
 extern "C" unsigned ramd_chain_abort_word(void) {
   return g_chain_abort_host ? *(volatile unsigned *)g_chain_abort_host : 0u;
@@ -1255,7 +1263,18 @@ static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
                                  XcWork *xcp) {
   HoWork hw = {};
   XcWork xc = {};
-  if (xcp) xc = *xcp;
+  /* RECUR_AMD_CHAIN_CHECK=1 -- for a GPU that is shared, where a co-tenant may take CUs in mid-run: every chain
+   * launch is followed by a synchronisation and a look at the abort word.  A launch that gave up is then not fatal:
+   * the word is reset, the one-launch chain is switched off for the process and THIS call's chain runs again a
+   * launch per step (the one-launch chain reads error plane 0 and writes planes >= 1 only: its input is intact).
+   * The extras and the control logic do not ride in a launch that may be discarded (they update per-stream state --
+   * min_error_factor, the depth statistics -- that a repeat would update twice).  Costs the host-side pipelining:
+   * ~15 us per generation.  RECUR_AMD_CHAIN_TEST_GIVEUP=n (n > 1) implies it and pretends that the n-th launch
+   * gave up (tests). */
+  const int test_giveup = env_int("RECUR_AMD_CHAIN_TEST_GIVEUP", 0);
+  const bool checked = env_int("RECUR_AMD_CHAIN_CHECK", 0) || test_giveup > 1;
+  if (xcp && !checked) xc = *xcp;
+  if (xcp && !xc.on) xcp->on = 0; /* (the caller then runs the extras as a launch of their own) */
   if (ho && !ho->done) {
     hw = *ho;
     /* the launch's workgroups without chain work, if they are at least half of it, else all 256 */
@@ -1282,6 +1301,22 @@ static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
   else CHAIN_PERSIST(1);
 #undef CHAIN_PERSIST
   timing_end(st, ev);
+  if (checked) {
+    static int checked_launches = 0;
+    HIP_CHECK(hipStreamSynchronize(st));
+    const unsigned word = *(volatile unsigned *)g_chain_abort_host;
+    if (word || ++checked_launches == test_giveup) {
+      fprintf(stderr, "librecur_amd: a one-launch BPTT chain gave up in mid-run (code %u: its 256 workgroups were no longer "
+                      "all resident, or a hand-off timed out); this call's chain runs again a launch per step, which is "
+                      "what the process uses from here on\n", word);
+      *(volatile unsigned *)g_chain_abort_host = 0;
+      HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
+      g_chain_seq = 0;
+      g_ticket_launches = 0;
+      g_chain_broken = true;
+      return false;
+    }
+  }
   if (ho && hw.dst) ho->done = 1;
   return true;
 }
@@ -1330,7 +1365,7 @@ int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const R
         if (n > left) n = left;
       }
       if (!launch_chain_persist(st, d_view, sh, b, row0 + r, n, one, real_left < n ? real_left : n, 0, ho, xc)) {
-        persist = false; /* (only a process's first launch can fail here: r == 0, nothing done yet) */
+        persist = false; /* (RECUR_AMD_CHAIN_CHECK: the launch gave up; all of the call's rows go through the steps below) */
         break;
       }
       r += n;

@@ -225,6 +225,12 @@ void ramd_launch_apply_multi(ramd_stream_t st, int method, int nseg, float *cons
                              const size_t *n, const float *rate, float momentum,
                              float momentum_weight, const float *rate_scale_dev,
                              const RamdPendingDelta *pend);
+/* the exchange step as kernel-issued peer traffic (kernels_apply.hip: k_apply_xchg, k_xchg_barrier) */
+void ramd_launch_xchg_barrier(ramd_stream_t st, unsigned *flags_dev, int rank, int world, unsigned seq,
+                              unsigned *abort_word_dev);
+void ramd_launch_apply_xchg(ramd_stream_t st, int method, int rank, int world, float *const *w,
+                            const float *const *delta, float *const *m, float *const *aux, float *const *delta_out,
+                            const size_t *n, const float *rate, float momentum, float mw);
 /* conditioning pieces (recur-nn.c:782-855) */
 void ramd_launch_scale(ramd_stream_t st, float *a, size_t n, float scale);
 void ramd_launch_zero_small(ramd_stream_t st, float *a, size_t n);
@@ -238,6 +244,7 @@ void ramd_launch_fused_updates(ramd_stream_t st, const RamdShape *sh, const Ramd
 /* non-zero once the one-launch BPTT chain has given up (its workgroups were not all
  * resident, or a poll timed out): the results of that launch are not valid */
 unsigned ramd_chain_abort_word(void);
+unsigned *ramd_abort_word_dev(void);
 /* the library has created a second stream with work that may run beside the BPTT chain: the chain then stops
  * deriving its workgroups' XCDs from their numbers (kernels_chain.hip) */
 void ramd_note_side_stream(void);

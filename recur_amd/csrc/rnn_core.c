@@ -12,6 +12,7 @@
 #include "rnn_host.h"
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
+#include <unistd.h>
 
 #define HIP_OK(x)                                                                  \
   do {                                                                             \
@@ -711,6 +712,11 @@ static void engine_ensure_device(RamdEngine *e) {
   int same_bottom = bI == e->sh.bI && bO == e->sh.bO;
   if (e->dev_ready && e->sh.Scap >= e->n_streams && e->sh.Fcap >= e->n_fwd && same_bottom) {
     return;
+  }
+  if (e->dev_ready && e->xchg_world) {
+    fprintf(stderr, "librecur_amd: the device image has to grow (a clone made after rnn_amd_set_exchange_join?) while "
+                    "other ranks hold pointers into it; leave the exchange first\n");
+    abort();
   }
   unsigned char *keep_text = NULL;
   int keep_text_len = 0;
@@ -2448,7 +2454,180 @@ static void delta_half_ready(void *ctx, int half, size_t first_float, size_t n_f
   g_halves_seen |= 1 << half;
 }
 
+/* ---- the exchange step as kernel-issued peer traffic (include/recur_amd.h; kernels_apply.hip: k_apply_xchg) ---- */
+typedef struct XchgBlob {
+  uint64_t pid;
+  uint64_t raw[3];    /* delta, ih_w, ho_w as this process sees them                        */
+  uint64_t offset[3]; /* of each inside its allocation (IPC handles name whole allocations) */
+  hipIpcMemHandle_t handle[3];
+} XchgBlob;
+
+void rnn_amd_set_exchange_export(RnnAmdSet *set, void *blob) {
+  RamdEngine *e = set->eng;
+  _Static_assert(sizeof(XchgBlob) <= RNN_AMD_EXCHANGE_BLOB_BYTES, "the blob outgrew its public size");
+  engine_need_dev(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+  deltas_materialize(e);
+  XchgBlob b;
+  memset(&b, 0, sizeof(b));
+  b.pid = (uint64_t)getpid();
+  void *arrays[3] = {e->b.ih_delta, e->b.ih_w, e->b.ho_w};
+  for (int k = 0; k < 3; k++) {
+    hipDeviceptr_t base = NULL;
+    size_t size = 0;
+    HIP_OK(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)arrays[k]));
+    b.raw[k] = (uint64_t)(uintptr_t)arrays[k];
+    b.offset[k] = (uint64_t)((char *)arrays[k] - (char *)base);
+    if (hipIpcGetMemHandle(&b.handle[k], (void *)base) != hipSuccess) {
+      (void)hipGetLastError(); /* (peers of the same process do not need it) */
+      memset(&b.handle[k], 0, sizeof(b.handle[k]));
+    }
+  }
+  memset(blob, 0, RNN_AMD_EXCHANGE_BLOB_BYTES);
+  memcpy(blob, &b, sizeof(b));
+}
+
+void rnn_amd_set_exchange_leave(RnnAmdSet *set) {
+  RamdEngine *e = set->eng;
+  if (!e->xchg_world) {
+    return;
+  }
+  dsync();
+  for (int p = 0; p < e->xchg_world; p++) {
+    for (int k = 0; k < 3; k++) {
+      if (e->xchg_opened[p][k]) {
+        (void)hipIpcCloseMemHandle(e->xchg_opened[p][k]);
+        e->xchg_opened[p][k] = NULL;
+      }
+    }
+  }
+  if (e->xchg_flags_host) {
+    (void)hipHostUnregister(e->xchg_flags_host);
+  }
+  e->xchg_flags_host = NULL;
+  e->xchg_flags_dev = NULL;
+  e->xchg_world = 0;
+}
+
+int rnn_amd_set_exchange_join(RnnAmdSet *set, int rank, int world, const void *blobs, void *counters, int lockstep) {
+  RamdEngine *e = set->eng;
+  set_need_training(set, "rnn_amd_set_exchange_join");
+  if (world < 1 || world > 8 || rank < 0 || rank >= world || !blobs || (!lockstep && !counters) || e->sh.bI ||
+      e->xchg_world || e->delta_external) {
+    fprintf(stderr, "librecur_amd: rnn_amd_set_exchange_join(rank %d, world %d): 1..8 ranks, every rank's blob, shared "
+                    "counters unless in lock step, no bottom layer, no external delta buffer, not joined already\n",
+            rank, world);
+    return -1;
+  }
+  engine_need_dev(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+  deltas_materialize(e);
+  float **dst[3] = {e->xchg_delta, e->xchg_ihw, e->xchg_how};
+  void *own[3] = {e->b.ih_delta, e->b.ih_w, e->b.ho_w};
+  memset(e->xchg_opened, 0, sizeof(e->xchg_opened));
+  for (int p = 0; p < world; p++) {
+    XchgBlob b;
+    memcpy(&b, (const char *)blobs + (size_t)p * RNN_AMD_EXCHANGE_BLOB_BYTES, sizeof(b));
+    for (int k = 0; k < 3; k++) {
+      if (p == rank) {
+        dst[k][p] = own[k];
+      } else if (b.pid == (uint64_t)getpid()) {
+        dst[k][p] = (float *)(uintptr_t)b.raw[k]; /* another set of this process */
+      } else {
+        void *base = NULL;
+        if (hipIpcOpenMemHandle(&base, b.handle[k], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+          fprintf(stderr, "librecur_amd: rank %d cannot open rank %d's arrays (%s): is there peer access between the "
+                          "two GPUs, HSA_ENABLE_IPC_MODE_LEGACY=0 set?\n", rank, p, hipGetErrorString(hipGetLastError()));
+          e->xchg_world = p + 1;
+          rnn_amd_set_exchange_leave(set);
+          return -1;
+        }
+        e->xchg_opened[p][k] = base;
+        dst[k][p] = (float *)((char *)base + b.offset[k]);
+      }
+    }
+  }
+  e->xchg_flags_dev = NULL;
+  e->xchg_flags_host = NULL;
+  if (!lockstep) {
+    if (hipHostRegister(counters, 64, hipHostRegisterMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&e->xchg_flags_dev, counters, 0) != hipSuccess) {
+      fprintf(stderr, "librecur_amd: the shared counters cannot be mapped (%s)\n", hipGetErrorString(hipGetLastError()));
+      e->xchg_world = world;
+      rnn_amd_set_exchange_leave(set);
+      return -1;
+    }
+    e->xchg_flags_host = counters;
+    ramd_note_side_stream(); /* the peers' work runs beside ours where the ranks share a GPU */
+  }
+  e->xchg_world = world;
+  e->xchg_rank = rank;
+  e->xchg_lockstep = lockstep;
+  e->xchg_seq = 0;
+  return 0;
+}
+
+void rnn_amd_set_exchange_range(const RnnAmdSet *set, int which, size_t *first, size_t *count) {
+  const RamdEngine *e = set->eng;
+  const size_t n4 = (which ? e->ho_size : e->ih_size) / 4;
+  const int world = e->xchg_world ? e->xchg_world : 1, rank = e->xchg_world ? e->xchg_rank : 0;
+  const size_t lo = n4 * (size_t)rank / world, hi = n4 * (size_t)(rank + 1) / world;
+  *first = 4 * lo;
+  *count = 4 * (hi - lo);
+}
+
+static void xchg_barrier(RamdEngine *e) {
+  if (!e->xchg_lockstep) {
+    ramd_launch_xchg_barrier(g_stream, e->xchg_flags_dev, e->xchg_rank, e->xchg_world, ++e->xchg_seq, ramd_abort_word_dev());
+  }
+}
+
+void rnn_amd_set_apply_exchange(RnnAmdSet *set, int learning_style, float momentum) {
+  RamdEngine *e = set->eng;
+  RecurNN *net = set->nets[0];
+  RecurNNBPTT *bptt = net->bptt;
+  if (!e->xchg_world) {
+    fprintf(stderr, "librecur_amd: rnn_amd_set_apply_exchange without rnn_amd_set_exchange_join\n");
+    abort();
+  }
+  engine_need_dev(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+  deltas_materialize(e);
+  float mw; /* (as apply_learning) */
+  if (learning_style == RNN_MOMENTUM_SIMPLIFIED_NESTEROV) {
+    mw = momentum / (1.0 + momentum);
+  } else if (learning_style == RNN_MOMENTUM_CLASSICAL) {
+    mw = 1.0f;
+  } else {
+    mw = bptt->momentum_weight;
+  }
+  int method = learning_style;
+  if (learning_style == RNN_MOMENTUM_SIMPLIFIED_NESTEROV || learning_style == RNN_MOMENTUM_CLASSICAL ||
+      learning_style >= RNN_LAST_LEARNING_METHOD || learning_style < 0) {
+    method = RNN_MOMENTUM_WEIGHTED;
+  }
+  check_method_arrays(e, method);
+  const int W = e->xchg_world;
+  float *w[16];
+  const float *d[16];
+  for (int p = 0; p < W; p++) { /* segment 0: the top layer, 1: the recurrent layer */
+    w[p] = e->xchg_how[p];
+    w[W + p] = e->xchg_ihw[p];
+    d[p] = e->xchg_delta[p] + e->ih_size;
+    d[W + p] = e->xchg_delta[p];
+  }
+  float *m[2] = {e->b.ho_m, e->b.ih_m}, *aux[2] = {e->b.ho_aux, e->b.ih_aux}, *dout[2] = {e->b.ho_delta, e->b.ih_delta};
+  size_t n[2] = {e->ho_size, e->ih_size};
+  float rate[2] = {bptt->learn_rate * bptt->ho_scale, bptt->learn_rate};
+  xchg_barrier(e); /* every rank's local sums are complete (and nobody still multiplies with the old weights) */
+  ramd_launch_apply_xchg(g_stream, method, e->xchg_rank, W, w, d, m, aux, dout, n, rate, momentum, mw);
+  xchg_barrier(e); /* every range of the weights has arrived here */
+  engine_dev_wrote(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+}
+
 void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float momentum) {
+  if (set->eng->xchg_world) { /* deltas -> (barrier) -> sharded update with the sum over the ranks in it -> (barrier) */
+    char_step_deltas(set, i, NULL);
+    rnn_amd_set_apply_exchange(set, learning_style, momentum);
+    return;
+  }
   /* the deltas go straight from the GEMM's K slabs into the update (and into ih_delta) when
    * nothing can look at them in between: library-owned storage, no log on the prototype */
   RamdPendingDelta pend = {0};

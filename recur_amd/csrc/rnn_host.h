@@ -75,6 +75,14 @@ typedef struct RamdEngine {
    * rnn_amd_dist_init): only then are the replicated host draws (weight noise, perforation,
    * random damage) a collective that takes rank 0's generator (ramd_shared_rng) */
   int sharded;
+  /* the exchange step as kernel-issued peer traffic (rnn_amd_set_exchange_join): every rank's delta and weight
+   * arrays as device pointers valid HERE (own ones at index xchg_rank), the shared arrival counters */
+  int xchg_world, xchg_rank, xchg_lockstep;
+  float *xchg_delta[8], *xchg_ihw[8], *xchg_how[8];
+  void *xchg_opened[8][3];   /* what hipIpcOpenMemHandle returned (to close), NULL for same-process peers */
+  unsigned *xchg_flags_dev;  /* the callers' shared host counters, mapped                                  */
+  void *xchg_flags_host;
+  unsigned xchg_seq;
 } RamdEngine;
 
 struct RnnAmdSet {

@@ -108,6 +108,149 @@ def test_two_emulated_ranks_equal_the_single_set_and_the_oracle(amd, hip, label,
     o.close()
 
 
+@pytest.mark.parametrize("world,label,kw,method", [
+    (2, "dma_path", dict(input_size=42, hidden_size=128, output_size=42, D=6, learn_rate=2e-3, seed=21), rc.WEIGHTED),
+    (4, "dma_path_4", dict(input_size=42, hidden_size=128, output_size=42, D=6, learn_rate=2e-3, seed=24), rc.NESTEROV),
+    (8, "one_launch_chain_8", dict(input_size=42, hidden_size=256, output_size=42, D=5, learn_rate=1e-3, seed=25), rc.WEIGHTED),
+    (3, "ragged_3", dict(input_size=42, hidden_size=45, output_size=42, D=7, learn_rate=5e-3, seed=23), rc.ADAGRAD),
+])
+def test_kernel_issued_exchange_with_emulated_ranks(amd, world, label, kw, method):
+    """The exchange step without a collective library (include/recur_amd.h: rnn_amd_set_exchange_*; kernels_apply.hip:
+    k_apply_xchg): every rank adds the ranks' local delta sums for ITS range of the weight arrays in rank order through
+    peer pointers, updates weights and momentum there and stores the new weights into every rank's arrays.  `world`
+    virtual ranks = `world` engines of this process in lock step (deltas on every rank, then the update on every rank):
+    after 10 generations the replicas' weights are bit-identical, they and the momentum assembled from the ranks' own
+    ranges equal the single set of all the streams and the oracle at 1e-4, the generator states are exact."""
+    S = 16 if "ragged" not in label else 3
+    steps = 10
+    text = sc.synthetic_text(6000)
+    ranks = [sc.AmdBatchedSet(amd, S=S, shard=(r * S, world * S), **kw) for r in range(world)]
+    blobs = C.create_string_buffer(rc.RNN_AMD_EXCHANGE_BLOB_BYTES * world)
+    for r, g in enumerate(ranks):
+        g.load_text(text)
+        amd.rnn_amd_set_shard(g.handle, r * S, world * S)
+        if method == rc.ADAGRAD:
+            amd.rnn_set_momentum_values(g.net, 0.1)
+        amd.rnn_amd_set_exchange_export(g.handle, C.byref(blobs, r * rc.RNN_AMD_EXCHANGE_BLOB_BYTES))
+    for r, g in enumerate(ranks):
+        assert amd.rnn_amd_set_exchange_join(g.handle, r, world, blobs, None, 1) == 0
+    single = sc.AmdBatchedSet(amd, S=world * S, **kw)
+    single.load_text(text)
+    o = sc.OracleSet(S=world * S, **kw)
+    if method == rc.ADAGRAD:
+        amd.rnn_set_momentum_values(single.net, 0.1)
+        o.arrays()["ih_m"][:] = 0.1
+        o.arrays()["ho_m"][:] = 0.1
+    for i in range(steps):
+        for g in ranks:
+            amd.rnn_amd_set_char_step_deltas(g.handle, i)
+        for g in ranks:
+            amd.rnn_amd_set_apply_exchange(g.handle, method, 0.9)
+        single.char_step(text, i, method, 0.9)
+        o.char_step(text, i, method, 0.9)
+    snaps = [g.snapshot() for g in ranks]
+    ss, so = single.snapshot(), o.snapshot()
+    for r in range(1, world):  # replicas: identical weights
+        for k in ("ih_w", "ho_w"):
+            assert np.array_equal(snaps[0][k], snaps[r][k]), (k, r)
+    # momentum and summed deltas live in each rank's own range: put them together
+    joined = {k: np.zeros_like(ss[k]).reshape(-1) for k in ("ih_m", "ho_m", "ih_delta", "ho_delta")}
+    first, count = C.c_size_t(), C.c_size_t()
+    for r, g in enumerate(ranks):
+        for which, names in ((0, ("ih_m", "ih_delta")), (1, ("ho_m", "ho_delta"))):
+            amd.rnn_amd_set_exchange_range(g.handle, which, C.byref(first), C.byref(count))
+            for k in names:
+                joined[k][first.value:first.value + count.value] = snaps[r][k].reshape(-1)[first.value:first.value + count.value]
+    got = dict(snaps[0])
+    for k in joined:
+        got[k] = joined[k].reshape(ss[k].shape)
+    for want in (ss, so):
+        replay.check(got, want, RTOL, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta"], exact=())
+        both = {k: np.concatenate([sn[k] for sn in snaps], axis=1 if k == "hist" else 0)
+                for k in ("hist", "hidden", "min_error_factor", "ih_scale", "index", "generation", "rng")}
+        replay.check(both, want, RTOL, keys=["hist", "hidden", "min_error_factor", "ih_scale"],
+                     exact=("index", "generation", "rng"))
+    for g in ranks:
+        amd.rnn_amd_set_exchange_leave(g.handle)
+        g.close()
+    single.close()
+    o.close()
+
+
+XCHG_IPC_SCRIPT = r"""
+import ctypes as C, mmap, os, sys, time, json
+sys.path.insert(0, %(tests)r)
+import numpy as np, recur_ctypes as rc, scenarios as sc
+rank, world, shm_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+B = rc.RNN_AMD_EXCHANGE_BLOB_BYTES
+fd = os.open(shm_path, os.O_RDWR)
+mm = mmap.mmap(fd, 4096)          # [0, 64): the arrival counters; [256 ...): the blobs; [3072 + r]: "blob r is there"
+amd = rc.load_amd()
+amd.rnn_amd_use_device(0, None)
+S = 16
+kw = dict(input_size=42, hidden_size=128, output_size=42, D=6, learn_rate=2e-3, seed=21)
+text = sc.synthetic_text(6000)
+g = sc.AmdBatchedSet(amd, S=S, shard=(rank * S, world * S), **kw)
+g.load_text(text)
+amd.rnn_amd_set_shard(g.handle, rank * S, world * S)
+blob = C.create_string_buffer(B)
+amd.rnn_amd_set_exchange_export(g.handle, blob)
+mm[256 + rank * B:256 + (rank + 1) * B] = blob.raw
+mm[3072 + rank] = 1
+t0 = time.time()
+while not all(mm[3072 + r] for r in range(world)):
+    assert time.time() - t0 < 120, "the other rank never exported"
+    time.sleep(0.01)
+blobs = C.create_string_buffer(bytes(mm[256:256 + world * B]), world * B)
+counters = (C.c_char * 64).from_buffer(mm, 0)
+assert amd.rnn_amd_set_exchange_join(g.handle, rank, world, blobs, counters, 0) == 0
+for i in range(8):
+    amd.rnn_amd_set_char_step(g.handle, i, rc.WEIGHTED, 0.9)
+s = g.snapshot()
+np.savez(shm_path + ".rank%%d.npz" %% rank, ih_w=s["ih_w"], ho_w=s["ho_w"])
+amd.rnn_amd_set_exchange_leave(g.handle)
+del counters
+print("RESULT ok")
+"""
+
+
+def test_kernel_issued_exchange_between_two_processes_on_one_gpu(amd, tmp_path):
+    """The same exchange between two PROCESSES that share this GPU (RCCL refuses duplicate GPUs; this exchange does not):
+    the ranks' delta and weight arrays cross the process boundary as hipIpcMemHandles inside the 256-byte blobs, the
+    arrival counters are a file in /dev/shm that both map, every generation is rnn_amd_set_char_step = deltas -> barrier
+    kernel -> k_apply_xchg -> barrier kernel.  Both replicas must end bit-identical and equal the single set of all the
+    streams at 1e-4."""
+    shm = "/dev/shm/recur_amd_xchg_%d" % os.getpid()
+    with open(shm, "wb") as f:
+        f.write(b"\0" * 4096)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    script = XCHG_IPC_SCRIPT % {"tests": os.path.dirname(os.path.abspath(__file__))}
+    try:
+        procs = [subprocess.Popen([sys.executable, "-c", script, str(r), "2", shm], stdout=subprocess.PIPE,
+                                  stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+        outs = [p.communicate(timeout=600) for p in procs]
+        for p, (so_, se_) in zip(procs, outs):
+            assert p.returncode == 0 and "RESULT ok" in so_, so_[-1500:] + se_[-3000:]
+        a, b = (np.load(shm + ".rank%d.npz" % r) for r in range(2))
+        for k in ("ih_w", "ho_w"):
+            assert np.array_equal(a[k], b[k]), k
+        kw = dict(input_size=42, hidden_size=128, output_size=42, D=6, learn_rate=2e-3, seed=21)
+        text = sc.synthetic_text(6000)
+        single = sc.AmdBatchedSet(amd, S=32, **kw)
+        single.load_text(text)
+        for i in range(8):
+            single.char_step(text, i, rc.WEIGHTED, 0.9)
+        ss = single.snapshot()
+        for k in ("ih_w", "ho_w"):
+            assert rc.rel_err(a[k], ss[k]) < RTOL and rc.max_err(a[k], ss[k]) < RTOL, k
+        single.close()
+    finally:
+        for f in (shm, shm + ".rank0.npz", shm + ".rank1.npz"):
+            if os.path.exists(f):
+                os.unlink(f)
+
+
 def test_regrow_keeps_the_text_and_the_external_delta_buffer(amd, hip):
     """A clone made after rnn_amd_set_open (a validation net, say) regrows the device image;
     the registered text and the external delta buffer must survive it."""

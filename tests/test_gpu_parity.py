@@ -81,7 +81,8 @@ def _stepwise(amd, kw, text, steps, method, depth):
         same_depth = np.allclose(sg["ih_scale"] == 1.0, so["ih_scale"] == 1.0)
         clamped = bool((so["ih_scale"] < 1.0).any())
         if same_depth:
-            replay.check(sg, so, 2e-4, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "hidden", "ih_scale",
+            # 1e-4 (north_star's bar): every array here is ONE generation deep from the oracle's own state
+            replay.check(sg, so, 1e-4, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "hidden", "ih_scale",
                                              "min_error_factor"])
             compared += 1
             compared_clamped += clamped
@@ -122,6 +123,8 @@ def test_bottom_layer_in_the_hot_regime(amd, orc, batched):
         if (not np.array_equal(sg["hidden"] != 0, so["hidden"] != 0) or not np.array_equal(sg["hist"] != 0, so["hist"] != 0)
                 or not np.array_equal(sg["ih_scale"] == 1.0, so["ih_scale"] == 1.0)):
             break
+        # 2e-4, not 1e-4: this run is NOT re-synchronised (the bottom layer's accumulator integrates over streams and
+        # generations, which is the point of the test), so every array carries the whole sequence's rounding in the hot regime
         replay.check(sg, so, 2e-4, keys=["b_delta", "b_o_error", "b_w", "b_m", "ih_delta", "ho_delta", "ih_w", "ho_w",
                                          "hidden", "ih_scale"], exact=("index", "generation"))
         compared += 1
@@ -528,6 +531,40 @@ def test_mask_flips_stay_at_the_rounding_level_rate(amd, full_set):
             assert np.abs(np.where(hg[flipped] != 0, hg[flipped], ho[flipped])).max() < 1e-5
     print("mask flips: %d of %d hidden values (%.2f per million)" % (differing, values, 1e6 * differing / values))
     assert 1e6 * differing / values <= 10.0
+    o.close()
+
+
+def test_two_hundred_generations_at_full_size_track_the_oracle(amd):
+    """Long-run behaviour AT SIZE (it was pinned only at hidden 99 through the erewhon curve, and at
+    full size one generation at a time from synchronised state): 200 generations of the north-star text step -- hidden
+    1024, 256 streams, depth 20 -- from the same cold start on the device and on the oracle, at a learn rate at which
+    the net actually learns.  The training entropy of every window of 25 generations must track the oracle's within
+    1 % (the erewhon test's bar: 200 generations amplify fp32 summation-order differences far beyond the 1e-4 of a single
+    step), the mean executed BPTT depth within 1 %, and the entropy must have fallen."""
+    kw = dict(input_size=42, hidden_size=1024, output_size=42, S=256, D=20, learn_rate=3e-4, seed=3)
+    text = sc.synthetic_text(30000)
+    g = sc.AmdBatchedSet(amd, **kw)
+    o = sc.OracleSet(fast=True, **kw)  # (the -Ofast build of the same restatement: 200 x 256 stream-steps of hidden 1024)
+    g.load_text(text)
+    win, n_gen = 25, 200
+    ent_g, ent_o, depth_g, depth_o = [], [], [], []
+    for w in range(n_gen // win):
+        z = o.z.contents
+        e0, c0, d0 = z.stat_entropy, z.stat_count, z.stat_depth
+        for i in range(w * win, (w + 1) * win):
+            g.char_step(text, i, rc.WEIGHTED, 0.9)
+            o.char_step(text, i, rc.WEIGHTED, 0.9)
+        st = g.stats(clear=True)
+        z = o.z.contents
+        ent_g.append(-st.entropy / st.count)
+        depth_g.append(st.bptt_depth_sum / st.count)
+        ent_o.append(-(z.stat_entropy - e0) / (z.stat_count - c0))
+        depth_o.append((z.stat_depth - d0) / (z.stat_count - c0))
+    print("training entropy per window  device:", np.round(ent_g, 4), " oracle:", np.round(ent_o, 4))
+    assert np.allclose(ent_g, ent_o, rtol=1e-2), (ent_g, ent_o)
+    assert np.allclose(depth_g, depth_o, rtol=1e-2), (depth_g, depth_o)
+    assert ent_g[-1] < ent_g[0] - 0.1, ent_g  # it learns
+    g.close()
     o.close()
 
 
@@ -1212,12 +1249,28 @@ print("RESULT", "ok" if not bad else "; ".join(bad))
 """
 
 
+def test_a_chain_that_gives_up_in_mid_run_is_redone_a_launch_per_step():
+    """A co-tenant that takes CUs in mid-run makes a one-launch chain give up.  With RECUR_AMD_CHAIN_CHECK=1 (implied by
+    RECUR_AMD_CHAIN_TEST_GIVEUP=n, n > 1, which pretends that the n-th launch gave up) every chain launch is checked:
+    the launcher resets the abort word, switches the kernel off for the process and runs THAT call's chain again a
+    launch per step -- the results must be the oracle's, before and after (kernels_chain.hip: launch_chain_persist)."""
+    import subprocess
+    import sys as _sys
+    script = GIVEUP_SCRIPT.replace("for i in range(4):", "for i in range(9):")
+    env = dict(os.environ, RECUR_AMD_CHAIN_TEST_GIVEUP="5")
+    r = subprocess.run([_sys.executable, "-c", script % {"tests": os.path.dirname(os.path.abspath(__file__))}],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "gave up in mid-run" in r.stderr and "launch per step" in r.stderr
+    assert [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1] == "RESULT ok"
+
+
 def test_a_chain_that_gives_up_on_its_first_launch_falls_back_for_that_call():
-    """The one-launch chain needs its 256 workgroups resident together; where they are not (a CU-masked queue, a
-    partition mode, a co-tenant) its first launch of the process raises the abort word.  The launcher then resets
-    it, stops using the kernel and runs the launch-per-step chain FOR THE SAME CALL (kernels_chain.hip:
-    g_chain_validated).  RECUR_AMD_CHAIN_TEST_GIVEUP=1 takes that branch on a healthy device: the run must say so
-    and its results must be the oracle's."""
+    """The one-launch chain needs its 256 workgroups resident together; whether the device and queue grant that (no
+    CU mask, no partition mode, no co-tenant holding CUs) is found out by a probe launch before the process's first
+    chain (kernels_chain.hip: chain_validate).  Where the probe fails the launch-per-step chain is used from the first
+    call on.  RECUR_AMD_CHAIN_TEST_GIVEUP=1 takes that branch on a healthy device: the run must say so and its
+    results must be the oracle's."""
     import subprocess
     import sys as _sys
     env = dict(os.environ, RECUR_AMD_CHAIN_TEST_GIVEUP="1")
