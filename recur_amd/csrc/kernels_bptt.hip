@@ -229,6 +229,125 @@ __global__ __launch_bounds__(1024) void k_top_backprop_ranged(View v, int row0, 
   }
 }
 
+// backprop_single_layer_sparse (recur-nn.c:156-196) for a multi-head output layer as ONE fp32 MFMA GEMM over all
+// streams: E_h[s][y] = sum_k o_error[s][k] W_ho[y][k] with K = the whole output row (3652 columns at 73 symbols x 50
+// heads), instead of k_top_backprop_ranged's per-(stream, row, range) gathers (93 us, 480 MB of W_ho columns at
+// 256 streams).  What makes that legitimate for the multi-head loss and for nothing else (launcher flag
+// RAMD_RANGES_ARE_HEADS): the loss has cleared the error row outside the trained heads, so the columns between a
+// stream's ranges contribute exact zeros, and its ranges -- runs of whole heads of >= 24 columns -- lie >= 16 columns
+// apart.  The reference's error sum is NOT sum |e|: it adds |running value| after every range (recur-nn.c:178-191),
+// so the running values at the range ends are needed, per (stream, row).  K therefore runs IN ORDER inside one
+// accumulator chain per element (no split over waves or workgroups), in blocks of 16 columns, and after a block in
+// which a stream's range ends -- the zeros up to the block boundary change nothing -- the lanes that hold that
+// stream's rows add |accumulator| to their sums (a 32-bit mask per block says which streams: built in LDS from the
+// range lists).  Workgroup = 4 waves = 32 streams x 32 rows, each wave a 16 x 16 tile (v_mfma_f32_16x16x4_f32: lane
+// (m, kq) brings o_error[s0 + m][16 b + 4 kq ..] and W_ho[y0 + m][same] as one float4 each per block, four MFMAs);
+// 264 workgroups at 256 streams, all resident.  Rows whose hidden value is zero keep the stale entry of the last
+// BPTT run and add nothing; the unscaled values go to error plane 0 and the per-tile sums to
+// `part` for k_top_backprop_scale, as with k_top_backprop_ranged's shared-out form.
+constexpr int TBH_PF = 16; /* K blocks in flight per wave: a block is 128 matrix-pipe cycles, a load 1-2 us away */
+__global__ __launch_bounds__(256) void k_top_backprop_heads(View v, int row0, int nrows, const int *ranges,
+                                                            int range_stride, const unsigned char *active, float *part,
+                                                            int nb, int tm) {
+  extern __shared__ unsigned endmask[]; /* [KB] bit s: stream s0 + s has a range ending in this block */
+  const RamdShape &s = v.sh;
+  const int KB = (s.O + 15) / 16;
+  const int mt = blockIdx.x % tm, nt = blockIdx.x / tm;
+  const int s0 = mt * 32, y0 = nt * 32;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1, m = lane & 15, kq = lane >> 4;
+  for (int kb = tid; kb < KB; kb += 256) endmask[kb] = 0u;
+  __syncthreads();
+  if (tid < 32 && s0 + tid < nrows) {
+    const int *rg = ranges + (size_t)(s0 + tid) * range_stride;
+    for (int i = 0; i < 64 && rg[2 * i] >= 0; i++) {
+      const int end = (rg[2 * i] & ~3) + ((rg[2 * i + 1] + 3) & ~3);
+      int kbe = (end + 15) / 16 - 1;
+      kbe = kbe < 0 ? 0 : kbe >= KB ? KB - 1 : kbe;
+      atomicOr(&endmask[kbe], 1u << tid);
+    }
+  }
+  __syncthreads();
+  const int sa = min(s0 + 16 * wr + m, nrows - 1), yb = min(y0 + 16 * wc + m, s.H - 1);
+  const float *arow = v.b.o_error + (size_t)(row0 + sa) * s.O + 4 * kq;
+  const float *brow = v.b.ho_w + (size_t)yb * s.O + 4 * kq;
+  const int last = s.O - 4 - 4 * kq; /* the last float4 of a row that this lane may read */
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float sabs[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 a[TBH_PF], b[TBH_PF];
+  const int KBF = s.O / 16; /* whole blocks: their loads are unconditional and nothing selects on what they bring (hipcc
+                             * would wait for a load right behind it if a select consumed it there) */
+  const unsigned msh = 16u * (unsigned)wr + 4u * (unsigned)kq; /* this lane's four streams: bits msh .. msh + 3 */
+  auto block = [&](const float4 av, const float4 bv, const int kb) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+    const unsigned em = (endmask[kb] >> (16u * (unsigned)wr)) & 0xffffu;
+    if (em) { /* a range of one of this wave's streams ends here: |running value| joins its sum */
+      const unsigned mine = (endmask[kb] >> msh) & 15u;
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if ((mine >> r) & 1u) sabs[r] += fabsf(acc[r]);
+    }
+  };
+  if (KBF > 0) {
+#pragma unroll
+    for (int p = 0; p < TBH_PF; p++) {
+      const int kb = p < KBF ? p : KBF - 1;
+      a[p] = ld4(arow + 16 * kb);
+      b[p] = ld4(brow + 16 * kb);
+    }
+    for (int kb0 = 0; kb0 < KBF; kb0 += TBH_PF) {
+#pragma unroll
+      for (int p = 0; p < TBH_PF; p++) {
+        const int kb = kb0 + p;
+        if (kb < KBF) { /* (wave-uniform) */
+          const float4 av = a[p], bv = b[p];
+          const int nxt = kb + TBH_PF < KBF ? kb + TBH_PF : KBF - 1;
+          a[p] = ld4(arow + 16 * nxt);
+          b[p] = ld4(brow + 16 * nxt);
+          block(av, bv, kb);
+        }
+      }
+    }
+  }
+  if (KBF < KB) { /* the row's last columns: a partial block, zeros beyond the row */
+    const int k = 16 * KBF;
+    const bool in = k <= last;
+    const float4 x = ld4(arow + (in ? k : 0)), w = ld4(brow + (in ? k : 0));
+    block(in ? x : zero4(), in ? w : zero4(), KBF);
+  }
+  // accumulator register r: stream 4 kq + r of the wave's sixteen, row (column of the tile) m
+  const int y = y0 + 16 * wc + m;
+  float psum[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int sj = s0 + 16 * wr + 4 * kq + r; /* within the call's rows */
+    const bool valid = sj < nrows && y < s.H && !(active && !active[sj < nrows ? sj : 0]);
+    const size_t rr = (size_t)(row0 + (sj < nrows ? sj : 0));
+    const float hv = v.b.hidden[rr * s.H + (y < s.H ? y : 0)];
+    const bool act = valid && y > 0 && hv != 0.0f;
+    if (valid) {
+      const float stale = v.b.err_a[rr * s.I + y];
+      const float val = (y == 0) ? 0.0f : act ? acc[r] : stale;
+      v.b.ehi[rr * s.I + y] = (y == 0 || y > s.hidden_size) ? 0.0f : val;
+    }
+    psum[r] = act ? sabs[r] : 0.0f;
+  }
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+    for (int r = 0; r < 4; r++) psum[r] += __shfl_xor(psum[r], off, 64);
+  if (m == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int sj = s0 + 16 * wr + 4 * kq + r;
+      if (sj < nrows) part[(size_t)sj * nb + 2 * nt + wc] = psum[r];
+    }
+  }
+}
+
 /* the end of backprop_single_layer_sparse + the soft clip (recur-nn.c:719-721) for streams whose
  * rows were shared out over nb workgroups: the partial sums in order, the scale, the row */
 __global__ __launch_bounds__(256) void k_top_backprop_scale(View v, int row0, const unsigned char *active,
@@ -1057,7 +1176,14 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   // top layer
   size_t shm = (size_t)(sh->O + sh->H) * sizeof(float);
   if (!(flags & 0x40000000u)) { /* ramd_launch_text_top has already done the top backprop */
-    if (ranges && env_int("RECUR_AMD_TOP_RANGED", 1)) {
+    if (ranges && range_stride && (flags & RAMD_RANGES_ARE_HEADS) && sh->O % 4 == 0 && sh->O >= 64 &&
+        (size_t)nrows * 2 * ((sh->H + 31) / 32) <= b->slab_floats && env_int("RECUR_AMD_TOP_HEADS", 1)) {
+      /* the multi-head loss's ranges: one GEMM over all streams (k_top_backprop_heads), then the sums and the clip */
+      const int tm = (nrows + 31) / 32, tn = (sh->H + 31) / 32, nb = 2 * tn;
+      RAMD_LAUNCH(k_top_backprop_heads, dim3(tm * tn), dim3(256), (size_t)((sh->O + 15) / 16) * sizeof(unsigned), st, v,
+                  row0, nrows, ranges, range_stride, active, b->slab, nb, tm);
+      RAMD_LAUNCH(k_top_backprop_scale, dim3(nrows), dim3(256), 0, st, v, row0, active, b->slab, nb);
+    } else if (ranges && env_int("RECUR_AMD_TOP_RANGED", 1)) {
       /* up to 16 workgroups per stream (their partial sums sit in the split-K workspace, which
        * nothing uses at this point) */
       /* (measured: 256 streams with 1 / 2 / 4 / 8 / 16 workgroups per stream = 552 / 548 / 538 /

@@ -146,6 +146,9 @@ int ramd_launch_forward_hidden(ramd_stream_t st, const RamdShape *sh, const Ramd
  * ramd_launch_calc_deltas do); follow with ramd_launch_calc_deltas(flags | RAMD_TOP_DONE).
  * ramd_text_top_ok says whether the shape allows it. */
 #define RAMD_TOP_DONE 0x40000000u
+/* flag of ramd_launch_calc_deltas: the per-stream range lists are the multi-head loss's (runs of whole heads of at
+ * least 24 columns, the error row zero outside them): the top backprop may run as one GEMM (k_top_backprop_heads) */
+#define RAMD_RANGES_ARE_HEADS 0x10000000u
 int ramd_text_top_ok(const RamdShape *sh);
 int ramd_launch_forward_fused(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0,
                               int nrows, int mode, int text_i, int global_first, int n_set);

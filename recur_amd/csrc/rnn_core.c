@@ -2275,6 +2275,7 @@ static void noise_speculate(RnnAmdSet *set) {
 static void multi_loss(RnnAmdSet *set, const int *target_class, int alphabet_len, int n_classes,
                        float leakage) {
   RamdEngine *e = set->eng;
+  e->mheads_alen = alphabet_len;
   e->rng_version++; /* the leak decisions are draws from the streams' generators */
   if (target_class) {
     upload(e->d_mclass + set->row0, target_class, set->n * sizeof(int));
@@ -2297,7 +2298,8 @@ void rnn_amd_set_multi_calc_deltas(RnnAmdSet *set, int accumulate) {
     fprintf(stderr, "librecur_amd: rnn_amd_set_multi_calc_deltas before any multi-head loss\n");
     abort();
   }
-  set_calc_deltas(set, accumulate, NULL, NULL, 0,
+  /* (heads of at least 24 columns: a stream's ranges then lie at least 16 columns apart, see k_top_backprop_heads) */
+  set_calc_deltas(set, accumulate, NULL, NULL, e->mheads_alen >= 24 ? RAMD_RANGES_ARE_HEADS : 0,
                   e->d_mranges + (size_t)set->row0 * MULTI_RANGE_STRIDE, MULTI_RANGE_STRIDE, NULL);
 }
 

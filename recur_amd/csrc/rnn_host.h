@@ -75,6 +75,7 @@ typedef struct RamdEngine {
    * rnn_amd_dist_init): only then are the replicated host draws (weight noise, perforation,
    * random damage) a collective that takes rank 0's generator (ramd_shared_rng) */
   int sharded;
+  int mheads_alen; /* symbols per head of the last multi-head loss (0: none yet) */
   /* the exchange step as kernel-issued peer traffic (rnn_amd_set_exchange_join): every rank's delta and weight
    * arrays as device pointers valid HERE (own ones at index xchg_rank), the shared arrival counters */
   int xchg_world, xchg_rank, xchg_lockstep;

@@ -537,12 +537,14 @@ def test_mask_flips_stay_at_the_rounding_level_rate(amd, full_set):
 def test_two_hundred_generations_at_full_size_track_the_oracle(amd):
     """Long-run behaviour AT SIZE (it was pinned only at hidden 99 through the erewhon curve, and at
     full size one generation at a time from synchronised state): 200 generations of the north-star text step -- hidden
-    1024, 256 streams, depth 20 -- from the same cold start on the device and on the oracle, at a learn rate at which
-    the net actually learns.  The training entropy of every window of 25 generations must track the oracle's within
-    1 % (the erewhon test's bar: 200 generations amplify fp32 summation-order differences far beyond the 1e-4 of a single
-    step), the mean executed BPTT depth within 1 %, and the entropy must have fallen."""
-    kw = dict(input_size=42, hidden_size=1024, output_size=42, S=256, D=20, learn_rate=3e-4, seed=3)
-    text = sc.synthetic_text(30000)
+    1024, 256 streams, depth 20 -- on erewhon.txt (the synthetic symbol stream is uniform noise: nothing to learn) from
+    the same cold start on the device and on the oracle, at a learn rate at which the net learns without blowing up
+    (the deltas of 256 streams are summed: at 3e-6 and above the reference itself diverges within 150 generations).
+    The training entropy of every window of 25 generations must track the oracle's within 1 % (the erewhon test's bar:
+    200 generations amplify fp32 summation-order differences far beyond the 1e-4 of a single step), the mean executed
+    BPTT depth within 1 %, and the entropy must have fallen."""
+    kw = dict(input_size=42, hidden_size=1024, output_size=42, S=256, D=20, learn_rate=1e-6, seed=3)
+    text = rc.encode_erewhon(amd)
     g = sc.AmdBatchedSet(amd, **kw)
     o = sc.OracleSet(fast=True, **kw)  # (the -Ofast build of the same restatement: 200 x 256 stream-steps of hidden 1024)
     g.load_text(text)
@@ -563,7 +565,7 @@ def test_two_hundred_generations_at_full_size_track_the_oracle(amd):
     print("training entropy per window  device:", np.round(ent_g, 4), " oracle:", np.round(ent_o, 4))
     assert np.allclose(ent_g, ent_o, rtol=1e-2), (ent_g, ent_o)
     assert np.allclose(depth_g, depth_o, rtol=1e-2), (depth_g, depth_o)
-    assert ent_g[-1] < ent_g[0] - 0.1, ent_g  # it learns
+    assert min(ent_g[-2:]) < ent_g[0] - 0.3, ent_g  # it learns
     g.close()
     o.close()
 
