@@ -240,23 +240,58 @@ __global__ __launch_bounds__(1024) void k_top_backprop_ranged(View v, int row0, 
 // accumulator chain per element (no split over waves or workgroups), in blocks of 16 columns, and after a block in
 // which a stream's range ends -- the zeros up to the block boundary change nothing -- the lanes that hold that
 // stream's rows add |accumulator| to their sums (a 32-bit mask per block says which streams: built in LDS from the
-// range lists).  Workgroup = 4 waves = 32 streams x 32 rows, each wave a 16 x 16 tile (v_mfma_f32_16x16x4_f32: lane
-// (m, kq) brings o_error[s0 + m][16 b + 4 kq ..] and W_ho[y0 + m][same] as one float4 each per block, four MFMAs);
-// 264 workgroups at 256 streams, all resident.  Rows whose hidden value is zero keep the stale entry of the last
+// range lists).  Workgroup = 32 streams x 32 rows: four multiplying waves with a 16 x 16 tile each
+// (v_mfma_f32_16x16x4_f32) and four loader waves that stage both operands through an LDS ring in k_chain_main's
+// manner, 64 columns at a time (as direct per-wave loads every wave fetched its own 16 + 16 rows: 87 us, bound by
+// the traffic out of the L2); 264 workgroups at 256 streams, two per CU.  Rows whose hidden value is zero keep the stale entry of the last
 // BPTT run and add nothing; the unscaled values go to error plane 0 and the per-tile sums to
 // `part` for k_top_backprop_scale, as with k_top_backprop_ranged's shared-out form.
-constexpr int TBH_PF = 16; /* K blocks in flight per wave: a block is 128 matrix-pipe cycles, a load 1-2 us away */
-__global__ __launch_bounds__(256) void k_top_backprop_heads(View v, int row0, int nrows, const int *ranges,
-                                                            int range_stride, const unsigned char *active, float *part,
-                                                            int nb, int tm) {
+constexpr int TBH_K = 64, TBH_STAGES = 4;              /* columns per stage, stages of the ring: 64 KB, two workgroups per CU */
+constexpr int TBH_STAGE_FLOATS = (32 + 32) * TBH_K;     /* 16 KB */
+__global__ __launch_bounds__(512, 2) void k_top_backprop_heads(View v, int row0, int nrows, const int *ranges,
+                                                               int range_stride, const unsigned char *active, float *part,
+                                                               int nb, int tm) {
+  __shared__ __attribute__((aligned(16))) float smem[TBH_STAGES * TBH_STAGE_FLOATS];
   extern __shared__ unsigned endmask[]; /* [KB] bit s: stream s0 + s has a range ending in this block */
   const RamdShape &s = v.sh;
-  const int KB = (s.O + 15) / 16;
+  const int KB = (s.O + 15) / 16, nstages = (s.O + TBH_K - 1) / TBH_K;
   const int mt = blockIdx.x % tm, nt = blockIdx.x / tm;
   const int s0 = mt * 32, y0 = nt * 32;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave8 = tid >> 6, lane = tid & 63;
+  const bool loader = wave8 >= 4;
+  const int wave = wave8 & 3;
   const int wr = wave >> 1, wc = wave & 1, m = lane & 15, kq = lane >> 4;
-  for (int kb = tid; kb < KB; kb += 256) endmask[kb] = 0u;
+  // --- loader waves: both operands are K-contiguous rows (32 error rows, 32 rows of W_ho), staged 64 columns at a
+  // time by LDS-DMA the way k_chain_main stages its operands (kernels_chain.hip): instruction i of a stage fills rows
+  // 4 i .. 4 i + 3 of A (i < 8) or of B, the 16-byte chunk c of row r at position c ^ (r & 15) (conflict-free
+  // ds_read_b128 of sixteen rows at once); four instructions per loader wave and stage
+  const float *src[4];
+  int kcol[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i = wave * 4 + j;
+    const int row = 4 * (i & 7) + (lane >> 4);
+    const int c = (lane & 15) ^ (row & 15);
+    const float *base = (i < 8) ? v.b.o_error + (size_t)(row0 + min(s0 + row, nrows - 1)) * s.O
+                                : v.b.ho_w + (size_t)min(y0 + row, s.H - 1) * s.O;
+    src[j] = base + 4 * c;
+    kcol[j] = 4 * c;
+  }
+  auto issue = [&](int stage) {
+    float *dst = smem + (stage % TBH_STAGES) * TBH_STAGE_FLOATS + wave * 4 * 256;
+    const int k0 = stage * TBH_K;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { /* chunks past the row's end come from a zero line */
+      const float *g = (k0 + kcol[j] + 4 <= s.O) ? src[j] + k0 : v.b.zeros;
+      __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(dst + j * 256), 16, 0, 0);
+    }
+  };
+  if (loader) {
+#pragma unroll
+    for (int p = 0; p < TBH_STAGES - 1; p++)
+      if (p < nstages) issue(p);
+  }
+  for (int kb = tid; kb < KB; kb += 512) endmask[kb] = 0u;
   __syncthreads();
   if (tid < 32 && s0 + tid < nrows) {
     const int *rg = ranges + (size_t)(s0 + tid) * range_stride;
@@ -268,55 +303,54 @@ __global__ __launch_bounds__(256) void k_top_backprop_heads(View v, int row0, in
     }
   }
   __syncthreads();
-  const int sa = min(s0 + 16 * wr + m, nrows - 1), yb = min(y0 + 16 * wc + m, s.H - 1);
-  const float *arow = v.b.o_error + (size_t)(row0 + sa) * s.O + 4 * kq;
-  const float *brow = v.b.ho_w + (size_t)yb * s.O + 4 * kq;
-  const int last = s.O - 4 - 4 * kq; /* the last float4 of a row that this lane may read */
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float sabs[4] = {0.f, 0.f, 0.f, 0.f};
-  float4 a[TBH_PF], b[TBH_PF];
-  const int KBF = s.O / 16; /* whole blocks: their loads are unconditional and nothing selects on what they bring (hipcc
-                             * would wait for a load right behind it if a select consumed it there) */
+  if (loader) {
+    for (int st = 0; st < nstages; st++) {
+      const int ahead = min(TBH_STAGES - 2, nstages - 1 - st); /* stages that may stay in flight: 4 DMAs each */
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); /* stage st has landed; stage st - 1's buffer is free */
+      if (st + TBH_STAGES - 1 < nstages) issue(st + TBH_STAGES - 1);
+    }
+    return;
+  }
   const unsigned msh = 16u * (unsigned)wr + 4u * (unsigned)kq; /* this lane's four streams: bits msh .. msh + 3 */
-  auto block = [&](const float4 av, const float4 bv, const int kb) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
-    const unsigned em = (endmask[kb] >> (16u * (unsigned)wr)) & 0xffffu;
-    if (em) { /* a range of one of this wave's streams ends here: |running value| joins its sum */
-      const unsigned mine = (endmask[kb] >> msh) & 15u;
+  const uint32_t lds0 = lds_byte_addr(smem);
+  const uint32_t a_off = (uint32_t)(16 * wr + m) * (TBH_K * 4u);
+  const uint32_t b_off = (uint32_t)(32 * TBH_K) * 4u + (uint32_t)(16 * wc + m) * (TBH_K * 4u);
+  for (int st = 0; st < nstages; st++) {
+    __builtin_amdgcn_s_barrier(); /* stage st has landed */
+    const uint32_t base = lds0 + (uint32_t)((st % TBH_STAGES) * TBH_STAGE_FLOATS) * 4u;
+    f32x4 a[4], b[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++)
-        if ((mine >> r) & 1u) sabs[r] += fabsf(acc[r]);
+    for (int u = 0; u < 4; u++) {
+      const uint32_t pos = (uint32_t)(((4 * u + kq) ^ m) * 16);
+      a[u] = lds_read_b128(base + a_off + pos);
+      b[u] = lds_read_b128(base + b_off + pos);
     }
-  };
-  if (KBF > 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 :
+                 : "memory");
 #pragma unroll
-    for (int p = 0; p < TBH_PF; p++) {
-      const int kb = p < KBF ? p : KBF - 1;
-      a[p] = ld4(arow + 16 * kb);
-      b[p] = ld4(brow + 16 * kb);
-    }
-    for (int kb0 = 0; kb0 < KBF; kb0 += TBH_PF) {
+    for (int u = 0; u < 4; u++) {
+      const int kb = 4 * st + u;
+      if (kb < KB) { /* (wave-uniform) */
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc, 0, 0, 0);
+        const unsigned em = (endmask[kb] >> (16u * (unsigned)wr)) & 0xffffu;
+        if (em) { /* a range of one of this wave's streams ends here: |running value| joins its sum */
+          const unsigned mine = (endmask[kb] >> msh) & 15u;
 #pragma unroll
-      for (int p = 0; p < TBH_PF; p++) {
-        const int kb = kb0 + p;
-        if (kb < KBF) { /* (wave-uniform) */
-          const float4 av = a[p], bv = b[p];
-          const int nxt = kb + TBH_PF < KBF ? kb + TBH_PF : KBF - 1;
-          a[p] = ld4(arow + 16 * nxt);
-          b[p] = ld4(brow + 16 * nxt);
-          block(av, bv, kb);
+          for (int r = 0; r < 4; r++)
+            if ((mine >> r) & 1u) sabs[r] += fabsf(acc[r]);
         }
       }
     }
-  }
-  if (KBF < KB) { /* the row's last columns: a partial block, zeros beyond the row */
-    const int k = 16 * KBF;
-    const bool in = k <= last;
-    const float4 x = ld4(arow + (in ? k : 0)), w = ld4(brow + (in ? k : 0));
-    block(in ? x : zero4(), in ? w : zero4(), KBF);
   }
   // accumulator register r: stream 4 kq + r of the wave's sixteen, row (column of the tile) m
   const int y = y0 + 16 * wc + m;
@@ -1180,7 +1214,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
         (size_t)nrows * 2 * ((sh->H + 31) / 32) <= b->slab_floats && env_int("RECUR_AMD_TOP_HEADS", 1)) {
       /* the multi-head loss's ranges: one GEMM over all streams (k_top_backprop_heads), then the sums and the clip */
       const int tm = (nrows + 31) / 32, tn = (sh->H + 31) / 32, nb = 2 * tn;
-      RAMD_LAUNCH(k_top_backprop_heads, dim3(tm * tn), dim3(256), (size_t)((sh->O + 15) / 16) * sizeof(unsigned), st, v,
+      RAMD_LAUNCH(k_top_backprop_heads, dim3(tm * tn), dim3(512), (size_t)((sh->O + 15) / 16) * sizeof(unsigned), st, v,
                   row0, nrows, ranges, range_stride, active, b->slab, nb, tm);
       RAMD_LAUNCH(k_top_backprop_scale, dim3(nrows), dim3(256), 0, st, v, row0, active, b->slab, nb);
     } else if (ranges && env_int("RECUR_AMD_TOP_RANGED", 1)) {
