@@ -550,7 +550,10 @@ def main():
     if roofline is not None:
         out["roofline"] = roofline
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base = cpu_one_core(rc, sc, gpu, text, i, args.cpu_seconds)
+        sys.path.insert(0, TESTS)  # the checker's loaders (compiled reference, oracle): this leg only
+        import recur_ctypes as checker_rc
+        import scenarios as checker_sc
+        base = cpu_one_core(checker_rc, checker_sc, gpu, text, i, args.cpu_seconds)
         # The all-core leg comes LAST and in a child process: run before the GPU legs, its half
         # minute of load on every host core left the GPU measurably slower for the timed region
         # that followed (chain kernel 133.8 against 127.8 us, 879 k against 900 k stream-timesteps/s,

@@ -313,7 +313,7 @@ __device__ __forceinline__ void extras_control_stream(const View &v, int r, int 
 // wave 0, the control logic's inputs.  A handful of registers held across the chain.
 constexpr int XT_B = 3, XT_BL = 2; /* items per batch of an early wave; items of a late wave (see extras_control_tail) */
 struct TailPre {
-  float xi[XT_B];
+  float xi[XT_B][2]; /* [item][columns lane, lane + 64] */
   ControlIn ci;
 };
 /* the first item, the stride and the end of wave `wave`'s items (NW waves, the upper half late) */
@@ -338,20 +338,21 @@ __device__ __forceinline__ TailPre extras_tail_prefetch(const View &v, int r, in
   TailPre p;
   p.ci = ControlIn{0.0f, 0.0f, 1.0f, 0.0, true};
   if (wave == 0) p.ci = bptt_control_load(v, r, j, active);
-  const int xcol = (lane == 0 || lane >= nx) ? 0 : s.hidden_size + lane;
-  const unsigned xmask = lane < nx ? 0xffffffffu : 0u;
+  const int xcol[2] = {(lane == 0 || lane >= nx) ? 0 : s.hidden_size + lane, lane + 64 < nx ? s.hidden_size + lane + 64 : 0};
+  const unsigned xmask[2] = {lane < nx ? 0xffffffffu : 0u, lane + 64 < nx ? 0xffffffffu : 0u};
   int t0, stride, t_end;
   tail_items(wave, NW, D, t0, stride, t_end);
 #pragma unroll
   for (int b = 0; b < XT_B; b++) {
     const int t = t0 + stride * b;
-    const float xv = as_global(input_row<true>(v, r, t < D ? t : D - 1))[xcol];
-    p.xi[b] = __uint_as_float(__float_as_uint(xv) & xmask);
+    const auto *x = as_global(input_row<true>(v, r, t < D ? t : D - 1));
+#pragma unroll
+    for (int h = 0; h < 2; h++) p.xi[b][h] = __uint_as_float(__float_as_uint(x[xcol[h]]) & xmask[h]);
   }
   return p;
 }
 
-// The same for the tail of the one-launch chain (tn == 0, nx <= 64, THREADS threads that all call it), written
+// The same for the tail of the one-launch chain (tn == 0, nx <= 128, THREADS threads that all call it), written
 // for latency: behind the chain every error row is in the XCD's L2 and the tail is a handful of dependent
 // round trips, so a wave requests EVERYTHING its items need before it computes anything -- the input values
 // of all its items first (they name the weight rows), the error rows (past the L1: other CUs wrote them
@@ -380,8 +381,9 @@ __device__ __forceinline__ void extras_control_tail(const View &v, int r, int j,
   if (pre) ci = pre->ci;
   else if (wave == 0) ci = bptt_control_load(v, r, j, active);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)v.b.ehi, 0, 0x7fffffff, 0x00020000);
-  const int xcol = (lane == 0 || lane >= nx) ? 0 : s.hidden_size + lane; /* column 0, then the input columns */
-  const unsigned xmask = lane < nx ? 0xffffffffu : 0u;
+  /* column 0, then the input columns: a lane looks after columns lane and lane + 64 (nx <= 128) */
+  const int xcol[2] = {(lane == 0 || lane >= nx) ? 0 : s.hidden_size + lane, lane + 64 < nx ? s.hidden_size + lane + 64 : 0};
+  const unsigned xmask[2] = {lane < nx ? 0xffffffffu : 0u, lane + 64 < nx ? 0xffffffffu : 0u};
   unsigned koff[MAXQ]; /* byte offset of this lane's chunk i within a row (clamped) */
   float km[MAXQ];      /* 1 where the chunk is part of the row, else 0 */
 #pragma unroll
@@ -405,19 +407,21 @@ __device__ __forceinline__ void extras_control_tail(const View &v, int r, int j,
   XC_STAMP(3);
   constexpr int NE = NW / 2; /* early waves */
   /* items tb, tb + t_stride, ... (BB of them, those below t_end) */
-  auto batch = [&](auto BC, const int tb, const int t_stride, const int t_end, const float *xpre) {
+  auto batch = [&](auto BC, const int tb, const int t_stride, const int t_end, const float (*xpre)[2]) {
     constexpr int BB = decltype(BC)::value;
-    float xi[BB];
+    float xi[BB][2];
     float4 ev[BB][MAXQ], wh[BB][MAXQ], w0[MAXQ];
     // 1. the input values
 #pragma unroll
     for (int b = 0; b < BB; b++) {
       if (xpre) { /* (uniform) */
-        xi[b] = xpre[b];
+        xi[b][0] = xpre[b][0];
+        xi[b][1] = xpre[b][1];
       } else {
         const int t = tb + t_stride * b;
-        const float xv = as_global(input_row<true>(v, r, t < D ? t : D - 1))[xcol]; /* (the one-launch chain: one ring position) */
-        xi[b] = __uint_as_float(__float_as_uint(xv) & xmask);
+        const auto *x = as_global(input_row<true>(v, r, t < D ? t : D - 1)); /* (the one-launch chain: one ring position) */
+#pragma unroll
+        for (int h = 0; h < 2; h++) xi[b][h] = __uint_as_float(__float_as_uint(x[xcol[h]]) & xmask[h]);
       }
     }
     // 2. the bias row of W and the error rows
@@ -430,14 +434,15 @@ __device__ __forceinline__ void extras_control_tail(const View &v, int r, int j,
     }
     XC_STAMP(5);
     // 3. each item's first live input row (a one-hot stream has exactly one beside the bias)
-    unsigned long long live[BB];
+    unsigned long long live[BB][2]; /* columns 0 .. 63, 64 .. 127 */
     int l1[BB];
+    auto value_of = [&](const float (&x)[2], int col) { return __shfl(col < 64 ? x[0] : x[1], col & 63, 64); };
 #pragma unroll
     for (int b = 0; b < BB; b++) {
-      const bool on = xi[b] != 0.0f && (s.activation != 5 || xi[b] < 20.0f);
-      live[b] = __ballot(on);
-      const unsigned long long rest = live[b] & ~1ull;
-      l1[b] = rest ? __ffsll((long long)rest) - 1 : -1;
+#pragma unroll
+      for (int h = 0; h < 2; h++) live[b][h] = __ballot(xi[b][h] != 0.0f && (s.activation != 5 || xi[b][h] < 20.0f));
+      const unsigned long long rest = live[b][0] & ~1ull;
+      l1[b] = rest ? __ffsll((long long)rest) - 1 : live[b][1] ? 64 + __ffsll((long long)live[b][1]) - 1 : -1;
       const char *wr = reinterpret_cast<const char *>(v.b.ih_w + (size_t)(l1[b] >= 0 ? s.hidden_size + l1[b] : 0) * s.H);
 #pragma unroll
       for (int i = 0; i < MAXQ; i++) wh[b][i] = ld4g(wr + koff[i]);
@@ -470,26 +475,38 @@ __device__ __forceinline__ void extras_control_tail(const View &v, int r, int j,
       const int t = tb + t_stride * b;
       if (t >= t_end) continue;
       if (lane == 0) hs_sh[t] = hs[b];
-      const bool has0 = (live[b] & 1ull) != 0;
+      const bool has0 = (live[b][0] & 1ull) != 0;
       float e0 = has0 ? a0[b] : 0.0f, e1 = l1[b] >= 0 ? a1[b] : 0.0f;
       if (s.activation == 2) {
-        e0 /= 2 * (__shfl(xi[b], 0, 64) + 1.0f);
-        e1 /= 2 * (__shfl(xi[b], l1[b] >= 0 ? l1[b] : 0, 64) + 1.0f);
+        e0 /= 2 * (value_of(xi[b], 0) + 1.0f);
+        e1 /= 2 * (value_of(xi[b], l1[b] >= 0 ? l1[b] : 0) + 1.0f);
       }
       auto *dst = as_global(v.b.ex + ((size_t)(t + 1) * s.Scap + r) * nxp);
       if (lane < nx) dst[lane] = (lane == 0 && has0) ? e0 : (lane == l1[b]) ? e1 : 0.0f;
+      if (lane + 64 < nx) dst[lane + 64] = (lane + 64 == l1[b]) ? e1 : 0.0f;
       float sq = 0.0f;
       if (has0) sq += e0 * e0;
       if (l1[b] >= 0) sq += e1 * e1;
       // further live columns (dense inputs): two at a time, as extras_compute does
-      unsigned long long more = live[b] & ~1ull;
-      more &= more - 1;
-      while (more) {
-        const int la = __ffsll((long long)more) - 1;
-        more &= more - 1;
-        const int lb = more ? __ffsll((long long)more) - 1 : -1;
-        if (lb >= 0) more &= more - 1;
-        const float xa = __shfl(xi[b], la, 64), xb = __shfl(xi[b], lb >= 0 ? lb : la, 64);
+      unsigned long long more[2] = {live[b][0] & ~1ull, live[b][1]};
+      auto pop = [&]() { /* the lowest live column left, or -1 */
+        if (more[0]) {
+          const int c = __ffsll((long long)more[0]) - 1;
+          more[0] &= more[0] - 1;
+          return c;
+        }
+        if (more[1]) {
+          const int c = 64 + __ffsll((long long)more[1]) - 1;
+          more[1] &= more[1] - 1;
+          return c;
+        }
+        return -1;
+      };
+      (void)pop(); /* l1: done above */
+      while (more[0] | more[1]) {
+        const int la = pop();
+        const int lb = pop();
+        const float xa = value_of(xi[b], la), xb = value_of(xi[b], lb >= 0 ? lb : la);
         const char *wa = reinterpret_cast<const char *>(v.b.ih_w + (size_t)(s.hidden_size + la) * s.H);
         const char *wb = reinterpret_cast<const char *>(v.b.ih_w + (size_t)(s.hidden_size + (lb >= 0 ? lb : la)) * s.H);
         float acca = 0.0f, accb = 0.0f;
@@ -522,14 +539,14 @@ __device__ __forceinline__ void extras_control_tail(const View &v, int r, int j,
   const int first_late = D > NE * BL ? D - NE * BL : 0;
   if (wave < NE) {
     for (int tb = wave; tb < first_late; tb += NE * B)
-      batch(std::integral_constant<int, B>{}, tb, NE, first_late, (pre && tb == wave) ? pre->xi : nullptr);
+      batch(std::integral_constant<int, B>{}, tb, NE, first_late, (pre && tb == wave) ? pre->xi : (const float (*)[2])nullptr);
   } else {
     float4 elast[MAXQ]; /* the last plane's row: the sum of squares of step D - 1's output row */
     if (wave == NW - 1) {
       wait_last();
       load_row(D, elast);
     }
-    batch(std::integral_constant<int, BL>{}, first_late + (wave - NE), NE, D, pre ? pre->xi : nullptr);
+    batch(std::integral_constant<int, BL>{}, first_late + (wave - NE), NE, D, pre ? pre->xi : (const float (*)[2])nullptr);
     if (wave == NW - 1) {
       mask_row(elast);
       float h = 0.0f;

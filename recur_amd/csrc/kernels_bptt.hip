@@ -1339,7 +1339,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
      * (XcWork, k_common.h); where the chain declines, the launch below */
     const bool extras_gather = sh->H <= 2304 && !env_int("RECUR_AMD_EXTRAS_GEMM", 0) && !(b->dense_inputs && nx > 8);
     XcWork xc_req = {};
-    if (extras_gather && nx <= 64 && !env_int("RECUR_AMD_EXTRAS_SPLIT", 0) && env_int("RECUR_AMD_XC_IN_CHAIN", 1) &&
+    if (extras_gather && nx <= 128 && !env_int("RECUR_AMD_EXTRAS_SPLIT", 0) && env_int("RECUR_AMD_XC_IN_CHAIN", 1) &&
         (size_t)(sh->D + 1) * sh->Scap * sh->I * sizeof(float) < ((size_t)1 << 31)) { /* (32-bit byte offsets into the planes) */
       xc_req.on = 1;
       xc_req.row0 = row0;

@@ -113,10 +113,21 @@ static void dsync(void) {
   HIP_OK(hipStreamSynchronize(g_stream));
   g_syncs++;
   if (ramd_chain_abort_word()) {
-    fprintf(stderr, "librecur_amd: the one-launch BPTT chain gave up (code %u: its 256 workgroups were "
-                    "not all resident, one per CU, or a hand-off timed out); its results are invalid.  "
-                    "Set RECUR_AMD_CHAIN_PERSIST=0 to use the launch-per-step chain.\n",
-            ramd_chain_abort_word());
+    const unsigned code = ramd_chain_abort_word();
+    if (code == 6) {
+      fprintf(stderr, "librecur_amd: a rank waited ~20 s at a barrier of the kernel-issued exchange: not every rank "
+                      "reached it (did one die, or drive fewer generations?); the replicas are out of step.\n");
+    } else if (code == 2) {
+      fprintf(stderr, "librecur_amd: a workgroup of the one-launch BPTT chain was not on the XCD its number implies (code 2): "
+                      "something else ran on this GPU beside the chain and the dispatcher interleaved the two launches; "
+                      "its results are invalid.  Set RECUR_AMD_XCD_STATIC=0 (the chain then draws tickets) or, on a GPU "
+                      "that is shared, RECUR_AMD_CHAIN_CHECK=1 or RECUR_AMD_CHAIN_PERSIST=0.\n");
+    } else {
+      fprintf(stderr, "librecur_amd: the one-launch BPTT chain gave up (code %u: its 256 workgroups were "
+                      "not all resident, one per CU, or a hand-off timed out); its results are invalid.  "
+                      "Set RECUR_AMD_CHAIN_CHECK=1 (every launch checked, a chain that gives up is redone) or "
+                      "RECUR_AMD_CHAIN_PERSIST=0 (the launch-per-step chain).\n", code);
+    }
     abort();
   }
 }

@@ -1,7 +1,7 @@
 """Development aid: the memory / wait instructions of k_chain_persist<1,1024>'s tail (after its last MFMA) from build/dis."""
 import re, sys
 s = open('/root/repo/build/dis/kernels_chain.s').read()
-i = s.index('_Z15k_chain_persistILi1ELi1024ELb0ELb0EEvPK4ViewiiiijP9ChainSyncPjii6HoWork6XcWork:')
+i = s.index('_Z15k_chain_persistILi1ELi1024ELb0ELb0EEvPK4ViewiiiijP9ChainSyncPjii6HoWork6XcWorkij:')
 j = s.index('.end_amdhsa_kernel', i)
 body = s[i:j].split('\n')
 for k in ('next_free_vgpr', 'next_free_sgpr', 'private_segment_fixed_size'):
