@@ -467,7 +467,8 @@ def main():
         }
         per_gen_bytes = {  # algorithmic: W ONCE PER LAUNCH (it stays in registers) + per step E in, X mask,
             # E out / X, E, dW once
-            "bptt_chain_gemm": 4.0 * (Hd * Hd + 3 * S * Hd * D),
+            # (+ since round 4 the launch's tail: the extras and the control logic read every error plane once more)
+            "bptt_chain_gemm": 4.0 * (Hd * Hd + 3 * S * Hd * D) + 4.0 * S * (D + 1) * gH,
             "delta_gemm": 4.0 * (2 * S * D * Hd + I * Hd),
         }
         dom = max(per_gen_flops, key=lambda k: cls[k][0])
