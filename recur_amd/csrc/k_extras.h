@@ -23,34 +23,12 @@ template <int MAXQ> struct ExtrasIn {
   float4 ev[MAXQ];
   float xi, pv;
 };
-/* L2ONLY: the error row is read past this CU's L1 (buffer loads with sc1, from the XCD's L2) -- for the tail of the
- * one-launch chain, where the rows were written by other CUs of the XCD during the same launch (an agent-scope
- * acquire instead would also walk the L2 for lines of other XCDs' memory: 11 us, measured).  The offsets are 32-bit
- * byte offsets from ehi (the launcher checks that the planes fit). */
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-template <int MAXQ, bool L2ONLY = false> /* float4 per lane: 5 covers h_size <= 1280, 8 h_size <= 2048, 9 h_size <= 2304 */
+template <int MAXQ> /* float4 per lane: 5 covers h_size <= 1280, 8 h_size <= 2048, 9 h_size <= 2304 */
 __device__ __forceinline__ void extras_load(const View &v, int t, int r, int nx, int tn, int lane,
                                             ExtrasIn<MAXQ> &in) {
   const RamdShape &s = v.sh;
   const float *erow = v.b.ehi + (t * s.Scap + r) * s.I;
-  if constexpr (L2ONLY) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)v.b.ehi, 0, 0x7fffffff, 0x00020000);
-    const unsigned row_off = (unsigned)((t * s.Scap + r) * s.I) * 4u;
-    const int nq = (s.H / 4 + 63) / 64, last4 = s.H / 4 - 1;
-#pragma unroll
-    for (int i = 0; i < MAXQ; i++) {
-      const int k4 = lane + 64 * i;
-      const u32x4_t e = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(row_off + 16u * (unsigned)min(k4, last4)), 0, 16 /* sc1 */);
-      in.ev[i] = (i < nq && k4 <= last4)
-                     ? make_float4(__uint_as_float(e.x), __uint_as_float(e.y), __uint_as_float(e.z), __uint_as_float(e.w))
-                     : zero4();
-    }
-    const float *x = input_row_auto(v, r, t);
-    const float xv = x[(lane == 0 || lane >= nx) ? 0 : s.hidden_size + lane];
-    in.xi = (lane < nx) ? xv : 0.0f;
-    in.pv = 0.0f; /* (tn == 0 behind the one-launch chain: no per-tile partial sums) */
-    return;
-  }
   const float *x = input_row_auto(v, r, t);
   const int nq = (s.H / 4 + 63) / 64;
   /* Every load is UNCONDITIONAL from a clamped (always valid) address, the select comes after: as
@@ -259,7 +237,7 @@ __device__ __forceinline__ void bptt_control_wave(const View &v, int r, int j, i
 // steps, leave each step's error sum in LDS (es_sh: 2 D + 1 floats), and wave 0 then runs the control
 // logic on them (nothing else needs the sums of other streams).  Ends without a barrier: es_sh may
 // be reused after the caller's next one.
-template <int MAXQ, int THREADS, bool L2ONLY = false>
+template <int MAXQ, int THREADS>
 __device__ __forceinline__ void extras_control_stream(const View &v, int r, int j, int nx, int nxp, int tn,
                                                       const unsigned char *active, unsigned flags,
                                                       float *es_sh) {
@@ -276,10 +254,10 @@ __device__ __forceinline__ void extras_control_stream(const View &v, int r, int 
   ExtrasIn<MAXQ> cur, nxt;
   ControlIn ci = {0.0f, 0.0f, 1.0f, 0.0, true};
   if (wave == 0) ci = bptt_control_load(v, r, j, active);
-  if (wave < items) extras_load<MAXQ, L2ONLY>(v, wave, r, nx, tn, lane, cur);
+  if (wave < items) extras_load<MAXQ>(v, wave, r, nx, tn, lane, cur);
   for (int t = wave; t < items; t += THREADS / 64) {
     const int tnext = t + THREADS / 64;
-    if (tnext < items) extras_load<MAXQ, L2ONLY>(v, tnext, r, nx, tn, lane, nxt);
+    if (tnext < items) extras_load<MAXQ>(v, tnext, r, nx, tn, lane, nxt);
     if (tn == 0) {
       const float hs = row_sumsq<MAXQ>(cur);
       if (lane == 0) hs_sh[t] = hs;

@@ -1,5 +1,5 @@
-// k_top.h -- the text model's loss on one stream as a device function: what k_text_top (kernels_loss.hip) and the
-// fused forward + top launch (k_fwd_fused<.., TOP>, kernels_forward.hip) share.
+// k_top.h -- the text model's loss on one stream as device functions (k_text_top, kernels_loss.hip; factored out for the
+// fused forward + top launch that round 4 built, measured and removed: profiles/NOTES_r04.md section 2).
 #pragma once
 #include "k_common.h"
 
