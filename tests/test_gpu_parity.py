@@ -572,6 +572,10 @@ def test_two_hundred_generations_at_full_size_track_the_oracle(amd):
 
 @pytest.mark.parametrize("label,kw", [
     ("configs1_text_1024_64_20", dict(input_size=42, hidden_size=1024, output_size=42, S=64, D=20)),
+    # a GPU's share of 256 streams over 8 GPUs (BASELINE.json configs[3]'s sharding; `bench.py --scaling strong
+    # --streams-global 32`; 64 = the share over 4 GPUs is configs[1]'s shape above): two 16-stream row tiles, three
+    # quarters of the chain launch's workgroups idle, the extras + control in the tails of the others
+    ("small_set_1024_32_20", dict(input_size=42, hidden_size=1024, output_size=42, S=32, D=20)),
     ("configs2_classify_like_512_128_30", dict(input_size=42, hidden_size=512, output_size=42, S=128, D=30)),
     ("configs4_rnnca_like_2048_512_10", dict(input_size=42, hidden_size=2048, output_size=42, S=512, D=10)),
     # more than 8 row tiles: the one-launch chain once per 256 streams
