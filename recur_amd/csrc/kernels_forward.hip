@@ -285,13 +285,28 @@ __global__ __launch_bounds__(256) void k_fwd_finalize(View v, int row0, int nrow
 // at column 0 and the last one runs past h_size, where nothing is stored.  The sums go to slab
 // plane 0 for k_fwd_finalize (noise, activation, bias node).
 // Preconditions (launcher): rows % 64 == 0, NS == ceil(i_size / 64).
+// The same plan serves the OUTPUT layer of a wide net (the multi-head nets' 3652 columns: out = hidden . W_ho, 1.9 GFLOP
+// at 256 streams, recur-nn.c:150-151): the operands come as a WideOp -- A rows K-contiguous with stride lda, B K-major
+// with stride ldb, K and N their extents, C with stride ldc -- and the full K in every workgroup means the tile is the
+// result (no K slabs to add up).  a == nullptr: the hidden layer's operands, from the View.
+struct WideOp {
+  const float *a; /* [rows][lda], K contiguous */
+  const float *b; /* [K][ldb]                  */
+  float *c;       /* [rows][ldc]               */
+  int lda, ldb, ldc, K, N;
+};
 template <int NS>
 __global__ __launch_bounds__(512) void k_fwd_wide(const View *__restrict__ vp, int uniform_idx, int row0,
-                                                  int nrows, int tm, int tn) {
+                                                  int nrows, int tm, int tn, WideOp op) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];
   View v = *vp;
   v.b.uniform_idx = uniform_idx;
   const RamdShape &s = v.sh;
+  const bool hidden_layer = op.a == nullptr;
+  const int opK = hidden_layer ? s.I : op.K, opN = hidden_layer ? s.H : op.N;
+  const int ldb = hidden_layer ? s.H : op.ldb, ldc = hidden_layer ? s.H : op.ldc;
+  const float *opB = hidden_layer ? v.b.ih_w : op.b;
+  float *opC = hidden_layer ? v.b.slab : op.c;
   /* Blocks are dealt round-robin over the 8 XCDs and an XCD runs 32 workgroups at a time: those 32
    * are a supertile of 4 row tiles x 8 column tiles, so that while they walk K together every
    * stage of the input rows is fetched into that XCD's L2 once per 8 workgroups and every stage of
@@ -322,11 +337,11 @@ __global__ __launch_bounds__(512) void k_fwd_wide(const View *__restrict__ vp, i
       if (i < 16) {
         const int row = 4 * i + (lane >> 4);
         const int c = (lane & 15) ^ (row & 15);
-        src[j] = input_row<false>(v, row0 + m0 + row, 0) + 4 * c;
+        src[j] = (hidden_layer ? input_row<false>(v, row0 + m0 + row, 0) : op.a + (size_t)(m0 + row) * op.lda) + 4 * c;
         kofs[j] = 4 * c;
       } else {
         const int k = 4 * (i - 16) + (lane >> 4);
-        src[j] = v.b.ih_w + (size_t)k * s.H + n0 + 4 * (lane & 15);
+        src[j] = opB + (size_t)k * ldb + n0 + 4 * (lane & 15);
         kofs[j] = k;
       }
     }
@@ -336,8 +351,8 @@ __global__ __launch_bounds__(512) void k_fwd_wide(const View *__restrict__ vp, i
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const bool a_side = wave * 8 + j < 16;
-        const float *g = a_side ? src[j] + k0 : src[j] + (size_t)k0 * s.H;
-        if ((k0 + WK > s.I && k0 + kofs[j] >= s.I) || (!a_side && n0 + 4 * (lane & 15) >= s.H))
+        const float *g = a_side ? src[j] + k0 : src[j] + (size_t)k0 * ldb;
+        if ((k0 + WK > opK && k0 + kofs[j] >= opK) || (!a_side && n0 + 4 * (lane & 15) >= opN))
           g = v.b.zeros + 4 * (lane & 15); /* past K, or past the last column of W: zeros */
         __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(dst + j * 256), 16, 0, 0);
       }
@@ -413,11 +428,11 @@ __global__ __launch_bounds__(512) void k_fwd_wide(const View *__restrict__ vp, i
   }
   __syncthreads();
   const int etid = threadIdx.x, rq = etid >> 4, c4 = (etid & 15) * 4;
-  if (n0 + c4 < s.H) { /* h_size % 4 == 0: whole float4s */
+  if (n0 + c4 < opN) { /* h_size % 4 == 0, o_size % 4 == 0: whole float4s */
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
       const int row = 4 * rq + rr;
-      *reinterpret_cast<float4 *>(v.b.slab + (size_t)(m0 + row) * s.H + n0 + c4) = ld4(red + row * WN + c4);
+      *reinterpret_cast<float4 *>(opC + (size_t)(m0 + row) * ldc + n0 + c4) = ld4(red + row * WN + c4);
     }
   }
 }
@@ -998,6 +1013,29 @@ extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, cons
   } else if (sh->O <= 256 && !env_int("RECUR_AMD_OUT_GEMM", 0)) {
     RAMD_LAUNCH(k_out_layer, dim3(nrows), dim3(1024),
                        (size_t)(sh->H + OUT_SEGS * 64) * sizeof(float), st, v, row0);
+  } else if (nrows % WM == 0 && sh->O >= 1024 && ((sh->H + WK - 1) / WK == 9 || (sh->H + WK - 1) / WK == 17 || (sh->H + WK - 1) / WK == 33) &&
+             (nrows / WM) * ((sh->O + WN - 1) / WN) >= 128 && env_int("RECUR_AMD_OUT_WIDE", 1)) {
+    /* wide output layers with enough tiles to fill the device (the multi-head nets: 4 x 58 at 256 streams): k_fwd_wide's
+     * 64 x 64 tiles with the full K in every workgroup write `out` directly (33 + 6 us as k_gemm + k_sum_slabs) */
+    static bool attr_set2 = false;
+    const size_t shm = (size_t)W_STAGES * W_STAGE_FLOATS * sizeof(float);
+    if (!attr_set2) {
+      HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_wide<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_wide<17>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_wide<33>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      attr_set2 = true;
+    }
+    const View *d_view = device_view(st, v);
+    const int ns = (sh->H + WK - 1) / WK;
+    const int wtm = nrows / WM, wtn = (sh->O + WN - 1) / WN;
+    const int supertiles = ((wtm + 3) / 4) * ((wtn + 7) / 8);
+    const int wblocks = ((supertiles + 7) / 8) * 8 * 32;
+    WideOp op = {b->hidden + (size_t)row0 * sh->H, b->ho_w, b->out + (size_t)row0 * sh->O, sh->H, sh->O, sh->O, sh->H, sh->O};
+    int ev = timing_begin(st, T_OTHER);
+    if (ns == 33) RAMD_LAUNCH(k_fwd_wide<33>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, wtm, wtn, op);
+    else if (ns == 17) RAMD_LAUNCH(k_fwd_wide<17>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, wtm, wtn, op);
+    else RAMD_LAUNCH(k_fwd_wide<9>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, wtm, wtn, op);
+    timing_end(st, ev);
   } else { /* wide output layers (multi-head nets, O in the thousands): the MFMA GEMM */
     int tm = (nrows + BM - 1) / BM;
     int tn = (sh->O + BN - 1) / BN, nkt = (sh->H + BK - 1) / BK;
@@ -1043,11 +1081,11 @@ extern "C" int ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh
       const int wblocks = ((supertiles + 7) / 8) * 8 * 32;
       int ev = timing_begin(st, T_FWD);
       if (wide_ns == 33)
-        RAMD_LAUNCH(k_fwd_wide<33>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, wtm, wtn);
+        RAMD_LAUNCH(k_fwd_wide<33>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, wtm, wtn, WideOp{});
       else if (wide_ns == 17)
-        RAMD_LAUNCH(k_fwd_wide<17>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, wtm, wtn);
+        RAMD_LAUNCH(k_fwd_wide<17>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, wtm, wtn, WideOp{});
       else
-        RAMD_LAUNCH(k_fwd_wide<9>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, wtm, wtn);
+        RAMD_LAUNCH(k_fwd_wide<9>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, wtm, wtn, WideOp{});
       timing_end(st, ev);
       ks = 1;
     } else if (b->uniform_idx >= 0) {
