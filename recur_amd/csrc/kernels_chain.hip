@@ -1091,6 +1091,13 @@ const View *device_view(hipStream_t st, const View &v) {
   static bool have = false;
   View cur = v;
   cur.b.uniform_idx = 0;
+  /* what changes from call to call and none of those kernels reads (the speculated noise's buffers change places every
+   * generation; the flags are per pass): left out, or every generation of a noisy net would rewrite the copy twice
+   * (5 us each, seen in the multi-head generation's timeline) */
+  cur.b.noise_spec = nullptr;
+  cur.b.rng_spec = nullptr;
+  cur.b.noise_spec_use = 0;
+  cur.b.dense_inputs = 0;
   if (!d_view) HIP_CHECK(hipMalloc(&d_view, sizeof(View)));
   if (!have || memcmp(&cur, &h_view, sizeof(View)) != 0) {
     RAMD_LAUNCH(k_store_view, dim3(1), dim3(1), 0, st, cur, d_view);
