@@ -410,6 +410,128 @@ __global__ void k_live_mask(float *dst, const unsigned char *active, int n) {
   if (j < n) dst[j] = (!active || active[j]) ? 1.0f : 0.0f;
 }
 
+// The top layer's weight deltas under the multi-head loss (recur-nn.c:256-301 with per-stream range lists): of a
+// stream's error row only the heads it trained are non-zero (a handful of, say, 50), so hidden^T . o_error as a dense
+// GEMM over all streams is mostly products with zero.  Here a workgroup owns head c's columns of 32 rows of ho_delta:
+// it lists the streams that trained head c (the bit per head the loss left behind each range list), in ascending order
+// -- the order in which the reference adds the streams' products -- stages their error segments and their 32 hidden
+// values in LDS, up to 48 streams at a time with every load requested at once, and sums from there on the matrix
+// cores: wave w the 32 columns 32 w .. of the head.  The untrained heads' columns get their zeros (or keep what they
+// had, accumulating) from the same store.  Heads of up to 128 symbols, any number of streams.
+constexpr int HDH_U = 12, HDH_K = 48; /* (20 KB of LDS at 73 symbols: seven workgroups per CU, the whole grid of 50 x 32 resident at once) */
+__global__ __launch_bounds__(256) void k_ho_delta_heads(View v, int row0, int nrows, const int *ranges, int range_stride,
+                                                        const unsigned char *active, int alen, int ncls, int accumulate) {
+  extern __shared__ float hdh_sh[]; /* [HDH_K][alenp] error segments + 4, [HDH_K][32] hidden values + 4 */
+  __shared__ short list[256];
+  __shared__ int wcount[4];
+  const RamdShape &s = v.sh;
+  const int c = blockIdx.x, h0 = blockIdx.y * 32;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int col0 = c * alen, alenp = alen | 1; /* (an odd row stride: the staging writes spread over the banks) */
+  float *e_sh = hdh_sh, *h_sh = hdh_sh + HDH_K * alenp + 4; /* (e_sh[dump], four spare floats behind h_sh) */
+  const int dump = HDH_K * alenp;
+  const int lm = lane & 31, kh = lane >> 5;
+  const bool tile_live = 32 * wave < alen, col_live = 32 * wave + lm < alen;
+  const int ecol = col_live ? 32 * wave + lm : 0;
+  const int kstep = 256 / alen, xstep = 256 - kstep * alen; /* a thread's next element of an [nk][alen] block */
+  f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int base = 0; base < nrows; base += 256) {
+    const int sj = base + tid;
+    const int sjc = min(sj, nrows - 1);
+    const unsigned long long bits =
+        *reinterpret_cast<const unsigned long long *>(ranges + (size_t)sjc * range_stride + RAMD_HEADBITS_AT);
+    const unsigned char live = active ? active[sjc] : 1;
+    const bool mine = sj < nrows && live && ((bits >> c) & 1ull);
+    const unsigned long long bal = __ballot(mine);
+    if (lane == 0) wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      if (w < wave) off += wcount[w];
+      total += wcount[w];
+    }
+    if (mine) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (short)tid;
+    __syncthreads();
+    for (int k0 = 0; k0 < total; k0 += HDH_K) {
+      const int nk = min(HDH_K, total - k0);
+      /* Staging without a branch: every load is made (of a clamped, valid address) and every value stored, those
+       * outside the block into a spare slot behind the arrays -- under a condition the compiler sinks each load into
+       * its store's branch and waits there, a round trip to the L2 per element (30 us for the kernel).
+       * hidden: thread t the float4 t % 8 of streams t / 8 and 32 + t / 8; the error segments: elements
+       * t + 256 u of the [nk][alen] block, HDH_U of them in flight per thread */
+      float4 hq[2];
+      int hat[2];
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const int k = (tid >> 3) + 32 * half, q = tid & 7;
+        const bool in = k < nk && h0 + 4 * q < s.H;
+        const size_t rr = (size_t)(row0 + base + list[k0 + (in ? k : 0)]);
+        hq[half] = *reinterpret_cast<const float4 *>(v.b.hidden + rr * s.H + (in ? h0 + 4 * q : 0));
+        hat[half] = in ? k * 32 + 4 * q : HDH_K * 32;
+      }
+      const int n = nk * alen;
+      int ek = tid / alen, ex = tid - ek * alen;
+      float t[HDH_U];
+      int at[HDH_U];
+      auto request = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < HDH_U; u++) {
+          const bool in = i0 + 256 * u < n;
+          at[u] = in ? ek * alenp + ex : dump;
+          t[u] = v.b.o_error[(size_t)(row0 + base + list[k0 + (in ? ek : 0)]) * s.O + col0 + (in ? ex : 0)];
+          ek += kstep;
+          ex += xstep;
+          if (ex >= alen) {
+            ex -= alen;
+            ek++;
+          }
+        }
+      };
+      /* (the first batch by every thread, the hidden values stored with it: left behind the loop the compiler moves
+       * their loads there too, one more round trip) */
+      request(tid);
+#pragma unroll
+      for (int u = 0; u < HDH_U; u++) e_sh[at[u]] = t[u];
+#pragma unroll
+      for (int half = 0; half < 2; half++) *reinterpret_cast<float4 *>(h_sh + hat[half]) = hq[half];
+      for (int i0 = tid + HDH_U * 256; i0 < n; i0 += HDH_U * 256) {
+        request(i0);
+#pragma unroll
+        for (int u = 0; u < HDH_U; u++) e_sh[at[u]] = t[u];
+      }
+      __syncthreads();
+      /* wave w: the 32 x 32 tile of columns 32 w .. of the head, two streams per v_mfma_f32_32x32x2_f32 (operand lane
+       * l: stream l / 32, row or column l % 32).  As FMAs with the hidden values broadcast from LDS the sum was bound by
+       * the LDS (a broadcast ds_read_b128 costs what a full one does): 10 of the kernel's 27 us. */
+      if (tile_live) {
+#pragma unroll 4
+        for (int k = 0; k < nk; k += 2) {
+          const bool in = k + kh < nk;
+          const int kk = in ? k + kh : 0;
+          float a = h_sh[kk * 32 + lm], bb = e_sh[kk * alenp + ecol];
+          a = in ? a : 0.0f;
+          bb = (in && col_live) ? bb : 0.0f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+        }
+      }
+      __syncthreads(); /* before the next streams are staged (or the list rebuilt) */
+    }
+  }
+  if (tile_live && col_live) {
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+      const int h = h0 + (g & 3) + 8 * (g >> 2) + 4 * kh;
+      if (h >= s.H) continue;
+      float *d = v.b.ho_delta + (size_t)h * s.O + col0 + 32 * wave + lm;
+      *d = (accumulate ? *d : 0.0f) + acc[g];
+    }
+  }
+  /* the columns behind the last head (o_size is padded to a multiple of 4): no error ever, zero unless accumulating */
+  if (c == ncls - 1 && !accumulate && tid < 32 && h0 + tid < s.H)
+    for (int x = ncls * alen; x < s.O; x++) v.b.ho_delta[(size_t)(h0 + tid) * s.O + x] = 0.0f;
+}
+
 // single_layer_sgd / _sparse for all streams at once (recur-nn.c:256-301):
 // hidden^T . o_error comes from the MFMA GEMM (ProbHoDelta); this sums its K
 // slabs into ho_delta.  With error ranges only the columns inside a range
@@ -1252,6 +1374,16 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   const bool ho_asked = !(flags & 0x80000000u) && !ranges && !accumulate && nrows >= 16 && nrows <= 256 && sh->O <= 48 &&
                         env_int("RECUR_AMD_HO_IN_CHAIN", 1);
   auto ho_classic = [&]() { /* (the fused single-net path, flag 0x80000000, updates W_ho directly) */
+    if (ranges && range_stride && (flags & RAMD_RANGES_ARE_HEADS) && b->mheads_alen >= 24 && b->mheads_alen <= 128 &&
+        sh->output_size % b->mheads_alen == 0 && env_int("RECUR_AMD_HO_HEADS", 1)) {
+      /* the multi-head loss: only the heads a stream trained carry error (k_ho_delta_heads) */
+      const int alen = b->mheads_alen, ncls = sh->output_size / alen;
+      if (defer) defer->ho_slab = nullptr;
+      RAMD_LAUNCH(k_ho_delta_heads, dim3(ncls, (sh->H + 31) / 32), dim3(256),
+                  (size_t)(HDH_K * ((alen | 1) + 32) + 8) * sizeof(float), st, v, row0, nrows, ranges, range_stride, active, alen,
+                  ncls, accumulate);
+      return;
+    }
     int tm = (sh->H + BM - 1) / BM, tn = (sh->O + BN - 1) / BN;
     int nkt = (nrows + BK - 1) / BK;
     int ho = sh->H * sh->O;

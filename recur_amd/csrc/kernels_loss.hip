@@ -385,12 +385,14 @@ __global__ __launch_bounds__(64 * MS_WAVES) void k_multi_softmax_error(View v, i
     int *rg = ranges + (size_t)j * range_stride;
     DevRng g = reinterpret_cast<DevRng *>(v.b.rng)[r];
     int nt = 0, nr = 0, prev_start = 0, prev_len = 0;
+    unsigned long long bits = 0;
     for (int c = 0; c < ncls; c++) {
       bool train = (c == own);
       if (!train) train = dev_rand64(g) < threshold;
       if (!train) continue;
       if (lane == 0) trained[nt] = (short)c;
       nt++;
+      bits |= 1ull << (c & 63);
       const int offset = c * alen;
       int start = offset & ~3, end = (offset + alen + 3) & ~3;
       if (nr && prev_start + prev_len >= start) {
@@ -409,6 +411,8 @@ __global__ __launch_bounds__(64 * MS_WAVES) void k_multi_softmax_error(View v, i
     if (lane == 0) {
       rg[2 * nr] = -1;
       rg[2 * nr + 1] = 0;
+      if (range_stride >= RAMD_HEADBITS_AT + 2 && ncls <= 64) /* (k_ho_delta_heads reads these, not the ranges) */
+        *reinterpret_cast<unsigned long long *>(rg + RAMD_HEADBITS_AT) = bits;
       reinterpret_cast<DevRng *>(v.b.rng)[r] = g;
       ntrained = nt;
     }

@@ -89,6 +89,9 @@ typedef struct RamdBuffers {
    * one-hot symbols -- the extras of the BPTT chain are then a GEMM, not a gather over the few
    * non-zero input rows (either is correct for any input) */
   int dense_inputs;
+  /* symbols per head of the last multi-head loss on these rows (0: none): with RAMD_RANGES_ARE_HEADS the range lists
+   * are runs of whole heads of this many columns */
+  int mheads_alen;
 } RamdBuffers;
 
 /* ih_delta left as un-summed K slabs by ramd_launch_calc_deltas, for the optimiser launch
@@ -149,6 +152,10 @@ int ramd_launch_forward_hidden(ramd_stream_t st, const RamdShape *sh, const Ramd
 /* flag of ramd_launch_calc_deltas: the per-stream range lists are the multi-head loss's (runs of whole heads of at
  * least 24 columns, the error row zero outside them): the top backprop may run as one GEMM (k_top_backprop_heads) */
 #define RAMD_RANGES_ARE_HEADS 0x10000000u
+/* a stream's range list as the multi-head loss leaves it: up to 64 + 1 (start, len) pairs, then one bit per head the
+ * stream trained (an unsigned long long at this int offset; the stride keeps it 8-byte aligned) */
+#define RAMD_HEADBITS_AT 130
+#define RAMD_MULTI_RANGE_STRIDE 132
 int ramd_text_top_ok(const RamdShape *sh);
 int ramd_launch_forward_fused(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0,
                               int nrows, int mode, int text_i, int global_first, int n_set);

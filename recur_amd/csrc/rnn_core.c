@@ -2221,7 +2221,7 @@ void rnn_amd_set_grouped_softmax_error(RnnAmdSet *set, int n_groups, const int *
  * accumulating on top of stream j - 1.  The loss half leaves o_error and one range list
  * per stream on the device; the deltas half consumes them.  In between the caller may
  * apply the previous batch's deltas, as text_train does (244-252). */
-static const int MULTI_RANGE_STRIDE = 2 * (64 + 1);
+static const int MULTI_RANGE_STRIDE = RAMD_MULTI_RANGE_STRIDE; /* 2 x (64 + 1) ints and the head bits */
 
 static int multi_heads(RamdEngine *e, int alphabet_len) {
   const RamdShape *s = &e->sh;
@@ -2287,6 +2287,7 @@ static void multi_loss(RnnAmdSet *set, const int *target_class, int alphabet_len
                        float leakage) {
   RamdEngine *e = set->eng;
   e->mheads_alen = alphabet_len;
+  e->b.mheads_alen = alphabet_len;
   e->rng_version++; /* the leak decisions are draws from the streams' generators */
   if (target_class) {
     upload(e->d_mclass + set->row0, target_class, set->n * sizeof(int));
