@@ -405,6 +405,208 @@ __global__ __launch_bounds__(256) void k_top_backprop_scale(View v, int row0, co
   }
 }
 
+// backprop_single_layer_sparse for the multi-head loss WITHOUT the zeros, in two launches.  A stream's error row is
+// non-zero only in the heads it trained (its own and the few that leaked: ~6 of 50), so of k_top_backprop_heads' one
+// GEMM over the whole output row (1.9 GFLOP, all of W_ho through every row tile's workgroups: 52 us at 1024 / 256 /
+// 73 x 50) seven eighths are products with zeros.  Here
+//   1. k_top_heads_partial: a workgroup takes head c and 128 rows of W_ho.  It lists the streams that trained the head
+//      (the bit per head the loss left behind each range list, as k_ho_delta_heads does), stages W_ho[rows][head c]
+//      once and the streams' error segments 32 streams at a time, and forms P[stream][c][row] = sum over the head's
+//      columns on the matrix cores (wave w: rows 32 w .., v_mfma_f32_32x32x2_f32 with the streams as M).  W_ho is
+//      read from memory exactly once.
+//   2. k_top_heads_combine: a workgroup per stream walks its trained heads in ascending order, adds P[stream][c][.]
+//      to the running values and, after a head that is not followed by the next one -- the end of one of the
+//      reference's merged ranges -- adds |running value| to the row's share of the error sum (recur-nn.c:178-191);
+//      then the stale entries, the sum, the soft clip (recur-nn.c:719-721) and the row, which is
+//      what k_top_backprop_heads + k_top_backprop_scale left behind.
+constexpr int THP_ROWS = 128, THP_U = 10;
+__global__ __launch_bounds__(256) void k_top_heads_partial(View v, int row0, int nrows, const int *ranges, int range_stride,
+                                                           const unsigned char *active, int alen, int ncls, float *P) {
+  extern __shared__ float thp_sh[]; /* [THP_ROWS][ld] rows of W_ho, [32][ld] error segments */
+  __shared__ short list[256];
+  __shared__ int wcount[4];
+  const RamdShape &s = v.sh;
+  const int c = blockIdx.x, y0 = blockIdx.y * THP_ROWS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 31, kh = lane >> 5;
+  const int col0 = c * alen, a0 = col0 & ~3, lead = col0 - a0; /* the aligned span starts `lead` columns before the head */
+  const int span4 = (lead + alen + 3) >> 2;                     /* float4s of the span */
+  const int ld = (4 * span4) | 1;
+  float *w_sh = thp_sh, *e_sh = thp_sh + THP_ROWS * ld;
+  /* the rows of W_ho: float4 t of the [THP_ROWS][span4] block (the span may reach past the head into the next one and
+   * up to the padded row end: o_size is a multiple of 4).  Ten loads in flight per thread (all of the block at 73 symbols), no branch around a load
+   * (see k_ho_delta_heads): what lies outside the block lands in a spare slot */
+  const int dump = (THP_ROWS + 32) * ld;
+  /* (the first 256 streams' head bits are asked for before the rows: one round trip less in the workgroup's chain) */
+  const unsigned long long bits0 =
+      *reinterpret_cast<const unsigned long long *>(ranges + (size_t)min(tid, nrows - 1) * range_stride + RAMD_HEADBITS_AT);
+  const unsigned char live0 = active ? active[min(tid, nrows - 1)] : 1;
+  for (int i0 = tid; i0 < THP_ROWS * span4; i0 += THP_U * 256) {
+    float4 w[THP_U];
+    int at[THP_U];
+#pragma unroll
+    for (int u = 0; u < THP_U; u++) {
+      const int i = i0 + 256 * u;
+      const bool in = i < THP_ROWS * span4;
+      const int row = in ? i / span4 : 0, q = in ? i - row * span4 : 0;
+      const int y = min(y0 + row, s.H - 1);
+      w[u] = *reinterpret_cast<const float4 *>(v.b.ho_w + (size_t)y * s.O + a0 + 4 * q);
+      at[u] = in ? row * ld + 4 * q : dump;
+    }
+#pragma unroll
+    for (int u = 0; u < THP_U; u++) {
+      float *d = w_sh + at[u];
+      d[0] = w[u].x;
+      d[1] = w[u].y;
+      d[2] = w[u].z;
+      d[3] = w[u].w;
+    }
+  }
+  for (int base = 0; base < nrows; base += 256) {
+    const int sj = base + tid, sjc = min(sj, nrows - 1);
+    unsigned long long bits = bits0;
+    unsigned char live = live0;
+    if (base) {
+      bits = *reinterpret_cast<const unsigned long long *>(ranges + (size_t)sjc * range_stride + RAMD_HEADBITS_AT);
+      live = active ? active[sjc] : 1;
+    }
+    const bool mine = sj < nrows && live && ((bits >> c) & 1ull);
+    const unsigned long long bal = __ballot(mine);
+    if (lane == 0) wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      if (w < wave) off += wcount[w];
+      total += wcount[w];
+    }
+    if (mine) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (short)tid;
+    __syncthreads();
+    for (int k0 = 0; k0 < total; k0 += 32) {
+      const int nk = min(32, total - k0);
+      /* error segments: float4 q of stream k; what lies outside the head (the neighbours' columns) is cleared */
+      {
+        float4 e[5]; /* (32 streams of up to 34 float4s: 128 symbols) */
+        int at[5], xs[5];
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+          const int i = tid + 256 * u;
+          const bool in = i < 32 * span4;
+          const int k = in ? i / span4 : 0, q = in ? i - k * span4 : 0;
+          const bool have = in && k < nk;
+          e[u] = *reinterpret_cast<const float4 *>(v.b.o_error + (size_t)(row0 + base + list[k0 + (have ? k : 0)]) * s.O + a0 + 4 * q);
+          at[u] = in ? k * ld + 4 * q : dump;
+          xs[u] = have ? 4 * q - lead : -8; /* column of e.x within the head (-8: nothing of it) */
+        }
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+          float *d = e_sh + at[u] - (at[u] == dump ? THP_ROWS * ld : 0);
+          const int x = xs[u];
+          d[0] = (x >= 0 && x < alen) ? e[u].x : 0.0f;
+          d[1] = (x + 1 >= 0 && x + 1 < alen) ? e[u].y : 0.0f;
+          d[2] = (x + 2 >= 0 && x + 2 < alen) ? e[u].z : 0.0f;
+          d[3] = (x + 3 >= 0 && x + 3 < alen) ? e[u].w : 0.0f;
+        }
+      }
+      __syncthreads();
+      f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      const float *ea = e_sh + lm * ld + kh, *wb = w_sh + (32 * wave + lm) * ld + kh;
+      const int kend = 4 * span4; /* even */
+#pragma unroll 4
+      for (int k = 0; k < kend; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ea[k], wb[k], acc, 0, 0, 0);
+      const int y = y0 + 32 * wave + lm;
+      if (y < s.H) {
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+          const int sr = (g & 3) + 8 * (g >> 2) + 4 * kh;
+          if (sr < nk) P[((size_t)(row0 + base + list[k0 + sr]) * ncls + c) * s.H + y] = acc[g];
+        }
+      }
+      __syncthreads(); /* before the next streams are staged (or the list rebuilt) */
+    }
+  }
+}
+
+constexpr int THC_THREADS = 320; /* a float4 of the row per thread: h_size <= 1280 in one pass (more: the loop) */
+__global__ __launch_bounds__(THC_THREADS) void k_top_heads_combine(View v, int row0, const int *ranges, int range_stride,
+                                                                   const unsigned char *active, int ncls, const float *P) {
+  __shared__ float red[THC_THREADS / 64];
+  __shared__ signed char heads[64];
+  __shared__ unsigned char ends[64];
+  const RamdShape &s = v.sh;
+  const int j = blockIdx.x, r = row0 + j, tid = threadIdx.x;
+  if (active && !active[j]) return;
+  const unsigned long long bits =
+      *reinterpret_cast<const unsigned long long *>(ranges + (size_t)j * range_stride + RAMD_HEADBITS_AT);
+  const int nh = __popcll(bits);
+  if (tid < 64 && ((bits >> tid) & 1ull)) {
+    const int k = __popcll(bits & ((1ull << tid) - 1ull));
+    heads[k] = (signed char)tid;
+    ends[k] = tid == 63 || !((bits >> (tid + 1)) & 1ull); /* not followed by the next head: one of the merged ranges ends */
+  }
+  __syncthreads();
+  const float *Pj = P + (size_t)r * ncls * s.H;
+  float *dst = v.b.ehi + (size_t)r * s.I;
+  float psum = 0.0f;
+  for (int y4 = 4 * tid; y4 < s.H; y4 += 4 * THC_THREADS) { /* (h_size is a multiple of 4) */
+    float e[4] = {0.f, 0.f, 0.f, 0.f}, sabs[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < nh; k0 += 8) { /* eight heads' values requested together (a stream trains ~6) */
+      float4 pv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) pv[u] = *reinterpret_cast<const float4 *>(Pj + (size_t)heads[min(k0 + u, nh - 1)] * s.H + y4);
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (k0 + u < nh) {
+          const float p[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
+          const bool end = ends[k0 + u];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            e[i] += p[i];
+            if (end) sabs[i] += fabsf(e[i]);
+          }
+        }
+      }
+    }
+    const float4 hv4 = *reinterpret_cast<const float4 *>(v.b.hidden + (size_t)r * s.H + y4);
+    const float4 st4 = *reinterpret_cast<const float4 *>(v.b.err_a + (size_t)r * s.I + y4);
+    const float hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, stale[4] = {st4.x, st4.y, st4.z, st4.w};
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int y = y4 + i;
+      const bool act = y > 0 && hv[i] != 0.0f;
+      const float val = (y == 0) ? 0.0f : act ? e[i] : stale[i];
+      o[i] = (y == 0 || y > s.hidden_size) ? 0.0f : val;
+      if (act) psum += sabs[i];
+    }
+    *reinterpret_cast<float4 *>(dst + y4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) psum += __shfl_xor(psum, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = psum;
+  __syncthreads();
+  float sum = 0.0f;
+#pragma unroll
+  for (int w = 0; w < THC_THREADS / 64; w++) sum += red[w];
+  const float halfmax = s.H * MAX_TOP_ERROR_FACTOR_F;
+  float scaled = sum;
+  if (sum > halfmax) {
+    const float scale = soft_clip_dev(sum, halfmax);
+    scaled = scale * sum;
+    for (int y4 = 4 * tid; y4 < s.H; y4 += 4 * THC_THREADS) { /* (this thread's own entries; 0 stays 0) */
+      float4 o = *reinterpret_cast<float4 *>(dst + y4);
+      o.x *= scale;
+      o.y *= scale;
+      o.z *= scale;
+      o.w *= scale;
+      *reinterpret_cast<float4 *>(dst + y4) = o;
+    }
+  }
+  if (tid == 0) {
+    v.b.top_raw[r] = sum;
+    v.b.top_scaled[r] = scaled;
+  }
+}
+
 __global__ void k_live_mask(float *dst, const unsigned char *active, int n) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) dst[j] = (!active || active[j]) ? 1.0f : 0.0f;
@@ -1332,7 +1534,20 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   // top layer
   size_t shm = (size_t)(sh->O + sh->H) * sizeof(float);
   if (!(flags & 0x40000000u)) { /* ramd_launch_text_top has already done the top backprop */
-    if (ranges && range_stride && (flags & RAMD_RANGES_ARE_HEADS) && sh->O % 4 == 0 && sh->O >= 64 &&
+    const int h_alen = b->mheads_alen, h_ncls = h_alen > 0 ? sh->output_size / h_alen : 0;
+    if (ranges && range_stride && (flags & RAMD_RANGES_ARE_HEADS) && h_alen >= 24 && h_alen <= 128 && h_ncls <= 64 &&
+        sh->output_size == h_ncls * h_alen && b->mheads_part &&
+        (size_t)sh->Scap * h_ncls * sh->H <= b->mheads_part_floats && row0 + nrows <= sh->Scap &&
+        env_int("RECUR_AMD_TOP_SPARSE", 1)) {
+      /* the multi-head loss's ranges, only the heads a stream trained: partial products per (stream, head), then the
+       * ordered sums and the clip */
+      const int span4 = (3 + h_alen + 3) / 4, ld = (4 * span4) | 1; /* (the widest span: a head that starts 3 columns into its float4) */
+      RAMD_LAUNCH(k_top_heads_partial, dim3(h_ncls, (sh->H + THP_ROWS - 1) / THP_ROWS), dim3(256),
+                  (size_t)((THP_ROWS + 32) * ld + 4) * sizeof(float), st, v, row0, nrows, ranges, range_stride, active, h_alen,
+                  h_ncls, b->mheads_part);
+      RAMD_LAUNCH(k_top_heads_combine, dim3(nrows), dim3(THC_THREADS), 0, st, v, row0, ranges, range_stride, active, h_ncls,
+                  b->mheads_part);
+    } else if (ranges && range_stride && (flags & RAMD_RANGES_ARE_HEADS) && sh->O % 4 == 0 && sh->O >= 64 &&
         (size_t)nrows * 2 * ((sh->H + 31) / 32) <= b->slab_floats && env_int("RECUR_AMD_TOP_HEADS", 1)) {
       /* the multi-head loss's ranges: one GEMM over all streams (k_top_backprop_heads), then the sums and the clip */
       const int tm = (nrows + 31) / 32, tn = (sh->H + 31) / 32, nb = 2 * tn;

@@ -92,6 +92,9 @@ typedef struct RamdBuffers {
   /* symbols per head of the last multi-head loss on these rows (0: none): with RAMD_RANGES_ARE_HEADS the range lists
    * are runs of whole heads of this many columns */
   int mheads_alen;
+  /* [Scap][heads][H] partial products of the sparse top backprop (k_top_heads_partial), or NULL */
+  float *mheads_part;
+  size_t mheads_part_floats;
 } RamdBuffers;
 
 /* ih_delta left as un-summed K slabs by ramd_launch_calc_deltas, for the optimiser launch

@@ -360,6 +360,9 @@ static void engine_free_device(RamdEngine *e) {
   dev_free(b->binp); dev_free(b->bout); dev_free(b->berr); dev_free(b->bcarry); dev_free(b->blast);
   dev_free(e->d_scratch); dev_free(e->d_ranges); dev_free(e->d_dense);
   dev_free(e->d_mranges); dev_free(e->d_mclass); dev_free(e->d_group);
+  dev_free(b->mheads_part);
+  b->mheads_part = NULL;
+  b->mheads_part_floats = 0;
   e->d_group = NULL;
   e->d_group_bytes = 0;
   e->d_mranges = NULL;
@@ -2234,6 +2237,14 @@ static int multi_heads(RamdEngine *e, int alphabet_len) {
   if (!e->d_mranges) {
     e->d_mranges = dev_alloc((size_t)s->Scap * MULTI_RANGE_STRIDE * sizeof(int));
     e->d_mclass = dev_alloc((size_t)s->Scap * sizeof(int));
+  }
+  /* the sparse top backprop's partial products, one row of h_size per (stream, head): 53 MB at 256 streams of 50
+   * heads and 1024 hidden units; sets too large for that keep the one-GEMM form (k_top_backprop_heads) */
+  size_t part = (size_t)s->Scap * n_classes * s->H;
+  if (alphabet_len >= 24 && alphabet_len <= 128 && part > e->b.mheads_part_floats && part * sizeof(float) <= ((size_t)2 << 30)) {
+    dev_free(e->b.mheads_part);
+    e->b.mheads_part = dev_alloc(part * sizeof(float));
+    e->b.mheads_part_floats = part;
   }
   return n_classes;
 }

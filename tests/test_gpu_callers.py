@@ -117,6 +117,23 @@ def test_config3_multi_head_generation_at_size(amd, S):
     o.close()
 
 
+@pytest.mark.parametrize("off", ["RECUR_AMD_TOP_SPARSE RECUR_AMD_HO_HEADS",
+                                 "RECUR_AMD_TOP_SPARSE RECUR_AMD_TOP_HEADS RECUR_AMD_HO_HEADS"])
+def test_config3_generation_with_the_head_kernels_switched_off(off):
+    """The multi-head top layer has three forms: per trained head (k_top_heads_partial / _combine, k_ho_delta_heads),
+    one masked GEMM over the whole output row (k_top_backprop_heads; taken when the partial products would not fit)
+    and the per-stream ranged gathers (any range list).  The library reads its switches once per process, so the
+    other two run here in a process of their own, on the 32-stream case."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, **{k: "0" for k in off.split()})
+    node = "%s::test_config3_multi_head_generation_at_size[32]" % os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", node, "-q", "-x", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=os.path.dirname(os.path.abspath(__file__)))
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("method,batch,leakage,noise", [(rc.ADAGRAD, 5, 0.3, 0.0), (rc.WEIGHTED, 1, 0.0, 0.0),
                                                         (rc.NESTEROV, 7, 0.8, 0.02)])
 def test_multitext_trainer_loop_matches_oracle(amd, method, batch, leakage, noise):
