@@ -271,6 +271,64 @@ __global__ __launch_bounds__(256) void k_fwd_finalize(View v, int row0, int nrow
       make_float4(h[0], h[1], h[2], h[3]);
 }
 
+// the same for k_fwd_fused's result (one plane of sums for the columns inside its tiles, per-tile partial sums
+// [tn][nrows][4] for the last four columns of h_size): the set calls that go on to a generic output layer, where
+// k_text_top is not there to do it.  with_spec: the presynaptic noise generated ahead (noise_speculate) is added here
+// and its generator states adopted (k_noise_apply's work).
+__global__ __launch_bounds__(256) void k_fwd_finalize_fused(View v, int row0, int nrows, int tn, int with_spec, int nmain) {
+  const RamdShape &s = v.sh;
+  const int per_row = (s.H >> 2) - 1; /* float4s of a row inside the tiles */
+  int j, c;
+  float4 a;
+  if ((int)blockIdx.x < nmain) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nrows * per_row) return;
+    j = q / per_row;
+    c = (q - j * per_row) * 4;
+    a = ld4(v.b.slab + (size_t)j * s.H + c);
+  } else {
+    /* the last four columns: 32 lanes per row, lane t the partial sums of tiles t, t + 32, ..; eight rows per workgroup */
+    const int t = threadIdx.x & 31;
+    j = ((int)blockIdx.x - nmain) * 8 + (threadIdx.x >> 5);
+    c = s.H - 4;
+    const int jc = min(j, nrows - 1);
+    a = zero4();
+    for (int tt = t; tt < tn; tt += 32) {
+      const float4 p = ld4(v.b.slab + (size_t)nrows * s.H + ((size_t)tt * nrows + jc) * 4);
+      a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+    }
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      a.x += __shfl_xor(a.x, off, 64);
+      a.y += __shfl_xor(a.y, off, 64);
+      a.z += __shfl_xor(a.z, off, 64);
+      a.w += __shfl_xor(a.w, off, 64);
+    }
+    if (t != 0 || j >= nrows) return;
+  }
+  if (with_spec) {
+    const float4 n4 = ld4(v.b.noise_spec + (size_t)j * s.H + c);
+    a.x += n4.x; a.y += n4.y; a.z += n4.z; a.w += n4.w;
+    if (c == 0) reinterpret_cast<DevRng *>(v.b.rng)[row0 + j] = reinterpret_cast<const DevRng *>(v.b.rng_spec)[j];
+  }
+  float h[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float x = h[i];
+    if (s.activation == 2) { /* RNN_RESQRT */
+      x = (x > 0.0f) ? sqrtf(x + 1.0f) - 1.0f : 0.0f;
+    } else if (s.activation == 5) { /* RNN_RECLIP20 */
+      x = x < 20.0f ? x : 20.0f;
+      x = (x > 0.0f) ? x : 0.0f;
+    } else {
+      x = (x > 0.0f) ? x : 0.0f;
+    }
+    h[i] = x;
+  }
+  if (c == 0) h[0] = 1.0f; /* the bias node, recur-nn.c:148 */
+  *reinterpret_cast<float4 *>(v.b.hidden + (size_t)(row0 + j) * s.H + c) = make_float4(h[0], h[1], h[2], h[3]);
+}
+
 // ------------------------------------ forward GEMM, 64 x 64 tiles (big sets) --
 //
 // hidden sums = X . W_ih (recur-nn.c:117-119) for big sets of dense-input nets -- rnnca's frame
@@ -959,9 +1017,12 @@ extern "C" void ramd_launch_bottom_forward(ramd_stream_t st_, const RamdShape *s
  * partials), or 0 when the preconditions do not hold and nothing was launched */
 extern "C" int ramd_launch_forward_fused(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
                                          int row0, int nrows, int mode, int text_i,
-                                         int global_first, int n_set) {
+                                         int global_first, int n_set, int for_top) {
+  /* for_top: the text step, which stops after the hidden layer's sums (k_text_top takes them from there); otherwise a
+   * one-hot or text pass that goes on to ramd_launch_forward_finish */
   if (b->uniform_idx < 0 || sh->bI || sh->hidden_size % CN != 0 || row0 + nrows > sh->Scap ||
-      mode != RAMD_IN_TEXT /* the only caller that stops after the hidden layer */ || !ramd_text_top_ok(sh) ||
+      (for_top ? (mode != RAMD_IN_TEXT || !ramd_text_top_ok(sh))
+               : ((mode != RAMD_IN_TEXT && mode != RAMD_IN_ONE_HOT) || !env_int("RECUR_AMD_FWD_FUSED_ANY", 1))) ||
       env_int("RECUR_AMD_NO_FWD_FUSED", 0))
     return 0;
   const int tm = (nrows + CM - 1) / CM, tn = sh->hidden_size / CN;
@@ -1003,11 +1064,28 @@ extern "C" int ramd_launch_forward_small(ramd_stream_t st_, const RamdShape *sh,
   return 1;
 }
 
+static void launch_output_layer(hipStream_t st, const RamdShape *sh, const RamdBuffers *b, int row0, int nrows);
+
 extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
                                     int row0, int nrows, float noise) {
+  ramd_launch_forward_hidden(st_, sh, b, row0, nrows, noise, 0);
+  launch_output_layer((hipStream_t)st_, sh, b, row0, nrows);
+}
+
+/* what follows ramd_launch_forward_fused(for_top = 0): the sums' tail columns, the noise generated ahead
+ * (b->noise_spec_use), the activation; then the output layer */
+extern "C" void ramd_launch_forward_finish(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b, int row0,
+                                           int nrows, int fused) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  ramd_launch_forward_hidden(st_, sh, b, row0, nrows, noise, 0);
+  const int nmain = (nrows * (sh->H / 4 - 1) + 255) / 256;
+  RAMD_LAUNCH(k_fwd_finalize_fused, dim3(nmain + (nrows + 7) / 8), dim3(256), 0, st, v, row0, nrows, -fused,
+              b->noise_spec_use, nmain);
+  launch_output_layer(st, sh, b, row0, nrows);
+}
+
+static void launch_output_layer(hipStream_t st, const RamdShape *sh, const RamdBuffers *b, int row0, int nrows) {
+  View v = make_view(sh, b);
   if (sh->O == 4 && nrows >= 64) {
     RAMD_LAUNCH(k_out_layer_o4, dim3((nrows + 3) / 4), dim3(256), 0, st, v, row0, nrows);
   } else if (sh->O <= 256 && !env_int("RECUR_AMD_OUT_GEMM", 0)) {

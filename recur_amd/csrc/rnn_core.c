@@ -2036,10 +2036,25 @@ static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, i
       /* the text step: building the input rows and the hidden layer's GEMM in one launch
        * (the ring index the kernel stores is the host's, which has just stepped) */
       int fused = ramd_launch_forward_fused(g_stream, &e->sh, &e->b, r0, set->n, mode, text_i,
-                                            set->global_first, set->global_count);
+                                            set->global_first, set->global_count, 1);
       if (fused) {
         set_streams_dev_wrote(set);
         return fused;
+      }
+    } else if (!hidden_only && advance && !set->fwd_only && (noise == 0.0f || e->b.noise_spec_use)) {
+      /* the same launch for the one-hot and text passes that go on to a generic output layer (the multi-head step);
+       * presynaptic noise only as the values generated ahead, which the finishing kernel adds */
+      int fused = ramd_launch_forward_fused(g_stream, &e->sh, &e->b, r0, set->n, mode, text_i,
+                                            set->global_first, set->global_count, 0);
+      if (fused) {
+        ramd_launch_forward_finish(g_stream, &e->sh, &e->b, r0, set->n, fused);
+        e->b.noise_spec_use = 0;
+        set_streams_dev_wrote(set);
+        if (outputs) {
+          d2h(outputs, e->b.out + (size_t)r0 * e->sh.O, (size_t)set->n * e->sh.O * sizeof(float));
+          dsync();
+        }
+        return 0;
       }
     }
     ramd_launch_assemble(g_stream, &e->sh, &e->b, r0, set->n, mode, d_dense, ld, text_i,
