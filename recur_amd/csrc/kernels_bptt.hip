@@ -1444,6 +1444,16 @@ __global__ __launch_bounds__(256) void k_delta_finalize(float *delta, const floa
   *reinterpret_cast<float4 *>(delta + 4 * q) = a;
 }
 
+extern "C" void ramd_launch_pending_finalize(ramd_stream_t st_, const RamdPendingDelta *p) {
+  hipStream_t st = (hipStream_t)st_;
+  const size_t n4 = p->slab ? p->n / 4 : 0;
+  const unsigned blocks = (unsigned)((n4 + 255) / 256) + (p->ho_slab ? (unsigned)((p->ho_n / 4 + 255) / 256) : 0u);
+  if (!blocks) return;
+  RAMD_LAUNCH(k_delta_finalize, dim3(blocks), dim3(256), 0, st, p->delta_out, p->slab, n4, p->n, p->ks, 0, p->H,
+              p->hidden_size, p->rows_core, p->ks_rest, p->rest, p->rest_stride, p->ho_delta_out, p->ho_slab, p->ho_n,
+              p->ho_ks);
+}
+
 // Rebuilds bptt->h_error (err_a) and bptt->i_error (err_b) as the reference
 // leaves them: the loop ping-pongs between the two buffers (recur-nn.c:384-386),
 // zeroing element 0 and the pad of whichever one it reads (334-337).  Columns
@@ -1749,6 +1759,15 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     RAMD_LAUNCH(k_bptt_control, dim3((nrows + 3) / 4), dim3(256), 0, st, v, row0, nrows,
                        active, flags, tn);
   // weight deltas: one GEMM over (step, stream)
+  RamdBuffers own_ws;
+  if (defer && defer->own_slab && !accumulate) {
+    /* planes that are to outlive this call go to the caller's workspace (the kernels' View, made above, is not
+     * concerned: the planes reach them as arguments) */
+    own_ws = *b;
+    own_ws.slab = defer->own_slab;
+    own_ws.slab_floats = defer->own_slab_floats;
+    b = &own_ws;
+  }
   {
     /* only columns 1..hidden_size of the delta can be non-zero (h_error[0] and the pad are
      * zero, recur-nn.c:334-337), so the column tiles start at 1: at hidden 1024 that is 16

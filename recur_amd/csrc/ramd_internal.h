@@ -112,11 +112,18 @@ typedef struct RamdPendingDelta {
   size_t ho_n;         /* plane stride = H * O */
   int ho_ks;
   float *ho_delta_out;
+  /* in: a workspace of the caller's own for the planes (own_slab_floats of it) instead of the shared split-K
+   * workspace -- for sums that are to outlive the call (the engine's kept deltas, rnn_core.c) */
+  float *own_slab;
+  size_t own_slab_floats;
 } RamdPendingDelta;
 
 enum { RAMD_IN_KEEP = 0, RAMD_IN_ONE_HOT = 1, RAMD_IN_DENSE = 2, RAMD_IN_TEXT = 3 };
 
 typedef void *ramd_stream_t;
+
+/* sums what ramd_launch_calc_deltas left pending into the delta arrays after all (nobody took it along) */
+void ramd_launch_pending_finalize(ramd_stream_t st, const RamdPendingDelta *p);
 
 /* ---- forward ---- */
 void ramd_launch_advance(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,

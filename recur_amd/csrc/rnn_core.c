@@ -363,6 +363,10 @@ static void engine_free_device(RamdEngine *e) {
   dev_free(b->mheads_part);
   b->mheads_part = NULL;
   b->mheads_part_floats = 0;
+  dev_free(e->d_kept_slab);
+  e->d_kept_slab = NULL;
+  e->kept_floats = 0;
+  e->kept_live = 0;
   e->d_group = NULL;
   e->d_group_bytes = 0;
   e->d_mranges = NULL;
@@ -553,6 +557,12 @@ static void stream_need_dev(RamdEngine *e, RecurNN *net) {
  * with an accumulating rnn_bptt_calc_deltas, which can just as well not accumulate -- two memset
  * launches less.  Whoever else needs the delta arrays gets the zeros first. */
 static void deltas_materialize(RamdEngine *e) {
+  if (e->kept_live) { /* (never together with a pending clear: whichever came later dropped the other) */
+    e->kept_live = 0;
+    if (e->dev_ready) {
+      ramd_launch_pending_finalize(g_stream, &e->kept);
+    }
+  }
   if (e->deltas_zero_pending) {
     e->deltas_zero_pending = 0;
     if (e->dev_ready) {
@@ -1495,6 +1505,7 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
     e->deltas_zero_pending = 0;
   }
   engine_need_dev(e, RNN_AMD_WEIGHTS | (accumulate ? RNN_AMD_DELTAS : 0));
+  e->kept_live = 0; /* (a set call's kept sums: added up just now if this call accumulates, otherwise overwritten) */
   if (fused) {
     /* (the fused path rewrites ih_delta only: the rest of the delta arrays has to be the device's
      * own before they are declared written -- after a regrow the device copy is blank) */
@@ -1560,6 +1571,7 @@ void rnn_bptt_calc_deltas(RecurNN *net, int accumulate_delta, RecurErrorRange *t
 void rnn_bptt_clear_deltas(RecurNN *net) {
   RamdEngine *e = ramd_engine_of(net);
   engine_ensure_device(e);
+  e->kept_live = 0; /* sums nobody asked for */
   if (e->sh.bI) { /* the bottom layer's error accumulator is cleared with them: at once */
     e->deltas_zero_pending = 0;
     ramd_launch_clear_deltas(g_stream, &e->sh, &e->b);
@@ -1611,7 +1623,14 @@ static void apply_learning(RecurNN *net, int learning_method, float momentum,
                            const RamdPendingDelta *pend) {
   RamdEngine *e = ramd_engine_of(net);
   engine_ensure_device(e);
-  engine_need_dev(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+  if (!pend && e->kept_live && e->dev_ready) {
+    /* the last set call's sums, still planes: this launch adds them up (and stores them) on its way */
+    pend = &e->kept;
+    e->kept_live = 0;
+    engine_need_dev(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS);
+  } else {
+    engine_need_dev(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+  }
   RecurNNBPTT *bptt = net->bptt;
   float mw;
   if (learning_method == RNN_MOMENTUM_SIMPLIFIED_NESTEROV) {
@@ -2129,6 +2148,29 @@ void rnn_amd_set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ra
   set_calc_deltas(set, accumulate, ranges, active, 0, NULL, 0, NULL);
 }
 
+/* may this set call leave its delta sums as planes (RamdEngine.kept)?  Not with a bottom layer (its deltas follow in
+ * a launch of their own that accumulates), an exchange between ranks or a caller's delta buffer (both want the sums
+ * as such, at once); the workspace is the engine's own, made on first use: eight planes and the rest rows' planes */
+static int kept_deltas_ok(RamdEngine *e) {
+  static int on = -1;
+  if (on < 0) {
+    const char *v = getenv("RECUR_AMD_KEEP_DELTAS");
+    on = !(v && *v == '0');
+  }
+  if (!on || e->sh.bI || e->xchg_world || e->delta_external || rnn_amd_dist_world() > 1) {
+    return 0;
+  }
+  if (!e->d_kept_slab) {
+    size_t fl = 8 * e->ih_size + (size_t)64 * 128 * e->sh.H;
+    if (fl * sizeof(float) > ((size_t)2 << 30)) {
+      return 0;
+    }
+    e->d_kept_slab = dev_alloc(fl * sizeof(float));
+    e->kept_floats = fl;
+  }
+  return 1;
+}
+
 /* dev_ranges: one range list per stream already on the device (range_stride ints apart),
  * instead of the shared host list `ranges` */
 static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ranges,
@@ -2141,13 +2183,20 @@ static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ran
     e->deltas_zero_pending = 0;
   }
   engine_need_dev(e, RNN_AMD_WEIGHTS | (accumulate ? RNN_AMD_DELTAS : 0));
+  e->kept_live = 0; /* (summed just now if this call accumulates, otherwise overwritten) */
+  if (!defer && !accumulate && kept_deltas_ok(e)) {
+    /* leave the sums as planes for the rnn_apply_learning that normally follows (see RamdEngine.kept) */
+    memset(&e->kept, 0, sizeof(e->kept));
+    e->kept.own_slab = e->d_kept_slab;
+    e->kept.own_slab_floats = e->kept_floats;
+    defer = &e->kept;
+  }
   set_streams_to_dev(set);
   push_learn_rates(e, set->row0, set->n);
   const int *d_ranges = dev_ranges ? dev_ranges : push_ranges(e, ranges);
   const unsigned char *d_active = NULL;
   if (active) {
-    h2d(e->b.active, active, set->n);
-    dsync();
+    upload(e->b.active, active, set->n); /* (through the mailbox when the set is a whole number of words) */
     d_active = e->b.active;
   }
   if (e->err_pending && (d_ranges || e->err_row0 != set->row0 || e->err_nrows != set->n)) {
@@ -2169,6 +2218,9 @@ static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ran
   e->err_pending = 1;
   e->err_row0 = set->row0;
   e->err_nrows = set->n;
+  if (defer == &e->kept) {
+    e->kept_live = e->kept.slab || e->kept.ho_slab;
+  }
   engine_dev_wrote(e, RNN_AMD_DELTAS);
   set_streams_dev_wrote(set);
   for (int j = 0; j < set->n; j++) {
@@ -2347,10 +2399,14 @@ void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *ne
   RamdEngine *e = set->eng;
   set_need_training(set, "rnn_amd_set_multi_step_deltas");
   int n_classes = multi_heads(e, alphabet_len);
+  /* the three small uploads leave with one launch */
   upload_q(e->b.hot + set->row0, hot, set->n * sizeof(int));
+  if (target_class) {
+    upload_q(e->d_mclass + set->row0, target_class, set->n * sizeof(int));
+  }
   upload(e->b.target + set->row0, next, set->n * sizeof(int));
   set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, NULL, 1, 0);
-  multi_loss(set, target_class, alphabet_len, n_classes, leakage);
+  multi_loss(set, NULL, alphabet_len, n_classes, leakage);
   rnn_amd_set_multi_calc_deltas(set, accumulate);
 }
 

@@ -55,6 +55,14 @@ typedef struct RamdEngine {
   float *d_dense;       /* staging for dense inputs, [Scap+Fcap][input_size] */
   float *delta_own;     /* library-owned ih_delta||ho_delta                */
   int delta_external;
+  /* The delta sums of the last set call, kept as the un-summed planes the GEMM left (in a workspace of their own)
+   * for the rnn_apply_learning that normally follows to sum on its way -- the separate calls then cost what the
+   * one-call text step costs, a k_delta_finalize launch less.  Whoever else wants the delta arrays gets them summed
+   * first (deltas_materialize). */
+  RamdPendingDelta kept;
+  int kept_live;
+  float *d_kept_slab;
+  size_t kept_floats;
   /* h_error/i_error images are rebuilt lazily from ehi */
   int err_pending, err_row0, err_nrows;
   /* last per-stream scalars pushed to the device */
