@@ -135,11 +135,21 @@ __global__ void k_presynaptic_noise(View v, int row0, int nrows, float deviation
 /* The same values without touching anything: out[j][1..H) and the generator state after them
  * (see noise_speculate in rnn_core.c: runs on a second stream while the rest of the previous
  * generation is still being computed) */
-__global__ void k_noise_speculate(View v, int row0, int nrows, float deviation, float *out, DevRng *state) {
+/* src / tclass: the early form for the multi-head step -- start from the states the pass before adopted (`src`, which
+ * may be `state` itself: read here, written at the end) and first make the draws the multi-head loss is about to make
+ * from the stream's generator, one per head other than the stream's own (k_multi_softmax_error), so that the values
+ * are those of the pass AFTER that loss although the loss has not run yet */
+__global__ void k_noise_speculate(View v, int row0, int nrows, float deviation, float *out, DevRng *state,
+                                  const DevRng *src, const int *tclass, int ncls) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nrows) return;
   const RamdShape &s = v.sh;
-  DevRng g = reinterpret_cast<DevRng *>(v.b.rng)[row0 + j];
+  DevRng g = src ? src[j] : reinterpret_cast<DevRng *>(v.b.rng)[row0 + j];
+  if (tclass) {
+    const int own = tclass[j];
+    const int skip = ncls - ((own >= 0 && own < ncls) ? 1 : 0);
+    for (int i = 0; i < skip; i++) (void)dev_rand64(g);
+  }
   float *row = out + (size_t)j * s.H;
   for (int i0 = 0; i0 < s.H; i0 += 16) {
     float nz[16];
@@ -1075,13 +1085,15 @@ extern "C" void ramd_launch_forward(ramd_stream_t st_, const RamdShape *sh, cons
 /* what follows ramd_launch_forward_fused(for_top = 0): the sums' tail columns, the noise generated ahead
  * (b->noise_spec_use), the activation; then the output layer */
 extern "C" void ramd_launch_forward_finish(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b, int row0,
-                                           int nrows, int fused) {
+                                           int nrows, int fused, int part) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  const int nmain = (nrows * (sh->H / 4 - 1) + 255) / 256;
-  RAMD_LAUNCH(k_fwd_finalize_fused, dim3(nmain + (nrows + 7) / 8), dim3(256), 0, st, v, row0, nrows, -fused,
-              b->noise_spec_use, nmain);
-  launch_output_layer(st, sh, b, row0, nrows);
+  if (part != 2) { /* the hidden layer's end */
+    const int nmain = (nrows * (sh->H / 4 - 1) + 255) / 256;
+    RAMD_LAUNCH(k_fwd_finalize_fused, dim3(nmain + (nrows + 7) / 8), dim3(256), 0, st, v, row0, nrows, -fused,
+                b->noise_spec_use, nmain);
+  }
+  if (part != 1) launch_output_layer(st, sh, b, row0, nrows);
 }
 
 static void launch_output_layer(hipStream_t st, const RamdShape *sh, const RamdBuffers *b, int row0, int nrows) {
@@ -1188,10 +1200,12 @@ extern "C" int ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh
 }
 
 extern "C" void ramd_launch_noise_speculate(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
-                                            int row0, int nrows, float noise) {
+                                            int row0, int nrows, float noise, const int *loss_classes, int n_classes) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
+  /* loss_classes: the early form, from the adopted states in b->rng_spec (see the kernel) */
   RAMD_LAUNCH(k_noise_speculate, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows, noise, b->noise_spec,
-              (DevRng *)b->rng_spec);
+              (DevRng *)b->rng_spec, loss_classes ? (const DevRng *)b->rng_spec : (const DevRng *)nullptr, loss_classes,
+              n_classes);
 }
 

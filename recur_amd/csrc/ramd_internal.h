@@ -172,7 +172,7 @@ int ramd_launch_forward_fused(ramd_stream_t st, const RamdShape *sh, const RamdB
 /* after ramd_launch_forward_fused(for_top = 0) returned `fused` != 0: tail columns, noise generated ahead, activation,
  * output layer */
 void ramd_launch_forward_finish(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0, int nrows,
-                                int fused);
+                                int fused, int part); /* part 1: the hidden layer's end, 2: the output layer, 0: both */
 void ramd_launch_text_top(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0,
                           int nrows, int fwd_ks);
 /* o_error = onehot(target) - softmax(out) and statistics
@@ -230,8 +230,8 @@ int ramd_calc_wrote_images(void);
 /* up to 12 word-wise copies (nwords[g] 32-bit words from src[g] to dst[g]) in one launch */
 /* the noise of the next forward pass of rows [row0, row0 + nrows), from the generators' current
  * states, into b->noise_spec / b->rng_spec; the generators themselves are not touched */
-void ramd_launch_noise_speculate(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0,
-                                 int nrows, float noise);
+void ramd_launch_noise_speculate(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0, int nrows,
+                                 float noise, const int *loss_classes, int n_classes);
 void ramd_launch_segcopy(ramd_stream_t st, int nseg, void *const *dst, const void *const *src,
                          const unsigned *nwords);
 /* rebuilds err_a / err_b (bptt->h_error, i_error) from ehi after a calc_deltas */

@@ -2000,6 +2000,7 @@ void rnn_amd_set_advance(RnnAmdSet *set) {
 
 /* hidden_only: stop after the hidden layer's GEMM and leave its K slabs for
  * ramd_launch_text_top; returns their number (0 otherwise) */
+static void noise_speculate_from(RnnAmdSet *set, int loss_classes);
 static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, int text_i,
                        float *outputs, int advance, int hidden_only) {
   RamdEngine *e = set->eng;
@@ -2034,6 +2035,7 @@ static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, i
     e->spec_pending = 0;
     e->rng_version++; /* this pass moves the generators, either way */
   }
+  e->spec_adopted = noise != 0.0f && e->b.noise_spec_use;
   for (int j = 1; j < set->n; j++) {
     if (set->nets[j]->presynaptic_noise != noise) {
       fprintf(stderr, "librecur_amd: the nets of a set must share presynaptic_noise\n");
@@ -2066,7 +2068,13 @@ static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, i
       int fused = ramd_launch_forward_fused(g_stream, &e->sh, &e->b, r0, set->n, mode, text_i,
                                             set->global_first, set->global_count, 0);
       if (fused) {
-        ramd_launch_forward_finish(g_stream, &e->sh, &e->b, r0, set->n, fused);
+        ramd_launch_forward_finish(g_stream, &e->sh, &e->b, r0, set->n, fused, 1);
+        if (set->early_spec_classes > 0 && e->spec_adopted) {
+          /* the multi-head step: the next pass's noise from here on, beside the output layer and the loss */
+          noise_speculate_from(set, set->early_spec_classes);
+          set->early_spec_classes = -1; /* done */
+        }
+        ramd_launch_forward_finish(g_stream, &e->sh, &e->b, r0, set->n, fused, 2);
         e->b.noise_spec_use = 0;
         set_streams_dev_wrote(set);
         if (outputs) {
@@ -2327,7 +2335,14 @@ static int multi_heads(RamdEngine *e, int alphabet_len) {
  * adopts the generator states that go with them (k_noise_apply) provided nothing has moved the
  * generators in between (rng_version: uploads of a generator, other passes, other losses),
  * otherwise it generates as before and the speculated values are dropped. */
-static void noise_speculate(RnnAmdSet *set) {
+static void noise_speculate_from(RnnAmdSet *set, int loss_classes);
+static void noise_speculate(RnnAmdSet *set) { noise_speculate_from(set, 0); }
+/* loss_classes > 0: the early form for the multi-head step, called between the forward pass and the loss.  When that
+ * pass adopted the speculated states they still sit in b.rng_spec, which the loss does not touch: the generator is
+ * started from there, `loss_classes` heads' worth of leak decisions on (one draw per head other than the stream's
+ * own, whatever the outcome), beside the output layer and the loss instead of after them -- at 1024 / 256 / 73 x 50
+ * the generator (0.31 ms beside the matrix kernels) had become the generation's critical path. */
+static void noise_speculate_from(RnnAmdSet *set, int loss_classes) {
   RamdEngine *e = set->eng;
   const float noise = set->nets[0]->presynaptic_noise;
   static int enabled = -1;
@@ -2352,17 +2367,18 @@ static void noise_speculate(RnnAmdSet *set) {
   }
   HIP_OK(hipEventRecord((hipEvent_t)e->spec_go, g_stream)); /* the draws made so far */
   HIP_OK(hipStreamWaitEvent(g_side, (hipEvent_t)e->spec_go, 0));
-  ramd_launch_noise_speculate(g_side, &e->sh, &e->b, set->row0, set->n, noise);
+  ramd_launch_noise_speculate(g_side, &e->sh, &e->b, set->row0, set->n, noise,
+                              loss_classes ? e->d_mclass + set->row0 : NULL, loss_classes);
   HIP_OK(hipEventRecord((hipEvent_t)e->spec_done, g_side));
   e->spec_pending = 1;
-  e->spec_version = e->rng_version;
+  e->spec_version = e->rng_version + (loss_classes ? 1 : 0); /* (the loss that follows counts as one move) */
   e->spec_row0 = set->row0;
   e->spec_n = set->n;
   e->spec_dev = noise;
 }
 
 static void multi_loss(RnnAmdSet *set, const int *target_class, int alphabet_len, int n_classes,
-                       float leakage) {
+                       float leakage, int speculated) {
   RamdEngine *e = set->eng;
   e->mheads_alen = alphabet_len;
   e->b.mheads_alen = alphabet_len;
@@ -2378,7 +2394,9 @@ static void multi_loss(RnnAmdSet *set, const int *target_class, int alphabet_len
                                   e->d_mranges + (size_t)set->row0 * MULTI_RANGE_STRIDE,
                                   MULTI_RANGE_STRIDE);
   set_streams_dev_wrote(set);
-  noise_speculate(set); /* the next draws are the next forward pass's noise */
+  if (!speculated) {
+    noise_speculate(set); /* the next draws are the next forward pass's noise */
+  }
 }
 
 void rnn_amd_set_multi_calc_deltas(RnnAmdSet *set, int accumulate) {
@@ -2405,8 +2423,15 @@ void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *ne
     upload_q(e->d_mclass + set->row0, target_class, set->n * sizeof(int));
   }
   upload(e->b.target + set->row0, next, set->n * sizeof(int));
+  set->early_spec_classes = set->fwd_only ? 0 : n_classes; /* (set_forward's fused branch takes it up) */
   set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, NULL, 1, 0);
-  multi_loss(set, NULL, alphabet_len, n_classes, leakage);
+  int early = set->early_spec_classes < 0;
+  set->early_spec_classes = 0;
+  if (!early && e->spec_adopted && !set->fwd_only) {
+    noise_speculate_from(set, n_classes);
+    early = 1;
+  }
+  multi_loss(set, NULL, alphabet_len, n_classes, leakage, early);
   rnn_amd_set_multi_calc_deltas(set, accumulate);
 }
 
@@ -2434,7 +2459,7 @@ void rnn_amd_set_multi_text_loss(RnnAmdSet *set, int i, const int *target_class,
   check_text_pos(e, i, 0, "rnn_amd_set_multi_text_loss");
   int n_classes = multi_heads(e, alphabet_len);
   set_forward(set, RAMD_IN_TEXT, NULL, 0, i, NULL, 1, 0); /* advance + one-hot opinion + b.target */
-  multi_loss(set, target_class, alphabet_len, n_classes, leakage);
+  multi_loss(set, target_class, alphabet_len, n_classes, leakage, 0);
 }
 
 /* rnn_bptt_advance (optional) + one_hot_opinion of the stream's text symbol, nothing else:

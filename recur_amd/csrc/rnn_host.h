@@ -75,6 +75,7 @@ typedef struct RamdEngine {
    * generators since (rng_version) */
   unsigned long rng_version, spec_version;
   int spec_pending, spec_row0, spec_n;
+  int spec_adopted; /* the set's last forward pass took its noise (and generator states) from the speculation */
   float spec_dev;
   void *spec_go, *spec_done; /* hipEvent_t */
   int scalars_dev_valid; /* device mef/ih_scale newer than the host structs */
@@ -102,6 +103,9 @@ struct RnnAmdSet {
   int fwd_only; /* the set is made of forward-only clones (no bptt): opinion calls only */
   int global_first, global_count;
   int sharded_before; /* the engine's `sharded` when the set was opened: put back when it is closed or dropped */
+  /* > 0 during the multi-head step's forward pass: the number of heads whose leak decisions follow the pass, for the
+   * early noise speculation (noise_speculate_from); -1 once that has been launched */
+  int early_spec_classes;
 };
 
 static inline RamdPriv *ramd_priv(const RecurNN *net) {
