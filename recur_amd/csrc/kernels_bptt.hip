@@ -1552,6 +1552,11 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       /* the multi-head loss's ranges, only the heads a stream trained: partial products per (stream, head), then the
        * ordered sums and the clip */
       const int span4 = (3 + h_alen + 3) / 4, ld = (4 * span4) | 1; /* (the widest span: a head that starts 3 columns into its float4) */
+      static bool thp_attr = false;
+      if (!thp_attr) { /* (85 KB at 128 symbols) */
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_top_heads_partial, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        thp_attr = true;
+      }
       RAMD_LAUNCH(k_top_heads_partial, dim3(h_ncls, (sh->H + THP_ROWS - 1) / THP_ROWS), dim3(256),
                   (size_t)((THP_ROWS + 32) * ld + 4) * sizeof(float), st, v, row0, nrows, ranges, range_stride, active, h_alen,
                   h_ncls, b->mheads_part);
@@ -1600,7 +1605,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
                         env_int("RECUR_AMD_HO_IN_CHAIN", 1);
   auto ho_classic = [&]() { /* (the fused single-net path, flag 0x80000000, updates W_ho directly) */
     if (ranges && range_stride && (flags & RAMD_RANGES_ARE_HEADS) && b->mheads_alen >= 24 && b->mheads_alen <= 128 &&
-        sh->output_size % b->mheads_alen == 0 && env_int("RECUR_AMD_HO_HEADS", 1)) {
+        sh->output_size % b->mheads_alen == 0 && sh->output_size / b->mheads_alen <= 64 && env_int("RECUR_AMD_HO_HEADS", 1)) {
       /* the multi-head loss: only the heads a stream trained carry error (k_ho_delta_heads) */
       const int alen = b->mheads_alen, ncls = sh->output_size / alen;
       if (defer) defer->ho_slab = nullptr;

@@ -68,14 +68,24 @@ def test_config3_multi_head_generation_at_size(amd, S):
     """hidden 1024, alphabet 73 x 50 heads (o_size 3652: the wide-output GEMM path, ranged top
     backprop with one range list per stream), ADAGRAD with ballast, RESQRT, leakage 0.1, noise
     on: the ring is warmed on the device, then one generation on both sides from the same state."""
-    lib = amd
-    A, NC, D = 73, 50, 20
-    kw = dict(input_size=A, hidden_size=1024, output_size=A * NC, S=S, D=D, learn_rate=1e-4, seed=61,
+    _multi_head_generation(amd, 73, 50, 1024, S, 20, 0.1, deep=True)
+
+
+@pytest.mark.parametrize("A,NC,H,S,D,leakage", [(128, 11, 256, 40, 6, 0.3), (24, 64, 512, 300, 5, 0.05),
+                                                 (100, 3, 128, 7, 4, 0.9), (31, 20, 256, 64, 6, 0.2)])
+def test_multi_head_generation_with_other_head_shapes(amd, A, NC, H, S, D, leakage):
+    """The per-head top-layer kernels at their limits: the widest head (128 symbols), the narrowest they take (24)
+    with the most heads (64) and more than 256 streams (two passes of the stream lists), three heads that nearly
+    every stream trains all of (leakage 0.9), 31-symbol heads (never aligned to a float4)."""
+    _multi_head_generation(amd, A, NC, H, S, D, leakage)
+
+
+def _multi_head_generation(lib, A, NC, H, S, D, leakage, deep=False):
+    kw = dict(input_size=A, hidden_size=H, output_size=A * NC, S=S, D=D, learn_rate=1e-4, seed=61,
               activation=rc.RESQRT, noise=0.01, flags=rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR)
     g = sc.AmdBatchedSet(lib, **kw)
     lib.rnn_set_momentum_values(g.net, 200.0)  # the ADAGRAD ballast of py-recur-text.c:437-449
     rs = np.random.default_rng(3)
-    leakage = 0.1
 
     def draw():
         return (rs.integers(0, A, S).astype(np.int32), rs.integers(0, A, S).astype(np.int32),
@@ -106,7 +116,7 @@ def test_config3_multi_head_generation_at_size(amd, S):
     o.orc.orc_apply_learning(o.z, rc.ADAGRAD, 0.9)
     sg, so = g.snapshot(), o.snapshot()
     # (the adaptive min_error_factor steers the executed depth towards D / 2, recur-nn.c:399-413)
-    assert g.stats().bptt_depth_sum == float(so["bptt_depth"].sum()) and so["bptt_depth"].mean() >= D / 4
+    assert g.stats().bptt_depth_sum == float(so["bptt_depth"].sum()) and (not deep or so["bptt_depth"].mean() >= D / 4)
     _same_mask(sg["hidden"], so["hidden"])
     trained = (np.abs(so["o_error"])[:, :A * NC].reshape(S, NC, A).sum(axis=2) > 0).sum(axis=1)
     assert trained.min() >= 1 and trained.max() > 1  # the leakage trained foreign heads too
