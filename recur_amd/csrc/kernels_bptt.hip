@@ -813,6 +813,137 @@ __global__ __launch_bounds__(64) void k_extras_finalize(View v, int row0, int nr
   }
 }
 
+// The extras of nets with DENSE inputs (audio features, pixels: every input row counts, so the gather form has
+// nothing to skip) as one launch: the GEMM [D x streams rows of the error planes] x [W_ih's bias row and input rows]^T
+// with K = h_size, N = 1 + the inputs (33 for gstclassify, 36 for rnnca), and k_extras_finalize's work on its result.
+// As k_gemm<ProbExtras> (64 x 64 tiles: one column tile, nine tenths of it padding, a K split and its slabs) + the
+// finalize launch this was 47 + 13 us at 2048 / 512 / 10 and 13 + 6 us at 512 / 128 / 30.
+// Workgroup = 16 or 32 (step, stream) rows x up to 48 columns, eight waves that each take every eighth 16-deep K chunk
+// (v_mfma_f32_16x16x4_f32: 1 or 2 row tiles x 3 column tiles per wave), operands straight from memory as float4s -- a lane's
+// four k of a chunk go to the chunk's four MFMAs, the same permutation of k on both sides -- four chunks in flight;
+// the waves' sums meet in LDS, then 8 threads per row apply the row rule, store ex, and add the squares to the
+// row's total (with the chain's partial sums, or the row's own sum of squares where it left none).
+constexpr int XD_NT = 3, XD_PF = 4, XD_WAVES = 8;
+template <int XD_MT> /* row tiles of 16 per workgroup: 2 where that still makes 128 workgroups (W_ih's rows are fetched by half as many), else 1 */
+__global__ __launch_bounds__(64 * XD_WAVES) void k_extras_dense(View v, int row0, int nrows, int nx, int nxp, int tn) {
+  constexpr int XD_ROWS = 16 * XD_MT;
+  __shared__ float red[XD_WAVES][XD_ROWS][16 * XD_NT + 1];
+  const RamdShape &s = v.sh;
+  const int M = s.D * nrows;
+  const int m0 = blockIdx.x * XD_ROWS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, kq = lane >> 4;
+  // operand rows of this lane: two error rows, three rows of W_ih
+  const float *arow[XD_MT], *brow[XD_NT];
+#pragma unroll
+  for (int i = 0; i < XD_MT; i++) {
+    const int m = min(m0 + 16 * i + lm, M - 1);
+    const int t = m / nrows, j = m - t * nrows;
+    arow[i] = v.b.ehi + ((size_t)t * s.Scap + row0 + j) * s.I;
+  }
+#pragma unroll
+  for (int jn = 0; jn < XD_NT; jn++) {
+    const int c = 16 * jn + lm;
+    brow[jn] = v.b.ih_w + (size_t)((c == 0 || c >= nx) ? 0 : s.hidden_size + c) * s.H; /* (columns >= nx: discarded below) */
+  }
+  f32x4 acc[XD_MT][XD_NT];
+#pragma unroll
+  for (int i = 0; i < XD_MT; i++)
+#pragma unroll
+    for (int jn = 0; jn < XD_NT; jn++) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nchunks = (s.H + 15) / 16; /* h_size is a multiple of 4: a lane's float4 is inside the row or wholly past it */
+  const int mine = (nchunks - wave + XD_WAVES - 1) / XD_WAVES; /* chunks wave, wave + XD_WAVES, .. */
+  float4 fa[XD_PF][XD_MT], fb[XD_PF][XD_NT];
+  auto request = [&](int slot, int n) {
+    const int k = 16 * (wave + XD_WAVES * n) + 4 * kq;
+    const bool in = n < mine && k < s.H;
+    const int kc = in ? k : 0;
+#pragma unroll
+    for (int i = 0; i < XD_MT; i++) fa[slot][i] = ld4(in ? arow[i] + k : v.b.zeros); /* (a select on the address: one on the value would wait for it here) */
+#pragma unroll
+    for (int jn = 0; jn < XD_NT; jn++) fb[slot][jn] = ld4(brow[jn] + kc);
+  };
+#pragma unroll
+  for (int p = 0; p < XD_PF; p++) request(p, p);
+  for (int n0 = 0; n0 < mine; n0 += XD_PF) {
+#pragma unroll
+    for (int p = 0; p < XD_PF; p++) {
+      if (n0 + p < mine) { /* (wave-uniform) */
+        float4 a[XD_MT], bb[XD_NT];
+#pragma unroll
+        for (int i = 0; i < XD_MT; i++) a[i] = fa[p][i];
+#pragma unroll
+        for (int jn = 0; jn < XD_NT; jn++) bb[jn] = fb[p][jn];
+        request(p, n0 + p + XD_PF);
+#pragma unroll
+        for (int i = 0; i < XD_MT; i++)
+#pragma unroll
+          for (int jn = 0; jn < XD_NT; jn++) {
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, bb[jn].x, acc[i][jn], 0, 0, 0);
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, bb[jn].y, acc[i][jn], 0, 0, 0);
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, bb[jn].z, acc[i][jn], 0, 0, 0);
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bb[jn].w, acc[i][jn], 0, 0, 0);
+          }
+      }
+    }
+  }
+  // accumulator register r of tile (i, jn): row 16 i + 4 kq + r, column 16 jn + lm
+#pragma unroll
+  for (int i = 0; i < XD_MT; i++)
+#pragma unroll
+    for (int jn = 0; jn < XD_NT; jn++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) red[wave][16 * i + 4 * kq + r][16 * jn + lm] = acc[i][jn][r];
+  __syncthreads();
+  if (tid >= 8 * XD_ROWS) return;
+  // eight threads per row: columns sub, sub + 8, ..
+  const int row = tid >> 3, sub = tid & 7;
+  const int m = m0 + row;
+  const bool live = m < M;
+  const int mm = live ? m : M - 1;
+  const int t = mm / nrows, j = mm - t * nrows, r = row0 + j;
+  const float *x = input_row_auto(v, r, t);
+  float *dst = v.b.ex + ((size_t)(t + 1) * s.Scap + r) * nxp;
+  float sq = 0.0f;
+  for (int c = sub; c < nx; c += 8) {
+    float e = 0.0f;
+#pragma unroll
+    for (int w = 0; w < XD_WAVES; w++) e += red[w][row][c];
+    const int n = c == 0 ? 0 : s.hidden_size + c;
+    const float xi = x[n];
+    const bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
+    e = on ? e : 0.0f;
+    if (on && s.activation == 2) e /= 2 * (xi + 1.0f);
+    if (live) dst[c] = e;
+    sq += e * e;
+  }
+  /* the step's total: the chain's column-tile partials in index order, or (tn == 0: the one-launch chain leaves none)
+   * the sum of squares of the step's OUTPUT row, error plane t + 1 */
+  float other = 0.0f;
+  if (tn == 0) {
+    const float *erow = v.b.ehi + ((size_t)(t + 1) * s.Scap + r) * s.I;
+    float p0 = 0.0f, p1 = 0.0f;
+    int k4 = sub;
+    for (; k4 + 8 < s.H / 4; k4 += 16) {
+      const float4 e0 = ld4(erow + 4 * k4), e1 = ld4(erow + 4 * (k4 + 8));
+      p0 += (e0.x * e0.x + e0.y * e0.y) + (e0.z * e0.z + e0.w * e0.w);
+      p1 += (e1.x * e1.x + e1.y * e1.y) + (e1.z * e1.z + e1.w * e1.w);
+    }
+    if (k4 < s.H / 4) {
+      const float4 e0 = ld4(erow + 4 * k4);
+      p0 += (e0.x * e0.x + e0.y * e0.y) + (e0.z * e0.z + e0.w * e0.w);
+    }
+    other = p0 + p1;
+  } else {
+    for (int p = sub; p < tn; p += 8) other += v.b.esum_part[((size_t)t * (tn + 1) + p) * s.Scap + r];
+  }
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    sq += __shfl_xor(sq, off, 64);
+    other += __shfl_xor(other, off, 64);
+  }
+  if (sub == 0 && live) v.b.esum[(size_t)t * s.Scap + r] = other + sq;
+}
+
 // ------------------------------------------------ weight-delta GEMM by LDS-DMA --
 //
 // ih_delta[m][n] = sum over (step t, stream r) of X_t[r][m] * coef[t][r] * E_t[r][n]
@@ -1754,6 +1885,12 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
                              nx, nxp, tn_parts, active, flags);
         control_done = true;
       }
+    } else if (nx <= 16 * XD_NT && env_int("RECUR_AMD_EXTRAS_DENSE", 1)) {
+      /* dense inputs, up to 47 of them: GEMM and finalize in one launch */
+      if (M / 32 >= 128)
+        RAMD_LAUNCH(k_extras_dense<2>, dim3((M + 31) / 32), dim3(64 * XD_WAVES), 0, st, v, row0, nrows, nx, nxp, tn_parts);
+      else
+        RAMD_LAUNCH(k_extras_dense<1>, dim3((M + 15) / 16), dim3(64 * XD_WAVES), 0, st, v, row0, nrows, nx, nxp, tn_parts);
     } else { /* very wide nets: the dense GEMM over all extra columns */
       ProbExtras p = {v, row0, nrows, nx};
       launch_gemm<false, false, ProbExtras>(st, p, b->slab, M, nxp, nkt, ks, T_OTHER);
