@@ -135,21 +135,22 @@ __global__ void k_presynaptic_noise(View v, int row0, int nrows, float deviation
 /* The same values without touching anything: out[j][1..H) and the generator state after them
  * (see noise_speculate in rnn_core.c: runs on a second stream while the rest of the previous
  * generation is still being computed) */
-/* src / tclass: the early form for the multi-head step -- start from the states the pass before adopted (`src`, which
- * may be `state` itself: read here, written at the end) and first make the draws the multi-head loss is about to make
- * from the stream's generator, one per head other than the stream's own (k_multi_softmax_error), so that the values
- * are those of the pass AFTER that loss although the loss has not run yet */
+/* src / tclass / skip: the forms for the multi-head step -- start from the states an earlier pass left (`src`: the ones
+ * the pass before adopted, or the ones the speculation before this one wrote) and first make the draws the multi-head
+ * loss makes from the stream's generator in between, one per head other than the stream's own
+ * (k_multi_softmax_error): `ncls` heads with the classes in `tclass`, or `skip` draws for every stream where the classes
+ * are not known yet -- so that the values are those of the pass AFTER that loss although the loss has not run */
 __global__ void k_noise_speculate(View v, int row0, int nrows, float deviation, float *out, DevRng *state,
-                                  const DevRng *src, const int *tclass, int ncls) {
+                                  const DevRng *src, const int *tclass, int ncls, int skip) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nrows) return;
   const RamdShape &s = v.sh;
   DevRng g = src ? src[j] : reinterpret_cast<DevRng *>(v.b.rng)[row0 + j];
   if (tclass) {
     const int own = tclass[j];
-    const int skip = ncls - ((own >= 0 && own < ncls) ? 1 : 0);
-    for (int i = 0; i < skip; i++) (void)dev_rand64(g);
+    skip = ncls - ((own >= 0 && own < ncls) ? 1 : 0);
   }
+  for (int i = 0; i < skip; i++) (void)dev_rand64(g);
   float *row = out + (size_t)j * s.H;
   for (int i0 = 0; i0 < s.H; i0 += 16) {
     float nz[16];
@@ -1200,12 +1201,11 @@ extern "C" int ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh
 }
 
 extern "C" void ramd_launch_noise_speculate(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
-                                            int row0, int nrows, float noise, const int *loss_classes, int n_classes) {
+                                            int row0, int nrows, float noise, float *out_noise, void *out_states,
+                                            const void *src_states, const int *loss_classes, int n_classes, int skip) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  /* loss_classes: the early form, from the adopted states in b->rng_spec (see the kernel) */
-  RAMD_LAUNCH(k_noise_speculate, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows, noise, b->noise_spec,
-              (DevRng *)b->rng_spec, loss_classes ? (const DevRng *)b->rng_spec : (const DevRng *)nullptr, loss_classes,
-              n_classes);
+  RAMD_LAUNCH(k_noise_speculate, dim3((nrows + 63) / 64), dim3(64), 0, st, v, row0, nrows, noise, out_noise,
+              (DevRng *)out_states, (const DevRng *)src_states, loss_classes, n_classes, skip);
 }
 

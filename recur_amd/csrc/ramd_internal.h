@@ -231,7 +231,8 @@ int ramd_calc_wrote_images(void);
 /* the noise of the next forward pass of rows [row0, row0 + nrows), from the generators' current
  * states, into b->noise_spec / b->rng_spec; the generators themselves are not touched */
 void ramd_launch_noise_speculate(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0, int nrows,
-                                 float noise, const int *loss_classes, int n_classes);
+                                 float noise, float *out_noise, void *out_states, const void *src_states,
+                                 const int *loss_classes, int n_classes, int skip);
 void ramd_launch_segcopy(ramd_stream_t st, int nseg, void *const *dst, const void *const *src,
                          const unsigned *nwords);
 /* rebuilds err_a / err_b (bptt->h_error, i_error) from ehi after a calc_deltas */

@@ -328,6 +328,7 @@ static RamdEngine *engine_new(RecurNN *owner) {
   e->ih_size = (size_t)owner->ih_size;
   e->ho_size = (size_t)owner->ho_size;
   e->host_valid = RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS;
+  e->sp_adopted = -1;
   e->next = g_engines;
   g_engines = e;
   return e;
@@ -339,12 +340,19 @@ static void engine_free_device(RamdEngine *e) {
     return;
   }
   RamdBuffers *b = &e->b;
-  if (e->spec_pending && g_side) {
+  if ((e->sp[0].pending || e->sp[1].pending) && g_side) {
     HIP_OK(hipStreamSynchronize(g_side)); /* it writes into the buffers freed below */
   }
-  e->spec_pending = 0;
-  dev_free(b->noise_spec);
-  dev_free(b->rng_spec);
+  for (int k = 0; k < 2; k++) {
+    e->sp[k].pending = 0;
+    dev_free(e->sp[k].noise);
+    dev_free(e->sp[k].states);
+    e->sp[k].noise = NULL;
+    e->sp[k].states = NULL;
+  }
+  e->sp_adopted = -1;
+  b->noise_spec = NULL;
+  b->rng_spec = NULL;
   dev_free(b->ih_w); dev_free(b->ho_w); dev_free(b->ih_m); dev_free(b->ho_m);
   dev_free(b->ih_aux); dev_free(b->ho_aux); dev_free(e->delta_own);
   dev_free(b->arena); dev_free(b->hidden); dev_free(b->out); dev_free(b->o_error);
@@ -388,8 +396,9 @@ static void engine_delete(RamdEngine *e) {
   engine_free_device(e);
   if (e->spec_go) { /* noise_speculate's hand-over events */
     HIP_OK(hipEventDestroy((hipEvent_t)e->spec_go));
-    HIP_OK(hipEventDestroy((hipEvent_t)e->spec_done));
-    e->spec_go = e->spec_done = NULL;
+    HIP_OK(hipEventDestroy((hipEvent_t)e->sp[0].done));
+    HIP_OK(hipEventDestroy((hipEvent_t)e->sp[1].done));
+    e->spec_go = e->sp[0].done = e->sp[1].done = NULL;
   }
   /* clones may outlive the net that owns the weights (text-predict.c:654-656 deletes the
    * training set, then its confab and validation clones): detach them so that their own
@@ -2027,15 +2036,24 @@ static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, i
   float noise = set->nets[0]->presynaptic_noise;
   if (noise != 0.0f) {
     /* values generated ahead for exactly this pass, and nothing has touched the generators since? */
-    e->b.noise_spec_use = e->spec_pending && e->spec_version == e->rng_version && e->spec_row0 == r0 &&
-                          e->spec_n == set->n && e->spec_dev == noise && !e->sh.bI;
+    const int k = e->sp_head;
+    e->b.noise_spec_use = e->sp[k].pending && e->sp[k].version == e->rng_version && e->sp[k].row0 == r0 &&
+                          e->sp[k].n == set->n && e->sp[k].dev == noise && !e->sh.bI;
+    e->sp_adopted = -1;
     if (e->b.noise_spec_use) {
-      HIP_OK(hipStreamWaitEvent(g_stream, (hipEvent_t)e->spec_done, 0));
+      HIP_OK(hipStreamWaitEvent(g_stream, (hipEvent_t)e->sp[k].done, 0));
+      e->b.noise_spec = e->sp[k].noise;
+      e->b.rng_spec = e->sp[k].states;
+      e->sp[k].pending = 0;
+      e->sp_head = k ^ 1; /* (the other buffer: the pass after this one, if it has been started) */
+      e->sp_adopted = k;
+    } else {
+      e->sp[0].pending = e->sp[1].pending = 0; /* nothing that was started fits: the second one hangs on the first */
     }
-    e->spec_pending = 0;
     e->rng_version++; /* this pass moves the generators, either way */
+  } else {
+    e->sp_adopted = -1;
   }
-  e->spec_adopted = noise != 0.0f && e->b.noise_spec_use;
   for (int j = 1; j < set->n; j++) {
     if (set->nets[j]->presynaptic_noise != noise) {
       fprintf(stderr, "librecur_amd: the nets of a set must share presynaptic_noise\n");
@@ -2069,7 +2087,7 @@ static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, i
                                             set->global_first, set->global_count, 0);
       if (fused) {
         ramd_launch_forward_finish(g_stream, &e->sh, &e->b, r0, set->n, fused, 1);
-        if (set->early_spec_classes > 0 && e->spec_adopted) {
+        if (set->early_spec_classes > 0 && e->sp_adopted >= 0) {
           /* the multi-head step: the next pass's noise from here on, beside the output layer and the loss */
           noise_speculate_from(set, set->early_spec_classes);
           set->early_spec_classes = -1; /* done */
@@ -2345,10 +2363,11 @@ static void noise_speculate(RnnAmdSet *set) { noise_speculate_from(set, 0); }
 static void noise_speculate_from(RnnAmdSet *set, int loss_classes) {
   RamdEngine *e = set->eng;
   const float noise = set->nets[0]->presynaptic_noise;
-  static int enabled = -1;
+  static int enabled = -1, two_ahead = -1;
   if (enabled < 0) {
     const char *env = getenv("RECUR_AMD_NOISE_AHEAD");
     enabled = !(env && atoi(env) == 0);
+    two_ahead = !(env && atoi(env) == 1); /* (1: one pass ahead only) */
   }
   if (noise == 0.0f || e->sh.bI || set->fwd_only || !enabled) {
     return;
@@ -2359,22 +2378,68 @@ static void noise_speculate_from(RnnAmdSet *set, int loss_classes) {
   }
   if (!e->spec_go) {
     HIP_OK(hipEventCreateWithFlags((hipEvent_t *)&e->spec_go, hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags((hipEvent_t *)&e->spec_done, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags((hipEvent_t *)&e->sp[0].done, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags((hipEvent_t *)&e->sp[1].done, hipEventDisableTiming));
   }
-  if (!e->b.noise_spec) {
-    e->b.noise_spec = dev_alloc((size_t)e->sh.Scap * e->sh.H * sizeof(float));
-    e->b.rng_spec = dev_alloc((size_t)e->sh.Scap * sizeof(rand_ctx));
+  for (int k = 0; k < 2; k++) {
+    if (!e->sp[k].noise) {
+      e->sp[k].noise = dev_alloc((size_t)e->sh.Scap * e->sh.H * sizeof(float));
+      e->sp[k].states = dev_alloc((size_t)e->sh.Scap * sizeof(rand_ctx));
+    }
   }
-  HIP_OK(hipEventRecord((hipEvent_t)e->spec_go, g_stream)); /* the draws made so far */
-  HIP_OK(hipStreamWaitEvent(g_side, (hipEvent_t)e->spec_go, 0));
-  ramd_launch_noise_speculate(g_side, &e->sh, &e->b, set->row0, set->n, noise,
-                              loss_classes ? e->d_mclass + set->row0 : NULL, loss_classes);
-  HIP_OK(hipEventRecord((hipEvent_t)e->spec_done, g_side));
-  e->spec_pending = 1;
-  e->spec_version = e->rng_version + (loss_classes ? 1 : 0); /* (the loss that follows counts as one move) */
-  e->spec_row0 = set->row0;
-  e->spec_n = set->n;
-  e->spec_dev = noise;
+  const int r0 = set->row0;
+  int launched = 0;
+  /* the next pass (buffer sp_head), unless an earlier call has started it already */
+  int k = e->sp_head;
+  if (!e->sp[k].pending) {
+    const int early = loss_classes > 0 && e->sp_adopted >= 0;
+    if (loss_classes > 0 && !early) {
+      return; /* (between the pass and the loss only the adopted states are safe to start from) */
+    }
+    HIP_OK(hipEventRecord((hipEvent_t)e->spec_go, g_stream)); /* the draws made so far, the buffers' last readers */
+    HIP_OK(hipStreamWaitEvent(g_side, (hipEvent_t)e->spec_go, 0));
+    ramd_launch_noise_speculate(g_side, &e->sh, &e->b, r0, set->n, noise, e->sp[k].noise, e->sp[k].states,
+                                early ? e->sp[e->sp_adopted].states : NULL, early ? e->d_mclass + r0 : NULL,
+                                early ? loss_classes : 0, 0);
+    HIP_OK(hipEventRecord((hipEvent_t)e->sp[k].done, g_side));
+    e->sp[k].pending = 1;
+    e->sp[k].version = e->rng_version + (early ? 1 : 0); /* (the loss that follows counts as one move) */
+    e->sp[k].row0 = r0;
+    e->sp[k].n = set->n;
+    e->sp[k].dev = noise;
+    e->sp[k].assumed_classes = 0;
+    launched = 1;
+  }
+  /* ... and, in the multi-head step, the pass after it: from the states the first one leaves, past the draws of a
+   * loss whose classes nobody has yet -- one per head but the stream's own, so on the assumption that every stream's own
+   * class is one of the heads (multi_loss checks it when it comes and drops what was built on it otherwise).  The
+   * generator then runs a whole generation ahead and is off the critical path even where it is as long as the
+   * generation (32 streams per GPU). */
+  const int k2 = k ^ 1;
+  if (two_ahead && loss_classes > 0 && e->sp[k].pending && !e->sp[k2].pending && e->sp[k].row0 == r0 &&
+      e->sp[k].n == set->n && e->sp[k].dev == noise) {
+    if (!launched) {
+      HIP_OK(hipEventRecord((hipEvent_t)e->spec_go, g_stream)); /* buffer k2's last reader: the pass just made */
+      HIP_OK(hipStreamWaitEvent(g_side, (hipEvent_t)e->spec_go, 0));
+    }
+    ramd_launch_noise_speculate(g_side, &e->sh, &e->b, r0, set->n, noise, e->sp[k2].noise, e->sp[k2].states,
+                                e->sp[k].states, NULL, 0, loss_classes - 1);
+    HIP_OK(hipEventRecord((hipEvent_t)e->sp[k2].done, g_side));
+    e->sp[k2].pending = 1;
+    e->sp[k2].version = e->sp[k].version + 2; /* one more pass and one more loss on */
+    e->sp[k2].row0 = r0;
+    e->sp[k2].n = set->n;
+    e->sp[k2].dev = noise;
+    e->sp[k2].assumed_classes = loss_classes;
+  }
+}
+
+static void mclass_note(RamdEngine *e, const int *target_class, int n, int n_classes) {
+  int ok = 1;
+  for (int j = 0; j < n; j++) {
+    ok &= target_class[j] >= 0 && target_class[j] < n_classes;
+  }
+  e->mclass_in_range = ok;
 }
 
 static void multi_loss(RnnAmdSet *set, const int *target_class, int alphabet_len, int n_classes,
@@ -2385,6 +2450,14 @@ static void multi_loss(RnnAmdSet *set, const int *target_class, int alphabet_len
   e->rng_version++; /* the leak decisions are draws from the streams' generators */
   if (target_class) {
     upload(e->d_mclass + set->row0, target_class, set->n * sizeof(int));
+    mclass_note(e, target_class, set->n, n_classes);
+  }
+  /* noise that was generated past THIS loss before its classes were known */
+  for (int k = 0; k < 2; k++) {
+    if (e->sp[k].pending && e->sp[k].assumed_classes && e->sp[k].version == e->rng_version &&
+        (e->sp[k].assumed_classes != n_classes || !e->mclass_in_range)) {
+      e->sp[0].pending = e->sp[1].pending = 0; /* (the other one hangs on it, or is the pass in between: redone) */
+    }
   }
   /* u64 threshold = leakage * UINT64_MAX (charmodel-multi-predict.c:27): float arithmetic */
   float tf = leakage * (float)UINT64_MAX;
@@ -2421,13 +2494,14 @@ void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *ne
   upload_q(e->b.hot + set->row0, hot, set->n * sizeof(int));
   if (target_class) {
     upload_q(e->d_mclass + set->row0, target_class, set->n * sizeof(int));
+    mclass_note(e, target_class, set->n, n_classes);
   }
   upload(e->b.target + set->row0, next, set->n * sizeof(int));
   set->early_spec_classes = set->fwd_only ? 0 : n_classes; /* (set_forward's fused branch takes it up) */
   set_forward(set, RAMD_IN_ONE_HOT, NULL, 0, 0, NULL, 1, 0);
   int early = set->early_spec_classes < 0;
   set->early_spec_classes = 0;
-  if (!early && e->spec_adopted && !set->fwd_only) {
+  if (!early && e->sp_adopted >= 0 && !set->fwd_only) {
     noise_speculate_from(set, n_classes);
     early = 1;
   }

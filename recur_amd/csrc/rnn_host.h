@@ -73,11 +73,23 @@ typedef struct RamdEngine {
   int deltas_zero_pending;
   /* noise generated ahead (noise_speculate): valid while nothing else has moved the device's
    * generators since (rng_version) */
-  unsigned long rng_version, spec_version;
-  int spec_pending, spec_row0, spec_n;
-  int spec_adopted; /* the set's last forward pass took its noise (and generator states) from the speculation */
-  float spec_dev;
-  void *spec_go, *spec_done; /* hipEvent_t */
+  unsigned long rng_version;
+  /* Two passes' worth of buffers: sp[k] holds (or is being filled with) the noise of one coming pass and the generator
+   * states after it; sp_head is the one the NEXT forward pass takes.  `version`: rng_version as it must stand when that
+   * pass begins; `assumed_classes` != 0: generated before the multi-head loss in front of it had its classes -- on the
+   * assumption that every stream's own class is one of that many heads, checked when the loss comes (multi_loss). */
+  struct {
+    float *noise;
+    void *states;
+    void *done; /* hipEvent_t */
+    int pending, row0, n, assumed_classes;
+    unsigned long version;
+    float dev;
+  } sp[2];
+  int sp_head;
+  int sp_adopted;        /* the buffer the set's last forward pass took its noise and states from, or -1 */
+  int mclass_in_range;   /* every stream's class of the last multi-head upload is one of the heads */
+  void *spec_go;         /* hipEvent_t */
   int scalars_dev_valid; /* device mef/ih_scale newer than the host structs */
   /* this engine hosts ONE SHARD of a training set spread over the ranks of the process group
    * (rnn_amd_new_training_set_shard, rnn_amd_set_shard, or a training set opened after
