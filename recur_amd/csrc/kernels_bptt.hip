@@ -992,6 +992,10 @@ extern "C" void ramd_delta_stamps(unsigned long long *out) {
 /* RR: rows of the rest tile: 0 (none), 64 or 128 (a wave then has 32 or 64 rest rows x its 64 columns) */
 template <int RR>
 __global__ __launch_bounds__(512) void k_delta_dma(View v, int row0, int nrows, GemmOut o, DeltaRest dr) {
+  /* above the noise generator's waves (priority 0), which share four SIMDs with workgroups of this launch while the set
+   * has presynaptic noise: the launch runs at the pace of its slowest workgroup (multi-head step, 256 / 32 streams:
+   * 369 -> 360 / 221 -> 218 us per generation; nothing else changes) */
+  __builtin_amdgcn_s_setprio(2);
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const RamdShape &s = v.sh;
   const int L = blockIdx.x;

@@ -614,6 +614,10 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
                                                        int row0, int nrows, int depth, unsigned seq,
                                                        ChainSync *sy, unsigned *host_abort, int nvalid, int vlo,
                                                        HoWork hw, XcWork xc, int static_map, unsigned tseq) {
+  /* above the noise generator's waves (priority 0), which share four SIMDs with workgroups of this launch while the set
+   * has presynaptic noise: the launch runs at the pace of its slowest workgroup (multi-head step, 256 / 32 streams:
+   * 369 -> 360 / 221 -> 218 us per generation; nothing else changes) */
+  __builtin_amdgcn_s_setprio(2);
   extern __shared__ __attribute__((aligned(16))) float psm[];
   constexpr int BUF = PC_SUB * K;             /* one sub-chain's operand (64 KB at K = 1024) */
   constexpr int NT = K / 32;                  /* column tiles of a row tile            */
