@@ -371,6 +371,9 @@ static void engine_free_device(RamdEngine *e) {
   dev_free(b->mheads_part);
   b->mheads_part = NULL;
   b->mheads_part_floats = 0;
+  free(e->active_host); /* (b.active goes with the device arrays) */
+  e->active_host = NULL;
+  e->active_host_n = 0;
   dev_free(e->d_kept_slab);
   e->d_kept_slab = NULL;
   e->kept_floats = 0;
@@ -2174,6 +2177,25 @@ void rnn_amd_set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ra
   set_calc_deltas(set, accumulate, ranges, active, 0, NULL, 0, NULL);
 }
 
+/* the set calls' active mask on the device (b.active, written by nothing else): uploaded unless these very flags are
+ * there already -- the class-group loss sends the flags it returns along with its own uploads, because its caller passes
+ * them straight on to the delta call (one launch less per generation).  queued: leaves with the caller's next flush */
+static void active_mask_to_dev(RamdEngine *e, const u8 *active, int n, int queued) {
+  if (e->active_host && e->active_host_n == n && memcmp(e->active_host, active, (size_t)n) == 0) {
+    return;
+  }
+  if (!e->active_host) {
+    e->active_host = ramd_zalloc((size_t)e->sh.Scap + 4);
+  }
+  memcpy(e->active_host, active, (size_t)n);
+  e->active_host_n = n;
+  if (queued) {
+    upload_q(e->b.active, active, (size_t)n);
+  } else {
+    upload(e->b.active, active, (size_t)n); /* (through the mailbox when the set is a whole number of words) */
+  }
+}
+
 /* may this set call leave its delta sums as planes (RamdEngine.kept)?  Not with a bottom layer (its deltas follow in
  * a launch of their own that accumulates), an exchange between ranks or a caller's delta buffer (both want the sums
  * as such, at once); the workspace is the engine's own, made on first use: eight planes and the rest rows' planes */
@@ -2222,7 +2244,7 @@ static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ran
   const int *d_ranges = dev_ranges ? dev_ranges : push_ranges(e, ranges);
   const unsigned char *d_active = NULL;
   if (active) {
-    upload(e->b.active, active, set->n); /* (through the mailbox when the set is a whole number of words) */
+    active_mask_to_dev(e, active, set->n, 0);
     d_active = e->b.active;
   }
   if (e->err_pending && (d_ranges || e->err_row0 != set->row0 || e->err_nrows != set->n)) {
@@ -2296,10 +2318,6 @@ void rnn_amd_set_grouped_softmax_error(RnnAmdSet *set, int n_groups, const int *
     dw = (float *)(d + ints);
     upload_q(dw, error_weight, (size_t)s->output_size * sizeof(float));
   }
-  mail_in_flush();
-  ramd_launch_grouped_softmax_error(g_stream, s, &e->b, set->row0, set->n, n_groups, largest, d,
-                                    d + n_groups, d + 2 * n_groups, dw);
-  set_streams_dev_wrote(set);
   if (trained) { /* a stream is trained if any of its groups has a usable target */
     for (int j = 0; j < set->n; j++) {
       trained[j] = 0;
@@ -2308,7 +2326,16 @@ void rnn_amd_set_grouped_softmax_error(RnnAmdSet *set, int n_groups, const int *
         trained[j] |= (t >= 0 && t < group_size[i]);
       }
     }
+    /* the caller hands these flags to rnn_amd_set_calc_deltas next (gstclassify.c:2120-2127): they travel with this
+     * call's uploads, and that call finds them in place (active_mask_to_dev) */
+    if (set->n % 4 == 0 && !set->fwd_only) {
+      active_mask_to_dev(e, trained, set->n, 1);
+    }
   }
+  mail_in_flush();
+  ramd_launch_grouped_softmax_error(g_stream, s, &e->b, set->row0, set->n, n_groups, largest, d,
+                                    d + n_groups, d + 2 * n_groups, dw);
+  set_streams_dev_wrote(set);
 }
 
 /* The multi-head text model for the whole set, per generation: what

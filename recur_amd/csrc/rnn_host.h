@@ -59,6 +59,8 @@ typedef struct RamdEngine {
    * for the rnn_apply_learning that normally follows to sum on its way -- the separate calls then cost what the
    * one-call text step costs, a k_delta_finalize launch less.  Whoever else wants the delta arrays gets them summed
    * first (deltas_materialize). */
+  u8 *active_host; /* what b.active holds (the last active mask sent), or NULL */
+  int active_host_n;
   RamdPendingDelta kept;
   int kept_live;
   float *d_kept_slab;
