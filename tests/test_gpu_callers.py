@@ -142,20 +142,27 @@ def _multi_head_generation(lib, A, NC, H, S, D, leakage, deep=False, stray_every
     o.close()
 
 
-@pytest.mark.parametrize("off", ["RECUR_AMD_TOP_SPARSE RECUR_AMD_HO_HEADS",
-                                 "RECUR_AMD_TOP_SPARSE RECUR_AMD_TOP_HEADS RECUR_AMD_HO_HEADS"])
-def test_config3_generation_with_the_head_kernels_switched_off(off):
-    """The multi-head top layer has three forms: per trained head (k_top_heads_partial / _combine, k_ho_delta_heads),
-    one masked GEMM over the whole output row (k_top_backprop_heads; taken when the partial products would not fit)
-    and the per-stream ranged gathers (any range list).  The library reads its switches once per process, so the
-    other two run here in a process of their own, on the 32-stream case."""
+@pytest.mark.parametrize("env,node", [
+    ("RECUR_AMD_TOP_SPARSE=0 RECUR_AMD_HO_HEADS=0", "test_config3_multi_head_generation_at_size[32]"),
+    ("RECUR_AMD_TOP_SPARSE=0 RECUR_AMD_TOP_HEADS=0 RECUR_AMD_HO_HEADS=0", "test_config3_multi_head_generation_at_size[32]"),
+    ("RECUR_AMD_FWD_FUSED_ANY=0 RECUR_AMD_KEEP_DELTAS=0 RECUR_AMD_NOISE_AHEAD=1", "test_config3_multi_head_generation_at_size[32]"),
+    ("RECUR_AMD_NOISE_AHEAD=0", "test_multi_head_generation_with_streams_that_have_no_head_of_their_own[2]"),
+    ("RECUR_AMD_EXTRAS_DENSE=0 RECUR_AMD_KEEP_DELTAS=0", "test_config2_classify_generations_with_balanced_training"),
+])
+def test_callers_generations_with_the_newer_kernels_switched_off(env, node):
+    """Every specialised form has the form it replaced behind it: the multi-head top layer per trained head
+    (k_top_heads_partial / _combine, k_ho_delta_heads) falls back to one masked GEMM over the whole output row
+    (k_top_backprop_heads; taken when the partial products would not fit) and that to the per-stream ranged gathers
+    (any range list); the fused forward launch to assemble + GEMM + finalize; kept delta planes to k_delta_finalize; the
+    noise generator two passes ahead to one, to none; k_extras_dense to the generic GEMM.  The library reads its
+    switches once per process, so each combination runs here in a process of its own."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, **{k: "0" for k in off.split()})
-    node = "%s::test_config3_multi_head_generation_at_size[32]" % os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, "-m", "pytest", node, "-q", "-x", "-p", "no:cacheprovider"],
-                       capture_output=True, text=True, env=env, timeout=900, cwd=os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **dict(kv.split("=") for kv in env.split()))
+    path = "%s::%s" % (os.path.abspath(__file__), node)
+    r = subprocess.run([sys.executable, "-m", "pytest", path, "-q", "-x", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, env=e, timeout=900, cwd=os.path.dirname(os.path.abspath(__file__)))
     assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
