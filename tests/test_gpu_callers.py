@@ -254,12 +254,23 @@ def test_multi_confab_object_and_line(amd):
 
 # ------------------------------------------------------------------ configs[4] --
 
-def _rnnca_inputs(rs, S):
+def _rnnca_inputs(rs, S, n_in=35):
     """35 inputs per cell: 17 luma + 16 chroma neighbours as BYTE_TO_UNIT bytes, 2 position
-    values (gstrnnca.c:668-690)"""
-    x = (rs.integers(0, 256, (S, 35)) / np.float32(255.0)).astype(np.float32)
-    x[:, 33:] = rs.random((S, 2)).astype(np.float32)
+    values (gstrnnca.c:668-690); byte 0 is a zero input, which the row rule leaves out"""
+    x = (rs.integers(0, 256, (S, n_in)) / np.float32(255.0)).astype(np.float32)
+    if n_in >= 3:
+        x[:, n_in - 2:] = rs.random((S, 2)).astype(np.float32)
     return np.ascontiguousarray(x)
+
+
+@pytest.mark.parametrize("hidden,S,D,n_in,activation", [(36, 5, 3, 1, rc.RELU), (100, 33, 7, 46, rc.RESQRT),
+                                                         (516, 17, 5, 15, rc.RECLIP20), (256, 48, 4, 47, rc.RELU),
+                                                         (128, 9, 6, 16, rc.RESQRT)])
+def test_dense_input_generation_with_other_shapes(amd, hidden, S, D, n_in, activation):
+    """k_extras_dense at its edges: 1 to 47 dense inputs (2 to 48 extra columns: the three 16-column tiles full), h_size
+    not a multiple of the 16-deep K chunks, fewer (step, stream) rows than a workgroup takes, every activation's row
+    rule.  (48 inputs and more take the generic GEMM: the rnnca test below at 35, the fuzzer at others.)"""
+    _rnnca_generation(amd, hidden, S, D, n_in=n_in, activation=activation)
 
 
 @pytest.mark.parametrize("hidden,S,D", [(2048, 512, 10), (64, 20, 4)])
@@ -269,9 +280,14 @@ def test_config4_rnnca_training_generation(amd, hidden, S, D):
     accumulating calc_deltas, weighted-momentum update with the soft start.  The reference's
     trainer never advances the ring (effective depth 1); the synthetic driver adds
     rnn_bptt_advance so that depth 10 is exercised."""
-    lib = amd
-    kw = dict(input_size=35, hidden_size=hidden, output_size=3, S=S, D=D, learn_rate=1e-5 if hidden > 1000 else 1e-3,
+    _rnnca_generation(amd, hidden, S, D)
+
+
+def _rnnca_generation(lib, hidden, S, D, n_in=35, activation=None):
+    kw = dict(input_size=n_in, hidden_size=hidden, output_size=3, S=S, D=D, learn_rate=1e-5 if hidden > 1000 else 1e-3,
               seed=81, momentum=0.95)
+    if activation is not None:
+        kw["activation"] = activation
     g = sc.AmdBatchedSet(lib, **kw)
     rs = np.random.default_rng(11)
 
@@ -280,7 +296,7 @@ def test_config4_rnnca_training_generation(amd, hidden, S, D):
         if gpu is not None:
             lib.rnn_bptt_clear_deltas(gpu.net)
             lib.rnn_amd_set_advance(gpu.handle)
-            lib.rnn_amd_set_opinion(gpu.handle, rc.fptr(x), 35, None)
+            lib.rnn_amd_set_opinion(gpu.handle, rc.fptr(x), n_in, None)
             lib.rnn_amd_set_sigmoid_mse_error(gpu.handle, rc.fptr(tgt), 3, 3)
             lib.rnn_amd_set_calc_deltas(gpu.handle, 1, None, None)
             lib.rnn_apply_learning(gpu.net, rc.WEIGHTED, m)
@@ -297,7 +313,7 @@ def test_config4_rnnca_training_generation(amd, hidden, S, D):
     n_warm = D + 2
     t0 = time.perf_counter()
     for gen in range(n_warm):
-        generation(g, None, _rnnca_inputs(rs, S), (rs.integers(0, 256, (S, 3)) / np.float32(255)).astype(np.float32),
+        generation(g, None, _rnnca_inputs(rs, S, n_in), (rs.integers(0, 256, (S, 3)) / np.float32(255)).astype(np.float32),
                    gen)
     lib.rnn_amd_synchronize()
     print("configs[4] rnnca training generation, hidden %d, %d cells: %.0f cell-timesteps/s"
@@ -310,7 +326,7 @@ def test_config4_rnnca_training_generation(amd, hidden, S, D):
         # shows in one column of the deltas.  Such a generation is not a parity case: go on
         # from where the device is and take the next one.
         _sync_oracle_to(o, g.snapshot())
-        x = _rnnca_inputs(rs, S)
+        x = _rnnca_inputs(rs, S, n_in)
         tgt = np.ascontiguousarray((rs.integers(0, 256, (S, 3)) / np.float32(255)).astype(np.float32))
         generation(g, o, x, tgt, n_warm + attempt)
         sg, so = g.snapshot(), o.snapshot()
