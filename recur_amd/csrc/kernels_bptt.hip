@@ -528,7 +528,8 @@ __global__ __launch_bounds__(256) void k_top_heads_partial(View v, int row0, int
 
 constexpr int THC_THREADS = 320; /* a float4 of the row per thread: h_size <= 1280 in one pass (more: the loop) */
 __global__ __launch_bounds__(THC_THREADS) void k_top_heads_combine(View v, int row0, const int *ranges, int range_stride,
-                                                                   const unsigned char *active, int ncls, const float *P) {
+                                                                   const unsigned char *active, int ncls, const float *P,
+                                                                   int images_pending) {
   __shared__ float red[THC_THREADS / 64];
   __shared__ signed char heads[64];
   __shared__ unsigned char ends[64];
@@ -546,6 +547,15 @@ __global__ __launch_bounds__(THC_THREADS) void k_top_heads_combine(View v, int r
   __syncthreads();
   const float *Pj = P + (size_t)r * ncls * s.H;
   float *dst = v.b.ehi + (size_t)r * s.I;
+  /* the stale entries: err_a as the last BPTT run left it -- which, while k_err_writeback has not rebuilt the images,
+   * is that run's error plane n (n its executed steps, even) or n - 1 (odd) in columns 1 .. hidden_size, the only ones
+   * used here (k_err_writeback's rule; plane 0 is the row this thread is about to overwrite: read first).  A launch
+   * less per generation of the multi-head step. */
+  const float *stale_row = v.b.err_a + (size_t)r * s.I;
+  if (images_pending) {
+    const int n = v.b.n_exec[r];
+    if (n > 0) stale_row = v.b.ehi + ((size_t)((n & 1) ? n - 1 : n) * s.Scap + r) * s.I;
+  }
   float psum = 0.0f;
   for (int y4 = 4 * tid; y4 < s.H; y4 += 4 * THC_THREADS) { /* (h_size is a multiple of 4) */
     float e[4] = {0.f, 0.f, 0.f, 0.f}, sabs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -567,7 +577,7 @@ __global__ __launch_bounds__(THC_THREADS) void k_top_heads_combine(View v, int r
       }
     }
     const float4 hv4 = *reinterpret_cast<const float4 *>(v.b.hidden + (size_t)r * s.H + y4);
-    const float4 st4 = *reinterpret_cast<const float4 *>(v.b.err_a + (size_t)r * s.I + y4);
+    const float4 st4 = *reinterpret_cast<const float4 *>(stale_row + y4);
     const float hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, stale[4] = {st4.x, st4.y, st4.z, st4.w};
     float o[4];
 #pragma unroll
@@ -1678,12 +1688,20 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   View v = make_view(sh, b);
   // top layer
   size_t shm = (size_t)(sh->O + sh->H) * sizeof(float);
+  bool images_done = !(flags & RAMD_IMAGES_PENDING);
+  const int h_alen0 = b->mheads_alen, h_ncls0 = h_alen0 > 0 ? sh->output_size / h_alen0 : 0;
+  const bool top_sparse = !(flags & 0x40000000u) && ranges && range_stride && (flags & RAMD_RANGES_ARE_HEADS) &&
+                          h_alen0 >= 24 && h_alen0 <= 128 && h_ncls0 <= 64 && sh->output_size == h_ncls0 * h_alen0 &&
+                          b->mheads_part && (size_t)sh->Scap * h_ncls0 * sh->H <= b->mheads_part_floats &&
+                          row0 + nrows <= sh->Scap && env_int("RECUR_AMD_TOP_SPARSE", 1);
+  if (!images_done && !(top_sparse && env_int("RECUR_AMD_STALE_FROM_PLANES", 1))) {
+    ramd_launch_err_writeback(st_, sh, b, row0, nrows); /* the images, before anything below overwrites the planes */
+    images_done = true;
+    flags &= ~RAMD_IMAGES_PENDING;
+  }
   if (!(flags & 0x40000000u)) { /* ramd_launch_text_top has already done the top backprop */
-    const int h_alen = b->mheads_alen, h_ncls = h_alen > 0 ? sh->output_size / h_alen : 0;
-    if (ranges && range_stride && (flags & RAMD_RANGES_ARE_HEADS) && h_alen >= 24 && h_alen <= 128 && h_ncls <= 64 &&
-        sh->output_size == h_ncls * h_alen && b->mheads_part &&
-        (size_t)sh->Scap * h_ncls * sh->H <= b->mheads_part_floats && row0 + nrows <= sh->Scap &&
-        env_int("RECUR_AMD_TOP_SPARSE", 1)) {
+    const int h_alen = h_alen0, h_ncls = h_ncls0;
+    if (top_sparse) {
       /* the multi-head loss's ranges, only the heads a stream trained: partial products per (stream, head), then the
        * ordered sums and the clip */
       const int span4 = (3 + h_alen + 3) / 4, ld = (4 * span4) | 1; /* (the widest span: a head that starts 3 columns into its float4) */
@@ -1696,7 +1714,8 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
                   (size_t)((THP_ROWS + 32) * ld + 4) * sizeof(float), st, v, row0, nrows, ranges, range_stride, active, h_alen,
                   h_ncls, b->mheads_part);
       RAMD_LAUNCH(k_top_heads_combine, dim3(nrows), dim3(THC_THREADS), 0, st, v, row0, ranges, range_stride, active, h_ncls,
-                  b->mheads_part);
+                  b->mheads_part, (flags & RAMD_IMAGES_PENDING) ? 1 : 0);
+      images_done = true; /* (it took the stale entries from the planes) */
     } else if (ranges && range_stride && (flags & RAMD_RANGES_ARE_HEADS) && sh->O % 4 == 0 && sh->O >= 64 &&
         (size_t)nrows * 2 * ((sh->H + 31) / 32) <= b->slab_floats && env_int("RECUR_AMD_TOP_HEADS", 1)) {
       /* the multi-head loss's ranges: one GEMM over all streams (k_top_backprop_heads), then the sums and the clip */

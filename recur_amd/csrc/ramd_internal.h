@@ -162,6 +162,11 @@ int ramd_launch_forward_hidden(ramd_stream_t st, const RamdShape *sh, const Ramd
 /* flag of ramd_launch_calc_deltas: the per-stream range lists are the multi-head loss's (runs of whole heads of at
  * least 24 columns, the error row zero outside them): the top backprop may run as one GEMM (k_top_backprop_heads) */
 #define RAMD_RANGES_ARE_HEADS 0x10000000u
+/* flag of ramd_launch_calc_deltas: the error images (err_a / err_b) of these very rows have not been rebuilt since
+ * their last BPTT run (k_err_writeback pending).  The ranged top backprops keep the images' stale entries for rows
+ * whose hidden value is zero: the launcher rebuilds the images first, unless its top-layer form
+ * takes the stale entries from the error planes itself (k_top_heads_combine) */
+#define RAMD_IMAGES_PENDING 0x08000000u
 /* a stream's range list as the multi-head loss leaves it: up to 64 + 1 (start, len) pairs, then one bit per head the
  * stream trained (an unsigned long long at this int offset; the stride keeps it 8-byte aligned) */
 #define RAMD_HEADBITS_AT 130

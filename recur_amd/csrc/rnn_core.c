@@ -2247,7 +2247,12 @@ static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ran
     active_mask_to_dev(e, active, set->n, 0);
     d_active = e->b.active;
   }
-  if (e->err_pending && (d_ranges || e->err_row0 != set->row0 || e->err_nrows != set->n)) {
+  if (e->err_pending && d_ranges && e->err_row0 == set->row0 && e->err_nrows == set->n) {
+    /* the ranged top backprops keep stale entries of these rows' error images, which have not been rebuilt yet: the
+     * launcher sees to it (its per-head form reads them from the planes: no k_err_writeback launch) */
+    extra_flags |= RAMD_IMAGES_PENDING;
+    e->err_pending = 0;
+  } else if (e->err_pending && (d_ranges || e->err_row0 != set->row0 || e->err_nrows != set->n)) {
     err_flush(e);
   }
   set_uniform_idx(e, set->row0, set->n);

@@ -147,6 +147,7 @@ def _multi_head_generation(lib, A, NC, H, S, D, leakage, deep=False, stray_every
     ("RECUR_AMD_TOP_SPARSE=0 RECUR_AMD_TOP_HEADS=0 RECUR_AMD_HO_HEADS=0", "test_config3_multi_head_generation_at_size[32]"),
     ("RECUR_AMD_FWD_FUSED_ANY=0 RECUR_AMD_KEEP_DELTAS=0 RECUR_AMD_NOISE_AHEAD=1", "test_config3_multi_head_generation_at_size[32]"),
     ("RECUR_AMD_NOISE_AHEAD=0", "test_multi_head_generation_with_streams_that_have_no_head_of_their_own[2]"),
+    ("RECUR_AMD_STALE_FROM_PLANES=0", "test_config3_multi_head_generation_at_size[32]"),
     ("RECUR_AMD_EXTRAS_DENSE=0 RECUR_AMD_KEEP_DELTAS=0", "test_config2_classify_generations_with_balanced_training"),
 ])
 def test_callers_generations_with_the_newer_kernels_switched_off(env, node):
@@ -154,7 +155,8 @@ def test_callers_generations_with_the_newer_kernels_switched_off(env, node):
     (k_top_heads_partial / _combine, k_ho_delta_heads) falls back to one masked GEMM over the whole output row
     (k_top_backprop_heads; taken when the partial products would not fit) and that to the per-stream ranged gathers
     (any range list); the fused forward launch to assemble + GEMM + finalize; kept delta planes to k_delta_finalize; the
-    noise generator two passes ahead to one, to none; k_extras_dense to the generic GEMM.  The library reads its
+    noise generator two passes ahead to one, to none; k_extras_dense to the generic GEMM; the stale entries from the error
+    planes to k_err_writeback's images.  The library reads its
     switches once per process, so each combination runs here in a process of its own."""
     import os
     import subprocess
