@@ -361,16 +361,17 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
 // the reference builds for rnn_bptt_calc_deltas -- aligned, merged when they touch -- are
 // left in ranges[j].  One wave per stream; every lane runs the generator redundantly so
 // that the decisions are uniform.
-// Four waves per stream: wave 0 makes the leak decisions (the generator is sequential) and the
-// range list while all four clear the error row; then the trained heads are shared out over the
+// Eight waves per stream: wave 0 makes the leak decisions (the generator is sequential) and the
+// range list while all of them clear the error row; then the trained heads are shared out over the
 // waves, each head's softmax exactly as before (the sum of the exponentials in index order).
-// (As one wave per stream this was 35 us for 256 streams of 50 heads.)
-constexpr int MS_WAVES = 4, MS_MAXCLS = 256;
+// (As one wave per stream this was 35 us for 256 streams of 50 heads, as four 15.6, as eight with a head's
+// outputs loaded once and the ordered sum on float4 reads 11 us.)
+constexpr int MS_WAVES = 8, MS_MAXCLS = 256; /* (eight: a stream's ~6 trained heads in one round) */
 __global__ __launch_bounds__(64 * MS_WAVES) void k_multi_softmax_error(View v, int row0, int alen, int ncls,
                                                                        unsigned long long threshold,
                                                                        const int *tclass, int *ranges,
                                                                        int range_stride) {
-  extern __shared__ float exs[]; /* [MS_WAVES][alen] */
+  extern __shared__ __attribute__((aligned(16))) float exs[]; /* [MS_WAVES][alen rounded up to 4] */
   __shared__ short trained[MS_MAXCLS];
   __shared__ int ntrained;
   __shared__ float own_err_sh;
@@ -418,11 +419,49 @@ __global__ __launch_bounds__(64 * MS_WAVES) void k_multi_softmax_error(View v, i
     }
   }
   __syncthreads(); /* the row is clear, the list is there */
-  float *ex = exs + wave * alen;
+  const int alenp = (alen + 3) & ~3;
+  float *ex = exs + wave * alenp;
   const int nt = ntrained;
   for (int k = wave; k < nt; k += MS_WAVES) {
     const int c = trained[k], offset = c * alen;
     const float *gs = src + offset;
+    if (alen <= 128) {
+      /* the head's outputs once, in registers (as loads in each of the loops below they were two round trips per head) */
+      const bool in0 = lane < alen, in1 = lane + 64 < alen;
+      const float g0 = gs[in0 ? lane : 0], g1 = gs[in1 ? lane + 64 : 0];
+      float hi = fmaxf(g0, g1), lo = fminf(g0, g1); /* (a lane without a value holds gs[0]) */
+      for (int off = 32; off > 0; off >>= 1) {
+        hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+        lo = fminf(lo, __shfl_xor(lo, off, 64));
+      }
+      float adj = 0.0f;
+      if (hi > 50.0f) adj = 50.0f - hi;
+      else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+      const float e0 = fast_expf_dev(g0 + adj), e1 = fast_expf_dev(g1 + adj);
+      if (in0) ex[lane] = e0;
+      if (in1) ex[lane + 64] = e1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* one wave: its LDS writes are ordered */
+      /* the exponentials in index order, four float4 reads in flight instead of a read per addition */
+      float sum = 0.0f;
+      for (int i0 = 0; 4 * i0 < alen; i0 += 4) {
+        float4 q[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[i] = *reinterpret_cast<const float4 *>(ex + 4 * (4 * (i0 + i) < alenp ? i0 + i : 0));
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          if (4 * (i0 + i) + 0 < alen) sum += q[i].x;
+          if (4 * (i0 + i) + 1 < alen) sum += q[i].y;
+          if (4 * (i0 + i) + 2 < alen) sum += q[i].z;
+          if (4 * (i0 + i) + 3 < alen) sum += q[i].w;
+        }
+      }
+      const float q0 = e0 / sum, q1 = e1 / sum;
+      if (in0) err[offset + lane] = (lane == next) ? -q0 + 1.0f : -q0;
+      if (in1) err[offset + lane + 64] = (lane + 64 == next) ? -q1 + 1.0f : -q1;
+      if (c == own && lane == 0) own_err_sh = -(ex[next] / sum) + 1.0f;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* before this wave's next head rewrites ex */
+      continue;
+    }
     float lo = gs[0], hi = gs[0];
     for (int i = lane; i < alen; i += 64) {
       hi = fmaxf(hi, gs[i]);
@@ -679,7 +718,7 @@ extern "C" void ramd_launch_multi_softmax_error(ramd_stream_t st_, const RamdSha
     abort();
   }
   RAMD_LAUNCH(k_multi_softmax_error, dim3(nrows), dim3(64 * MS_WAVES),
-                     (size_t)MS_WAVES * alphabet_len * sizeof(float), st, v, row0, alphabet_len, n_classes,
+                     (size_t)MS_WAVES * ((alphabet_len + 3) & ~3) * sizeof(float), st, v, row0, alphabet_len, n_classes,
                      threshold, tclass, ranges, range_stride);
 }
 
