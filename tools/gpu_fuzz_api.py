@@ -424,6 +424,11 @@ for trial in range(trials):
                 for name, snap in (("product", sg), ("reference", sr)):
                     c, *_ = np.linalg.lstsq(E, snap["ho_delta"].ravel(), rcond=None)
                     print("      ho_delta of the %s = sum_j c_j hidden_j (x) o_error_j with c =" % name, np.round(c, 3))
+            if "ih_scale" in sg:  # the streams whose input error was clipped (ih_scale < 1) inherit their error sum's conditioning
+                d = np.abs(sg["ih_scale"] - sr["ih_scale"])
+                j = int(np.argmax(d))
+                print("      ih_scale: %d of %d streams clipped in the reference; largest difference at stream %d: product %.7g, reference %.7g"
+                      % (int((sr["ih_scale"] != 1.0).sum()), sr["ih_scale"].size, j, sg["ih_scale"].ravel()[j], sr["ih_scale"].ravel()[j]))
             for k in ("ih_delta", "ho_delta"):
                 print("      %s: product norm %.6g, reference norm %.6g, difference %.6g" % (
                     k, np.linalg.norm(sg[k]), np.linalg.norm(sr[k]), np.linalg.norm(sg[k] - sr[k])))
