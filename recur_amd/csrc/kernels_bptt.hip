@@ -954,6 +954,8 @@ __global__ __launch_bounds__(64 * XD_WAVES) void k_extras_dense(View v, int row0
   if (sub == 0 && live) v.b.esum[(size_t)t * s.Scap + r] = other + sq;
 }
 
+#include "k_delta_direct.h" /* the weight-delta GEMM without a K split over workgroups (hidden 1024 and up) */
+
 // ------------------------------------------------ weight-delta GEMM by LDS-DMA --
 //
 // ih_delta[m][n] = sum over (step t, stream r) of X_t[r][m] * coef[t][r] * E_t[r][n]
@@ -1951,6 +1953,103 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     int rows_core = sh->I, ks_rest = ks;
     float *rest_base = b->slab; /* planes of the rows from rows_core on: rest_base + z * rest_stride */
     size_t rest_stride = n;
+    /* ---- k_delta_direct (k_delta_direct.h): 64 x 64 tiles that own ALL of K, where those fill the chip (hidden 1024:
+     * 256 tiles); the sum goes straight into ih_delta -- and, when the caller's update is the momentum rule and
+     * nothing else wants the sums first, weights and momentum are updated in the same epilogue (fuse_want) */
+    {
+      constexpr int NW = 8, P = 5;
+      const int dtm = sh->I / 64, dtn = sh->hidden_size / 64, drest = sh->I - 64 * dtm;
+      const int QPS = nrows / 4, NQ = sh->D * QPS, n_it = QPS % NW == 0 ? sh->D * (QPS / NW) : -1;
+      const bool rest_ok = dtm > 0 && (drest == 0 || (drest <= 64 && NQ % dtm == 0 && (NQ / dtm) % (NW * P) == 0 &&
+                                          (size_t)dtm * drest * sh->H <= b->slab_floats));
+      const bool direct = b->uniform_idx >= 0 && sh->hidden_size % 64 == 0 && dtm * dtn >= 192 && nrows % (4 * NW) == 0 &&
+                          nrows <= 256 * (DD_FLAG_LOADS / 2) && row0 + nrows <= sh->Scap && sh->activation != 5 && n_it >= P &&
+                          n_it % P == 0 && rest_ok && !(g_delta_half_hook && env_int("RECUR_AMD_DIST_OVERLAP", 0)) &&
+                          env_int("RECUR_AMD_DELTA_DIRECT", 1);
+      if (direct) {
+        static bool attr_set = false;
+        if (!attr_set) {
+          HIP_CHECK(hipFuncSetAttribute((const void *)k_delta_direct<NW, P>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        dd_lds_bytes(NW)));
+          attr_set = true;
+        }
+        if (ho_paired) { /* the top layer's delta GEMM had been waiting for a pair launch */
+          launch_gemm<true, true, ProbHoDelta>(st, ho_p, b->ho_slab, sh->H, sh->O, ho_nkt, ho_ks, T_OTHER);
+          ho_paired = false;
+          if (ho_finalize_after)
+            RAMD_LAUNCH(k_ho_delta_finalize, dim3((sh->H * sh->O + 255) / 256), dim3(256), 0, st, v, b->ho_slab, ho_ks,
+                        accumulate, range_stride ? nullptr : ranges);
+        }
+        /* the top layer's sum as ONE array by now?  (the chain launch formed it, or a finalize has run) */
+        const float *ho_src = nullptr;
+        if (defer && defer->ho_slab && defer->ho_ks == 1) ho_src = defer->ho_slab;
+        else if (!defer || !defer->ho_slab) ho_src = b->ho_delta;
+        const bool fuse = defer && defer->fuse_want && !accumulate && ho_src && !(flags & 0xa0000000u);
+        DdArgs a = {};
+        a.x = b->arena + (size_t)row0 * sh->I;
+        a.e = b->ehi + (size_t)row0 * sh->I + 1;
+        a.coef = b->coef + row0;
+        a.n_exec = b->n_exec + row0;
+        a.ih_scale = b->ih_scale + row0;
+        a.w = b->ih_w + 1;
+        a.m = b->ih_m + 1;
+        a.delta = b->ih_delta + 1;
+        a.rest_planes = b->slab + 1;
+        a.plane = (size_t)sh->Scap * sh->I;
+        a.rest_stride = (size_t)drest * sh->H;
+        a.I = sh->I;
+        a.H = sh->H;
+        a.Scap = sh->Scap;
+        a.nrows = nrows;
+        a.D = sh->D;
+        a.uidx = b->uniform_idx;
+        a.tm = dtm;
+        a.tn = dtn;
+        a.rest = drest;
+        a.mode = fuse ? 2 : accumulate ? 1 : 0;
+        a.rate = fuse ? defer->fuse_rate : 0.0f;
+        a.momentum = fuse ? defer->fuse_momentum : 0.0f;
+        a.mw = fuse ? defer->fuse_mw : 0.0f;
+        int ev = timing_begin(st, T_DELTA);
+        RAMD_LAUNCH((k_delta_direct<NW, P>), dim3(dtm * dtn), dim3(64 * NW), dd_lds_bytes(NW), st, a);
+        timing_end(st, ev);
+        DdEdgeArgs ea = {};
+        ea.w = b->ih_w;
+        ea.m = b->ih_m;
+        ea.delta = b->ih_delta;
+        ea.rest_planes = b->slab;
+        ea.rest_stride = a.rest_stride;
+        ea.tm_planes = dtm;
+        ea.rows_core = 64 * dtm;
+        ea.rest = drest;
+        ea.H = sh->H;
+        ea.hidden_size = sh->hidden_size;
+        ea.mode = a.mode;
+        ea.rate = a.rate;
+        ea.momentum = a.momentum;
+        ea.mw = a.mw;
+        if (fuse) {
+          ea.ho_w = b->ho_w;
+          ea.ho_m = b->ho_m;
+          ea.ho_delta = ho_src;
+          ea.ho_delta_out = ho_src == b->ho_delta ? nullptr : b->ho_delta;
+          ea.ho_n4 = (size_t)sh->H * sh->O / 4;
+          ea.ho_rate = defer->fuse_ho_rate;
+        }
+        const size_t etot = dd_edge_threads(ea);
+        ev = timing_begin(st, T_APPLY);
+        RAMD_LAUNCH(k_apply_edges, dim3((unsigned)((etot + 255) / 256)), dim3(256), 0, st, ea);
+        timing_end(st, ev);
+        if (defer) {
+          defer->slab = nullptr; /* ih_delta is complete */
+          if (fuse) {
+            defer->ho_slab = nullptr;
+            defer->fuse_done = 1;
+          }
+        }
+        return;
+      }
+    }
     if (dma) {
       /* whole 128-row tiles by LDS-DMA, one workgroup per CU; the rows above them (the
        * input rows of a text net) by the generic kernel with its own K split */

@@ -116,6 +116,12 @@ typedef struct RamdPendingDelta {
    * workspace -- for sums that are to outlive the call (the engine's kept deltas, rnn_core.c) */
   float *own_slab;
   size_t own_slab_floats;
+  /* in: the update that follows, should the weight-delta GEMM be able to carry it out itself (k_delta_direct's
+   * epilogue + k_apply_edges: rnn_apply_learning's momentum rule, recur-nn.c:482-487, with these rates) --
+   * fuse_want != 0 asks; out: fuse_done != 0 says that weights and momentum ARE updated (both layers) and the
+   * delta arrays hold the sums: nothing is left pending */
+  int fuse_want, fuse_done;
+  float fuse_rate, fuse_ho_rate, fuse_momentum, fuse_mw;
 } RamdPendingDelta;
 
 enum { RAMD_IN_KEEP = 0, RAMD_IN_ONE_HOT = 1, RAMD_IN_DENSE = 2, RAMD_IN_TEXT = 3 };

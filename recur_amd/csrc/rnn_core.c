@@ -2864,7 +2864,26 @@ void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float mome
     g_halves_seen = 0;
     ramd_set_delta_half_hook(delta_half_ready, set->eng);
   }
+  if (fuse && !set->eng->sh.bI &&
+      (learning_style == RNN_MOMENTUM_WEIGHTED || learning_style == RNN_MOMENTUM_SIMPLIFIED_NESTEROV ||
+       learning_style == RNN_MOMENTUM_CLASSICAL || learning_style >= RNN_LAST_LEARNING_METHOD || learning_style < 0)) {
+    /* the momentum rule (recur-nn.c:482-487, 653-676): the weight-delta GEMM may carry the update out in its own
+     * epilogue (kernels_bptt.hip: k_delta_direct), with the rates and weights apply_learning would use */
+    const RecurNNBPTT *bptt = set->nets[0]->bptt;
+    engine_need_dev(set->eng, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS);
+    pend.fuse_want = 1;
+    pend.fuse_rate = bptt->learn_rate;
+    pend.fuse_ho_rate = bptt->learn_rate * bptt->ho_scale;
+    pend.fuse_momentum = momentum;
+    pend.fuse_mw = learning_style == RNN_MOMENTUM_SIMPLIFIED_NESTEROV ? (float)(momentum / (1.0 + momentum))
+                   : learning_style == RNN_MOMENTUM_CLASSICAL         ? 1.0f
+                                                                       : bptt->momentum_weight;
+  }
   char_step_deltas(set, i, fuse ? &pend : NULL);
+  if (pend.fuse_done) { /* weights and momentum are updated, the delta arrays hold the sums */
+    engine_dev_wrote(set->eng, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
+    return;
+  }
   if (dist) {
     /* the one exchange step of the path: this rank's deltas become the sum over all ranks'
      * streams (recur-nn.c:724-739 distributed), then the identical update everywhere */
