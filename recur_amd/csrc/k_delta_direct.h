@@ -22,11 +22,13 @@
 // address from a scalar base + a launch-invariant per-lane offset: no vector-ALU instruction in the loop at all).
 // No barrier, no LDS read and no loader wave stands between the matrix pipe and its operands.
 //
-// The rows above the last whole 64-row tile (the input rows of a text net: 44 at the north star) ride along as in
-// k_delta_dma: the tm workgroups of a column tile each take 1 / tm of K for them, after their own tile, into a second
-// set of accumulators (the error quad is fetched again: it is in the L2, usually in the L1), and leave tm partial
-// planes for the small launch that updates those rows, the columns outside 1 .. hidden_size and the top layer
-// (k_apply_edges).
+// The rows above the last whole 64-row tile (the input rows of a text net: 44 at the north star) need no K split
+// either: the error quad a workgroup has in registers anyway is four interleaved 16-column groups, and the 16 workgroups of a column tile (mt = 0 .. 15) each
+// take ONE (quarter of the rest rows mt / 4, column group mt % 4) pair for all of K: one more dword load and one more MFMA per 16,
+// the same 6 % as sharing the rest tile out by K would cost, and no partial planes to add up afterwards.  The
+// workgroup updates its 16 x 16 piece like its tile.  The columns outside 1 .. hidden_size (delta 0 there:
+// recur-nn.c:334-337) are the first and last column tiles' business, the top layer's update (45 k weights) is shared
+// out over all workgroups: with the momentum rule the launch leaves NOTHING for an optimiser launch.
 //
 // Coefficients: a stream's ih_scale while the step counted, 0 for steps past its break (which may hold inf: the
 // product is v_mul_legacy_f32's, 0 * anything = 0).  In steady state every coefficient is exactly 1.0 (census: round 3);
@@ -46,15 +48,20 @@ struct DdArgs {
   const int *n_exec;   /* [Scap] executed steps and ...                                                  */
   const float *ih_scale; /* ... ih_scale of the call's streams (from its first): all D and all 1.0 <=> every coefficient is 1.0 */
   float *w, *m, *delta; /* [I][H] weights, momentum, ih_delta                                          */
-  float *rest_planes;  /* [tm][rest][H] partial sums of the rows from 64 tm on                          */
   size_t plane;        /* Scap * I: floats between slots / planes                                       */
-  size_t rest_stride;  /* rest * H                                                                      */
   int I, H, Scap;
   int nrows, D, uidx;  /* streams of the call (a multiple of 4 NW), steps, ring position of step 0     */
   int tm, tn;          /* 64-row and 64-column tiles (columns start at column 1)                       */
-  int rest;            /* I - 64 tm (a multiple of 4, <= 64), 0: none                                   */
+  int rest;            /* I - 64 tm (a multiple of 4, <= 64; tm >= 16), 0: none                         */
+  int hidden_size;     /* 64 tn                                                                         */
   int mode;            /* 0: delta = sum, 1: delta += sum, 2: delta = sum and the update (method 0)     */
   float rate, momentum, mw;
+  /* mode 2: the top layer's update rides along (recur-nn.c:653-676): ho_n4 float4s shared out over the workgroups */
+  float *ho_w, *ho_m;
+  const float *ho_delta;
+  float *ho_delta_out; /* where the top layer's sums are to be stored as well (they came as a plane), or NULL */
+  unsigned ho_n4;
+  float ho_rate;
 };
 
 __device__ __forceinline__ dd_f4 dd_load4(const void *sbase, unsigned voff) {
@@ -79,11 +86,24 @@ template <int N> __device__ __forceinline__ void dd_flag_wait(dd_i4 (&n)[DD_FLAG
   static_assert(DD_FLAG_LOADS == 8, "operand list");
   asm volatile("s_waitcnt vmcnt(%8)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]) : "n"(N));
 }
-template <int N> __device__ __forceinline__ void dd_wait2(dd_f4 &a, dd_f4 &b) {
-  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
-}
 template <int N> __device__ __forceinline__ void dd_wait3(dd_f4 &a, dd_f4 &b, float &c) {
   asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void dd_wait4(dd_f4 &a, dd_f4 &b, float &c, float &d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+/* Wait for EVERY load of the wave, with the ring's registers as operands: hipcc does not know that the loads of the
+ * inline asm are asynchronous, and a register of the ring that it considers dead it hands to something else -- which
+ * the load then overwrites when it lands (seen: the accumulators, moved into ring registers behind the loop, took
+ * the values of the surplus loads of the last round).  As operands of this wait the registers are alive until it. */
+template <int P> __device__ __forceinline__ void dd_drain(const dd_f4 (&a)[P], const dd_f4 (&b)[P], const float (&c)[P], const float (&d)[P]) {
+  static_assert(P == 5, "operand list");
+  /* (inputs only: as tied operands hipcc copied the registers -- loads outstanding -- in front of the wait) */
+  asm volatile("s_waitcnt vmcnt(0)"
+               :
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]),
+                 "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4])
+               : "memory");
 }
 template <int... Is, class F>
 __device__ __forceinline__ void dd_static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
@@ -94,7 +114,6 @@ template <int N, class F> __device__ __forceinline__ void dd_static_for(F &&f) {
 }
 
 constexpr int DD_LD = 64; /* floats per row of a wave's tile in LDS */
-constexpr int dd_lds_bytes(int NW) { return NW * 64 * DD_LD * 4; }
 
 /* NW: waves per workgroup (8: two per SIMD -- while one waits for operands or sits in its epilogue the other has the
  * matrix pipe; with 4 hipcc keeps the accumulators in AGPRs and shuffles ring registers through them between an
@@ -118,16 +137,20 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
   const int m0 = 64 * mt, n0 = 64 * nt; /* (a.e, a.w ... already point at column 1) */
   const int I = a.I;
   const int QPS = a.nrows >> 2;          /* K quads per step */
-  const int IPT = QPS / NW;              /* this wave's quads per step */
-  const int n_it = a.D * IPT;            /* its iterations over its own tile */
-  const int NQ = a.D * QPS;
-  const int rq = a.rest ? NQ / a.tm : 0; /* quads of the rest tile that this workgroup takes */
-  const int n_r = rq / NW;
-  const int total = n_it + n_r;
+  const int n_it = a.D * (QPS / NW);     /* this wave's iterations: every NW-th quad of K */
   const unsigned voff = (unsigned)(((size_t)(lane >> 4) * I + (lane & 15) * 4) * sizeof(float));
-  /* the rest rows: chunks past the last real row repeat the last one (nothing is read beyond a history row) */
-  const int rc = a.rest ? ((lane & 15) * 4 < a.rest ? (lane & 15) * 4 : a.rest - 4) : 0;
-  const unsigned voff_r = (unsigned)(((size_t)(lane >> 4) * I + rc) * sizeof(float));
+  /* the rest rows, for the first 16 row tiles of a column tile: row group ri = mt / 4 (the rest / 4 CONSECUTIVE rows
+   * 64 tm + ri rest / 4 + c, c = lane % 16 -- one or two cache lines per history row; lanes past the group's last row
+   * repeat it), column group rj = mt % 4 (columns n0 + 4 c + rj: register rj of the error quad).  The load's base is
+   * the A operand's: the column distance is in the per-lane offset.  (Workgroups without a share load and multiply
+   * all the same -- a branch would end the scheduling region --, their result is never stored.) */
+  const bool has_rest = a.rest > 0 && mt < 16;
+  const int rg = a.rest >> 2, ri = has_rest ? mt >> 2 : 0, rj = mt & 3;
+  int rcol = lane & 15;
+  rcol = has_rest ? 64 * a.tm - m0 + ri * rg + (rcol < rg ? rcol : rg - 1) : 0;
+  const unsigned voff_r = (unsigned)(((size_t)(lane >> 4) * I + rcol) * sizeof(float));
+  /* register rj of a quad, chosen by two wave-uniform masks (as ?: chains hipcc makes branches of it) */
+  const unsigned long long sel_lo = (rj & 1) ? ~0ull : 0ull, sel_hi = (rj & 2) ? ~0ull : 0ull;
   const unsigned voff_c = (unsigned)((lane >> 4) * sizeof(float));
 
   /* Is every coefficient of the call exactly 1.0?  They are when every stream ran all D steps unclipped: n_exec ==
@@ -145,60 +168,44 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
   }
 
   dd_f4 ra[P], re[P];
-  float rcf[P];
-  /* The operands of this wave's iterations, in order: quad (step t, streams 4 within .. + 3) advances by NW per
-   * iteration -- its own tile: from quad wv over all of K; then the rest tile's share: from quad mt * rq + wv.  The
-   * generator is scalar and branch-free (counters, selects and multiplies on the scalar ALU: it is scheduled into
-   * the shadows of the MFMAs; a division would go through the vector ALU, a branch would end the scheduling
-   * region).  Past the last iteration it keeps going over valid memory (step clamped): those loads only keep the
-   * counted waits exact. */
-  const int r_q0 = mt * rq + wv, r_t0 = r_q0 / QPS, r_w0 = r_q0 - r_t0 * QPS; /* the rest share's first quad */
-  int g_t = 0, g_within = wv, g_left = n_it, g_rest = 0;
+  float rr[P], rcf[P];
+  /* The operands of this wave's iterations, in order: quad (step t, streams 4 within .. + 3), from quad wv on in
+   * steps of NW.  The generator is scalar and branch-free (counters, selects and multiplies on the scalar ALU: it is
+   * scheduled into the shadows of the MFMAs; a division would go through the vector ALU, a branch would end the
+   * scheduling region).  Past the last iteration it keeps going over valid memory (step clamped): those loads only
+   * keep the counted waits exact. */
+  int g_t = 0, g_within = wv;
   const float *g_xb, *g_eb, *g_cb;
-  unsigned g_vo;
   auto advance = [&]() {
     const int t = g_t < a.D ? g_t : a.D - 1;
     int slot = a.uidx - t;
     slot = slot < 0 ? slot + a.D : slot;
     const size_t ro = (size_t)(g_within << 2) * I;
-    g_xb = a.x + (size_t)slot * a.plane + ro + (g_rest ? 64 * a.tm : m0);
+    g_xb = a.x + (size_t)slot * a.plane + ro + m0;
     g_eb = a.e + (size_t)t * a.plane + ro + n0;
     g_cb = a.coef + (size_t)t * a.Scap + (g_within << 2);
-    g_vo = g_rest ? voff_r : voff;
     g_within += NW;
     const int wrap = g_within >= QPS ? 1 : 0;
     g_within -= wrap ? QPS : 0;
     g_t += wrap;
-    g_left -= 1;
-    const int sw = (g_left == 0 && g_rest == 0 && n_r > 0) ? 1 : 0; /* on to the rest tile's share */
-    g_t = sw ? r_t0 : g_t;
-    g_within = sw ? r_w0 : g_within;
-    g_left = sw ? n_r : g_left;
-    g_rest = sw ? 1 : g_rest;
   };
-  /* ONE set of accumulators: the tile's, then (spilled to the wave's own part of LDS in between) the rest share's */
-  dd_f4 acc[4][4];
-  auto clear = [&]() {
+  dd_f4 acc[4][4], racc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+  for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = dd_f4{0.f, 0.f, 0.f, 0.f};
-  };
-  clear();
-  /* the ring's first tenants: the operands now, the coefficients (a third load per iteration) once they are known to
-   * be needed -- the coefficient of ring slot j then sits behind ALL P operand pairs in the queue, which the first
-   * round's waits account for (FIRST) */
-  const float *cb0[P];
+    for (int j = 0; j < 4; j++) acc[i][j] = dd_f4{0.f, 0.f, 0.f, 0.f};
+  /* the ring's first tenants, requested before the answer about the coefficients is there (their loop without
+   * multiplies is the usual one; the other one starts over: below) */
   dd_static_for<P>([&](auto JC) {
     constexpr int j = decltype(JC)::value;
     advance();
-    ra[j] = dd_load4(g_xb, g_vo);
+    ra[j] = dd_load4(g_xb, voff);
     re[j] = dd_load4(g_eb, voff);
-    cb0[j] = g_cb;
+    rr[j] = dd_load1(g_xb, voff_r);
   });
   int ones;
   {
-    dd_flag_wait<2 * P>(fl_n, fl_s);
+    dd_flag_wait<3 * P>(fl_n, fl_s);
     bool ok = true;
 #pragma unroll
     for (int u = 0; u < DD_FLAG_LOADS / 2; u++)
@@ -207,13 +214,15 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
     ones = __builtin_amdgcn_readfirstlane(__all(ok) ? 1 : 0);
   }
   /* one round of P iterations (a wave-uniform choice of body per launch, not per iteration) */
-  auto round = [&](auto ONESC, auto FIRSTC) {
-    constexpr bool ONES = decltype(ONESC)::value, FIRST = decltype(FIRSTC)::value;
+  auto round = [&](auto ONESC) {
+    constexpr bool ONES = decltype(ONESC)::value;
     dd_static_for<P>([&](auto JC) {
       constexpr int j = decltype(JC)::value;
-      if constexpr (ONES) dd_wait2<2 * (P - 1)>(ra[j], re[j]);
-      else dd_wait3<FIRST ? P - 1 + 2 * j : 3 * (P - 1)>(ra[j], re[j], rcf[j]);
+      if constexpr (ONES) dd_wait3<3 * (P - 1)>(ra[j], re[j], rr[j]);
+      else dd_wait4<4 * (P - 1)>(ra[j], re[j], rr[j], rcf[j]);
       dd_f4 fa = ra[j], fe = re[j];
+      const float fr = rr[j];
+#ifndef DD_DEBUG_NOMUL
       if constexpr (!ONES) {
         /* v_mul_legacy_f32: 0 * x is 0 for ANY x (a step past the break may hold inf), otherwise the IEEE product */
         asm volatile("v_mul_legacy_f32 %0, %4, %0\n\tv_mul_legacy_f32 %1, %4, %1\n\t"
@@ -221,27 +230,67 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
                      : "+v"(fe[0]), "+v"(fe[1]), "+v"(fe[2]), "+v"(fe[3])
                      : "v"(rcf[j]));
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       advance(); /* the slot's next tenant: its addresses, between the MFMAs */
+      float fsel;
+#ifdef DD_DEBUG_NOSEL
+      fsel = fe[0];
+#else
+      {
+        float s01, s23;
+        asm("v_cndmask_b32 %0, %2, %3, %6\n\tv_cndmask_b32 %1, %4, %5, %6"
+            : "=&v"(s01), "=&v"(s23) : "v"(fe[0]), "v"(fe[1]), "v"(fe[2]), "v"(fe[3]), "s"(sel_lo));
+        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(fsel) : "v"(s01), "v"(s23), "s"(sel_hi));
+      }
+#endif
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int jn = 0; jn < 4; jn++)
           acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fe[jn], acc[i][jn], 0, 0, 0);
+      racc = __builtin_amdgcn_mfma_f32_16x16x4f32(fr, fsel, racc, 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 16; g++) {
+      for (int g = 0; g < 17; g++) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA */
         __builtin_amdgcn_sched_group_barrier(0x004, 4, 0); /* up to four scalar-ALU instructions */
       }
       __builtin_amdgcn_sched_barrier(0);
-      ra[j] = dd_load4(g_xb, g_vo);
+      ra[j] = dd_load4(g_xb, voff);
       re[j] = dd_load4(g_eb, voff);
+      rr[j] = dd_load1(g_xb, voff_r);
       if constexpr (!ONES) rcf[j] = dd_load1(g_cb, voff_c);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
+  if (ones) {
+    for (int i0 = 0; i0 < n_it; i0 += P) round(std::true_type{});
+#pragma unroll
+    for (int j = 0; j < P; j++) rcf[j] = 0.0f;
+    dd_drain<P>(ra, re, rr, rcf); /* the surplus loads (a wait per path: one behind the join costs copies of the ring) */
+  } else {
+    /* the rare launch (a stream was soft-clipped or stopped early): drop the ring and start over with the
+     * coefficients as a fourth load per iteration -- one round trip, instead of a first round with waits of its
+     * own, whose code hipcc gave register copies between a load and its wait */
+#pragma unroll
+    for (int j = 0; j < P; j++) rcf[j] = 0.0f;
+    dd_drain<P>(ra, re, rr, rcf);
+    g_t = 0;
+    g_within = wv;
+    dd_static_for<P>([&](auto JC) {
+      constexpr int j = decltype(JC)::value;
+      advance();
+      ra[j] = dd_load4(g_xb, voff);
+      re[j] = dd_load4(g_eb, voff);
+      rr[j] = dd_load1(g_xb, voff_r);
+      rcf[j] = dd_load1(g_cb, voff_c);
+    });
+    for (int i0 = 0; i0 < n_it; i0 += P) round(std::false_type{});
+    dd_drain<P>(ra, re, rr, rcf);
+  }
+
   // ---- the waves' tiles meet in LDS; every thread then owns float4s of the finished tile
-  auto spill = [&]() {
+  {
     float *base = lds + (size_t)wv * 64 * DD_LD;
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -250,70 +299,97 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
         const int row = 16 * (lane >> 4) + 4 * r + i;
         *reinterpret_cast<dd_f4 *>(base + row * DD_LD + 4 * (lane & 15)) = dd_f4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
       }
-  };
-  using T_ = std::true_type;
-  using F_ = std::false_type;
-  if (ones) {
-    for (int i0 = 0; i0 < n_it; i0 += P) round(T_{}, F_{});
-    spill();
-    if (n_r > 0) {
-      clear();
-      for (int i0 = 0; i0 < n_r; i0 += P) round(T_{}, F_{});
-    }
-  } else {
-    dd_static_for<P>([&](auto JC) { rcf[decltype(JC)::value] = dd_load1(cb0[decltype(JC)::value], voff_c); });
-    round(F_{}, T_{});
-    for (int i0 = P; i0 < n_it; i0 += P) round(F_{}, F_{});
-    spill();
-    if (n_r > 0) {
-      clear();
-      for (int i0 = 0; i0 < n_r; i0 += P) round(F_{}, F_{});
-    }
+    /* the rest piece: [NW][16 rows c][16 columns c'] behind the tiles; register r of lane l is (4 (l / 16) + r, l % 16) */
+    float *rb = lds + (size_t)NW * 64 * DD_LD + wv * 256;
+#pragma unroll
+    for (int r = 0; r < 4; r++) rb[(4 * (lane >> 4) + r) * 16 + (lane & 15)] = racc[r];
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the surplus loads */
-  auto total4 = [&](int ch) { /* chunk ch: row ch / 16, columns 4 (ch % 16) .. + 3, the waves in order */
+  __syncthreads();
+  const bool upd = a.mode == 2;
+  auto update4 = [&](dd_f4 &W, dd_f4 &M, const dd_f4 &d, float rate) { /* recur-nn.c:482-487 */
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float t = d[k] * rate, mm = M[k];
+      W[k] += t + mm * a.mw;
+      M[k] = (mm + t) * a.momentum;
+    }
+  };
+  constexpr int CPT = 1024 / (64 * NW); /* chunks per thread */
+#pragma unroll
+  for (int u = 0; u < CPT; u++) {
+    const int ch = u * 64 * NW + threadIdx.x; /* chunk ch: row ch / 16, columns 4 (ch % 16) .. + 3, the waves in order */
     const float *p = lds + (ch >> 4) * DD_LD + 4 * (ch & 15);
     dd_f4 s = *reinterpret_cast<const dd_f4 *>(p);
 #pragma unroll
     for (int w2 = 1; w2 < NW; w2++) s += *reinterpret_cast<const dd_f4 *>(p + (size_t)w2 * 64 * DD_LD);
-    return s;
-  };
-  __syncthreads();
-  constexpr int CPT = 1024 / (64 * NW); /* chunks per thread */
-#pragma unroll
-  for (int u = 0; u < CPT; u++) {
-    const int ch = u * 64 * NW + threadIdx.x;
-    dd_f4 s = total4(ch);
     const size_t off = (size_t)(m0 + (ch >> 4)) * a.H + n0 + 4 * (ch & 15);
     if (a.mode == 1) s += *reinterpret_cast<const dd_f4u *>(a.delta + off);
     *reinterpret_cast<dd_f4u *>(a.delta + off) = s;
-    if (a.mode == 2) {
+    if (upd) {
       dd_f4 W = *reinterpret_cast<const dd_f4u *>(a.w + off), M = *reinterpret_cast<const dd_f4u *>(a.m + off);
-#pragma unroll
-      for (int k = 0; k < 4; k++) { /* recur-nn.c:482-487 */
-        const float t = s[k] * a.rate, mm = M[k];
-        W[k] += t + mm * a.mw;
-        M[k] = (mm + t) * a.momentum;
-      }
+      update4(W, M, s, a.rate);
       *reinterpret_cast<dd_f4u *>(a.w + off) = W;
       *reinterpret_cast<dd_f4u *>(a.m + off) = M;
     }
   }
-  if (n_r > 0) {
-    __syncthreads();
-    spill();
-    __syncthreads();
-    float *rp = a.rest_planes + (size_t)mt * a.rest_stride;
+  auto update1 = [&](size_t off, float d, float rate, float *w, float *m) {
+    const float t = d * rate, mm = m[off];
+    w[off] += t + mm * a.mw;
+    m[off] = (mm + t) * a.momentum;
+  };
+  /* the workgroup's 16 x 16 piece of the rest rows: thread (c, c') */
+  if (has_rest && threadIdx.x < 256) {
+    const int c = threadIdx.x >> 4, c2 = threadIdx.x & 15;
+    const int row = ri * rg + c;
+    if (c < rg) {
+      const float *p = lds + (size_t)NW * 64 * DD_LD + threadIdx.x;
+      float d = p[0];
 #pragma unroll
-    for (int u = 0; u < CPT; u++) {
-      const int ch = u * 64 * NW + threadIdx.x;
-      if ((ch >> 4) < a.rest) {
-        const dd_f4 s = total4(ch);
-        *reinterpret_cast<dd_f4u *>(rp + (size_t)(ch >> 4) * a.H + n0 + 4 * (ch & 15)) = s;
+      for (int w2 = 1; w2 < NW; w2++) d += p[w2 * 256];
+      const size_t off = (size_t)(64 * a.tm + row) * a.H + n0 + 4 * c2 + rj;
+      if (a.mode == 1) d += a.delta[off];
+      a.delta[off] = d;
+      if (upd) update1(off, d, a.rate, a.w, a.m);
+    }
+  }
+  /* The columns outside 1 .. hidden_size (a.w[-1] is column 0): the delta is 0 there, the update is the momentum's own
+   * (recur-nn.c:482-487 with t = 0).  Column 0 by the first column tile's workgroups, the columns above hidden_size
+   * by the last one's, for their 64 rows; row tile 0 also takes those columns of the rest rows. */
+  const int hi_cols = a.H - a.hidden_size - 1;
+  if (a.mode != 1 && (nt == 0 || nt == a.tn - 1)) {
+    const int ncol = nt == 0 && nt == a.tn - 1 ? 1 + hi_cols : nt == 0 ? 1 : hi_cols;
+    const int nrow = 64 + (mt == 0 ? a.rest : 0);
+    for (int e = threadIdx.x; e < nrow * ncol; e += 64 * NW) {
+      const int rr_ = e / ncol, cc = e - rr_ * ncol;
+      const int row = rr_ < 64 ? m0 + rr_ : 64 * a.tm + rr_ - 64;
+      const int col = (nt == 0 && cc == 0) ? -1 : a.hidden_size + (nt == 0 ? cc - 1 : cc);
+      const ptrdiff_t off = (ptrdiff_t)row * a.H + col;
+      a.delta[off] = 0.0f;
+      if (upd) {
+        const float mm = a.m[off];
+        a.w[off] += mm * a.mw;
+        a.m[off] = mm * a.momentum;
       }
     }
   }
+  /* the top layer's update, shared out over the workgroups */
+  if (upd && a.ho_n4) {
+    const unsigned per = (a.ho_n4 + gridDim.x - 1) / gridDim.x;
+    const unsigned k = threadIdx.x;
+    const unsigned idx = blockIdx.x * per + k;
+    if (k < per && idx < a.ho_n4) {
+      const size_t off = 4 * (size_t)idx;
+      const dd_f4 d = *reinterpret_cast<const dd_f4 *>(a.ho_delta + off);
+      if (a.ho_delta_out) *reinterpret_cast<dd_f4 *>(a.ho_delta_out + off) = d;
+      dd_f4 W = *reinterpret_cast<const dd_f4 *>(a.ho_w + off), M = *reinterpret_cast<const dd_f4 *>(a.ho_m + off);
+      update4(W, M, d, a.ho_rate);
+      *reinterpret_cast<dd_f4 *>(a.ho_w + off) = W;
+      *reinterpret_cast<dd_f4 *>(a.ho_m + off) = M;
+    }
+  }
 }
+
+constexpr int dd_lds_bytes(int NW) { return (NW * 64 * DD_LD + NW * 256) * 4; }
 
 /* (one workgroup per CU: NW / 4 waves per SIMD, with the registers that leaves each -- told to hipcc, which otherwise
  * aims at a higher occupancy and parks ring registers in AGPRs between an asynchronous load and its wait) */
@@ -322,102 +398,4 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
   extern __shared__ __attribute__((aligned(16))) float dd_lds[];
   __builtin_amdgcn_s_setprio(2);
   dd_body<NW, P>(a, dd_lds);
-}
-
-/* What k_delta_direct leaves for the update: the rows from 64 tm on (sum of the tm partial planes), the columns
- * outside 1 .. hidden_size of every row (delta 0 there: recur-nn.c:334-337), and the top layer -- rnn_apply_learning's
- * momentum update (recur-nn.c:482-487, 653-676) for all of them, the rest rows' delta stored on the way.  One thread
- * per float4 of: [rest rows][H] | [core rows] x the edge float4s (column 0's and the last column's) | ho. */
-struct DdEdgeArgs {
-  float *w, *m, *delta;        /* [I][H] (column 0) */
-  const float *rest_planes;
-  size_t rest_stride;
-  int tm_planes, rows_core, rest, H, hidden_size;
-  float *ho_w, *ho_m;
-  const float *ho_delta;
-  float *ho_delta_out; /* where the top layer's sums are to be stored as well (they came as a plane), or NULL */
-  size_t ho_n4;        /* 0: the top layer is not this launch's business */
-  float rate, ho_rate, momentum, mw;
-  int mode; /* as DdArgs.mode: the update only with 2; 1 adds to delta */
-};
-static inline size_t dd_edge_threads(const DdEdgeArgs &a) {
-  const int h4 = a.H / 4, e4 = (a.hidden_size + 1) / 4;
-  return (size_t)a.rest * a.H / 4 + (size_t)a.rows_core * (1 + (h4 - e4)) + a.ho_n4;
-}
-__global__ __launch_bounds__(256) void k_apply_edges(DdEdgeArgs a) {
-  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t rest4 = (size_t)a.rest * a.H / 4;
-  const int h4 = a.H / 4;
-  const int e4 = (a.hidden_size + 1) / 4; /* the float4 that holds column hidden_size + 1 (== h4 - 1 when H = hidden + 4) */
-  const size_t edge4 = (size_t)a.rows_core * (1 + (h4 - e4));
-  float *w, *m;
-  dd_f4 d;
-  float rate = a.rate;
-  if (tid < rest4) {
-    const size_t off = 4 * tid;
-    const int c = (int)(off % (size_t)a.H);
-    /* the tm planes in plane order, sixteen loads in flight */
-    dd_f4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int z0 = 0; z0 < a.tm_planes; z0 += 16) {
-      dd_f4 t[16];
-#pragma unroll
-      for (int z = 0; z < 16; z++)
-        t[z] = *reinterpret_cast<const dd_f4 *>(a.rest_planes + (size_t)(z0 + z < a.tm_planes ? z0 + z : z0) * a.rest_stride + off);
-#pragma unroll
-      for (int z = 0; z < 16; z++)
-        if (z0 + z < a.tm_planes) s += t[z];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) d[k] = (c + k >= 1 && c + k <= a.hidden_size) ? s[k] : 0.0f;
-    const size_t g = (size_t)a.rows_core * a.H + off;
-    if (a.mode == 1) d += *reinterpret_cast<const dd_f4 *>(a.delta + g);
-    *reinterpret_cast<dd_f4 *>(a.delta + g) = d;
-    w = a.w + g;
-    m = a.m + g;
-  } else if (tid < rest4 + edge4) {
-    /* core rows: float4 0 (column 0 is outside, 1 .. 3 are the tile kernel's) and the float4s from e4 on */
-    const size_t k = tid - rest4;
-    const int per = 1 + (h4 - e4);
-    const int row = (int)(k / per), which = (int)(k % per);
-    const int c = which == 0 ? 0 : 4 * (e4 + which - 1);
-    const size_t g = (size_t)row * a.H + c;
-    /* only the columns outside 1 .. hidden_size: delta = 0 there */
-    dd_f4 W = *reinterpret_cast<const dd_f4 *>(a.w + g), M = *reinterpret_cast<const dd_f4 *>(a.m + g);
-    dd_f4 Dl = *reinterpret_cast<const dd_f4 *>(a.delta + g);
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      if (c + kk >= 1 && c + kk <= a.hidden_size) continue;
-      if (a.mode != 1) Dl[kk] = 0.0f;
-      if (a.mode == 2) {
-        const float mm = M[kk];
-        W[kk] += mm * a.mw; /* t = 0 * rate */
-        M[kk] = mm * a.momentum;
-      }
-    }
-    *reinterpret_cast<dd_f4 *>(a.delta + g) = Dl;
-    if (a.mode == 2) {
-      *reinterpret_cast<dd_f4 *>(a.w + g) = W;
-      *reinterpret_cast<dd_f4 *>(a.m + g) = M;
-    }
-    return;
-  } else if (tid < rest4 + edge4 + a.ho_n4) {
-    const size_t off = 4 * (tid - rest4 - edge4);
-    d = *reinterpret_cast<const dd_f4 *>(a.ho_delta + off);
-    if (a.ho_delta_out) *reinterpret_cast<dd_f4 *>(a.ho_delta_out + off) = d;
-    w = a.ho_w + off;
-    m = a.ho_m + off;
-    rate = a.ho_rate;
-  } else {
-    return;
-  }
-  if (a.mode != 2) return;
-  dd_f4 W = *reinterpret_cast<const dd_f4 *>(w), M = *reinterpret_cast<const dd_f4 *>(m);
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const float t = d[k] * rate, mm = M[k];
-    W[k] += t + mm * a.mw;
-    M[k] = (mm + t) * a.momentum;
-  }
-  *reinterpret_cast<dd_f4 *>(w) = W;
-  *reinterpret_cast<dd_f4 *>(m) = M;
 }

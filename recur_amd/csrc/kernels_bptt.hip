@@ -1959,13 +1959,11 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     {
       constexpr int NW = 8, P = 5;
       const int dtm = sh->I / 64, dtn = sh->hidden_size / 64, drest = sh->I - 64 * dtm;
-      const int QPS = nrows / 4, NQ = sh->D * QPS, n_it = QPS % NW == 0 ? sh->D * (QPS / NW) : -1;
-      const bool rest_ok = dtm > 0 && (drest == 0 || (drest <= 64 && NQ % dtm == 0 && (NQ / dtm) % (NW * P) == 0 &&
-                                          (size_t)dtm * drest * sh->H <= b->slab_floats));
-      const bool direct = b->uniform_idx >= 0 && sh->hidden_size % 64 == 0 && dtm * dtn >= 192 && nrows % (4 * NW) == 0 &&
-                          nrows <= 256 * (DD_FLAG_LOADS / 2) && row0 + nrows <= sh->Scap && sh->activation != 5 && n_it >= P &&
-                          n_it % P == 0 && rest_ok && !(g_delta_half_hook && env_int("RECUR_AMD_DIST_OVERLAP", 0)) &&
-                          env_int("RECUR_AMD_DELTA_DIRECT", 1);
+      const int QPS = nrows / 4, n_it = QPS % NW == 0 ? sh->D * (QPS / NW) : -1;
+      const bool direct = b->uniform_idx >= 0 && sh->hidden_size % 64 == 0 && dtm * dtn >= 192 && (drest == 0 || dtm >= 16) &&
+                          nrows % (4 * NW) == 0 && nrows <= 256 * (DD_FLAG_LOADS / 2) && row0 + nrows <= sh->Scap &&
+                          sh->activation != 5 && n_it >= P && n_it % P == 0 &&
+                          !(g_delta_half_hook && env_int("RECUR_AMD_DIST_OVERLAP", 0)) && env_int("RECUR_AMD_DELTA_DIRECT", 1);
       if (direct) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -1994,9 +1992,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
         a.w = b->ih_w + 1;
         a.m = b->ih_m + 1;
         a.delta = b->ih_delta + 1;
-        a.rest_planes = b->slab + 1;
         a.plane = (size_t)sh->Scap * sh->I;
-        a.rest_stride = (size_t)drest * sh->H;
         a.I = sh->I;
         a.H = sh->H;
         a.Scap = sh->Scap;
@@ -2006,39 +2002,21 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
         a.tm = dtm;
         a.tn = dtn;
         a.rest = drest;
+        a.hidden_size = sh->hidden_size;
         a.mode = fuse ? 2 : accumulate ? 1 : 0;
-        a.rate = fuse ? defer->fuse_rate : 0.0f;
-        a.momentum = fuse ? defer->fuse_momentum : 0.0f;
-        a.mw = fuse ? defer->fuse_mw : 0.0f;
+        if (fuse) {
+          a.rate = defer->fuse_rate;
+          a.momentum = defer->fuse_momentum;
+          a.mw = defer->fuse_mw;
+          a.ho_w = b->ho_w;
+          a.ho_m = b->ho_m;
+          a.ho_delta = ho_src;
+          a.ho_delta_out = ho_src == b->ho_delta ? nullptr : b->ho_delta;
+          a.ho_n4 = (unsigned)((size_t)sh->H * sh->O / 4);
+          a.ho_rate = defer->fuse_ho_rate;
+        }
         int ev = timing_begin(st, T_DELTA);
         RAMD_LAUNCH((k_delta_direct<NW, P>), dim3(dtm * dtn), dim3(64 * NW), dd_lds_bytes(NW), st, a);
-        timing_end(st, ev);
-        DdEdgeArgs ea = {};
-        ea.w = b->ih_w;
-        ea.m = b->ih_m;
-        ea.delta = b->ih_delta;
-        ea.rest_planes = b->slab;
-        ea.rest_stride = a.rest_stride;
-        ea.tm_planes = dtm;
-        ea.rows_core = 64 * dtm;
-        ea.rest = drest;
-        ea.H = sh->H;
-        ea.hidden_size = sh->hidden_size;
-        ea.mode = a.mode;
-        ea.rate = a.rate;
-        ea.momentum = a.momentum;
-        ea.mw = a.mw;
-        if (fuse) {
-          ea.ho_w = b->ho_w;
-          ea.ho_m = b->ho_m;
-          ea.ho_delta = ho_src;
-          ea.ho_delta_out = ho_src == b->ho_delta ? nullptr : b->ho_delta;
-          ea.ho_n4 = (size_t)sh->H * sh->O / 4;
-          ea.ho_rate = defer->fuse_ho_rate;
-        }
-        const size_t etot = dd_edge_threads(ea);
-        ev = timing_begin(st, T_APPLY);
-        RAMD_LAUNCH(k_apply_edges, dim3((unsigned)((etot + 255) / 256)), dim3(256), 0, st, ea);
         timing_end(st, ev);
         if (defer) {
           defer->slab = nullptr; /* ih_delta is complete */

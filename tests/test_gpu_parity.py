@@ -144,6 +144,34 @@ def test_hot_case_stepwise_on_the_dma_delta_path(amd):
     _stepwise(amd, kw, sc.synthetic_text(6000), 40, rc.WEIGHTED, 8)
 
 
+def test_hot_case_stepwise_on_the_direct_delta_path(amd):
+    """The same regime on k_delta_direct (hidden 1024: 64 x 64 tiles that own all of K, the momentum update in the
+    GEMM's epilogue): at learn rate 0.08 streams are soft-clipped (coefficients below 1) and chains end early (rows past
+    a break, never multiplied: coefficient 0 over whatever the step left), so the launch takes its coefficient loop --
+    chosen per launch from n_exec / ih_scale -- in most generations and the all-ones loop in the others; every
+    generation is compared with the oracle from the oracle's own state at 1e-4, weights included (the fused update)."""
+    kw = dict(input_size=42, hidden_size=1024, output_size=42, S=32, D=6, learn_rate=0.08, seed=12)
+    _stepwise(amd, kw, sc.synthetic_text(6000), 24, rc.WEIGHTED, 6)
+
+
+@pytest.mark.parametrize("env,node", [
+    ("RECUR_AMD_DELTA_DIRECT=0", "test_full_size_generation_matches_oracle"),
+    ("RECUR_AMD_DELTA_DIRECT=0", "test_hot_case_stepwise_on_the_direct_delta_path"),
+])
+def test_generations_with_the_direct_delta_gemm_switched_off(env, node):
+    """k_delta_direct has k_delta_dma + the optimiser launch behind it (split-K planes summed by k_apply): the full-size
+    generation and the hot regime at hidden 1024 once more with RECUR_AMD_DELTA_DIRECT=0, each in a process of its own
+    (the library reads its switches once per process)."""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ, **dict(kv.split("=") for kv in env.split()))
+    path = "%s::%s" % (os.path.abspath(__file__), node)
+    r = subprocess.run([sys.executable, "-m", "pytest", path, "-q", "-x", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, env=e, timeout=900, cwd=os.path.dirname(os.path.abspath(__file__)))
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("act,S,lr", [(rc.RELU, 1, 0.08), (rc.RESQRT, 3, 0.05), (rc.RECLIP20, 2, 0.08),
                                       (rc.RELU, 2, 1e-3)])
 def test_per_net_calls_on_a_small_net_stepwise(amd, orc, act, S, lr):
