@@ -153,6 +153,11 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
   const unsigned long long sel_lo = (rj & 1) ? ~0ull : 0ull, sel_hi = (rj & 2) ? ~0ull : 0ull;
   const unsigned voff_c = (unsigned)((lane >> 4) * sizeof(float));
 
+  constexpr int CPT = 1024 / (64 * NW); /* float4 chunks of the tile per thread */
+  const bool upd = a.mode == 2;
+  /* (requested at the start of the launch and kept in registers instead, the epilogue's weights and momentum changed
+   * nothing: 88.9 against 88.4 us per launch -- the epilogue's round trip hides behind the other workgroups' loops) */
+
   /* Is every coefficient of the call exactly 1.0?  They are when every stream ran all D steps unclipped: n_exec ==
    * D and ih_scale == 1.0 (k_extras.h: bptt_control_wave; an inactive stream has n_exec 0).  DD_FLAG_LOADS loads per
    * wave, four streams per lane each (a call of up to 1024 streams; lanes past the end repeat the last quad),
@@ -305,7 +310,6 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
     for (int r = 0; r < 4; r++) rb[(4 * (lane >> 4) + r) * 16 + (lane & 15)] = racc[r];
   }
   __syncthreads();
-  const bool upd = a.mode == 2;
   auto update4 = [&](dd_f4 &W, dd_f4 &M, const dd_f4 &d, float rate) { /* recur-nn.c:482-487 */
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -314,7 +318,6 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
       M[k] = (mm + t) * a.momentum;
     }
   };
-  constexpr int CPT = 1024 / (64 * NW); /* chunks per thread */
 #pragma unroll
   for (int u = 0; u < CPT; u++) {
     const int ch = u * 64 * NW + threadIdx.x; /* chunk ch: row ch / 16, columns 4 (ch % 16) .. + 3, the waves in order */

@@ -490,6 +490,16 @@ struct ChainSync {
   unsigned flags[32][2][4][32]; /* [row tile][sub-chain][fetching wave][column tile]   */
   unsigned abort;            /* raised by any workgroup that gives up                */
 };
+#define PC_SYNC_CLEAR_BYTES sizeof(ChainSync)
+/* The seat of the CU a workgroup finds itself on, by XCD and the CU's hardware number (HW_REG_HW_ID's se / sh / cu
+ * bits): made once from the residency probe (chain_validate), 0xff: no such CU.  A kernel ARGUMENT (2 KB): the lookup is
+ * one scalar load from the argument segment, issued beside the loads of the other arguments -- as a table in device
+ * memory it was a dependent vector load in front of everything (+1.3 us per generation). */
+struct SeatTable {
+  unsigned char seat[8][256];
+};
+/* HW_REG_HW_ID (register 4) bits 8 .. 15: cu_id[3:0], sh_id, se_id[2:0] -- the CU's number within its XCD */
+#define PC_HW_CU_KEY() (__builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4) & 0xffu)
 
 typedef __attribute__((address_space(1))) unsigned gu32;
 
@@ -613,7 +623,7 @@ template <int ACT, int K, bool ONE = false, bool PAD = false> /* rnn_activation;
 __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ vp, int uniform_idx,
                                                        int row0, int nrows, int depth, unsigned seq,
                                                        ChainSync *sy, unsigned *host_abort, int nvalid, int vlo,
-                                                       HoWork hw, XcWork xc, int static_map, unsigned tseq) {
+                                                       HoWork hw, XcWork xc, int static_map, unsigned tseq, SeatTable seats) {
   /* above the noise generator's waves (priority 0), which share four SIMDs with workgroups of this launch while the set
    * has presynaptic noise: the launch runs at the pace of its slowest workgroup (multi-head step, 256 / 32 streams:
    * 369 -> 360 / 221 -> 218 us per generation; nothing else changes) */
@@ -639,7 +649,12 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   // from the workgroup number, no ticket, no barrier -- each wave checks its XCD against the register, and a
   // mismatch gives the launch up (never silently wrong).  Otherwise: a ticket on the XCD the workgroup finds itself on.
   unsigned seat, my_xcc;
-  if (static_map) {
+  if (static_map == 2) {
+    /* the seat of the CU this workgroup runs on (one workgroup per CU: 137 KB of LDS): whatever order the dispatcher
+     * dealt the workgroups in, and whatever else it dealt between them -- no atomic, no barrier, one scalar load */
+    my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; /* HW_REG_XCC_ID */
+    seat = seats.seat[my_xcc][PC_HW_CU_KEY()];
+  } else if (static_map) {
     my_xcc = blockIdx.x & 7u;
     seat = blockIdx.x >> 3;
     const unsigned real = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; /* HW_REG_XCC_ID */
@@ -1122,16 +1137,19 @@ const View *device_view(hipStream_t st, const View &v) {
  * register) instead of drawing a ticket.  A probe that fails switches the kernel off for the process; the
  * launch-per-step chain takes its place from the first call on.  A give-up in
  * mid-run -- a co-tenant that arrives later -- is caught at the next synchronisation (rnn_core.c: dsync). */
-static bool g_chain_validated = false, g_chain_broken = false, g_xcd_static = false;
+static bool g_chain_validated = false, g_chain_broken = false, g_xcd_static = false, g_seat_table = false;
+static SeatTable g_seats;
 
 struct ProbeOut {
   unsigned arrived, fail;
   unsigned xcc[256];
+  unsigned cu_key[256];
 };
 __global__ __launch_bounds__(512) void k_residency_probe(ProbeOut *p) {
   extern __shared__ float probe_lds[]; /* (sized by the launch: what makes it one workgroup per CU) */
   if (threadIdx.x != 0) return;
   p->xcc[blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; /* HW_REG_XCC_ID */
+  p->cu_key[blockIdx.x] = PC_HW_CU_KEY();
   __hip_atomic_fetch_add(&p->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (unsigned spins = 0; __hip_atomic_load(&p->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; spins++) {
     if (spins > (1u << 20) || __hip_atomic_load(&p->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { /* ~0.5 s */
@@ -1173,7 +1191,7 @@ static void chain_validate(hipStream_t st) {
   }
   if (!g_chain_sync) {
     HIP_CHECK(hipMalloc(&g_chain_sync, sizeof(ChainSync)));
-    HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
+    HIP_CHECK(hipMemset(g_chain_sync, 0, PC_SYNC_CLEAR_BYTES));
     ramd_abort_word_dev();
   }
   ProbeOut *d_probe = nullptr, h_probe;
@@ -1193,7 +1211,35 @@ static void chain_validate(hipStream_t st) {
   }
   bool in_turn = true;
   for (int i = 0; i < 256; i++) in_turn = in_turn && h_probe.xcc[i] == (unsigned)(i & 7);
-  g_xcd_static = in_turn && env_int("RECUR_AMD_XCD_STATIC", 1);
+  /* XCD and seat from the workgroup NUMBER: only on request (RECUR_AMD_XCD_STATIC=1) -- anything else that runs on the
+   * GPU beside the chain, in this process or another, makes the dispatcher interleave the launches, and a chain whose
+   * workgroup is not where its number says gives the launch up (abort code 2) */
+  g_xcd_static = in_turn && env_int("RECUR_AMD_XCD_STATIC", 0);
+  /* XCD and seat from the CU the workgroup runs on (the default): the 256 workgroups of the probe, one per CU, named
+   * 32 different CUs on each XCD -- their hardware numbers in ascending order are the seats */
+  {
+    unsigned char (*tbl)[256] = g_seats.seat;
+    memset(&g_seats, 0xff, sizeof(g_seats));
+    bool ok = true;
+    for (int x = 0; x < 8 && ok; x++) {
+      unsigned keys[256];
+      int n = 0;
+      for (int i = 0; i < 256; i++)
+        if (h_probe.xcc[i] == (unsigned)x) keys[n++] = h_probe.cu_key[i] & 0xffu;
+      if (n != 32) ok = false;
+      for (int a = 1; a < n; a++) /* insertion sort */
+        for (int c = a; c > 0 && keys[c - 1] > keys[c]; c--) {
+          const unsigned t = keys[c];
+          keys[c] = keys[c - 1];
+          keys[c - 1] = t;
+        }
+      for (int a = 0; a < n && ok; a++) {
+        if (a > 0 && keys[a] == keys[a - 1]) ok = false; /* two workgroups on one CU number: not what this relies on */
+        tbl[x][keys[a]] = (unsigned char)a;
+      }
+    }
+    g_seat_table = ok && env_int("RECUR_AMD_XCD_TABLE", 1);
+  }
   g_chain_validated = true;
 }
 
@@ -1233,7 +1279,9 @@ template <int ACT, int K>
 static void launch_chain_persist_k(hipStream_t st, const View *d_view, const RamdShape *sh,
                                    const RamdBuffers *b, int row0, int nrows, unsigned seq, bool one, int nvalid,
                                    int vlo, const HoWork &hw, const XcWork &xc) {
-  const bool use_static = g_xcd_static && !g_side_streams;
+  /* 2: seat from the CU's hardware number (robust beside other work); 1: from the workgroup number (on request, and
+   * not beside this process's own side streams); 0: a ticket per workgroup */
+  const int use_static = g_seat_table ? 2 : (g_xcd_static && !g_side_streams) ? 1 : 0;
   const unsigned tseq = use_static ? 0u : ++g_ticket_launches;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1247,13 +1295,13 @@ static void launch_chain_persist_k(hipStream_t st, const View *d_view, const Ram
   }
   if (one && (nvalid < nrows || vlo > 0))
     RAMD_LAUNCH((k_chain_persist<ACT, K, true, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
-                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nvalid, vlo, hw, xc, (int)use_static, tseq);
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nvalid, vlo, hw, xc, (int)use_static, tseq, g_seats);
   else if (one)
     RAMD_LAUNCH((k_chain_persist<ACT, K, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
-                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw, xc, (int)use_static, tseq);
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw, xc, (int)use_static, tseq, g_seats);
   else
     RAMD_LAUNCH((k_chain_persist<ACT, K, false>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
-                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw, xc, (int)use_static, tseq);
+                b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw, xc, (int)use_static, tseq, g_seats);
 }
 
 /* row tiles per launch: 8 XCDs x (32 seats / column tiles) */
@@ -1295,7 +1343,7 @@ static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
   }
   if (g_chain_seq >= (1u << 25)) { /* flags are seq * 64 + step and compare as unsigned numbers: start over */
     HIP_CHECK(hipStreamSynchronize(st));
-    HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
+    HIP_CHECK(hipMemset(g_chain_sync, 0, PC_SYNC_CLEAR_BYTES));
     g_chain_seq = 0;
     g_ticket_launches = 0;
   }
@@ -1321,7 +1369,7 @@ static bool launch_chain_persist(hipStream_t st, const View *d_view, const RamdS
                       "all resident, or a hand-off timed out); this call's chain runs again a launch per step, which is "
                       "what the process uses from here on\n", word);
       *(volatile unsigned *)g_chain_abort_host = 0;
-      HIP_CHECK(hipMemset(g_chain_sync, 0, sizeof(ChainSync)));
+      HIP_CHECK(hipMemset(g_chain_sync, 0, PC_SYNC_CLEAR_BYTES));
       g_chain_seq = 0;
       g_ticket_launches = 0;
       g_chain_broken = true;

@@ -120,8 +120,8 @@ static void dsync(void) {
     } else if (code == 2) {
       fprintf(stderr, "librecur_amd: a workgroup of the one-launch BPTT chain was not on the XCD its number implies (code 2): "
                       "something else ran on this GPU beside the chain and the dispatcher interleaved the two launches; "
-                      "its results are invalid.  Set RECUR_AMD_XCD_STATIC=0 (the chain then draws tickets) or, on a GPU "
-                      "that is shared, RECUR_AMD_CHAIN_CHECK=1 or RECUR_AMD_CHAIN_PERSIST=0.\n");
+                      "its results are invalid.  That form is only taken with RECUR_AMD_XCD_STATIC=1: drop it (the default "
+                      "takes the seat from the CU a workgroup runs on, whatever runs beside it).\n");
     } else {
       fprintf(stderr, "librecur_amd: the one-launch BPTT chain gave up (code %u: its 256 workgroups were "
                       "not all resident, one per CU, or a hand-off timed out); its results are invalid.  "

@@ -37,6 +37,18 @@ def test_every_declared_symbol_is_exported():
     assert set(declared_functions()) <= bound
 
 
+def test_nothing_but_the_api_is_exported():
+    """The drop-in is loaded into somebody else's process (a GStreamer element, text-predict): its dynamic symbol table
+    holds the `rnn_` names of include/*.h and nothing else -- no kernel host stubs, no ramd_* internals, no cdb container
+    functions (recur_amd/csrc/librecur_amd.map)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "recur_amd", "lib", "librecur_amd.so")], capture_output=True, text=True, check=True).stdout
+    names = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    stray = [n for n in names if not n.startswith("rnn_")]
+    assert stray == [], stray[:20]
+    assert set(declared_functions()) <= set(names)
+
+
 def test_struct_layout_is_the_reference_abi():
     # offsets the reference's own Python extension relies on (py-recur-text.c:594-599)
     assert C.sizeof(rc.RecurNN) == 176 and C.sizeof(rc.RecurNNBPTT) == 128

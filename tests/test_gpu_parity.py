@@ -83,7 +83,7 @@ def _stepwise(amd, kw, text, steps, method, depth):
         if same_depth:
             # 1e-4 (north_star's bar): every array here is ONE generation deep from the oracle's own state
             replay.check(sg, so, 1e-4, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "hidden", "ih_scale",
-                                             "min_error_factor"])
+                                             "min_error_factor"], elem_floor=1e-1)  # (the hot regime's floor: replay.check)
             compared += 1
             compared_clamped += clamped
         seen_clamp |= clamped
@@ -126,7 +126,7 @@ def test_bottom_layer_in_the_hot_regime(amd, orc, batched):
         # 2e-4, not 1e-4: this run is NOT re-synchronised (the bottom layer's accumulator integrates over streams and
         # generations, which is the point of the test), so every array carries the whole sequence's rounding in the hot regime
         replay.check(sg, so, 2e-4, keys=["b_delta", "b_o_error", "b_w", "b_m", "ih_delta", "ho_delta", "ih_w", "ho_w",
-                                         "hidden", "ih_scale"], exact=("index", "generation"))
+                                         "hidden", "ih_scale"], exact=("index", "generation"), elem_floor=1e-1)
         compared += 1
         clipped += int((so["ih_scale"] < 1.0).sum())
     assert compared >= 10 and clipped >= 3, (compared, clipped)

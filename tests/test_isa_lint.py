@@ -1,0 +1,33 @@
+"""Build-time check of k_delta_direct's machine code (no GPU needed: hipcc cross-compiles).
+
+The kernel's operand loads are inline-asm global_load_* with counted s_waitcnt vmcnt waits; hipcc does not know that
+they are asynchronous.  While the kernel was written it twice produced code that read or re-used a register between a
+load and the wait that covers it (copies of ring registers in front of a tied wait; accumulators moved into ring
+registers whose surplus loads were still in flight) -- wrong results that depend on timing.  tools/isa_lint_async_loads.py
+walks the assembly with a model of the wave's load queue; this test compiles the kernel (through its microbenchmark's
+translation unit, which instantiates the same template as the library) and requires a clean walk, no scratch memory and
+no accumulation registers shuffled through AGPRs."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_delta_direct_touches_no_register_with_a_load_outstanding(tmp_path):
+    asm = str(tmp_path / "dd.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-I" + os.path.join(ROOT, "recur_amd", "csrc"),
+                    os.path.join(ROOT, "tools", "delta_direct_microbench.hip"), "-S", "--cuda-device-only", "-o", asm],
+                   check=True, capture_output=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_lint_async_loads.py"), asm, "k_delta_directILi8ELi5"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 problems" in r.stdout, r.stdout[-3000:]
+    text = open(asm).read()
+    body = text[text.index("_Z14k_delta_directILi8ELi5EEv6DdArgs:"):]
+    body = body[:body.index("s_endpgm")]
+    assert "scratch_" not in body and "v_accvgpr" not in body
+    assert body.count("v_mfma_f32_16x16x4_f32") == 2 * 5 * 17  # two loops (all-ones / coefficients) x ring x (16 + 1)
