@@ -276,7 +276,9 @@ def test_fused_path_leaves_the_delta_arrays_as_the_reference_does(amd, orc, hidd
         seen_clip |= bool(so["ih_scale"][0] < 0.999)
         assert np.abs(so["ho_delta"]).max() > 0
         replay.check(sg, so, RTOL, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "hist",
-                                         "min_error_factor", "ih_scale"], exact=("index", "generation"))
+                                         "min_error_factor", "ih_scale"], exact=("index", "generation"),
+                     elementwise=False)  # (learn rate 0.2, clipped, fifteen generations NOT re-synchronised: every array
+                                         # carries the run's rounding; the element-wise bar is for one-generation-deep comparisons)
     assert seen_clip, "the regime never clipped: the test would not see a scaled ih_delta"
     g.close()
     o.close()
@@ -311,7 +313,8 @@ def test_reclip20_units_at_the_ceiling_are_skipped_like_zeros(amd, orc, hidden, 
         at_ceiling += int((so["hist"] >= 20.0).sum())
         compared += 1
         replay.check(sg, so, RTOL, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "ih_m", "hidden", "hist",
-                                         "min_error_factor"], exact=("index", "generation"))
+                                         "min_error_factor"], exact=("index", "generation"),
+                     elementwise=False)  # (a saturated net run free: the element-wise bar is for one-generation-deep comparisons)
         # ih_scale is the soft clip of a stream's summed error norms, all of which have passed through the saturated
         # net: the one value here that carries the regime's amplification (1.3e-4 at 256 / 32; the oracle's own two
         # builds differ by 2e-5 in this regime)

@@ -13,7 +13,7 @@ Two regimes, two bars:
     reaches a few 1e-4.  Bar: 2e-4 of the largest element and of the 2-norm.
   * FUZZ_RESYNC=1: after every operation the product's host structs are overwritten with the reference's (every array,
     every scalar, the generators) and declared written, so each comparison is ONE operation deep.  Bar: north_star's
-    1e-4, on the 2-norm, on the largest element AND element by element (|a - b| <= 1e-4 |b| wherever |b| >= 1e-3 max|b|).
+    1e-4, on the 2-norm, on the largest element AND element by element (|a - b| <= 1e-4 |b| wherever |b| >= 1e-2 max|b|).
     An operation that leaves it names the kernel at fault; with FUZZ_KEEP_GOING=1 the trial goes on past it."""
 import ctypes as C
 import os
@@ -84,9 +84,10 @@ def resync(G, R):
     amd.rnn_amd_host_written(G.net, rc.RNN_AMD_EVERYTHING)
 
 
-def elementwise(got, want, keys, rtol=1e-4, floor=1e-3):
+def elementwise(got, want, keys, rtol=1e-4, floor=1e-2):
     """north_star's "1e-4 relative" read element by element: |a - b| <= rtol |b| on every element that is not small
-    (|b| >= floor max|b|)"""
+    (|b| >= floor max|b|; the floor is recur_amd.api.elem_err's: where the reference's own two builds agree to 3e-5 --
+    at 1e-3 they are up to 3.9e-4 apart, profiles/r05_reference_elementwise_self_difference.txt)"""
     bad_ = []
     for k in keys:
         if k in got and k in want:
