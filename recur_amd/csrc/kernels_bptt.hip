@@ -1960,7 +1960,11 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       constexpr int NW = 8, P = 5;
       const int dtm = sh->I / 64, dtn = sh->hidden_size / 64, drest = sh->I - 64 * dtm;
       const int QPS = nrows / 4, n_it = QPS % NW == 0 ? sh->D * (QPS / NW) : -1;
-      const bool direct = b->uniform_idx >= 0 && sh->hidden_size % 64 == 0 && dtm * dtn >= 192 && (drest == 0 || dtm >= 16) &&
+      /* (whole rounds of 256 workgroups, or nearly: 17 x 16 = 272 tiles -- a multi-head net's 1100 input rows -- would
+       * be a round of 256 and a round of 16, twice the time) */
+      const int dtiles = dtm * dtn, drounds = (dtiles + 255) / 256;
+      const bool direct = b->uniform_idx >= 0 && sh->hidden_size % 64 == 0 && dtiles >= 192 && 10 * dtiles >= 9 * 256 * drounds &&
+                          (drest == 0 || dtm >= 16) &&
                           nrows % (4 * NW) == 0 && nrows <= 256 * (DD_FLAG_LOADS / 2) && row0 + nrows <= sh->Scap &&
                           sh->activation != 5 && n_it >= P && n_it % P == 0 &&
                           !(g_delta_half_hook && env_int("RECUR_AMD_DIST_OVERLAP", 0)) && env_int("RECUR_AMD_DELTA_DIRECT", 1);

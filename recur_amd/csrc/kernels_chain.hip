@@ -274,9 +274,16 @@ __global__ __launch_bounds__(512) void k_chain_main(const View *__restrict__ vp,
 // derivative, store, per-tile sum of squares), one partial per 64 columns.
 // Preconditions (launcher): every stream at one ring position, streams % 64 == 0,
 // hidden_size == 64 * NS.
-template <int NS>
+// MT = 32 (round 5): tiles of 32 streams for sets that leave the 64-stream grid short of the chip -- hidden 2048 with
+// 256 streams is 4 x 32 = 128 tiles of 64 x 64 on 256 CUs, 0.48 of peak; as 32 x 64 tiles it is 256 -- with the K of
+// every stage split over the two wave pairs instead (waves 0, 1: chunks 0 .. 7 of a stage's 16; waves 2, 3: 8 .. 15;
+// both pairs a 32 x 32 quadrant each) and the two partial tiles added in the epilogue.  A stage is then 8 KB of A
+// and 16 KB of B: six LDS-DMA instructions per loader wave.
+template <int NS, int MT = 64>
 __global__ __launch_bounds__(512) void k_chain_wide(const View *__restrict__ vp, int uniform_idx, int row0,
                                                     int nrows, int t, int tm, int tn) {
+  constexpr bool HALF = MT == 32;
+  constexpr int LPW = HALF ? 6 : 8; /* LDS-DMA instructions per loader wave and stage */
   extern __shared__ __attribute__((aligned(16))) float wsm[];
   View v = *vp;
   v.b.uniform_idx = uniform_idx;
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(512) void k_chain_wide(const View *__restrict__ vp,
   const int xcd = L & 7, q = L >> 3;
   const int mt = q % tm, nt = (q / tm) * 8 + xcd; /* the m tiles of one W panel share an XCD */
   if (nt >= tn) return;
-  const int m0 = mt * WM, n0 = 1 + nt * WN; /* output columns start at 1 */
+  const int m0 = mt * MT, n0 = 1 + nt * WN; /* output columns start at 1 */
   const int wave8 = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool loader = wave8 >= 4;
   const int wave = wave8 & 3;
@@ -294,21 +301,21 @@ __global__ __launch_bounds__(512) void k_chain_wide(const View *__restrict__ vp,
   const uint32_t lds0 = lds_byte_addr(wsm);
 
   if (loader) {
-    // instruction i (0..31 over the four loader waves) fills rows 4 (i & 15) .. + 3 of A (i < 16)
-    // or B: lane l brings chunk (l & 15) ^ (row & 15) of row 4 (i & 15) + (l >> 4)
-    const float *src[8];
+    // instruction i (0 .. 4 LPW - 1 over the four loader waves) fills four rows of the stage image -- the MT rows of A,
+    // then the 64 of B: image row R = 4 i + (l >> 4) --: lane l brings chunk (l & 15) ^ (R & 15) of it
+    const float *src[LPW];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int i = wave * 8 + j;
-      const int row = 4 * (i & 15) + (lane >> 4);
-      const int c = (lane & 15) ^ (row & 15);
-      const float *base = i < 16 ? ehi_t + (size_t)(m0 + row) * s.I : v.b.ih_w + (size_t)(n0 + row) * s.H;
+    for (int j = 0; j < LPW; j++) {
+      const int i = wave * LPW + j;
+      const int R = 4 * i + (lane >> 4);
+      const int c = (lane & 15) ^ (R & 15);
+      const float *base = R < MT ? ehi_t + (size_t)(m0 + R) * s.I : v.b.ih_w + (size_t)(n0 + R - MT) * s.H;
       src[j] = base + 1 + 4 * c; /* K runs over the hidden columns 1..hidden_size */
     }
     auto issue = [&](int stage) {
-      float *dst = wsm + (stage % W_STAGES) * W_STAGE_FLOATS + wave * 8 * 256;
+      float *dst = wsm + (stage % W_STAGES) * W_STAGE_FLOATS + wave * LPW * 256;
 #pragma unroll
-      for (int j = 0; j < 8; j++)
+      for (int j = 0; j < LPW; j++)
         __builtin_amdgcn_global_load_lds((glb_void_t *)(src[j] + stage * WK), (lds_void_t *)(dst + j * 256), 16, 0, 0);
     };
 #pragma unroll
@@ -317,8 +324,8 @@ __global__ __launch_bounds__(512) void k_chain_wide(const View *__restrict__ vp,
 #pragma unroll
     for (int st = 0; st < NS; st++) {
       const int ahead = (NS - 1 - st) < (W_STAGES - 2) ? (NS - 1 - st) : (W_STAGES - 2);
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier(); /* stage st has landed; stage st - 1's buffer is free */
       if (st + W_STAGES - 1 < NS) issue(st + W_STAGES - 1);
@@ -328,31 +335,32 @@ __global__ __launch_bounds__(512) void k_chain_wide(const View *__restrict__ vp,
   }
 
   // ------------------------------------------------------------------ multiply
-  const int wm = wave >> 1, wn = wave & 1;
-  // the gate values of this thread's 4 x 4 outputs in the epilogue, requested now
+  const int wm = wave >> 1, wn = wave & 1; /* HALF: wm is the wave pair's half of each stage's K */
+  // the gate values of this thread's RPT x 4 outputs in the epilogue, requested now
+  constexpr int RPT = MT / 16, NU = HALF ? 4 : 8; /* rows per thread; fragment pairs per stage and wave */
   const int etid = threadIdx.x; /* 0..255 */
   const int rq = etid >> 4, c4 = (etid & 15) * 4;
-  float xin[4][4];
+  float xin[RPT][4];
 #pragma unroll
-  for (int rr = 0; rr < 4; rr++) {
-    const float *xrow = input_row<true>(v, row0 + m0 + 4 * rq + rr, t) + n0 + c4;
+  for (int rr = 0; rr < RPT; rr++) {
+    const float *xrow = input_row<true>(v, row0 + m0 + RPT * rq + rr, t) + n0 + c4;
 #pragma unroll
     for (int i = 0; i < 4; i++) xin[rr][i] = xrow[i];
   }
   f32x16 acc; /* (a second accumulator taking turns with this one measured no difference) */
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-  const uint32_t arow = (uint32_t)(wm * 32 + lm) * (WK * 4u), brow = (uint32_t)(WM + wn * 32 + lm) * (WK * 4u);
-  auto rd = [&](int st, f32x4 (&a)[8], f32x4 (&b)[8]) {
+  const uint32_t arow = (uint32_t)((HALF ? 0 : wm * 32) + lm) * (WK * 4u), brow = (uint32_t)(MT + wn * 32 + lm) * (WK * 4u);
+  auto rd = [&](int st, f32x4 (&a)[NU], f32x4 (&b)[NU]) {
     const uint32_t base = lds0 + (uint32_t)((st % W_STAGES) * W_STAGE_FLOATS) * 4u;
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const uint32_t off = (uint32_t)(((2 * u + kh) ^ (lm & 15)) * 16);
+    for (int u = 0; u < NU; u++) {
+      const uint32_t off = (uint32_t)(((2 * (u + (HALF ? NU * wm : 0)) + kh) ^ (lm & 15)) * 16);
       a[u] = lds_read_b128(base + arow + off);
       b[u] = lds_read_b128(base + brow + off);
     }
   };
-  auto step = [&](int st, f32x4 (&a)[8], f32x4 (&b)[8], f32x4 (&an)[8], f32x4 (&bn)[8]) {
+  auto step = [&](int st, f32x4 (&a)[NU], f32x4 (&b)[NU], f32x4 (&an)[NU], f32x4 (&bn)[NU]) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this stage's fragments have arrived */
     if (st + 1 < NS) {
       __builtin_amdgcn_s_barrier(); /* stage st + 1 has landed */
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(512) void k_chain_wide(const View *__restrict__ vp,
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < NU; u++) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(512) void k_chain_wide(const View *__restrict__ vp,
     __builtin_amdgcn_sched_barrier(0);
   };
   {
-    f32x4 a0[8], b0[8], a1[8], b1[8];
+    f32x4 a0[NU], b0[NU], a1[NU], b1[NU];
     __builtin_amdgcn_s_barrier(); /* stage 0 has landed */
     rd(0, a0, b0);
 #pragma unroll
@@ -378,7 +386,8 @@ __global__ __launch_bounds__(512) void k_chain_wide(const View *__restrict__ vp,
       if (st + 1 < NS) step(st + 1, a1, b1, a0, b0);
     }
   }
-  // the tile through LDS (the ring buffer stage NS would have used was read four barriers ago)
+  // the tile through LDS (the ring buffer stage NS would have used was read four barriers ago); HALF: the two K
+  // halves' tiles, [2][32][64], as rows 0 .. 31 and 32 .. 63 of the same image
   float *red = wsm + (NS % W_STAGES) * W_STAGE_FLOATS; /* [64][64] */
 #pragma unroll
   for (int g = 0; g < 16; g++) {
@@ -388,9 +397,16 @@ __global__ __launch_bounds__(512) void k_chain_wide(const View *__restrict__ vp,
   __syncthreads();
   float *dst0 = v.b.ehi + ((size_t)(t + 1) * s.Scap + row0 + m0) * s.I + n0 + c4;
 #pragma unroll
-  for (int rr = 0; rr < 4; rr++) {
-    const int row = 4 * rq + rr;
-    const float4 e4 = ld4(red + row * WN + c4);
+  for (int rr = 0; rr < RPT; rr++) {
+    const int row = RPT * rq + rr;
+    float4 e4 = ld4(red + row * WN + c4);
+    if (HALF) {
+      const float4 f4 = ld4(red + (32 + row) * WN + c4);
+      e4.x += f4.x;
+      e4.y += f4.y;
+      e4.z += f4.z;
+      e4.w += f4.w;
+    }
     const float e[4] = {e4.x, e4.y, e4.z, e4.w};
     float sq = 0.0f;
 #pragma unroll
@@ -1434,9 +1450,13 @@ int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const R
   if (persist && xc && xc->on) xc->done = 1; /* every launch of the chain carried its rows' extras and control */
   /* big sets of a wide net: 64 x 64 tiles (k_chain_wide), one partial sum per 64 columns */
   const int wide_ns = sh->hidden_size / WK;
-  const bool wide = !persist && b->uniform_idx >= 0 && nrows % WM == 0 && sh->hidden_size % WN == 0 &&
+  /* ... as 32 x 64 tiles where that fills more of the chip: fewer than 192 tiles of 64 streams, and streams a multiple of 32 */
+  const bool wide_half = !persist && b->uniform_idx >= 0 && nrows % 32 == 0 && sh->hidden_size % WN == 0 &&
+                         (nrows / WM) * (sh->hidden_size / WN) < 192 && (nrows / 32) * (sh->hidden_size / WN) >= 128 &&
+                         env_int("RECUR_AMD_CHAIN_WIDE_HALF", 1);
+  const bool wide = !persist && b->uniform_idx >= 0 && (nrows % WM == 0 || wide_half) && sh->hidden_size % WN == 0 &&
                     (wide_ns == 16 || wide_ns == 24 || wide_ns == 32) &&
-                    (nrows / WM) * (sh->hidden_size / WN) >= 128 && env_int("RECUR_AMD_CHAIN_WIDE", 1);
+                    ((nrows / WM) * (sh->hidden_size / WN) >= 128 || wide_half) && env_int("RECUR_AMD_CHAIN_WIDE", 1);
   if (wide) {
     static bool attr_set = false;
     const size_t shm = (size_t)W_STAGES * W_STAGE_FLOATS * sizeof(float);
@@ -1444,14 +1464,23 @@ int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const R
       HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_wide<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
       HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_wide<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
       HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_wide<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      HIP_CHECK(hipFuncSetAttribute((const void *)(k_chain_wide<16, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      HIP_CHECK(hipFuncSetAttribute((const void *)(k_chain_wide<24, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      HIP_CHECK(hipFuncSetAttribute((const void *)(k_chain_wide<32, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
       attr_set = true;
     }
-    const int wtm = nrows / WM, wtn = sh->hidden_size / WN;
+    const int wtm = nrows / (wide_half ? 32 : WM), wtn = sh->hidden_size / WN;
     const int wblocks = ((wtn + 7) / 8) * 8 * wtm;
     tn_parts = wtn;
     int evw = timing_begin(st, T_CHAIN, sh->D);
     for (int t = 0; t < sh->D; t++) {
-      if (wide_ns == 32)
+      if (wide_half && wide_ns == 32)
+        RAMD_LAUNCH((k_chain_wide<32, 32>), dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, t, wtm, wtn);
+      else if (wide_half && wide_ns == 24)
+        RAMD_LAUNCH((k_chain_wide<24, 32>), dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, t, wtm, wtn);
+      else if (wide_half)
+        RAMD_LAUNCH((k_chain_wide<16, 32>), dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, t, wtm, wtn);
+      else if (wide_ns == 32)
         RAMD_LAUNCH(k_chain_wide<32>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, t, wtm, wtn);
       else if (wide_ns == 24)
         RAMD_LAUNCH(k_chain_wide<24>, dim3(wblocks), dim3(512), shm, st, d_view, b->uniform_idx, row0, nrows, t, wtm, wtn);

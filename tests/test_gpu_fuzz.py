@@ -34,3 +34,25 @@ def test_random_call_sequences_against_the_compiled_reference(seed):
     ok = len(re.findall(r"operations ok", r.stdout))
     assert int(m.group(1)) == 0, [l for l in r.stdout.splitlines() if "MISMATCH" in l][:3]
     assert ok + int(m.group(2)) == 10 and ok >= 8     # every trial ran to its end or to a rounding-level flip
+
+
+@pytest.mark.skipif(not rc.have_ref(), reason="oracle/_ref/librecur_ref.so was not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", [10113, 10223, 36])
+def test_random_call_sequences_one_operation_deep_hold_the_north_star_bar(seed):
+    """FUZZ_RESYNC=1: after every operation the product's host structs are overwritten with the compiled reference's
+    (every array, every scalar, the generators), so each comparison is ONE operation deep -- and the bar is north_star's
+    1e-4: 2-norm, largest element AND element by element (elements >= 1e-2 of the array's largest).  Seeds 10113 and
+    10223 are the two trials that round 4's free-running soak reported at 5e-4 .. 7e-4 after 22 .. 28 operations
+    (exploding nets: every stream soft-clipped): from re-synchronised state none of their operations leaves 1e-4
+    (profiles/r05_fuzz_resync_seed10113.txt, _seed10223.txt) -- what the soak saw was the two sides' independent
+    rounding integrated over the sequence, not a kernel."""
+    env = dict(os.environ, FUZZ_RESYNC="1", FUZZ_LARGE="0.2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz_api.py"), str(seed), "10", "30"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    m = re.match(r"bad: (\d+), trials ended by a mask flip: (\d+)", last)
+    assert m, r.stdout[-2000:]
+    ok = len(re.findall(r"operations ok", r.stdout))
+    assert int(m.group(1)) == 0, [l for l in r.stdout.splitlines() if "MISMATCH" in l or "LEAVES" in l][:3]
+    assert ok + int(m.group(2)) == 10 and ok >= 8

@@ -609,6 +609,12 @@ def test_two_hundred_generations_at_full_size_track_the_oracle(amd):
     ("small_set_1024_32_20", dict(input_size=42, hidden_size=1024, output_size=42, S=32, D=20)),
     ("configs2_classify_like_512_128_30", dict(input_size=42, hidden_size=512, output_size=42, S=128, D=30)),
     ("configs4_rnnca_like_2048_512_10", dict(input_size=42, hidden_size=2048, output_size=42, S=512, D=10)),
+    # hidden 2048 with fewer streams: the 64 x 64-tile chain step would leave half the chip idle (128 tiles), so
+    # the step runs as 32 x 64 tiles with the K of a stage split over the wave pairs (k_chain_wide<NS, 32>);
+    # 96 streams: a multiple of 32 that is not one of 64
+    ("wide_half_tiles_2048_256_7", dict(input_size=42, hidden_size=2048, output_size=42, S=256, D=7)),
+    ("wide_half_tiles_resqrt_2048_160_4", dict(input_size=42, hidden_size=2048, output_size=42, S=160, D=4,
+                                                activation=rc.RESQRT)),
     # more than 8 row tiles: the one-launch chain once per 256 streams
     ("two_chain_launches_1024_512_20", dict(input_size=42, hidden_size=1024, output_size=42, S=512, D=20)),
     # fewer than 8 row tiles: XCDs without a row tile leave at once
