@@ -508,12 +508,14 @@ struct ChainSync {
 };
 #define PC_SYNC_CLEAR_BYTES sizeof(ChainSync)
 /* The seat of the CU a workgroup finds itself on, by XCD and the CU's hardware number (HW_REG_HW_ID's se / sh / cu
- * bits): made once from the residency probe (chain_validate), 0xff: no such CU.  A kernel ARGUMENT (2 KB): the lookup is
- * one scalar load from the argument segment, issued beside the loads of the other arguments -- as a table in device
- * memory it was a dependent vector load in front of everything (+1.3 us per generation). */
+ * bits): made once from the residency probe (chain_validate), 0xff: no such CU.  In device memory, never written
+ * while a chain runs, and read through a CONSTANT-address-space pointer as the kernel's first instructions: one
+ * scalar load beside the loads of the arguments and of the View.  (As a plain global pointer, and as a by-value
+ * argument, hipcc made it a vector load behind everything else: +1.3 us per generation.) */
 struct SeatTable {
-  unsigned char seat[8][256];
+  unsigned seat[8][256];
 };
+typedef const __attribute__((address_space(4))) unsigned *seat_tbl_p;
 /* HW_REG_HW_ID (register 4) bits 8 .. 15: cu_id[3:0], sh_id, se_id[2:0] -- the CU's number within its XCD */
 #define PC_HW_CU_KEY() (__builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4) & 0xffu)
 
@@ -639,11 +641,14 @@ template <int ACT, int K, bool ONE = false, bool PAD = false> /* rnn_activation;
 __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ vp, int uniform_idx,
                                                        int row0, int nrows, int depth, unsigned seq,
                                                        ChainSync *sy, unsigned *host_abort, int nvalid, int vlo,
-                                                       HoWork hw, XcWork xc, int static_map, unsigned tseq, SeatTable seats) {
+                                                       HoWork hw, XcWork xc, int static_map, unsigned tseq, const unsigned *seats) {
   /* above the noise generator's waves (priority 0), which share four SIMDs with workgroups of this launch while the set
    * has presynaptic noise: the launch runs at the pace of its slowest workgroup (multi-head step, 256 / 32 streams:
    * 369 -> 360 / 221 -> 218 us per generation; nothing else changes) */
   __builtin_amdgcn_s_setprio(2);
+  /* (first: see SeatTable) */
+  const unsigned hw_xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; /* HW_REG_XCC_ID */
+  const unsigned hw_seat = static_map == 2 ? ((seat_tbl_p)seats)[hw_xcc * 256u + PC_HW_CU_KEY()] : 0u;
   extern __shared__ __attribute__((aligned(16))) float psm[];
   constexpr int BUF = PC_SUB * K;             /* one sub-chain's operand (64 KB at K = 1024) */
   constexpr int NT = K / 32;                  /* column tiles of a row tile            */
@@ -668,8 +673,8 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   if (static_map == 2) {
     /* the seat of the CU this workgroup runs on (one workgroup per CU: 137 KB of LDS): whatever order the dispatcher
      * dealt the workgroups in, and whatever else it dealt between them -- no atomic, no barrier, one scalar load */
-    my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; /* HW_REG_XCC_ID */
-    seat = seats.seat[my_xcc][PC_HW_CU_KEY()];
+    my_xcc = hw_xcc;
+    seat = hw_seat;
   } else if (static_map) {
     my_xcc = blockIdx.x & 7u;
     seat = blockIdx.x >> 3;
@@ -1154,7 +1159,7 @@ const View *device_view(hipStream_t st, const View &v) {
  * launch-per-step chain takes its place from the first call on.  A give-up in
  * mid-run -- a co-tenant that arrives later -- is caught at the next synchronisation (rnn_core.c: dsync). */
 static bool g_chain_validated = false, g_chain_broken = false, g_xcd_static = false, g_seat_table = false;
-static SeatTable g_seats;
+static unsigned *g_seats = nullptr; /* SeatTable, device */
 
 struct ProbeOut {
   unsigned arrived, fail;
@@ -1234,8 +1239,9 @@ static void chain_validate(hipStream_t st) {
   /* XCD and seat from the CU the workgroup runs on (the default): the 256 workgroups of the probe, one per CU, named
    * 32 different CUs on each XCD -- their hardware numbers in ascending order are the seats */
   {
-    unsigned char (*tbl)[256] = g_seats.seat;
-    memset(&g_seats, 0xff, sizeof(g_seats));
+    static SeatTable h_seats;
+    unsigned (*tbl)[256] = h_seats.seat;
+    memset(&h_seats, 0xff, sizeof(h_seats));
     bool ok = true;
     for (int x = 0; x < 8 && ok; x++) {
       unsigned keys[256];
@@ -1251,10 +1257,14 @@ static void chain_validate(hipStream_t st) {
         }
       for (int a = 0; a < n && ok; a++) {
         if (a > 0 && keys[a] == keys[a - 1]) ok = false; /* two workgroups on one CU number: not what this relies on */
-        tbl[x][keys[a]] = (unsigned char)a;
+        tbl[x][keys[a]] = (unsigned)a;
       }
     }
     g_seat_table = ok && env_int("RECUR_AMD_XCD_TABLE", 1);
+    if (g_seat_table) {
+      if (!g_seats) HIP_CHECK(hipMalloc(&g_seats, sizeof(SeatTable)));
+      HIP_CHECK(hipMemcpy(g_seats, &h_seats, sizeof(SeatTable), hipMemcpyHostToDevice));
+    }
   }
   g_chain_validated = true;
 }
