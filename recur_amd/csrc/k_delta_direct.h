@@ -52,7 +52,7 @@ struct DdArgs {
   int I, H, Scap;
   int nrows, D, uidx;  /* streams of the call (a multiple of 4 NW), steps, ring position of step 0     */
   int tm, tn;          /* 64-row and 64-column tiles (columns start at column 1)                       */
-  int rest;            /* I - 64 tm (a multiple of 4, <= 64; tm >= 16), 0: none                         */
+  int rest;            /* I - 64 tm (a multiple of 4, <= 64 NPW; tm >= 16), 0: none                     */
   int hidden_size;     /* 64 tn                                                                         */
   int mode;            /* 0: delta = sum, 1: delta += sum, 2: delta = sum and the update (method 0)     */
   float rate, momentum, mw;
@@ -92,17 +92,21 @@ template <int N> __device__ __forceinline__ void dd_wait3(dd_f4 &a, dd_f4 &b, fl
 template <int N> __device__ __forceinline__ void dd_wait4(dd_f4 &a, dd_f4 &b, float &c, float &d) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
+template <int N> __device__ __forceinline__ void dd_wait5(dd_f4 &a, dd_f4 &b, float &c, float &d, float &e) {
+  asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
+}
 /* Wait for EVERY load of the wave, with the ring's registers as operands: hipcc does not know that the loads of the
  * inline asm are asynchronous, and a register of the ring that it considers dead it hands to something else -- which
  * the load then overwrites when it lands (seen: the accumulators, moved into ring registers behind the loop, took
  * the values of the surplus loads of the last round).  As operands of this wait the registers are alive until it. */
-template <int P> __device__ __forceinline__ void dd_drain(const dd_f4 (&a)[P], const dd_f4 (&b)[P], const float (&c)[P], const float (&d)[P]) {
+template <int P> __device__ __forceinline__ void dd_drain(const dd_f4 (&a)[P], const dd_f4 (&b)[P], const float (&c)[2][P], const float (&d)[P]) {
   static_assert(P == 5, "operand list");
   /* (inputs only: as tied operands hipcc copied the registers -- loads outstanding -- in front of the wait) */
   asm volatile("s_waitcnt vmcnt(0)"
                :
                : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]),
-                 "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4])
+                 "v"(c[0][0]), "v"(c[0][1]), "v"(c[0][2]), "v"(c[0][3]), "v"(c[0][4]), "v"(c[1][0]), "v"(c[1][1]), "v"(c[1][2]),
+                 "v"(c[1][3]), "v"(c[1][4]), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4])
                : "memory");
 }
 template <int... Is, class F>
@@ -117,8 +121,9 @@ constexpr int DD_LD = 64; /* floats per row of a wave's tile in LDS */
 
 /* NW: waves per workgroup (8: two per SIMD -- while one waits for operands or sits in its epilogue the other has the
  * matrix pipe; with 4 hipcc keeps the accumulators in AGPRs and shuffles ring registers through them between an
- * asynchronous load and its wait); P: K quads in flight per wave (the ring). */
-template <int NW, int P>
+ * asynchronous load and its wait); P: K quads in flight per wave (the ring); NPW: pieces of the rest rows per
+ * workgroup (1: up to 64 rest rows, 2: up to 128). */
+template <int NW, int P, int NPW>
 __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   /* workgroup -> tile.  Workgroups are dealt to the XCDs in turn (speed only): XCD x takes a block of the tile
@@ -139,18 +144,30 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
   const int QPS = a.nrows >> 2;          /* K quads per step */
   const int n_it = a.D * (QPS / NW);     /* this wave's iterations: every NW-th quad of K */
   const unsigned voff = (unsigned)(((size_t)(lane >> 4) * I + (lane & 15) * 4) * sizeof(float));
-  /* the rest rows, for the first 16 row tiles of a column tile: row group ri = mt / 4 (the rest / 4 CONSECUTIVE rows
-   * 64 tm + ri rest / 4 + c, c = lane % 16 -- one or two cache lines per history row; lanes past the group's last row
-   * repeat it), column group rj = mt % 4 (columns n0 + 4 c + rj: register rj of the error quad).  The load's base is
-   * the A operand's: the column distance is in the per-lane offset.  (Workgroups without a share load and multiply
-   * all the same -- a branch would end the scheduling region --, their result is never stored.) */
+  /* the rest rows, for the first 16 row tiles of a column tile: NPW pieces each, piece pi = NPW mt + p = (row group
+   * pi / 4, column group pi % 4) of 4 NPW row groups x 4 column groups.  A row group is rg = ceil(rest / 4 NPW)
+   * CONSECUTIVE rows (64 tm + ri rg + c, c = lane % 16 -- one or two cache lines per history row; lanes past the
+   * group's last row repeat it), a column group the columns n0 + 4 c + rj: register rj of the error quad.  The
+   * load's base is the A operand's: the column distance is in the per-lane offset.  (Workgroups without a share
+   * load and multiply all the same -- a branch would end the scheduling region --, their result is never stored.) */
   const bool has_rest = a.rest > 0 && mt < 16;
-  const int rg = a.rest >> 2, ri = has_rest ? mt >> 2 : 0, rj = mt & 3;
-  int rcol = lane & 15;
-  rcol = has_rest ? 64 * a.tm - m0 + ri * rg + (rcol < rg ? rcol : rg - 1) : 0;
-  const unsigned voff_r = (unsigned)(((size_t)(lane >> 4) * I + rcol) * sizeof(float));
-  /* register rj of a quad, chosen by two wave-uniform masks (as ?: chains hipcc makes branches of it) */
-  const unsigned long long sel_lo = (rj & 1) ? ~0ull : 0ull, sel_hi = (rj & 2) ? ~0ull : 0ull;
+  const int rg = (a.rest + 4 * NPW - 1) / (4 * NPW);
+  int ri[NPW], rj[NPW], rrows[NPW]; /* (rrows: the group's rows that exist) */
+  unsigned voff_r[NPW];
+  unsigned long long sel_lo[NPW], sel_hi[NPW]; /* register rj of a quad, by two wave-uniform masks (as ?: chains hipcc makes branches of it) */
+#pragma unroll
+  for (int p = 0; p < NPW; p++) {
+    const int pi = has_rest ? NPW * mt + p : 0;
+    ri[p] = pi >> 2;
+    rj[p] = pi & 3;
+    int left = a.rest - ri[p] * rg;
+    rrows[p] = has_rest ? (left < 0 ? 0 : left < rg ? left : rg) : 0;
+    const int c = lane & 15;
+    const int rcol = rrows[p] > 0 ? 64 * a.tm - m0 + ri[p] * rg + (c < rrows[p] ? c : rrows[p] - 1) : 0;
+    voff_r[p] = (unsigned)(((size_t)(lane >> 4) * I + rcol) * sizeof(float));
+    sel_lo[p] = (rj[p] & 1) ? ~0ull : 0ull;
+    sel_hi[p] = (rj[p] & 2) ? ~0ull : 0ull;
+  }
   const unsigned voff_c = (unsigned)((lane >> 4) * sizeof(float));
 
   constexpr int CPT = 1024 / (64 * NW); /* float4 chunks of the tile per thread */
@@ -173,7 +190,7 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
   }
 
   dd_f4 ra[P], re[P];
-  float rr[P], rcf[P];
+  float rr[2][P], rcf[P]; /* (rr[1]: the second piece's loads, NPW == 2) */
   /* The operands of this wave's iterations, in order: quad (step t, streams 4 within .. + 3), from quad wv on in
    * steps of NW.  The generator is scalar and branch-free (counters, selects and multiplies on the scalar ALU: it is
    * scheduled into the shadows of the MFMAs; a division would go through the vector ALU, a branch would end the
@@ -194,7 +211,11 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
     g_within -= wrap ? QPS : 0;
     g_t += wrap;
   };
-  dd_f4 acc[4][4], racc = {0.f, 0.f, 0.f, 0.f};
+  dd_f4 acc[4][4], racc[NPW];
+#pragma unroll
+  for (int p = 0; p < NPW; p++) racc[p] = dd_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < P; j++) rr[1][j] = 0.0f;
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -206,11 +227,12 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
     advance();
     ra[j] = dd_load4(g_xb, voff);
     re[j] = dd_load4(g_eb, voff);
-    rr[j] = dd_load1(g_xb, voff_r);
+#pragma unroll
+    for (int p = 0; p < NPW; p++) rr[p][j] = dd_load1(g_xb, voff_r[p]);
   });
   int ones;
   {
-    dd_flag_wait<3 * P>(fl_n, fl_s);
+    dd_flag_wait<(2 + NPW) * P>(fl_n, fl_s);
     bool ok = true;
 #pragma unroll
     for (int u = 0; u < DD_FLAG_LOADS / 2; u++)
@@ -223,11 +245,15 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
     constexpr bool ONES = decltype(ONESC)::value;
     dd_static_for<P>([&](auto JC) {
       constexpr int j = decltype(JC)::value;
-      if constexpr (ONES) dd_wait3<3 * (P - 1)>(ra[j], re[j], rr[j]);
-      else dd_wait4<4 * (P - 1)>(ra[j], re[j], rr[j], rcf[j]);
+      constexpr int PER = 2 + NPW + (ONES ? 0 : 1); /* loads per iteration */
+      if constexpr (ONES && NPW == 1) dd_wait3<PER * (P - 1)>(ra[j], re[j], rr[0][j]);
+      else if constexpr (ONES) dd_wait4<PER * (P - 1)>(ra[j], re[j], rr[0][j], rr[1][j]);
+      else if constexpr (NPW == 1) dd_wait4<PER * (P - 1)>(ra[j], re[j], rr[0][j], rcf[j]);
+      else dd_wait5<PER * (P - 1)>(ra[j], re[j], rr[0][j], rr[1][j], rcf[j]);
       dd_f4 fa = ra[j], fe = re[j];
-      const float fr = rr[j];
-#ifndef DD_DEBUG_NOMUL
+      float fr[NPW];
+#pragma unroll
+      for (int p = 0; p < NPW; p++) fr[p] = rr[p][j];
       if constexpr (!ONES) {
         /* v_mul_legacy_f32: 0 * x is 0 for ANY x (a step past the break may hold inf), otherwise the IEEE product */
         asm volatile("v_mul_legacy_f32 %0, %4, %0\n\tv_mul_legacy_f32 %1, %4, %1\n\t"
@@ -235,35 +261,36 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
                      : "+v"(fe[0]), "+v"(fe[1]), "+v"(fe[2]), "+v"(fe[3])
                      : "v"(rcf[j]));
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       advance(); /* the slot's next tenant: its addresses, between the MFMAs */
-      float fsel;
-#ifdef DD_DEBUG_NOSEL
-      fsel = fe[0];
-#else
-      {
+      float fsel[NPW];
+#pragma unroll
+      for (int p = 0; p < NPW; p++) {
         float s01, s23;
         asm("v_cndmask_b32 %0, %2, %3, %6\n\tv_cndmask_b32 %1, %4, %5, %6"
-            : "=&v"(s01), "=&v"(s23) : "v"(fe[0]), "v"(fe[1]), "v"(fe[2]), "v"(fe[3]), "s"(sel_lo));
-        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(fsel) : "v"(s01), "v"(s23), "s"(sel_hi));
+            : "=&v"(s01), "=&v"(s23) : "v"(fe[0]), "v"(fe[1]), "v"(fe[2]), "v"(fe[3]), "s"(sel_lo[p]));
+        /* (s_nop 1: two wait states between a vector-ALU write and the MFMA that reads the register -- hipcc puts ONE
+         * behind an inline-asm output, and the second piece's MFMA directly behind its select then read the old value:
+         * tools/isa_lint_async_loads.py checks it) */
+        asm("v_cndmask_b32 %0, %1, %2, %3\n\ts_nop 1" : "=v"(fsel[p]) : "v"(s01), "v"(s23), "s"(sel_hi[p]));
       }
-#endif
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int jn = 0; jn < 4; jn++)
           acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fe[jn], acc[i][jn], 0, 0, 0);
-      racc = __builtin_amdgcn_mfma_f32_16x16x4f32(fr, fsel, racc, 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 17; g++) {
+      for (int p = 0; p < NPW; p++) racc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[p], fsel[p], racc[p], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 16 + NPW; g++) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA */
         __builtin_amdgcn_sched_group_barrier(0x004, 4, 0); /* up to four scalar-ALU instructions */
       }
       __builtin_amdgcn_sched_barrier(0);
       ra[j] = dd_load4(g_xb, voff);
       re[j] = dd_load4(g_eb, voff);
-      rr[j] = dd_load1(g_xb, voff_r);
+#pragma unroll
+      for (int p = 0; p < NPW; p++) rr[p][j] = dd_load1(g_xb, voff_r[p]);
       if constexpr (!ONES) rcf[j] = dd_load1(g_cb, voff_c);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -287,7 +314,8 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
       advance();
       ra[j] = dd_load4(g_xb, voff);
       re[j] = dd_load4(g_eb, voff);
-      rr[j] = dd_load1(g_xb, voff_r);
+#pragma unroll
+      for (int p = 0; p < NPW; p++) rr[p][j] = dd_load1(g_xb, voff_r[p]);
       rcf[j] = dd_load1(g_cb, voff_c);
     });
     for (int i0 = 0; i0 < n_it; i0 += P) round(std::false_type{});
@@ -304,10 +332,13 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
         const int row = 16 * (lane >> 4) + 4 * r + i;
         *reinterpret_cast<dd_f4 *>(base + row * DD_LD + 4 * (lane & 15)) = dd_f4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
       }
-    /* the rest piece: [NW][16 rows c][16 columns c'] behind the tiles; register r of lane l is (4 (l / 16) + r, l % 16) */
-    float *rb = lds + (size_t)NW * 64 * DD_LD + wv * 256;
+    /* the rest pieces: [NPW][NW][16 rows c][16 columns c'] behind the tiles; register r of lane l is (4 (l / 16) + r, l % 16) */
 #pragma unroll
-    for (int r = 0; r < 4; r++) rb[(4 * (lane >> 4) + r) * 16 + (lane & 15)] = racc[r];
+    for (int p = 0; p < NPW; p++) {
+      float *rb = lds + (size_t)NW * 64 * DD_LD + (p * NW + wv) * 256;
+#pragma unroll
+      for (int r = 0; r < 4; r++) rb[(4 * (lane >> 4) + r) * 16 + (lane & 15)] = racc[p][r];
+    }
   }
   __syncthreads();
   auto update4 = [&](dd_f4 &W, dd_f4 &M, const dd_f4 &d, float rate) { /* recur-nn.c:482-487 */
@@ -340,16 +371,18 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
     w[off] += t + mm * a.mw;
     m[off] = (mm + t) * a.momentum;
   };
-  /* the workgroup's 16 x 16 piece of the rest rows: thread (c, c') */
-  if (has_rest && threadIdx.x < 256) {
-    const int c = threadIdx.x >> 4, c2 = threadIdx.x & 15;
-    const int row = ri * rg + c;
-    if (c < rg) {
-      const float *p = lds + (size_t)NW * 64 * DD_LD + threadIdx.x;
-      float d = p[0];
+  /* the workgroup's 16 x 16 pieces of the rest rows: thread (piece, c, c') */
+  if (has_rest && threadIdx.x < 256 * NPW) {
+    const int p = threadIdx.x >> 8, t8 = threadIdx.x & 255;
+    const int c = t8 >> 4, c2 = t8 & 15;
+    const int pri = NPW == 1 ? ri[0] : (p ? ri[NPW - 1] : ri[0]), prj = NPW == 1 ? rj[0] : (p ? rj[NPW - 1] : rj[0]);
+    const int prows = NPW == 1 ? rrows[0] : (p ? rrows[NPW - 1] : rrows[0]);
+    if (c < prows) {
+      const float *q = lds + (size_t)NW * 64 * DD_LD + (size_t)p * NW * 256 + t8;
+      float d = q[0];
 #pragma unroll
-      for (int w2 = 1; w2 < NW; w2++) d += p[w2 * 256];
-      const size_t off = (size_t)(64 * a.tm + row) * a.H + n0 + 4 * c2 + rj;
+      for (int w2 = 1; w2 < NW; w2++) d += q[w2 * 256];
+      const size_t off = (size_t)(64 * a.tm + pri * rg + c) * a.H + n0 + 4 * c2 + prj;
       if (a.mode == 1) d += a.delta[off];
       a.delta[off] = d;
       if (upd) update1(off, d, a.rate, a.w, a.m);
@@ -392,13 +425,13 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
   }
 }
 
-constexpr int dd_lds_bytes(int NW) { return (NW * 64 * DD_LD + NW * 256) * 4; }
+constexpr int dd_lds_bytes(int NW, int NPW = 1) { return (NW * 64 * DD_LD + NPW * NW * 256) * 4; }
 
 /* (one workgroup per CU: NW / 4 waves per SIMD, with the registers that leaves each -- told to hipcc, which otherwise
  * aims at a higher occupancy and parks ring registers in AGPRs between an asynchronous load and its wait) */
-template <int NW, int P>
+template <int NW, int P, int NPW = 1>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void k_delta_direct(DdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dd_lds[];
   __builtin_amdgcn_s_setprio(2);
-  dd_body<NW, P>(a, dd_lds);
+  dd_body<NW, P, NPW>(a, dd_lds);
 }

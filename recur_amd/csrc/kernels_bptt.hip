@@ -1958,21 +1958,33 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
      * nothing else wants the sums first, weights and momentum are updated in the same epilogue (fuse_want) */
     {
       constexpr int NW = 8, P = 5;
-      const int dtm = sh->I / 64, dtn = sh->hidden_size / 64, drest = sh->I - 64 * dtm;
+      /* row tiles: as many whole ones as make whole rounds of 256 workgroups, or nearly -- a multi-head net's 1100
+       * input rows are 17 x 16 = 272 tiles, a round of 256 and a round of 16: twice the time; as 16 row tiles they
+       * are one round with 76 rest rows, two pieces of them per workgroup (NPW) */
+      const int dtn = sh->hidden_size / 64;
+      int dtm = sh->I / 64, drest = sh->I - 64 * dtm;
+      auto rounds_ok = [&](int tm_) {
+        const int tiles = tm_ * dtn, rounds = (tiles + 255) / 256;
+        return tiles >= 192 && 10 * tiles >= 9 * 256 * rounds;
+      };
+      if (!rounds_ok(dtm) && dtm > 16 && sh->I - 64 * (dtm - 1) <= 128 && rounds_ok(dtm - 1)) {
+        dtm--;
+        drest = sh->I - 64 * dtm;
+      }
+      const int npw = drest > 64 ? 2 : 1;
       const int QPS = nrows / 4, n_it = QPS % NW == 0 ? sh->D * (QPS / NW) : -1;
-      /* (whole rounds of 256 workgroups, or nearly: 17 x 16 = 272 tiles -- a multi-head net's 1100 input rows -- would
-       * be a round of 256 and a round of 16, twice the time) */
-      const int dtiles = dtm * dtn, drounds = (dtiles + 255) / 256;
-      const bool direct = b->uniform_idx >= 0 && sh->hidden_size % 64 == 0 && dtiles >= 192 && 10 * dtiles >= 9 * 256 * drounds &&
-                          (drest == 0 || dtm >= 16) &&
+      const bool direct = b->uniform_idx >= 0 && sh->hidden_size % 64 == 0 && dtn > 0 && rounds_ok(dtm) &&
+                          (drest == 0 || (dtm >= 16 && drest <= 128)) &&
                           nrows % (4 * NW) == 0 && nrows <= 256 * (DD_FLAG_LOADS / 2) && row0 + nrows <= sh->Scap &&
                           sh->activation != 5 && n_it >= P && n_it % P == 0 &&
                           !(g_delta_half_hook && env_int("RECUR_AMD_DIST_OVERLAP", 0)) && env_int("RECUR_AMD_DELTA_DIRECT", 1);
       if (direct) {
         static bool attr_set = false;
         if (!attr_set) {
-          HIP_CHECK(hipFuncSetAttribute((const void *)k_delta_direct<NW, P>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        dd_lds_bytes(NW)));
+          HIP_CHECK(hipFuncSetAttribute((const void *)(k_delta_direct<NW, P, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        dd_lds_bytes(NW, 1)));
+          HIP_CHECK(hipFuncSetAttribute((const void *)(k_delta_direct<NW, P, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        dd_lds_bytes(NW, 2)));
           attr_set = true;
         }
         if (ho_paired) { /* the top layer's delta GEMM had been waiting for a pair launch */
@@ -2020,7 +2032,10 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
           a.ho_rate = defer->fuse_ho_rate;
         }
         int ev = timing_begin(st, T_DELTA);
-        RAMD_LAUNCH((k_delta_direct<NW, P>), dim3(dtm * dtn), dim3(64 * NW), dd_lds_bytes(NW), st, a);
+        if (npw == 2)
+          RAMD_LAUNCH((k_delta_direct<NW, P, 2>), dim3(dtm * dtn), dim3(64 * NW), dd_lds_bytes(NW, 2), st, a);
+        else
+          RAMD_LAUNCH((k_delta_direct<NW, P, 1>), dim3(dtm * dtn), dim3(64 * NW), dd_lds_bytes(NW, 1), st, a);
         timing_end(st, ev);
         if (defer) {
           defer->slab = nullptr; /* ih_delta is complete */

@@ -23,11 +23,14 @@ def test_delta_direct_touches_no_register_with_a_load_outstanding(tmp_path):
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-I" + os.path.join(ROOT, "recur_amd", "csrc"),
                     os.path.join(ROOT, "tools", "delta_direct_microbench.hip"), "-S", "--cuda-device-only", "-o", asm],
                    check=True, capture_output=True)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_lint_async_loads.py"), asm, "k_delta_directILi8ELi5"],
-                       capture_output=True, text=True)
-    assert r.returncode == 0 and " 0 problems" in r.stdout, r.stdout[-3000:]
     text = open(asm).read()
-    body = text[text.index("_Z14k_delta_directILi8ELi5EEv6DdArgs:"):]
-    body = body[:body.index("s_endpgm")]
-    assert "scratch_" not in body and "v_accvgpr" not in body
-    assert body.count("v_mfma_f32_16x16x4_f32") == 2 * 5 * 17  # two loops (all-ones / coefficients) x ring x (16 + 1)
+    for npw in (1, 2):  # one piece of the rest rows per workgroup, or two
+        sym = "k_delta_directILi8ELi5ELi%dEE" % npw
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_lint_async_loads.py"), asm, sym],
+                           capture_output=True, text=True)
+        assert r.returncode == 0 and " 0 problems" in r.stdout, r.stdout[-3000:]
+        body = text[text.index("_Z14" + sym + "v6DdArgs:"):]
+        body = body[:body.index("s_endpgm")]
+        assert "scratch_" not in body and "v_accvgpr" not in body
+        # two loops (all-ones / coefficients) x ring x (16 + pieces)
+        assert body.count("v_mfma_f32_16x16x4_f32") == 2 * 5 * (16 + npw)

@@ -24,16 +24,16 @@ __global__ __launch_bounds__(256) void k_burn(float *out, int iters) {
   if (c0[0] + c1[0] == 12345.f) out[0] = c0[1];
 }
 
-template <int NW, int P>
+template <int NW, int P, int NPW>
 static double run(const char *name, DdArgs a, int reps, int burn, float *scratch) {
-  CK(hipFuncSetAttribute((const void *)k_delta_direct<NW, P>, hipFuncAttributeMaxDynamicSharedMemorySize, dd_lds_bytes(NW)));
+  CK(hipFuncSetAttribute((const void *)(k_delta_direct<NW, P, NPW>), hipFuncAttributeMaxDynamicSharedMemorySize, dd_lds_bytes(NW, NPW)));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const int grid = a.tm * a.tn;
   auto once = [&]() {
     if (burn) hipLaunchKernelGGL(k_burn, dim3(256), dim3(256), 0, 0, scratch, burn);
-    hipLaunchKernelGGL((k_delta_direct<NW, P>), dim3(grid), dim3(64 * NW), dd_lds_bytes(NW), 0, a);
+    hipLaunchKernelGGL((k_delta_direct<NW, P, NPW>), dim3(grid), dim3(64 * NW), dd_lds_bytes(NW, NPW), 0, a);
   };
   for (int i = 0; i < 20; i++) once();
   CK(hipDeviceSynchronize());
@@ -63,7 +63,8 @@ static double run(const char *name, DdArgs a, int reps, int burn, float *scratch
 
 int main(int argc, char **argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 200;
-  const int S = 256, D = 20, hidden = 1024, I = 1068, H = 1028, O = 44;
+  /* DDM_I=1100: a multi-head net's input rows (73 symbols): 16 row tiles and 76 rest rows, two pieces per workgroup */
+  const int S = 256, D = 20, hidden = 1024, I = getenv("DDM_I") ? atoi(getenv("DDM_I")) : 1068, H = 1028, O = 44;
   const size_t plane = (size_t)S * I;
   std::vector<float> hx((size_t)D * plane + 128), he((size_t)(D + 1) * plane), hc((size_t)D * S, 1.0f), hw((size_t)I * H), hm((size_t)I * H);
   for (auto &v : hx) { float u = urand(); v = u < 0.55f ? 0.0f : (u - 0.55f) * 2.0f; }
@@ -78,7 +79,8 @@ int main(int argc, char **argv) {
   }
   float *dx, *de, *dc, *dw, *dm, *dd, *dho, *dhom, *dhod, *scratch;
   int *dnex; float *dsc;
-  const int tm = I / 64, tn = hidden / 64, rest = I - 64 * tm;
+  const int tm = 16, tn = hidden / 64, rest = I - 64 * tm;
+  const bool two = rest > 64 || getenv("DDM_TWO");
   CK(hipMalloc(&dx, hx.size() * 4)); CK(hipMalloc(&de, he.size() * 4)); CK(hipMalloc(&dc, hc.size() * 4));
   CK(hipMalloc(&dw, hw.size() * 4)); CK(hipMalloc(&dm, hm.size() * 4)); CK(hipMalloc(&dd, hw.size() * 4));
   CK(hipMalloc(&dnex, S * 4)); CK(hipMalloc(&dsc, S * 4)); CK(hipMalloc(&scratch, 1024));
@@ -119,7 +121,7 @@ int main(int argc, char **argv) {
       return s;
     };
     for (int k = 0; k < 3000; k++) {
-      int m = k < 1500 ? (int)(urand() * I) : 1024 + (k % 44), n = (int)(urand() * H);
+      int m = k < 1500 ? (int)(urand() * I) : 1024 + (k % (I - 1024)), n = (int)(urand() * H);
       if (m >= I) m = I - 1;
       double want = (n >= 1 && n <= hidden) ? ref(m, n) : 0.0, got = out[(size_t)m * H + n];
       worst = fmax(worst, fabs(got - want)); scale = fmax(scale, fabs(want));
@@ -130,17 +132,29 @@ int main(int argc, char **argv) {
       for (int m = 0; m < I; m++) for (int n = 0; n < H; n++) if (out[(size_t)m * H + n] != 0.0f) { nz++; if (shown++ < 16) printf("   nonzero [%d][%d] = %g\n", m, n, out[(size_t)m * H + n]); }
       printf("   %ld nonzero outputs\n", nz);
     }
+    if (getenv("DDM_MAP")) { /* which (rest row, column mod 4) pairs are wrong */
+      for (int m = 1024; m < I; m++) {
+        int badc[4] = {0, 0, 0, 0};
+        for (int n = 1; n <= 64; n++) {
+          double want = ref(m, n), got = out[(size_t)m * H + n];
+          if (fabs(got - want) > 1e-5) badc[(n - 1) & 3]++;
+        }
+        printf("   rest row %2d: wrong columns by (column - 1) %% 4: %d %d %d %d\n", m - 1024, badc[0], badc[1], badc[2], badc[3]);
+      }
+    }
     printf("check %-28s max |err| %.3e of max |ref| %.3e -> %s\n", what, worst, scale, worst <= 2e-5 * scale ? "ok" : "MISMATCH");
     return worst <= 2e-5 * scale;
   };
   bool ok = true;
-  CK(hipFuncSetAttribute((const void *)k_delta_direct<8, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, dd_lds_bytes(8)));
+  CK(hipFuncSetAttribute((const void *)(k_delta_direct<8, 5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, dd_lds_bytes(8, 1)));
+  CK(hipFuncSetAttribute((const void *)(k_delta_direct<8, 5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, dd_lds_bytes(8, 2)));
   auto both = [&](const char *tag) {
     char nm[64];
     CK(hipMemset(dd, 0xff, hw.size() * 4));
-    hipLaunchKernelGGL((k_delta_direct<8, 5>), dim3(tm * tn), dim3(512), dd_lds_bytes(8), 0, a);
+    if (two) hipLaunchKernelGGL((k_delta_direct<8, 5, 2>), dim3(tm * tn), dim3(512), dd_lds_bytes(8, 2), 0, a);
+    else hipLaunchKernelGGL((k_delta_direct<8, 5, 1>), dim3(tm * tn), dim3(512), dd_lds_bytes(8, 1), 0, a);
     CK(hipDeviceSynchronize());
-    snprintf(nm, sizeof nm, "NW 8, P 5, %s", tag);
+    snprintf(nm, sizeof nm, "NW 8, P 5, %d piece(s), %s", two ? 2 : 1, tag);
     ok &= check(nm);
   };
   both("ones");
@@ -166,8 +180,9 @@ int main(int argc, char **argv) {
       for (int mode = 0; mode <= 2; mode += 2) {
         a.mode = mode;
         char nm[64];
-        snprintf(nm, sizeof nm, "NW 8 P 5  mode %d", mode);
-        run<8, 5>(nm, a, reps, b, scratch);
+        snprintf(nm, sizeof nm, "NW 8 P 5 pieces %d mode %d", two ? 2 : 1, mode);
+        if (two) run<8, 5, 2>(nm, a, reps, b, scratch);
+        else run<8, 5, 1>(nm, a, reps, b, scratch);
       }
     }
   }

@@ -24,6 +24,38 @@ def regs(text):
     return out
 
 
+def lint_valu_to_mfma(lines, need=2):
+    """A vector-ALU instruction of an inline-asm block that writes a VGPR, and an MFMA that reads that VGPR as an A / B
+    operand fewer than `need` wait states later: hipcc puts ONE wait state behind an inline-asm output, the matrix
+    instruction needs two (seen: k_delta_direct's second rest piece multiplied with the select's OLD register)."""
+    problems = []
+    recent = []  # (register set, wait states since)
+    in_asm = False
+    for no, raw in lines:
+        t = raw.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        line = raw.split(";")[0].strip()
+        if not line or line.startswith(".") or line.endswith(":"):
+            continue
+        op = line.split()[0]
+        ops = line[len(op):].split(",")
+        if op.startswith("v_mfma"):
+            src = regs(",".join(ops[1:3]))
+            for written, ws in recent:
+                if src & written and ws < need:
+                    problems.append((no, raw.strip(), sorted(src & written)))
+        states = int(line.split()[1]) + 1 if op == "s_nop" else 1
+        recent = [(w, ws + states) for w, ws in recent if ws + states < 8]
+        if in_asm and op.startswith("v_") and not op.startswith("v_mfma"):
+            recent.append((regs(ops[0]), 0))
+    return problems
+
+
 def lint(lines):
     queue = []          # outstanding loads, oldest first: sets of destination registers
     saved = {}          # label -> queue at the first branch that targets it
@@ -84,7 +116,7 @@ def main():
         body.append((i + 1, text[i]))
         if "s_endpgm" in text[i]:
             break
-    problems = lint(body)
+    problems = lint(body) + lint_valu_to_mfma(body)
     loads = sum(1 for _, l in body if l.strip().startswith("global_load"))
     print("%s: %d instructions, %d global loads, %d problems" % (sym, len(body), loads, len(problems)))
     for no, line, hit in problems[:40]:
