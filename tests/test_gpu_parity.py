@@ -318,7 +318,7 @@ def test_reclip20_units_at_the_ceiling_are_skipped_like_zeros(amd, orc, hidden, 
         # ih_scale is the soft clip of a stream's summed error norms, all of which have passed through the saturated
         # net: the one value here that carries the regime's amplification (1.3e-4 at 256 / 32; the oracle's own two
         # builds differ by 2e-5 in this regime)
-        replay.check(sg, so, 3 * RTOL, keys=["ih_scale"], exact=())
+        replay.check(sg, so, 3 * RTOL, keys=["ih_scale"], exact=(), elementwise=False)
     assert compared >= 6 and at_ceiling > 20
     g.close()
     o.close()
