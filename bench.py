@@ -387,6 +387,8 @@ def main():
         print(json.dumps(cpu_all_cores(args, text)), flush=True)
         return
 
+    if args.dist and world == 1:  # (with one rank the library skips the exchange step unless told to keep it in)
+        os.environ.setdefault("RECUR_AMD_DIST_ONE_RANK_EXCHANGE", "1")
     amd = rc.load_amd()
     ndev = amd.rnn_amd_device_count()
     if ndev < 1:

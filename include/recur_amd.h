@@ -513,12 +513,17 @@ int rnn_amd_dist_world(void); /* 1 when no group is joined */
  *      handles; same-process peers are recognised and take the plain pointers);
  *   2. the launcher hands every blob to every rank (a file, shared memory, a pipe) and provides `counters`: 64 bytes
  *      of zeroed host memory that ALL ranks have mapped (MAP_SHARED memory made before fork, or a file in /dev/shm);
+ *      ZEROED AGAIN before every join -- the barriers count from 0, and on counters left from an earlier session the
+ *      first ones would pass at once -- and no rank steps before every rank has joined (the launcher's rendezvous);
  *   3. each rank: rnn_amd_set_exchange_join(set, rank, world, blobs, counters, 0); from then on
  *      rnn_amd_set_char_step runs deltas -> barrier -> sharded update -> barrier.
  * lockstep != 0: the ranks are sets of ONE process driven by one thread (counters may be NULL): no barriers are
  * launched, the caller gives the order -- rnn_amd_set_char_step_deltas on every rank, then
  * rnn_amd_set_apply_exchange on every rank.  After a step ih_delta || ho_delta hold the sum over the ranks in the
  * rank's OWN range only, and momentum / aux arrays are current in the own range only (rnn_amd_set_exchange_range).
+ * With ONE rank rnn_amd_set_char_step is the plain generation (nothing to exchange); the arrays reached through peer
+ * pointers are ordinary device allocations whose visibility between ranks rests on kernel boundaries: on GPUs of
+ * different devices that has not run yet.
  * Returns 0, or -1 with a message (a peer's arrays cannot be opened, bad arguments). */
 #define RNN_AMD_EXCHANGE_BLOB_BYTES 256
 void rnn_amd_set_exchange_export(RnnAmdSet *set, void *blob);

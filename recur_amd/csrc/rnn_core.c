@@ -1264,6 +1264,7 @@ RecurNN **rnn_amd_new_training_set_shard(RecurNN *prototype, int n_local, int gl
     ramd_init_rand64_maybe_randomly(&prototype->rng, first_seed);
   }
   if (ramd_priv(prototype)->eng && n_local != global_count) {
+    ramd_priv(prototype)->eng->sharded_sticky = 1;
     ramd_priv(prototype)->eng->sharded = 1;
   }
   return nets;
@@ -1902,7 +1903,7 @@ RnnAmdSet *rnn_amd_set_open(RecurNN **nets, int n_nets) {
   set->fwd_only = fwd_only;
   set->global_first = 0;
   set->global_count = n_nets;
-  set->sharded_before = e->sharded;
+  set->counts_shard = 0;
   /* A set of ALL the engine's training streams opened inside a group is this rank's shard of the distributed
    * training set: rank r holds global streams [r n, (r + 1) n).  A set of some of them -- the host layers' one-net
    * passes, a validation or side net that one rank alone touches -- stays local: its host draws must not become
@@ -1910,9 +1911,23 @@ RnnAmdSet *rnn_amd_set_open(RecurNN **nets, int n_nets) {
   if (ramd_dist_active() && !fwd_only && n_nets == e->n_streams) {
     set->global_first = rnn_amd_dist_rank() * n_nets;
     set->global_count = rnn_amd_dist_world() * n_nets;
+    set->counts_shard = 1;
+    e->sharded_sets++;
     e->sharded = 1;
   }
   return set;
+}
+
+/* the engine stays a shard while ANY open set shards it (two sets may be open on one engine and close in any order:
+ * ADVICE.md round 4) or it was sharded explicitly (rnn_amd_set_shard, the shard constructor: the nets remain a shard
+ * whatever set drives them) */
+static void set_unshard(RnnAmdSet *set) {
+  RamdEngine *e = set->eng;
+  if (set->counts_shard && e->sharded_sets > 0) {
+    e->sharded_sets--;
+  }
+  set->counts_shard = 0;
+  e->sharded = e->sharded_sticky || e->sharded_sets > 0;
 }
 
 void rnn_amd_set_close(RnnAmdSet *set) {
@@ -1920,7 +1935,7 @@ void rnn_amd_set_close(RnnAmdSet *set) {
     return;
   }
   ramd_need_host(set->nets[0], RNN_AMD_EVERYTHING);
-  set->eng->sharded = set->sharded_before;
+  set_unshard(set);
   free(set->nets);
   free(set);
 }
@@ -1930,7 +1945,7 @@ void rnn_amd_set_drop(RnnAmdSet *set) {
   if (!set) {
     return;
   }
-  set->eng->sharded = set->sharded_before;
+  set_unshard(set);
   free(set->nets);
   free(set);
 }
@@ -1945,7 +1960,10 @@ void rnn_amd_set_shard(RnnAmdSet *set, int global_first, int global_count) {
   }
   set->global_first = global_first;
   set->global_count = global_count;
-  set->eng->sharded = global_count != set->n;
+  if (global_count != set->n) {
+    set->eng->sharded_sticky = 1;
+  }
+  set->eng->sharded = set->eng->sharded_sticky || set->eng->sharded_sets > 0;
 }
 
 void rnn_amd_set_dist_all_reduce_deltas(RnnAmdSet *set) {
@@ -2788,6 +2806,8 @@ int rnn_amd_set_exchange_join(RnnAmdSet *set, int rank, int world, const void *b
   e->xchg_world = world;
   e->xchg_rank = rank;
   e->xchg_lockstep = lockstep;
+  /* (the barriers count from 0: the launcher zeroes the shared counters before EVERY join -- a group that re-joins on
+   * counters left from an earlier session would see its first barriers pass at once; include/recur_amd.h says so) */
   e->xchg_seq = 0;
   return 0;
 }
@@ -2849,8 +2869,22 @@ void rnn_amd_set_apply_exchange(RnnAmdSet *set, int learning_style, float moment
   engine_dev_wrote(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
 }
 
+/* With ONE rank the sum over the ranks is the rank's own sum and the sharded update is the whole update: the exchange
+ * step -- the all-reduce, or the barriers and the peer-pointer update kernel -- is skipped and the generation is the
+ * plain one (one-rank cost of either exchange path: 0; round 4: +4.8 us through RCCL, +11 us kernel-issued).
+ * RECUR_AMD_DIST_ONE_RANK_EXCHANGE=1 keeps the exchange step in (tests and `bench.py --dist` exercise it on one GPU). */
+static int one_rank_exchange_forced(void) {
+  static int on = -1;
+  if (on < 0) {
+    const char *v = getenv("RECUR_AMD_DIST_ONE_RANK_EXCHANGE");
+    on = v && *v == '1';
+  }
+  return on;
+}
+
 void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float momentum) {
-  if (set->eng->xchg_world) { /* deltas -> (barrier) -> sharded update with the sum over the ranks in it -> (barrier) */
+  if (set->eng->xchg_world > 1 || (set->eng->xchg_world == 1 && one_rank_exchange_forced())) {
+    /* deltas -> (barrier) -> sharded update with the sum over the ranks in it -> (barrier) */
     char_step_deltas(set, i, NULL);
     rnn_amd_set_apply_exchange(set, learning_style, momentum);
     return;
@@ -2858,7 +2892,7 @@ void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float mome
   /* the deltas go straight from the GEMM's K slabs into the update (and into ih_delta) when
    * nothing can look at them in between: library-owned storage, no log on the prototype */
   RamdPendingDelta pend = {0};
-  const int dist = ramd_dist_active();
+  const int dist = ramd_dist_active() && (rnn_amd_dist_world() > 1 || one_rank_exchange_forced());
   int fuse = !set->eng->delta_external && !set->nets[0]->log && !dist;
   if (dist) {
     g_halves_seen = 0;

@@ -98,6 +98,7 @@ typedef struct RamdEngine {
    * rnn_amd_dist_init): only then are the replicated host draws (weight noise, perforation,
    * random damage) a collective that takes rank 0's generator (ramd_shared_rng) */
   int sharded;
+  int sharded_sets, sharded_sticky; /* open sets that shard the engine's streams; sharded for good (rnn_amd_set_shard, the shard constructor): sharded = sticky || sets > 0 */
   int mheads_alen; /* symbols per head of the last multi-head loss (0: none yet) */
   /* the exchange step as kernel-issued peer traffic (rnn_amd_set_exchange_join): every rank's delta and weight
    * arrays as device pointers valid HERE (own ones at index xchg_rank), the shared arrival counters */
@@ -116,7 +117,7 @@ struct RnnAmdSet {
   int row0;     /* first training-stream row, or first forward-only index when fwd_only */
   int fwd_only; /* the set is made of forward-only clones (no bptt): opinion calls only */
   int global_first, global_count;
-  int sharded_before; /* the engine's `sharded` when the set was opened: put back when it is closed or dropped */
+  int counts_shard;   /* this set made the engine's streams a shard when it was opened (RamdEngine.sharded_sets counts it) */
   /* > 0 during the multi-head step's forward pass: the number of heads whose leak decisions follow the pass, for the
    * early noise speculation (noise_speculate_from); -1 once that has been launched */
   int early_spec_classes;

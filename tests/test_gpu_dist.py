@@ -343,8 +343,9 @@ def test_library_exchange_step_through_rccl_with_one_rank():
     """rnn_amd_dist_init(0, 1, id) -> the generation goes deltas -> k_delta_finalize -> RCCL
     all-reduce on the library's stream -> rnn_apply_learning; with one rank the sum is the
     identity, so the weights must equal the plain path's (to the slab summation, i.e. exactly
-    or within rounding)."""
-    env = dict(os.environ)
+    or within rounding).  (RECUR_AMD_DIST_ONE_RANK_EXCHANGE=1: with one rank the library otherwise skips the
+    exchange step altogether.)"""
+    env = dict(os.environ, RECUR_AMD_DIST_ONE_RANK_EXCHANGE="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-c", RCCL_SCRIPT % {"tests": os.path.dirname(os.path.abspath(__file__))}],
                        capture_output=True, text=True, env=env, timeout=600)
@@ -363,7 +364,7 @@ def test_two_halves_exchange_equals_the_one_launch_form():
     behind both.  Hidden 1024 (eight row tiles, rest rows riding with the upper half), one rank: the sum is
     the identity, so weights, momentum and deltas must equal the plain path's to the summation order of
     the K slabs."""
-    env = dict(os.environ, RECUR_AMD_DIST_OVERLAP="1")
+    env = dict(os.environ, RECUR_AMD_DIST_OVERLAP="1", RECUR_AMD_DIST_ONE_RANK_EXCHANGE="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     script = RCCL_SCRIPT.replace("hidden_size=128, output_size=42, S=32, D=6, learn_rate=2e-3",
                                  "hidden_size=1024, output_size=42, S=64, D=5, learn_rate=1e-4")
