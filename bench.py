@@ -42,7 +42,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
 # HBM-side bytes per launch come from the PMC passes of THIS round's kernels, summarised by
 # tools/pmc_summary.py into this file (rocprofv3 cannot run inside the timed process)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
 
 
 def parse():
@@ -515,7 +515,8 @@ def main():
             # weight-delta accumulation), over the timed region's ms_per_step
             "generation": {"flop": S * (2.0 * gI * gH + 2.0 * gH * gO + 2.0 * (2.0 * gH * gO) + d_exec * 4.0 * gI * gH),
                            "note": "bptt_chain_gemm's launch includes the extras and the control logic of all steps "
-                                   "(its tail, ~6 us of the launch) since round 4"},
+                                   "(its tail, ~6 us of the launch) since round 4; delta_gemm's launch includes the "
+                                   "update of both layers (weights, momentum) since round 5: no optimiser launch"},
         }
         for k, d in roofline["per_kernel"].items():
             d["frac"] = d["achieved"] / PEAK_FP32_MFMA_TFLOPS

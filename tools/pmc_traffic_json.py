@@ -11,7 +11,7 @@ import sys
 
 from pmc_summary import per_kernel
 
-CLASSES = {"bptt_chain_gemm": ("k_chain_persist", "k_chain_main"), "delta_gemm": ("k_delta_dma",)}
+CLASSES = {"bptt_chain_gemm": ("k_chain_persist", "k_chain_main"), "delta_gemm": ("k_delta_direct", "k_delta_dma")}
 
 
 def durations(d):
