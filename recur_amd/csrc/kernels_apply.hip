@@ -157,7 +157,10 @@ struct XchgArgs {
   unsigned first1; /* first block of segment 1 */
 };
 template <int METHOD>
-__global__ __launch_bounds__(256) void k_apply_xchg(XchgArgs xa, float momentum, float mw) {
+__global__ __launch_bounds__(256) void k_apply_xchg(XchgArgs xa, float momentum, float mw, const unsigned *abort_word) {
+  /* a barrier in front of this launch gave up (a rank missing): the ranks' sums are not all there -- touch nothing;
+   * the host aborts at its next synchronisation (rnn_core.c: dsync), until then no weights are made from half a sum */
+  if (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
   const int g = blockIdx.x >= xa.first1 ? 1 : 0;
   const XchgSeg &sg = xa.seg[g];
   const size_t q = sg.lo4 + (size_t)(blockIdx.x - (g ? xa.first1 : 0u)) * 256 + threadIdx.x;
@@ -417,11 +420,11 @@ extern "C" void ramd_launch_apply_xchg(ramd_stream_t st_, int method, int rank, 
   dim3 gr(blocks), bl(256);
   int ev = timing_begin(st, T_APPLY);
   switch (method) {
-  case 1: RAMD_LAUNCH(k_apply_xchg<1>, gr, bl, 0, st, xa, momentum, mw); break;
-  case 4: RAMD_LAUNCH(k_apply_xchg<4>, gr, bl, 0, st, xa, momentum, mw); break;
-  case 5: RAMD_LAUNCH(k_apply_xchg<5>, gr, bl, 0, st, xa, momentum, mw); break;
-  case 6: RAMD_LAUNCH(k_apply_xchg<6>, gr, bl, 0, st, xa, momentum, mw); break;
-  default: RAMD_LAUNCH(k_apply_xchg<0>, gr, bl, 0, st, xa, momentum, mw); break;
+  case 1: RAMD_LAUNCH(k_apply_xchg<1>, gr, bl, 0, st, xa, momentum, mw, ramd_abort_word_dev()); break;
+  case 4: RAMD_LAUNCH(k_apply_xchg<4>, gr, bl, 0, st, xa, momentum, mw, ramd_abort_word_dev()); break;
+  case 5: RAMD_LAUNCH(k_apply_xchg<5>, gr, bl, 0, st, xa, momentum, mw, ramd_abort_word_dev()); break;
+  case 6: RAMD_LAUNCH(k_apply_xchg<6>, gr, bl, 0, st, xa, momentum, mw, ramd_abort_word_dev()); break;
+  default: RAMD_LAUNCH(k_apply_xchg<0>, gr, bl, 0, st, xa, momentum, mw, ramd_abort_word_dev()); break;
   }
   timing_end(st, ev);
 }

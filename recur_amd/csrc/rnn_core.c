@@ -488,6 +488,15 @@ static int state_row(const RamdEngine *e, const RamdPriv *p) {
 
 /* -------------------------------------------- host <-> device: one stream -- */
 
+/* A generator of this engine has been written from the host (a caller's draw, a per-net call's upload): nothing that was
+ * generated ahead from the device's states can be right any more.  (The version numbers of the two-ahead buffers are
+ * PREDICTED -- one pass and one loss on -- so a different sequence of the same length, an upload instead of the loss,
+ * would have been accepted: ADVICE.md round 4.) */
+static void rng_written_from_host(RamdEngine *e) {
+  e->rng_version++;
+  e->sp[0].pending = e->sp[1].pending = 0;
+}
+
 static void stream_copy(RamdEngine *e, RecurNN *net, int to_device) {
   RamdPriv *p = ramd_priv(net);
   const RamdShape *s = &e->sh;
@@ -503,7 +512,7 @@ static void stream_copy(RamdEngine *e, RecurNN *net, int to_device) {
   COPY(b->out + (size_t)r * O, net->output_layer, O);
   if (to_device) {
     h2d((char *)b->rng + (size_t)r * sizeof(rand_ctx), &net->rng, sizeof(rand_ctx));
-    e->rng_version++;
+    rng_written_from_host(e);
   } else {
     d2h(&net->rng, (char *)b->rng + (size_t)r * sizeof(rand_ctx), sizeof(rand_ctx));
   }
@@ -724,7 +733,7 @@ void ramd_rng_from_host(RecurNN *net) {
   RamdEngine *e = p->eng;
   if (e && e->dev_ready && p->dev_valid) {
     h2d((char *)e->b.rng + (size_t)state_row(e, p) * sizeof(rand_ctx), &net->rng, sizeof(rand_ctx));
-    e->rng_version++;
+    rng_written_from_host(e);
     dsync();
   }
 }
@@ -1450,7 +1459,7 @@ float *rnn_opinion(RecurNN *net, const float *inputs, float presynaptic_noise) {
   }
   if (presynaptic_noise != 0.0f) { /* the host generator is the one the caller may have used */
     mail_in((char *)e->b.rng + (size_t)r * sizeof(rand_ctx), &net->rng, sizeof(rand_ctx));
-    e->rng_version++;
+    rng_written_from_host(e);
   }
   if (bl) { /* recur-nn.c:88-103: the layer's one input buffer is shared by every clone */
     bl->inputs[0] = 1.0f;
