@@ -1308,6 +1308,29 @@ def test_a_chain_that_gives_up_in_mid_run_is_redone_a_launch_per_step():
     assert [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1] == "RESULT ok"
 
 
+def test_the_chain_beside_another_process_on_the_same_gpu():
+    """round 4's default took a chain workgroup's XCD and seat from its NUMBER, which anything
+    else on the GPU -- another stream of the embedding application, another process, a second GStreamer element --
+    invalidates by interleaving the dispatch: the launch gave up with abort code 2 and the host process was killed.  The
+    seat now comes from the CU a workgroup runs on (HW_REG_XCC_ID + HW_REG_HW_ID through the residency probe's table).
+    tools/gpu_cotenant_probe.py trains the north-star set while a SECOND PROCESS launches 256-workgroup kernels back to back
+    (build/delta_direct_microbench: one workgroup per CU): 200 generations must go through without a give-up and a
+    generation made beside the other process must match the oracle at 1e-4 -- and the same run with the workgroup-number
+    map (RECUR_AMD_XCD_STATIC=1, opt-in now) must end with that abort, which is why it is no longer the default."""
+    import subprocess
+    import sys as _sys
+    exe = os.path.join(rc.ROOT, "build", "delta_direct_microbench")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.join(rc.ROOT, "recur_amd", "csrc")], check=True)
+    probe = os.path.join(rc.ROOT, "tools", "gpu_cotenant_probe.py")
+    r = subprocess.run([_sys.executable, probe, "200"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+    assert "running at the end of the loop" in r.stdout, r.stdout[-500:]  # (the other process WAS there)
+    env = dict(os.environ, RECUR_AMD_XCD_TABLE="0", RECUR_AMD_XCD_STATIC="1")
+    r = subprocess.run([_sys.executable, probe, "200"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "code 2" in r.stderr, r.stdout[-1000:] + r.stderr[-2000:]
+
+
 def test_a_chain_that_gives_up_on_its_first_launch_falls_back_for_that_call():
     """The one-launch chain needs its 256 workgroups resident together; whether the device and queue grant that (no
     CU mask, no partition mode, no co-tenant holding CUs) is found out by a probe launch before the process's first

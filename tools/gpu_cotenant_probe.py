@@ -1,0 +1,55 @@
+"""GPU probe: the one-launch BPTT chain beside ANOTHER PROCESS's kernels on the same GPU.  A second
+process launches 256-workgroup kernels back to back (build/delta_direct_microbench: one workgroup per CU, 139 KB of LDS
+each) while this one trains the north-star set; the dispatcher interleaves the two processes' workgroups, so a chain
+workgroup's NUMBER says nothing about the XCD it lands on.  With the seat taken from the CU a workgroup runs on (the
+default) the generations are correct and nothing gives up; with RECUR_AMD_XCD_TABLE=0 RECUR_AMD_XCD_STATIC=1 (round 4's
+default) the first misplaced workgroup raises abort code 2.  Prints the parity of one generation from synchronised state
+against the oracle, made while the other process is running, and the rate.
+usage: python tools/gpu_cotenant_probe.py [generations=200]"""
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import recur_ctypes as rc
+import scenarios as sc
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+amd = rc.load_amd()
+kw = dict(input_size=42, hidden_size=1024, output_size=42, S=256, D=20, learn_rate=1e-5, seed=1)
+g = sc.AmdBatchedSet(amd, **kw)
+text = sc.synthetic_text(30000)
+g.load_text(text)
+for i in range(24):
+    g.char_step(text, i, rc.WEIGHTED, 0.95)
+amd.rnn_amd_synchronize()
+other = subprocess.Popen([os.path.join(ROOT, "build", "delta_direct_microbench"), "4000"], stdout=subprocess.DEVNULL,
+                         stderr=subprocess.DEVNULL)
+time.sleep(1.5)  # (its checks are over, its timing loops run)
+t0 = time.perf_counter()
+for i in range(24, 24 + N):
+    g.char_step(text, i, rc.WEIGHTED, 0.95)
+amd.rnn_amd_synchronize()
+dt = time.perf_counter() - t0
+alive = other.poll() is None
+snap = g.snapshot()
+o = sc.OracleSet(**kw)
+a = o.arrays()
+for k in ("ih_w", "ho_w", "ih_m", "ho_m", "hist", "hidden", "index", "min_error_factor"):
+    a[k][:] = snap[k]
+a["generation"][:] = snap["generation"]
+g.char_step(text, 24 + N, rc.WEIGHTED, 0.95)
+o.char_step(text, 24 + N, rc.WEIGHTED, 0.95)
+sg, so = g.snapshot(), o.snapshot()
+still = other.poll() is None
+worst = max(max(rc.rel_err(sg[k], so[k]), rc.max_err(sg[k], so[k])) for k in ("ih_delta", "ho_delta", "ih_w", "ho_w", "hidden"))
+print("%d generations beside the other process (%s at the end of the loop, %s at the compared generation): %.1f us per "
+      "generation; one generation from synchronised state against the oracle: worst error %.2e" % (
+          N, "running" if alive else "GONE", "running" if still else "gone", 1e6 * dt / N, worst))
+other.kill()
+other.wait()
+assert worst <= 1e-4
+print("ok")
