@@ -389,6 +389,112 @@ struct HoWork {
   int done;
   int workers, idle_only; /* (the launch's own: how many of its workgroups share the rows; only those without other work) */
 };
+#ifndef HO_BATCH
+#define HO_BATCH 8 /* streams whose loads are in flight together, per thread: all of a 256-stream set's */
+#endif
+/* HO_HR: rows per workgroup at most (5: h_size <= 1280 over 256 workgroups; 9: h_size <= 1152 over the 128 or more
+ * that have no chain work when the set is small) */
+template <bool MASK, int HO_HR, int BATCH>
+__device__ __forceinline__ void chain_ho_sum(const View &v, const HoWork &hw, int h0, int HR, int q4, int g,
+                                             float4 (&acc)[HO_HR]) {
+  const RamdShape &s = v.sh;
+  const float *hp = v.b.hidden + (size_t)hw.row0 * s.H;
+  const float *ep = v.b.o_error + (size_t)hw.row0 * s.O + 4 * q4;
+  int hc[HO_HR]; /* clamped row indices: every load from a valid address, the value selected afterwards */
+#pragma unroll
+  for (int rr = 0; rr < HO_HR; rr++) hc[rr] = (rr < HR && h0 + rr < s.H) ? h0 + rr : 0;
+  for (int s0 = g; s0 < hw.nrows; s0 += BATCH * 32) {
+    float hv[BATCH][HO_HR];
+    float4 e4[BATCH];
+    unsigned char am[BATCH];
+#pragma unroll
+    for (int i = 0; i < BATCH; i++) {
+      const int ss = s0 + i * 32, sc = ss < hw.nrows ? ss : s0;
+      e4[i] = ld4(ep + (size_t)sc * s.O);
+#pragma unroll
+      for (int rr = 0; rr < HO_HR; rr++) hv[i][rr] = hp[(size_t)sc * s.H + hc[rr]];
+      am[i] = MASK ? hw.active[sc] : (unsigned char)1;
+    }
+#pragma unroll
+    for (int i = 0; i < BATCH; i++) {
+      const bool keep = s0 + i * 32 < hw.nrows && am[i] != 0;
+#pragma unroll
+      for (int rr = 0; rr < HO_HR; rr++) {
+        const float x = keep ? hv[i][rr] : 0.0f;
+        acc[rr].x += x * e4[i].x;
+        acc[rr].y += x * e4[i].y;
+        acc[rr].z += x * e4[i].z;
+        acc[rr].w += x * e4[i].w;
+      }
+    }
+  }
+}
+/* the top layer's update for the rows a workgroup has just summed (recur-nn.c:482-487, 653-676), or w == nullptr */
+struct HoApply {
+  float *w, *m;
+  float rate, momentum, mw;
+};
+/* `rank`: this workgroup's number among the hw.workers that share the rows */
+template <int HO_HR, int BATCH>
+__device__ __forceinline__ void chain_ho_delta(const View &v, const HoWork &hw, float *lds, int rank, HoApply ap = HoApply{}) {
+  const RamdShape &s = v.sh;
+  const int H = s.H, O = s.O, OQ = O >> 2; /* OQ <= 12 (launcher) */
+  const int HR = (H + hw.workers - 1) / hw.workers; /* rows per workgroup, <= HO_HR (launcher) */
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane & 15, gl = lane >> 4;
+  const int h0 = rank * HR;
+  float4 acc[HO_HR];
+#pragma unroll
+  for (int rr = 0; rr < HO_HR; rr++) acc[rr] = zero4();
+  if (h0 < H) { /* (the whole workgroup) */
+    const int q4c = q4 < OQ ? q4 : 0; /* lanes 12-15 of a group repeat quad 0 and are not stored */
+    if (hw.active) chain_ho_sum<true, HO_HR, BATCH>(v, hw, h0, HR, q4c, 4 * wave + gl, acc);
+    else chain_ho_sum<false, HO_HR, BATCH>(v, hw, h0, HR, q4c, 4 * wave + gl, acc);
+#pragma unroll
+    for (int rr = 0; rr < HO_HR; rr++) {
+      acc[rr].x += __shfl_xor(acc[rr].x, 16, 64); acc[rr].x += __shfl_xor(acc[rr].x, 32, 64);
+      acc[rr].y += __shfl_xor(acc[rr].y, 16, 64); acc[rr].y += __shfl_xor(acc[rr].y, 32, 64);
+      acc[rr].z += __shfl_xor(acc[rr].z, 16, 64); acc[rr].z += __shfl_xor(acc[rr].z, 32, 64);
+      acc[rr].w += __shfl_xor(acc[rr].w, 16, 64); acc[rr].w += __shfl_xor(acc[rr].w, 32, 64);
+    }
+    if (gl == 0) {
+#pragma unroll
+      for (int rr = 0; rr < HO_HR; rr++) *reinterpret_cast<float4 *>(lds + 4 * ((wave * HO_HR + rr) * 16 + q4)) = acc[rr];
+    }
+  }
+  /* (the update's weights and momentum, requested before the barrier: they are there when the sums are) */
+  const bool fin = tid < HO_HR * 16 && (tid >> 4) < HR && h0 + (tid >> 4) < H && (tid & 15) < OQ;
+  const size_t fin_off = fin ? (size_t)(h0 + (tid >> 4)) * O + 4 * (tid & 15) : 0;
+  float4 W4 = zero4(), M4 = zero4();
+  if (fin && ap.w) {
+    W4 = ld4(ap.w + fin_off);
+    M4 = ld4(ap.m + fin_off);
+  }
+  __syncthreads();
+  if (fin) {
+    const int rr = tid >> 4, q = tid & 15;
+    float4 sum = *reinterpret_cast<const float4 *>(lds + 4 * (rr * 16 + q));
+    for (int w = 1; w < 8; w++) {
+      const float4 t = *reinterpret_cast<const float4 *>(lds + 4 * ((w * HO_HR + rr) * 16 + q));
+      sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+    }
+    *reinterpret_cast<float4 *>(hw.dst + fin_off) = sum;
+    if (ap.w) {
+      float wv[4] = {W4.x, W4.y, W4.z, W4.w}, mv[4] = {M4.x, M4.y, M4.z, M4.w};
+      const float dv[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float t = dv[i] * ap.rate, mm = mv[i];
+        wv[i] += t + mm * ap.mw;
+        mv[i] = (mm + t) * ap.momentum;
+      }
+      *reinterpret_cast<float4 *>(ap.w + fin_off) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+      *reinterpret_cast<float4 *>(ap.m + fin_off) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    }
+  }
+  __syncthreads(); /* `lds` is the caller's again */
+}
+
+
 /* The extras of every step (column 0 and the input columns of each step's error) and the per-stream control
  * logic (k_extras_control's work, k_extras.h) as a request of the same kind: the one-launch chain runs them in
  * its tail, each workgroup for the stream(s) of its row tile that its column tile number names, from error

@@ -64,21 +64,27 @@ struct DdArgs {
   float ho_rate;
 };
 
-__device__ __forceinline__ dd_f4 dd_load4(const void *sbase, unsigned voff) {
+/* COLD: outside the loop, with five wait states in front.  An SGPR base that a vector-ALU instruction has just written
+ * (v_readlane: hipcc keeps spilled SGPRs in VGPR lanes) may be read by a memory instruction five wait states later at the
+ * earliest; hipcc pads its own memory instructions and does not look into an asm block.  The loop's bases come from the
+ * scalar ALU (no hazard) and tools/isa_lint_async_loads.py checks every build for the pattern. */
+template <bool COLD = false> __device__ __forceinline__ dd_f4 dd_load4(const void *sbase, unsigned voff) {
   dd_f4 r;
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  if constexpr (COLD) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
   return r;
 }
-__device__ __forceinline__ float dd_load1(const void *sbase, unsigned voff) {
+template <bool COLD = false> __device__ __forceinline__ float dd_load1(const void *sbase, unsigned voff) {
   float r;
-  asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  if constexpr (COLD) asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  else asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
   return r;
 }
 typedef int dd_i4 __attribute__((ext_vector_type(4)));
 constexpr int DD_FLAG_LOADS = 8; /* 4 x 256 streams of n_exec, of ih_scale */
 __device__ __forceinline__ dd_i4 dd_load4i(const void *sbase, unsigned voff) {
   dd_i4 r;
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
   return r;
 }
 /* wait until at most N younger loads are outstanding: the flag loads (the wave's first) have landed */
@@ -123,8 +129,13 @@ constexpr int DD_LD = 64; /* floats per row of a wave's tile in LDS */
  * matrix pipe; with 4 hipcc keeps the accumulators in AGPRs and shuffles ring registers through them between an
  * asynchronous load and its wait); P: K quads in flight per wave (the ring); NPW: pieces of the rest rows per
  * workgroup (1: up to 64 rest rows, 2: up to 128). */
-template <int NW, int P, int NPW>
-__device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
+struct DdNoPre {
+  __device__ __forceinline__ void operator()() const {}
+};
+/* PRE: work of the caller's that runs once the ring's first operands have been requested and before anything waits for
+ * them (the fused text step's top-layer delta and update: kernels_bptt.hip) */
+template <int NW, int P, int NPW, class PRE = DdNoPre>
+__device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = PRE{}) {
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   /* workgroup -> tile.  Workgroups are dealt to the XCDs in turn (speed only): XCD x takes a block of the tile
    * grid, so that its L2 sees tm / 4 x tn / 2 of the operands' columns */
@@ -186,7 +197,7 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
     int r4 = 4 * (64 * u + lane);
     r4 = r4 < a.nrows ? r4 : a.nrows - 4;
     fl_n[u] = dd_load4i(a.n_exec, (unsigned)(r4 * sizeof(int)));
-    fl_s[u] = dd_load4(a.ih_scale, (unsigned)(r4 * sizeof(float)));
+    fl_s[u] = dd_load4<true>(a.ih_scale, (unsigned)(r4 * sizeof(float)));
   }
 
   dd_f4 ra[P], re[P];
@@ -225,11 +236,12 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
   dd_static_for<P>([&](auto JC) {
     constexpr int j = decltype(JC)::value;
     advance();
-    ra[j] = dd_load4(g_xb, voff);
-    re[j] = dd_load4(g_eb, voff);
+    ra[j] = dd_load4<true>(g_xb, voff);
+    re[j] = dd_load4<true>(g_eb, voff);
 #pragma unroll
-    for (int p = 0; p < NPW; p++) rr[p][j] = dd_load1(g_xb, voff_r[p]);
+    for (int p = 0; p < NPW; p++) rr[p][j] = dd_load1<true>(g_xb, voff_r[p]);
   });
+  pre(); /* (its own loads are younger than the ring's: every counted wait below then waits for them too, never for less) */
   int ones;
   {
     dd_flag_wait<(2 + NPW) * P>(fl_n, fl_s);
@@ -312,11 +324,11 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds) {
     dd_static_for<P>([&](auto JC) {
       constexpr int j = decltype(JC)::value;
       advance();
-      ra[j] = dd_load4(g_xb, voff);
-      re[j] = dd_load4(g_eb, voff);
+      ra[j] = dd_load4<true>(g_xb, voff);
+      re[j] = dd_load4<true>(g_eb, voff);
 #pragma unroll
-      for (int p = 0; p < NPW; p++) rr[p][j] = dd_load1(g_xb, voff_r[p]);
-      rcf[j] = dd_load1(g_cb, voff_c);
+      for (int p = 0; p < NPW; p++) rr[p][j] = dd_load1<true>(g_xb, voff_r[p]);
+      rcf[j] = dd_load1<true>(g_cb, voff_c);
     });
     for (int i0 = 0; i0 < n_it; i0 += P) round(std::false_type{});
     dd_drain<P>(ra, re, rr, rcf);

@@ -833,13 +833,21 @@ __global__ __launch_bounds__(64) void k_extras_finalize(View v, int row0, int nr
 // four k of a chunk go to the chunk's four MFMAs, the same permutation of k on both sides -- four chunks in flight;
 // the waves' sums meet in LDS, then 8 threads per row apply the row rule, store ex, and add the squares to the
 // row's total (with the chain's partial sums, or the row's own sum of squares where it left none).
-constexpr int XD_NT = 3, XD_PF = 4, XD_WAVES = 8;
+constexpr int XD_NT = 3, XD_PF = 8, XD_WAVES = 8;
+/* (round 5: eight chunks in flight instead of four, and nothing in the epilogue waits for memory on its own -- the input
+ * values of the row rule are requested before the K loop, the step's total apart from the extras (the chain's partial sums,
+ * or the output row's sum of squares) is formed by ALL threads behind the loop, 32 or 16 per row, every load of a thread in
+ * flight at once: as eight threads per row with two loads per trip that sum was 8 dependent round trips, half of the
+ * launch's 11 us at 512 / 128 / 30; 27 -> ... us at 2048 / 512 / 10) */
 template <int XD_MT> /* row tiles of 16 per workgroup: 2 where that still makes 128 workgroups (W_ih's rows are fetched by half as many), else 1 */
-__global__ __launch_bounds__(64 * XD_WAVES) void k_extras_dense(View v, int row0, int nrows, int nx, int nxp, int tn) {
+__global__ __launch_bounds__(64 * XD_WAVES) void k_extras_dense(View v, int row0, int nrows, int nx, int nxp, int tn, int t0, int nt) {
   constexpr int XD_ROWS = 16 * XD_MT;
+  constexpr int TPR = 64 * XD_WAVES / XD_ROWS; /* threads per row for the step's total */
   __shared__ float red[XD_WAVES][XD_ROWS][16 * XD_NT + 1];
+  __shared__ float oth_sh[XD_ROWS];
   const RamdShape &s = v.sh;
-  const int M = s.D * nrows;
+  /* rows: steps t0 .. t0 + nt - 1 of the call's streams (one launch for all steps, or one per step beside the chain) */
+  const int M = nt * nrows;
   const int m0 = blockIdx.x * XD_ROWS;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, kq = lane >> 4;
   // operand rows of this lane: two error rows, three rows of W_ih
@@ -847,7 +855,7 @@ __global__ __launch_bounds__(64 * XD_WAVES) void k_extras_dense(View v, int row0
 #pragma unroll
   for (int i = 0; i < XD_MT; i++) {
     const int m = min(m0 + 16 * i + lm, M - 1);
-    const int t = m / nrows, j = m - t * nrows;
+    const int t = t0 + m / nrows, j = m % nrows;
     arow[i] = v.b.ehi + ((size_t)t * s.Scap + row0 + j) * s.I;
   }
 #pragma unroll
@@ -874,6 +882,22 @@ __global__ __launch_bounds__(64 * XD_WAVES) void k_extras_dense(View v, int row0
   };
 #pragma unroll
   for (int p = 0; p < XD_PF; p++) request(p, p);
+  // the epilogue's row (eight threads per row: columns sub, sub + 8, ..) and the input values its rule asks for
+  const int row = (tid >> 3) & (XD_ROWS - 1), sub = tid & 7;
+  const int m = m0 + row;
+  const bool live = m < M;
+  const int mm = live ? m : M - 1;
+  const int t = t0 + mm / nrows, j = mm % nrows, r = row0 + j;
+  constexpr int XD_CPT = (16 * XD_NT + 7) / 8; /* columns per thread */
+  float xv[XD_CPT];
+  if (tid < 8 * XD_ROWS) {
+    const float *x = input_row_auto(v, r, t);
+#pragma unroll
+    for (int q = 0; q < XD_CPT; q++) {
+      const int c = sub + 8 * q;
+      xv[q] = x[(c == 0 || c >= nx) ? 0 : s.hidden_size + c];
+    }
+  }
   for (int n0 = 0; n0 < mine; n0 += XD_PF) {
 #pragma unroll
     for (int p = 0; p < XD_PF; p++) {
@@ -902,59 +926,92 @@ __global__ __launch_bounds__(64 * XD_WAVES) void k_extras_dense(View v, int row0
 #pragma unroll
     for (int jn = 0; jn < XD_NT; jn++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) red[wave][16 * i + 4 * kq + r][16 * jn + lm] = acc[i][jn][r];
+      for (int rr = 0; rr < 4; rr++) red[wave][16 * i + 4 * kq + rr][16 * jn + lm] = acc[i][jn][rr];
+  /* the step's total apart from the extras: the chain's column-tile partials, or (tn == 0: the one-launch chain leaves
+   * none) the sum of squares of the step's OUTPUT row, error plane t + 1 -- TPR threads per row, a fixed tree */
+  {
+    const int orow = tid / TPR, osub = tid % TPR;
+    const int om = min(m0 + orow, M - 1);
+    const int ot = t0 + om / nrows, orr = row0 + om % nrows;
+    float o = 0.0f;
+    if (tn == 0) {
+      const float *erow = v.b.ehi + ((size_t)(ot + 1) * s.Scap + orr) * s.I;
+      const int n4 = s.H / 4;
+      constexpr int NB = 9; /* float4 per thread and batch: h_size <= 1152 in one batch of 32 threads */
+      for (int b0 = osub; b0 < n4; b0 += TPR * NB) {
+        float4 e[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+          const int k4 = b0 + i * TPR;
+          e[i] = ld4(k4 < n4 ? erow + 4 * k4 : v.b.zeros);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) o += (e[i].x * e[i].x + e[i].y * e[i].y) + (e[i].z * e[i].z + e[i].w * e[i].w);
+      }
+    } else {
+      float pv[3]; /* (tn <= 33 column tiles, TPR >= 16) */
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const int p = osub + i * TPR;
+        pv[i] = p < tn ? v.b.esum_part[((size_t)ot * (tn + 1) + p) * s.Scap + orr] : 0.0f;
+      }
+      o = (pv[0] + pv[1]) + pv[2];
+      for (int p = osub + 3 * TPR; p < tn; p += TPR) o += v.b.esum_part[((size_t)ot * (tn + 1) + p) * s.Scap + orr];
+    }
+#pragma unroll
+    for (int off = 1; off < TPR; off <<= 1) o += __shfl_xor(o, off, 64);
+    if (osub == 0) oth_sh[orow] = o;
+  }
   __syncthreads();
   if (tid >= 8 * XD_ROWS) return;
-  // eight threads per row: columns sub, sub + 8, ..
-  const int row = tid >> 3, sub = tid & 7;
-  const int m = m0 + row;
-  const bool live = m < M;
-  const int mm = live ? m : M - 1;
-  const int t = mm / nrows, j = mm - t * nrows, r = row0 + j;
-  const float *x = input_row_auto(v, r, t);
   float *dst = v.b.ex + ((size_t)(t + 1) * s.Scap + r) * nxp;
   float sq = 0.0f;
-  for (int c = sub; c < nx; c += 8) {
-    float e = 0.0f;
 #pragma unroll
-    for (int w = 0; w < XD_WAVES; w++) e += red[w][row][c];
-    const int n = c == 0 ? 0 : s.hidden_size + c;
-    const float xi = x[n];
-    const bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
-    e = on ? e : 0.0f;
-    if (on && s.activation == 2) e /= 2 * (xi + 1.0f);
-    if (live) dst[c] = e;
-    sq += e * e;
-  }
-  /* the step's total: the chain's column-tile partials in index order, or (tn == 0: the one-launch chain leaves none)
-   * the sum of squares of the step's OUTPUT row, error plane t + 1 */
-  float other = 0.0f;
-  if (tn == 0) {
-    const float *erow = v.b.ehi + ((size_t)(t + 1) * s.Scap + r) * s.I;
-    float p0 = 0.0f, p1 = 0.0f;
-    int k4 = sub;
-    for (; k4 + 8 < s.H / 4; k4 += 16) {
-      const float4 e0 = ld4(erow + 4 * k4), e1 = ld4(erow + 4 * (k4 + 8));
-      p0 += (e0.x * e0.x + e0.y * e0.y) + (e0.z * e0.z + e0.w * e0.w);
-      p1 += (e1.x * e1.x + e1.y * e1.y) + (e1.z * e1.z + e1.w * e1.w);
+  for (int q = 0; q < XD_CPT; q++) {
+    const int c = sub + 8 * q;
+    if (c < nx) {
+      float e = 0.0f;
+#pragma unroll
+      for (int w = 0; w < XD_WAVES; w++) e += red[w][row][c];
+      const float xi = xv[q];
+      const bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
+      e = on ? e : 0.0f;
+      if (on && s.activation == 2) e /= 2 * (xi + 1.0f);
+      if (live) dst[c] = e;
+      sq += e * e;
     }
-    if (k4 < s.H / 4) {
-      const float4 e0 = ld4(erow + 4 * k4);
-      p0 += (e0.x * e0.x + e0.y * e0.y) + (e0.z * e0.z + e0.w * e0.w);
-    }
-    other = p0 + p1;
-  } else {
-    for (int p = sub; p < tn; p += 8) other += v.b.esum_part[((size_t)t * (tn + 1) + p) * s.Scap + r];
   }
 #pragma unroll
-  for (int off = 1; off < 8; off <<= 1) {
-    sq += __shfl_xor(sq, off, 64);
-    other += __shfl_xor(other, off, 64);
-  }
-  if (sub == 0 && live) v.b.esum[(size_t)t * s.Scap + r] = other + sq;
+  for (int off = 1; off < 8; off <<= 1) sq += __shfl_xor(sq, off, 64);
+  if (sub == 0 && live) v.b.esum[(size_t)t * s.Scap + r] = oth_sh[row] + sq;
+}
+
+/* (t0, nt: steps t0 .. t0 + nt - 1.  One launch per step on a second stream beside a launch-per-step chain was tried --
+ * hidden 2048: 10 steps of 40 us -- and lost: the chain's workgroups fill every CU's LDS, the extras' wait for a step to
+ * end and delay the next: 890 -> 1004 us per generation at 2048 / 512 / 10.  profiles/NOTES_r05.md) */
+static void ramd_launch_extras_dense(hipStream_t st, const View &v, const RamdShape *sh, int row0, int nrows, int nx, int nxp,
+                                     int tn_parts, int t0, int nt) {
+  const int M = nt * nrows;
+  if (M / 32 >= 128)
+    RAMD_LAUNCH(k_extras_dense<2>, dim3((M + 31) / 32), dim3(64 * XD_WAVES), 0, st, v, row0, nrows, nx, nxp, tn_parts, t0, nt);
+  else
+    RAMD_LAUNCH(k_extras_dense<1>, dim3((M + 15) / 16), dim3(64 * XD_WAVES), 0, st, v, row0, nrows, nx, nxp, tn_parts, t0, nt);
 }
 
 #include "k_delta_direct.h" /* the weight-delta GEMM without a K split over workgroups (hidden 1024 and up) */
+
+/* k_delta_direct with the top layer's weight delta AND its update in the launch's first microseconds (the fused text step):
+ * workgroup i forms rows 5 i .. of ho_delta = hidden^T . o_error over the call's streams (chain_ho_delta, k_common.h: what
+ * the chain launch otherwise does in ITS first 2.5 us, on the generation's critical path), stores them and updates those
+ * rows of W_ho and its momentum (recur-nn.c:482-487 with the top layer's rate, 653-676) -- between the request for the
+ * GEMM's first operands and the first wait for them (dd_body's PRE): the waves of this launch wait ~2 us there anyway. */
+template <int NW, int P, int NPW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void k_delta_direct_ho(DdArgs a, View v,
+                                                                                                                HoWork hw, HoApply ap) {
+  extern __shared__ __attribute__((aligned(16))) float ddh_lds[];
+  __builtin_amdgcn_s_setprio(2);
+  dd_body<NW, P, NPW>(a, ddh_lds, [&]() { chain_ho_delta<5, 8>(v, hw, ddh_lds, (int)blockIdx.x, ap); });
+}
 
 // ------------------------------------------------ weight-delta GEMM by LDS-DMA --
 //
@@ -1747,6 +1804,37 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   const bool dma = b->uniform_idx >= 0 && nrows % BK == 0 && sh->hidden_size % 128 == 0 &&
                    sh->I >= 128 && sh->activation != 5 && env_int("RECUR_AMD_DELTA_DMA", 1);
   const bool has_rest = dma && (sh->I / 128) * 128 < sh->I;
+  /* ---- the weight-delta GEMM's form is decided here already (k_delta_direct below): when it carries the update, the top
+   * layer's delta and update ride in ITS first microseconds instead of the chain launch's (ho_in_delta) */
+  constexpr int DNW = 8, DP = 5;
+  /* row tiles: as many whole ones as make whole rounds of 256 workgroups, or nearly -- a multi-head net's 1100
+   * input rows are 17 x 16 = 272 tiles, a round of 256 and a round of 16: twice the time; as 16 row tiles they
+   * are one round with 76 rest rows, two pieces of them per workgroup (NPW) */
+  const int dtn = sh->hidden_size / 64;
+  int dtm = sh->I / 64, drest = sh->I - 64 * dtm;
+  auto rounds_ok = [&](int tm_) {
+    const int tiles = tm_ * dtn, rounds = (tiles + 255) / 256;
+    return tiles >= 192 && 10 * tiles >= 9 * 256 * rounds;
+  };
+  if (!rounds_ok(dtm) && dtm > 16 && sh->I - 64 * (dtm - 1) <= 128 && rounds_ok(dtm - 1)) {
+    dtm--;
+    drest = sh->I - 64 * dtm;
+  }
+  const int npw = drest > 64 ? 2 : 1;
+  const int dQPS = nrows / 4, dn_it = dQPS % DNW == 0 ? sh->D * (dQPS / DNW) : -1;
+  const bool direct = b->uniform_idx >= 0 && sh->hidden_size % 64 == 0 && dtn > 0 && rounds_ok(dtm) &&
+                      (drest == 0 || (dtm >= 16 && drest <= 128)) &&
+                      nrows % (4 * DNW) == 0 && nrows <= 256 * (DD_FLAG_LOADS / 2) && row0 + nrows <= sh->Scap &&
+                      sh->activation != 5 && dn_it >= DP && dn_it % DP == 0 &&
+                      !(g_delta_half_hook && env_int("RECUR_AMD_DIST_OVERLAP", 0)) && env_int("RECUR_AMD_DELTA_DIRECT", 1);
+  const bool direct_fuse = direct && defer && defer->fuse_want && !accumulate && !(flags & 0xa0000000u);
+  /* (HoWork's preconditions: up to 256 streams, o_size <= 48, five rows of ho_delta per workgroup at most) */
+  /* (not where the chain launch has workgroups without chain work -- half of it or more, ramd_chain_steps: there the
+   * request costs the chain nothing, here it costs 2.4 us: the 48 loads per wave queue behind the ring's at the CU's
+   * 64 bytes per clock.  256 streams at hidden 1024: chain 107.6 -> 104.1 us, this launch 91.9 -> 94.3, generation 221.0 -> 219.9) */
+  const bool ho_in_delta = direct_fuse && !ranges && !active && nrows >= 16 && nrows <= 256 && sh->O <= 48 && sh->O % 4 == 0 &&
+                           sh->H <= 5 * dtm * dtn && (nrows / 32) * (sh->hidden_size / 32) > 128 &&
+                           env_int("RECUR_AMD_HO_IN_DELTA", 1);
   bool ho_paired = false, ho_finalize_after = false, ho_in_final = false;
   ProbHoDelta ho_p = {};
   int ho_nkt = 0, ho_ks = 0;
@@ -1757,7 +1845,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   /* (up to 256 streams: the request costs the chain launch 0.014 us per stream -- 3.6 us at 256 against the GEMM's
    * 6.2 us launch -- and nothing where the set leaves workgroups of that launch without chain work: 32 streams
    * 145.3 -> 141.0 us per generation, 64: 155.7 -> 151.2, 256: 244.8 -> 242.4) */
-  const bool ho_asked = !(flags & 0x80000000u) && !ranges && !accumulate && nrows >= 16 && nrows <= 256 && sh->O <= 48 &&
+  const bool ho_asked = !ho_in_delta && !(flags & 0x80000000u) && !ranges && !accumulate && nrows >= 16 && nrows <= 256 && sh->O <= 48 &&
                         env_int("RECUR_AMD_HO_IN_CHAIN", 1);
   auto ho_classic = [&]() { /* (the fused single-net path, flag 0x80000000, updates W_ho directly) */
     if (ranges && range_stride && (flags & RAMD_RANGES_ARE_HEADS) && b->mheads_alen >= 24 && b->mheads_alen <= 128 &&
@@ -1821,7 +1909,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     ho_req.active = active;
     ho_req.row0 = row0;
     ho_req.nrows = nrows;
-  } else if (!(flags & 0x80000000u)) {
+  } else if (!(flags & 0x80000000u) && !ho_in_delta) {
     ho_classic();
   }
   // BPTT chain: D dependent steps, one launch each, then the extras of all steps
@@ -1912,10 +2000,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       }
     } else if (nx <= 16 * XD_NT && env_int("RECUR_AMD_EXTRAS_DENSE", 1)) {
       /* dense inputs, up to 47 of them: GEMM and finalize in one launch */
-      if (M / 32 >= 128)
-        RAMD_LAUNCH(k_extras_dense<2>, dim3((M + 31) / 32), dim3(64 * XD_WAVES), 0, st, v, row0, nrows, nx, nxp, tn_parts);
-      else
-        RAMD_LAUNCH(k_extras_dense<1>, dim3((M + 15) / 16), dim3(64 * XD_WAVES), 0, st, v, row0, nrows, nx, nxp, tn_parts);
+      ramd_launch_extras_dense(st, v, sh, row0, nrows, nx, nxp, tn_parts, 0, sh->D);
     } else { /* very wide nets: the dense GEMM over all extra columns */
       ProbExtras p = {v, row0, nrows, nx};
       launch_gemm<false, false, ProbExtras>(st, p, b->slab, M, nxp, nkt, ks, T_OTHER);
@@ -1957,33 +2042,17 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
      * 256 tiles); the sum goes straight into ih_delta -- and, when the caller's update is the momentum rule and
      * nothing else wants the sums first, weights and momentum are updated in the same epilogue (fuse_want) */
     {
-      constexpr int NW = 8, P = 5;
-      /* row tiles: as many whole ones as make whole rounds of 256 workgroups, or nearly -- a multi-head net's 1100
-       * input rows are 17 x 16 = 272 tiles, a round of 256 and a round of 16: twice the time; as 16 row tiles they
-       * are one round with 76 rest rows, two pieces of them per workgroup (NPW) */
-      const int dtn = sh->hidden_size / 64;
-      int dtm = sh->I / 64, drest = sh->I - 64 * dtm;
-      auto rounds_ok = [&](int tm_) {
-        const int tiles = tm_ * dtn, rounds = (tiles + 255) / 256;
-        return tiles >= 192 && 10 * tiles >= 9 * 256 * rounds;
-      };
-      if (!rounds_ok(dtm) && dtm > 16 && sh->I - 64 * (dtm - 1) <= 128 && rounds_ok(dtm - 1)) {
-        dtm--;
-        drest = sh->I - 64 * dtm;
-      }
-      const int npw = drest > 64 ? 2 : 1;
-      const int QPS = nrows / 4, n_it = QPS % NW == 0 ? sh->D * (QPS / NW) : -1;
-      const bool direct = b->uniform_idx >= 0 && sh->hidden_size % 64 == 0 && dtn > 0 && rounds_ok(dtm) &&
-                          (drest == 0 || (dtm >= 16 && drest <= 128)) &&
-                          nrows % (4 * NW) == 0 && nrows <= 256 * (DD_FLAG_LOADS / 2) && row0 + nrows <= sh->Scap &&
-                          sh->activation != 5 && n_it >= P && n_it % P == 0 &&
-                          !(g_delta_half_hook && env_int("RECUR_AMD_DIST_OVERLAP", 0)) && env_int("RECUR_AMD_DELTA_DIRECT", 1);
+      constexpr int NW = DNW, P = DP;
       if (direct) {
         static bool attr_set = false;
         if (!attr_set) {
           HIP_CHECK(hipFuncSetAttribute((const void *)(k_delta_direct<NW, P, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         dd_lds_bytes(NW, 1)));
           HIP_CHECK(hipFuncSetAttribute((const void *)(k_delta_direct<NW, P, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        dd_lds_bytes(NW, 2)));
+          HIP_CHECK(hipFuncSetAttribute((const void *)(k_delta_direct_ho<NW, P, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        dd_lds_bytes(NW, 1)));
+          HIP_CHECK(hipFuncSetAttribute((const void *)(k_delta_direct_ho<NW, P, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         dd_lds_bytes(NW, 2)));
           attr_set = true;
         }
@@ -1998,7 +2067,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
         const float *ho_src = nullptr;
         if (defer && defer->ho_slab && defer->ho_ks == 1) ho_src = defer->ho_slab;
         else if (!defer || !defer->ho_slab) ho_src = b->ho_delta;
-        const bool fuse = defer && defer->fuse_want && !accumulate && ho_src && !(flags & 0xa0000000u);
+        const bool fuse = direct_fuse && (ho_src || ho_in_delta);
         DdArgs a = {};
         a.x = b->arena + (size_t)row0 * sh->I;
         a.e = b->ehi + (size_t)row0 * sh->I + 1;
@@ -2024,15 +2093,30 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
           a.rate = defer->fuse_rate;
           a.momentum = defer->fuse_momentum;
           a.mw = defer->fuse_mw;
-          a.ho_w = b->ho_w;
-          a.ho_m = b->ho_m;
-          a.ho_delta = ho_src;
-          a.ho_delta_out = ho_src == b->ho_delta ? nullptr : b->ho_delta;
-          a.ho_n4 = (unsigned)((size_t)sh->H * sh->O / 4);
-          a.ho_rate = defer->fuse_ho_rate;
+          if (!ho_in_delta) { /* the top layer's sums are there (the chain launch formed them): its update, shared out */
+            a.ho_w = b->ho_w;
+            a.ho_m = b->ho_m;
+            a.ho_delta = ho_src;
+            a.ho_delta_out = ho_src == b->ho_delta ? nullptr : b->ho_delta;
+            a.ho_n4 = (unsigned)((size_t)sh->H * sh->O / 4);
+            a.ho_rate = defer->fuse_ho_rate;
+          }
         }
         int ev = timing_begin(st, T_DELTA);
-        if (npw == 2)
+        if (fuse && ho_in_delta) {
+          /* ... or formed HERE, in the launch's first microseconds (its waves wait ~2 us for their first operands anyway):
+           * workgroup i sums and updates rows 5 i .. of ho_delta / W_ho / its momentum -- 2.5 us less in the chain launch */
+          HoWork hw = {};
+          hw.dst = b->ho_delta;
+          hw.row0 = row0;
+          hw.nrows = nrows;
+          hw.workers = dtm * dtn;
+          HoApply ap = {b->ho_w, b->ho_m, defer->fuse_ho_rate, defer->fuse_momentum, defer->fuse_mw};
+          if (npw == 2)
+            RAMD_LAUNCH((k_delta_direct_ho<NW, P, 2>), dim3(dtm * dtn), dim3(64 * NW), dd_lds_bytes(NW, 2), st, a, v, hw, ap);
+          else
+            RAMD_LAUNCH((k_delta_direct_ho<NW, P, 1>), dim3(dtm * dtn), dim3(64 * NW), dd_lds_bytes(NW, 1), st, a, v, hw, ap);
+        } else if (npw == 2)
           RAMD_LAUNCH((k_delta_direct<NW, P, 2>), dim3(dtm * dtn), dim3(64 * NW), dd_lds_bytes(NW, 2), st, a);
         else
           RAMD_LAUNCH((k_delta_direct<NW, P, 1>), dim3(dtm * dtn), dim3(64 * NW), dd_lds_bytes(NW, 1), st, a);

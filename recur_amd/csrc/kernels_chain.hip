@@ -547,88 +547,7 @@ __device__ unsigned long long g_pc_stamps[2][64][8];
 #ifndef PC_ONE_SHARED_FETCH
 #define PC_ONE_SHARED_FETCH 1
 #endif
-#ifndef HO_BATCH
-#define HO_BATCH 8 /* streams whose loads are in flight together, per thread: all of a 256-stream set's */
-#endif
-/* HO_HR: rows per workgroup at most (5: h_size <= 1280 over 256 workgroups; 9: h_size <= 1152 over the 128 or more
- * that have no chain work when the set is small) */
-template <bool MASK, int HO_HR, int BATCH>
-__device__ __forceinline__ void chain_ho_sum(const View &v, const HoWork &hw, int h0, int HR, int q4, int g,
-                                             float4 (&acc)[HO_HR]) {
-  const RamdShape &s = v.sh;
-  const float *hp = v.b.hidden + (size_t)hw.row0 * s.H;
-  const float *ep = v.b.o_error + (size_t)hw.row0 * s.O + 4 * q4;
-  int hc[HO_HR]; /* clamped row indices: every load from a valid address, the value selected afterwards */
-#pragma unroll
-  for (int rr = 0; rr < HO_HR; rr++) hc[rr] = (rr < HR && h0 + rr < s.H) ? h0 + rr : 0;
-  for (int s0 = g; s0 < hw.nrows; s0 += BATCH * 32) {
-    float hv[BATCH][HO_HR];
-    float4 e4[BATCH];
-    unsigned char am[BATCH];
-#pragma unroll
-    for (int i = 0; i < BATCH; i++) {
-      const int ss = s0 + i * 32, sc = ss < hw.nrows ? ss : s0;
-      e4[i] = ld4(ep + (size_t)sc * s.O);
-#pragma unroll
-      for (int rr = 0; rr < HO_HR; rr++) hv[i][rr] = hp[(size_t)sc * s.H + hc[rr]];
-      am[i] = MASK ? hw.active[sc] : (unsigned char)1;
-    }
-#pragma unroll
-    for (int i = 0; i < BATCH; i++) {
-      const bool keep = s0 + i * 32 < hw.nrows && am[i] != 0;
-#pragma unroll
-      for (int rr = 0; rr < HO_HR; rr++) {
-        const float x = keep ? hv[i][rr] : 0.0f;
-        acc[rr].x += x * e4[i].x;
-        acc[rr].y += x * e4[i].y;
-        acc[rr].z += x * e4[i].z;
-        acc[rr].w += x * e4[i].w;
-      }
-    }
-  }
-}
-/* `rank`: this workgroup's number among the hw.workers that share the rows */
-template <int HO_HR, int BATCH>
-__device__ __forceinline__ void chain_ho_delta(const View &v, const HoWork &hw, float *lds, int rank) {
-  const RamdShape &s = v.sh;
-  const int H = s.H, O = s.O, OQ = O >> 2; /* OQ <= 12 (launcher) */
-  const int HR = (H + hw.workers - 1) / hw.workers; /* rows per workgroup, <= HO_HR (launcher) */
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane & 15, gl = lane >> 4;
-  const int h0 = rank * HR;
-  float4 acc[HO_HR];
-#pragma unroll
-  for (int rr = 0; rr < HO_HR; rr++) acc[rr] = zero4();
-  if (h0 < H) { /* (the whole workgroup) */
-    const int q4c = q4 < OQ ? q4 : 0; /* lanes 12-15 of a group repeat quad 0 and are not stored */
-    if (hw.active) chain_ho_sum<true, HO_HR, BATCH>(v, hw, h0, HR, q4c, 4 * wave + gl, acc);
-    else chain_ho_sum<false, HO_HR, BATCH>(v, hw, h0, HR, q4c, 4 * wave + gl, acc);
-#pragma unroll
-    for (int rr = 0; rr < HO_HR; rr++) {
-      acc[rr].x += __shfl_xor(acc[rr].x, 16, 64); acc[rr].x += __shfl_xor(acc[rr].x, 32, 64);
-      acc[rr].y += __shfl_xor(acc[rr].y, 16, 64); acc[rr].y += __shfl_xor(acc[rr].y, 32, 64);
-      acc[rr].z += __shfl_xor(acc[rr].z, 16, 64); acc[rr].z += __shfl_xor(acc[rr].z, 32, 64);
-      acc[rr].w += __shfl_xor(acc[rr].w, 16, 64); acc[rr].w += __shfl_xor(acc[rr].w, 32, 64);
-    }
-    if (gl == 0) {
-#pragma unroll
-      for (int rr = 0; rr < HO_HR; rr++) *reinterpret_cast<float4 *>(lds + 4 * ((wave * HO_HR + rr) * 16 + q4)) = acc[rr];
-    }
-  }
-  __syncthreads();
-  if (tid < HO_HR * 16) {
-    const int rr = tid >> 4, q = tid & 15;
-    if (rr < HR && h0 + rr < H && q < OQ) {
-      float4 sum = *reinterpret_cast<const float4 *>(lds + 4 * (rr * 16 + q));
-      for (int w = 1; w < 8; w++) {
-        const float4 t = *reinterpret_cast<const float4 *>(lds + 4 * ((w * HO_HR + rr) * 16 + q));
-        sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
-      }
-      *reinterpret_cast<float4 *>(hw.dst + (size_t)(h0 + rr) * O + 4 * q) = sum;
-    }
-  }
-  __syncthreads(); /* `lds` is the chain's again */
-}
-
+/* (chain_ho_sum / chain_ho_delta: k_common.h -- the weight-delta launch of the fused text step runs them too) */
 /* ONE: row tiles of 16 streams, i.e. only sub-chain a exists and every other half-step is empty
  * (the workgroup multiplies, then finishes and publishes, then waits for the 32 producers of its
  * next operand): 4.5 instead of 6.4 us per step for HALF the streams per workgroup -- worse per

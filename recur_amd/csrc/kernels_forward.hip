@@ -551,17 +551,23 @@ extern "C" void ramd_fwd_stamps(unsigned long long *out) {
 #else
 #define FF_STAMP(i) do { } while (0)
 #endif
+constexpr int FF_MAXIN = 64;
 template <int NS = 0>
 __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, int new_idx, int row0,
                                                    int nrows, int tm, int tn, int nstages_arg,
                                                    int mode, int text_i, int global_first,
-                                                   int n_set) {
+                                                   int n_set, const float *__restrict__ dense, int ld) {
   FF_STAMP(0);
   View v = *vp;
   const int nstages = NS > 0 ? NS : nstages_arg;
   __shared__ __attribute__((aligned(16))) float smem[C_STAGES * C_STAGE_FLOATS];
   __shared__ float rs_sh[4][CM];
   __shared__ float4 wt_sh[CN];
+  /* dense inputs (mode RAMD_IN_DENSE: the feature vectors of gstclassify, rnnca's neighbourhoods -- up to FF_MAXIN
+   * columns): the tile's 32 input rows and the W rows of the input columns under its 32 columns, for the epilogue */
+  __shared__ float xin_sh[CM][FF_MAXIN + 1];
+  __shared__ __attribute__((aligned(16))) float win_sh[FF_MAXIN][CN];
+  __shared__ float4 wint_sh[FF_MAXIN]; /* ... and those rows' tail columns (column tile 0) */
   const RamdShape &s = v.sh;
   const int L = blockIdx.x;
   const int xcd = L & 7, q = L >> 3;
@@ -642,6 +648,24 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
   float xt[TAILK] = {0.f, 0.f, 0.f, 0.f};
   float4 wtl[TAILK] = {zero4(), zero4(), zero4(), zero4()}, wth = zero4();
   const bool tail_row = nt == 0 && (etid & 7) == 0;
+  const bool dns = mode == RAMD_IN_DENSE;
+  const int insz = dns ? s.input_size : 0;
+  float xin_r[CM * FF_MAXIN / 256]; /* requested here, stored to LDS behind the K loop: nobody waits for them */
+  float4 win_r[FF_MAXIN * (CN / 4) / 256], wint_r = zero4();
+  if (!loader && dns) {
+#pragma unroll
+    for (int u = 0; u < CM * FF_MAXIN / 256; u++) {
+      const int idx = etid + 256 * u, rr = idx / insz, k = idx - rr * insz;
+      const int rc = m0 + rr < nrows ? m0 + rr : nrows - 1;
+      xin_r[u] = idx < CM * insz ? dense[(size_t)rc * ld + k] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < FF_MAXIN * (CN / 4) / 256; u++) {
+      const int idx = etid + 256 * u, k = idx >> 3;
+      win_r[u] = k < insz ? ld4(v.b.ih_w + (size_t)(s.hidden_size + 1 + k) * s.H + n0 + 4 * (idx & 7)) : zero4();
+    }
+    if (nt == 0 && etid < insz) wint_r = ld4(v.b.ih_w + (size_t)(s.hidden_size + 1 + etid) * s.H + tail);
+  }
   if (!loader) {
     if (mode == RAMD_IN_TEXT) { /* charmodel-predict.c:273, 295-298 */
       int len = v.b.text_len;
@@ -649,7 +673,7 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
       text_o = text_i + (global_first + er) * spacing;
       if (text_o >= len - 1) text_o -= len - 1;
       hot = v.b.text[text_o];
-    } else {
+    } else if (!dns) {
       hot = v.b.hot[grow];
     }
     a4 = ld4(hid0 + (size_t)er * s.H + n0 + ec4);
@@ -763,6 +787,19 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
     rsum += __shfl_xor(rsum, 32, 64);
     if (kh == 0) rs_sh[wave][lm] = rsum;
     if (etid < CN) wt_sh[etid] = wt_mine;
+    if (dns) {
+#pragma unroll
+      for (int u = 0; u < CM * FF_MAXIN / 256; u++) {
+        const int idx = etid + 256 * u, rr = idx / insz, k = idx - rr * insz;
+        if (idx < CM * insz) xin_sh[rr][k] = xin_r[u];
+      }
+#pragma unroll
+      for (int u = 0; u < FF_MAXIN * (CN / 4) / 256; u++) {
+        const int idx = etid + 256 * u, k = idx >> 3;
+        if (k < insz) *reinterpret_cast<float4 *>(&win_sh[k][4 * (idx & 7)]) = win_r[u];
+      }
+      if (nt == 0 && etid < insz) wint_sh[etid] = wint_r;
+    }
   }
   __syncthreads();
   if (loader) return;
@@ -780,9 +817,19 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
     e.z = (p0.z + p1.z) + (p2.z + p3.z);
     e.w = (p0.w + p1.w) + (p2.w + p3.w);
   }
-  // the row's input sum: bias + previous hidden values + the one-hot input
+  // dense inputs: their products under this thread's four columns (the input rows of W_ih lie behind the hidden
+  // values', recur-nn.c:104-112), and their sum
+  float4 din = zero4();
+  float sum_in = 0.0f;
+  for (int k = 0; k < insz; k++) {
+    const float x = xin_sh[row][k];
+    const float4 w = *reinterpret_cast<const float4 *>(&win_sh[k][c4]);
+    din.x += x * w.x; din.y += x * w.y; din.z += x * w.z; din.w += x * w.w;
+    sum_in += x;
+  }
+  // the row's input sum: bias + previous hidden values + the one-hot input (or the dense ones)
   float sum = ((rs_sh[0][row] + rs_sh[1][row]) + (rs_sh[2][row] + rs_sh[3][row])) + 1.0f +
-              (hot >= 0 ? 1.0f : 0.0f);
+              (dns ? sum_in : hot >= 0 ? 1.0f : 0.0f);
   const float softclip = s.I * INPUT_MEAN_SOFT_TOP_F;
   const float scale = (sum > softclip) ? soft_clip_dev(sum, softclip) : 1.0f;
   const bool live = m0 + row < nrows;
@@ -804,10 +851,10 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
   float *slot = v.b.arena + ((size_t)new_idx * s.Scap + grow) * s.I;
   {
     float4 o;
-    o.x = ((e.x + wb.x) + (hot >= 0 ? ws.x : 0.0f)) * scale;
-    o.y = ((e.y + wb.y) + (hot >= 0 ? ws.y : 0.0f)) * scale;
-    o.z = ((e.z + wb.z) + (hot >= 0 ? ws.z : 0.0f)) * scale;
-    o.w = ((e.w + wb.w) + (hot >= 0 ? ws.w : 0.0f)) * scale;
+    o.x = ((e.x + wb.x) + (dns ? din.x : hot >= 0 ? ws.x : 0.0f)) * scale;
+    o.y = ((e.y + wb.y) + (dns ? din.y : hot >= 0 ? ws.y : 0.0f)) * scale;
+    o.z = ((e.z + wb.z) + (dns ? din.z : hot >= 0 ? ws.z : 0.0f)) * scale;
+    o.w = ((e.w + wb.w) + (dns ? din.w : hot >= 0 ? ws.w : 0.0f)) * scale;
     *reinterpret_cast<float4 *>(out + n0 + c4) = o;
     *reinterpret_cast<float4 *>(slot + n0 + c4) = make_float4(a4.x * scale, a4.y * scale, a4.z * scale, a4.w * scale);
   }
@@ -827,6 +874,11 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
       if (hot >= 0) {
         pp.x += wth.x; pp.y += wth.y; pp.z += wth.z; pp.w += wth.w;
       }
+      for (int k = 0; k < insz; k++) {
+        const float x = xin_sh[row][k];
+        const float4 w = wint_sh[k];
+        pp.x += x * w.x; pp.y += x * w.y; pp.z += x * w.z; pp.w += x * w.w;
+      }
     }
     float *pd = v.b.slab + (size_t)nrows * s.H + ((size_t)nt * nrows + er) * 4;
     *reinterpret_cast<float4 *>(pd) = make_float4(pp.x * scale, pp.y * scale, pp.z * scale, pp.w * scale);
@@ -837,7 +889,10 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
       v.b.idx[grow] = new_idx;
       if (mode == RAMD_IN_TEXT) v.b.target[grow] = v.b.text[text_o + 1];
     }
-    for (int k = sub; k < s.input_size; k += 8) slot[s.hidden_size + 1 + k] = (k == hot) ? scale : 0.0f;
+    if (dns)
+      for (int k = sub; k < s.input_size; k += 8) slot[s.hidden_size + 1 + k] = xin_sh[row][k] * scale;
+    else
+      for (int k = sub; k < s.input_size; k += 8) slot[s.hidden_size + 1 + k] = (k == hot) ? scale : 0.0f;
   }
   FF_STAMP(5);
 }
@@ -1028,17 +1083,33 @@ extern "C" void ramd_launch_bottom_forward(ramd_stream_t st_, const RamdShape *s
  * partials), or 0 when the preconditions do not hold and nothing was launched */
 extern "C" int ramd_launch_forward_fused(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b,
                                          int row0, int nrows, int mode, int text_i,
-                                         int global_first, int n_set, int for_top) {
+                                         int global_first, int n_set, int for_top, const float *dense, int ld) {
   /* for_top: the text step, which stops after the hidden layer's sums (k_text_top takes them from there); otherwise a
    * one-hot or text pass that goes on to ramd_launch_forward_finish */
   if (b->uniform_idx < 0 || sh->bI || sh->hidden_size % CN != 0 || row0 + nrows > sh->Scap ||
       (for_top ? (mode != RAMD_IN_TEXT || !ramd_text_top_ok(sh))
-               : ((mode != RAMD_IN_TEXT && mode != RAMD_IN_ONE_HOT) || !env_int("RECUR_AMD_FWD_FUSED_ANY", 1))) ||
-      env_int("RECUR_AMD_NO_FWD_FUSED", 0))
+               : ((mode != RAMD_IN_TEXT && mode != RAMD_IN_ONE_HOT &&
+                   !(mode == RAMD_IN_DENSE && dense && sh->input_size <= FF_MAXIN && env_int("RECUR_AMD_FWD_FUSED_DENSE", 1))) ||
+                  !env_int("RECUR_AMD_FWD_FUSED_ANY", 1))) ||
+      env_int("RECUR_AMD_NO_FWD_FUSED", 0)) {
+    if (env_int("RECUR_AMD_TRACE_FWD", 0))
+      fprintf(stderr, "librecur_amd: forward not fused: uniform_idx %d, bottom %d, hidden %d, rows %d + %d of %d, mode %d, "
+                      "for_top %d, dense %p, inputs %d\n", b->uniform_idx, sh->bI, sh->hidden_size, row0, nrows, sh->Scap, mode,
+              for_top, (const void *)dense, sh->input_size);
     return 0;
+  }
   const int tm = (nrows + CM - 1) / CM, tn = sh->hidden_size / CN;
+  /* dense inputs: where the 32 x 32 tiles are one round of workgroups (gstclassify's 512 / 128: 64 tiles; one launch less,
+   * the time of assemble + GEMM).  Beyond that the tiles' operand traffic decides -- 8 flop per byte from L2: 67.7 us at
+   * 2048 / 512 (1024 tiles) against 58.7 + 6.3 us for k_assemble and the 128 x 128 tiles of k_gemm */
+  if (mode == RAMD_IN_DENSE && tm * tn > 256 && !env_int("RECUR_AMD_FWD_FUSED_DENSE_ANY", 0)) return 0;
   /* plane 0: sums; plane 1: [tn][nrows][4] padding partials */
-  if ((size_t)nrows * sh->H + (size_t)tn * nrows * 4 > b->slab_floats || tn * 4 > sh->H) return 0;
+  if ((size_t)nrows * sh->H + (size_t)tn * nrows * 4 > b->slab_floats || tn * 4 > sh->H) {
+    if (env_int("RECUR_AMD_TRACE_FWD", 0))
+      fprintf(stderr, "librecur_amd: forward not fused: workspace of %zu floats, %zu wanted\n", b->slab_floats,
+              (size_t)nrows * sh->H + (size_t)tn * nrows * 4);
+    return 0;
+  }
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   const View *d_view = device_view(st, v);
@@ -1048,7 +1119,7 @@ extern "C" int ramd_launch_forward_fused(ramd_stream_t st_, const RamdShape *sh,
   const bool exact = sh->hidden_size % CK == 0 && !env_int("RECUR_AMD_FWD_NS0", 0);
 #define FWD_FUSED(NS)                                                                              \
   RAMD_LAUNCH((k_fwd_fused<NS>), dim3(blocks), dim3(512), 0, st, d_view, b->uniform_idx, row0, \
-                     nrows, tm, tn, nstages, mode, text_i, global_first, n_set)
+                     nrows, tm, tn, nstages, mode, text_i, global_first, n_set, dense, ld)
   if (exact && nstages == 8) FWD_FUSED(8);
   else if (exact && nstages == 4) FWD_FUSED(4);
   else if (exact && nstages == 2) FWD_FUSED(2);

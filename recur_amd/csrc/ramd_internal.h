@@ -179,7 +179,8 @@ int ramd_launch_forward_hidden(ramd_stream_t st, const RamdShape *sh, const Ramd
 #define RAMD_MULTI_RANGE_STRIDE 132
 int ramd_text_top_ok(const RamdShape *sh);
 int ramd_launch_forward_fused(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0,
-                              int nrows, int mode, int text_i, int global_first, int n_set, int for_top);
+                              int nrows, int mode, int text_i, int global_first, int n_set, int for_top,
+                              const float *dense, int ld); /* (dense, ld: the inputs of mode RAMD_IN_DENSE, [nrows][ld]) */
 /* after ramd_launch_forward_fused(for_top = 0) returned `fused` != 0: tail columns, noise generated ahead, activation,
  * output layer */
 void ramd_launch_forward_finish(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0, int nrows,

@@ -2105,16 +2105,22 @@ static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, i
       /* the text step: building the input rows and the hidden layer's GEMM in one launch
        * (the ring index the kernel stores is the host's, which has just stepped) */
       int fused = ramd_launch_forward_fused(g_stream, &e->sh, &e->b, r0, set->n, mode, text_i,
-                                            set->global_first, set->global_count, 1);
+                                            set->global_first, set->global_count, 1, NULL, 0);
       if (fused) {
         set_streams_dev_wrote(set);
         return fused;
       }
-    } else if (!hidden_only && advance && !set->fwd_only && (noise == 0.0f || e->b.noise_spec_use)) {
-      /* the same launch for the one-hot and text passes that go on to a generic output layer (the multi-head step);
-       * presynaptic noise only as the values generated ahead, which the finishing kernel adds */
+    } else if (getenv("RECUR_AMD_TRACE_FWD") && !(!hidden_only && (advance || mode == RAMD_IN_DENSE) && !set->fwd_only &&
+                                                 (noise == 0.0f || e->b.noise_spec_use))) {
+      fprintf(stderr, "librecur_amd: forward not fused: hidden_only %d advance %d mode %d fwd_only %d noise %g\n", hidden_only,
+              advance, mode, set->fwd_only, noise);
+    } else if (!hidden_only && (advance || mode == RAMD_IN_DENSE) && !set->fwd_only && (noise == 0.0f || e->b.noise_spec_use)) {
+      /* the same launch for the one-hot and text passes that go on to a generic output layer (the multi-head step),
+       * and for dense inputs (gstclassify's features, rnnca's neighbourhoods; their callers advance on their own, and
+       * the index the kernel stores is the one that is there); presynaptic noise only as the values generated
+       * ahead, which the finishing kernel adds */
       int fused = ramd_launch_forward_fused(g_stream, &e->sh, &e->b, r0, set->n, mode, text_i,
-                                            set->global_first, set->global_count, 0);
+                                            set->global_first, set->global_count, 0, d_dense, ld);
       if (fused) {
         ramd_launch_forward_finish(g_stream, &e->sh, &e->b, r0, set->n, fused, 1);
         if (set->early_spec_classes > 0 && e->sp_adopted >= 0) {

@@ -150,8 +150,9 @@ def test_hot_case_stepwise_on_the_direct_delta_path(amd):
     a break, never multiplied: coefficient 0 over whatever the step left), so the launch takes its coefficient loop --
     chosen per launch from n_exec / ih_scale -- in most generations and the all-ones loop in the others; every
     generation is compared with the oracle from the oracle's own state at 1e-4, weights included (the fused update)."""
-    kw = dict(input_size=42, hidden_size=1024, output_size=42, S=32, D=6, learn_rate=0.08, seed=12)
-    _stepwise(amd, kw, sc.synthetic_text(6000), 24, rc.WEIGHTED, 6)
+    # (depth 10: the direct kernel wants the K loop -- depth x streams / 32 -- in whole rings of five)
+    kw = dict(input_size=42, hidden_size=1024, output_size=42, S=32, D=10, learn_rate=0.08, seed=12)
+    _stepwise(amd, kw, sc.synthetic_text(6000), 30, rc.WEIGHTED, 10)
 
 
 @pytest.mark.parametrize("env,node", [
@@ -1328,6 +1329,16 @@ def test_the_chain_beside_another_process_on_the_same_gpu():
     assert "running at the end of the loop" in r.stdout, r.stdout[-500:]  # (the other process WAS there)
     env = dict(os.environ, RECUR_AMD_XCD_TABLE="0", RECUR_AMD_XCD_STATIC="1")
     r = subprocess.run([_sys.executable, probe, "200"], capture_output=True, text=True, timeout=600, env=env)
+    # (that run ended by abort(): its helper process dies with it -- PR_SET_PDEATHSIG in the probe -- and, belt and braces,
+    # by its exact pid here: a straggler would share the GPU with whatever runs after this test)
+    import re
+    import signal
+    m = re.search(r"other process: pid (\d+)", r.stdout)
+    if m:
+        try:
+            os.kill(int(m.group(1)), signal.SIGKILL)
+        except ProcessLookupError:
+            pass
     assert r.returncode != 0 and "code 2" in r.stderr, r.stdout[-1000:] + r.stderr[-2000:]
 
 

@@ -34,3 +34,27 @@ def test_delta_direct_touches_no_register_with_a_load_outstanding(tmp_path):
         assert "scratch_" not in body and "v_accvgpr" not in body
         # two loops (all-ones / coefficients) x ring x (16 + pieces)
         assert body.count("v_mfma_f32_16x16x4_f32") == 2 * 5 * (16 + npw)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_delta_direct_with_the_top_layer_in_its_launch(tmp_path):
+    """The library's own instantiations, k_delta_direct_ho among them (the top layer's delta and update between the
+    ring's first requests and the first wait): its register pressure made hipcc keep scalar bases in VGPR lanes, and a
+    v_readlane directly in front of an inline-asm load is a hazard that hipcc does not pad (the third rule of the lint:
+    five wait states between a vector-ALU write of an SGPR and a memory instruction that reads it) -- `Memory access
+    fault ... address (nil)` on the GPU until the loads outside the loop got their own s_nop."""
+    asm = str(tmp_path / "bptt.s")
+    src = os.path.join(ROOT, "recur_amd", "csrc")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-I" + src, "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(src, "kernels_bptt.hip"), "-S", "--cuda-device-only", "-o", asm],
+                   check=True, capture_output=True)
+    text = open(asm).read()
+    for sym in ("k_delta_direct_hoILi8ELi5ELi1EE", "k_delta_direct_hoILi8ELi5ELi2EE",
+                "k_delta_directILi8ELi5ELi1EE", "k_delta_directILi8ELi5ELi2EE"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_lint_async_loads.py"), asm, sym],
+                           capture_output=True, text=True)
+        assert r.returncode == 0 and " 0 problems" in r.stdout, r.stdout[-3000:]
+        start = next(i for i, l in enumerate(text.split("\n")) if l.startswith("_Z") and sym in l and l.split(";")[0].rstrip().endswith(":"))
+        body = "\n".join(text.split("\n")[start:])
+        body = body[:body.index("s_endpgm")]
+        assert "scratch_" not in body and "v_accvgpr" not in body

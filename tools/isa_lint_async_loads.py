@@ -56,6 +56,53 @@ def lint_valu_to_mfma(lines, need=2):
     return problems
 
 
+SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]")
+
+
+def sregs(text):
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def lint_valu_sgpr_to_vmem(lines, need=5):
+    """A vector-ALU instruction that writes an SGPR (v_readlane / v_readfirstlane: hipcc's SGPR spills live in VGPR
+    lanes; v_cmp with an SGPR destination) and an inline-asm memory instruction that takes that SGPR as its base fewer
+    than `need` wait states later.  hipcc's hazard recognizer pads its OWN memory instructions; it does not look into
+    an inline-asm block (seen: k_delta_direct's restart path with the top layer's delta in the launch -- SGPR pressure,
+    bases restored by v_readlane directly in front of the loads, `Memory access fault ... address (nil)`)."""
+    problems = []
+    recent = []  # (SGPR set, wait states since)
+    in_asm = False
+    for no, raw in lines:
+        t = raw.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        line = raw.split(";")[0].strip()
+        if not line or line.startswith(".") or line.endswith(":"):
+            continue
+        op = line.split()[0]
+        ops = line[len(op):].split(",")
+        if in_asm and (op.startswith("global_") or op.startswith("buffer_")):
+            used = sregs(",".join(ops[1:]))
+            for written, ws in recent:
+                if used & written and ws < need:
+                    problems.append((no, raw.strip(), ["s%d" % r for r in sorted(used & written)]))
+        states = int(line.split()[1]) + 1 if op == "s_nop" else 1
+        recent = [(w, ws + states) for w, ws in recent if ws + states < 8]
+        if op.startswith("v_") and sregs(ops[0]):
+            recent.append((sregs(ops[0]), 0))
+    return problems
+
+
 def lint(lines):
     queue = []          # outstanding loads, oldest first: sets of destination registers
     saved = {}          # label -> queue at the first branch that targets it
@@ -116,11 +163,12 @@ def main():
         body.append((i + 1, text[i]))
         if "s_endpgm" in text[i]:
             break
-    problems = lint(body) + lint_valu_to_mfma(body)
+    problems = lint(body) + lint_valu_to_mfma(body) + lint_valu_sgpr_to_vmem(body)
     loads = sum(1 for _, l in body if l.strip().startswith("global_load"))
     print("%s: %d instructions, %d global loads, %d problems" % (sym, len(body), loads, len(problems)))
     for no, line, hit in problems[:40]:
-        print("  line %d: %s   <- touches v%s with a load outstanding" % (no, line, hit))
+        print("  line %d: %s   <- %s" % (no, line, ("reads %s too early after a vector-ALU write" % hit) if hit and
+                                       isinstance(hit[0], str) else ("touches v%s with a load outstanding" % hit)))
     return 1 if problems else 0
 
 
