@@ -438,6 +438,18 @@ void rnn_amd_set_text_opinion(RnnAmdSet *set, int i, int advance);
  * as the reference's fast_sigmoid_array(answer, answer, 3) does to output_layer) and
  * o_error[i] = a (1 - a) (targets[j * ld + i] - a); the error never visits the host. */
 void rnn_amd_set_sigmoid_mse_error(RnnAmdSet *set, const float *targets, int ld, int n);
+/* rnn_amd_set_opinion (outputs not fetched) + rnn_amd_set_sigmoid_mse_error, resp. + rnn_amd_set_grouped_softmax_error,
+ * as ONE call: what train_net does per cell between two calc_deltas (gstrnnca.c:693-714) and train_channel per channel
+ * (gstclassify.c:2070-2119).  Same results as the two calls; the hidden layer's activation, the output layer, the loss
+ * and the top layer's backprop then share one launch (one workgroup per stream: the hidden row, the outputs and the
+ * output error never leave the CU), and the rnn_amd_set_calc_deltas that follows -- with `trained` as its active mask
+ * in the class-group case, no error ranges -- finds the top layer's backprop done.  Shapes outside that launch's
+ * reach (more than 64 outputs, a bottom layer, presynaptic noise) simply make the two calls. */
+void rnn_amd_set_opinion_sigmoid_mse(RnnAmdSet *set, const float *inputs, int ld_inputs, const float *targets, int ld,
+                                     int n);
+void rnn_amd_set_opinion_grouped_softmax(RnnAmdSet *set, const float *inputs, int ld_inputs, int n_groups,
+                                         const int *group_offset, const int *group_size, const int *targets,
+                                         const float *error_weight, u8 *trained);
 /* fill_frame's step after the opinion (gstrnnca.c:813-814): fast_sigmoid in place on the first
  * n outputs of every net of the set (training or forward-only clones); outputs (host, n_nets x
  * o_size, may be NULL) receives the answer rows, which synchronises. */

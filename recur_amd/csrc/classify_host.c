@@ -205,8 +205,12 @@ int rnn_amd_classify_generation(RnnAmdSet *set, const float *features, int ld_fe
   if (balance) {
     rnn_amd_balanced_begin(balance);
   }
-  /* every channel's forward pass (its own noise draws first, as in train_channel) */
-  rnn_amd_set_opinion(set, features, ld_features, NULL);
+  /* every channel's forward pass (its own noise draws first, as in train_channel); without presynaptic noise it draws
+   * nothing and can share a call -- and a launch -- with the loss below (rnn_amd_set_opinion_grouped_softmax) */
+  const int together = net->presynaptic_noise == 0.0f;
+  if (!together) {
+    rnn_amd_set_opinion(set, features, ld_features, NULL);
+  }
   /* which labelled (channel, group) pairs train: all of them, or the balanced sample -- decided here on
    * the host, in the reference's order, and handed to the device loss as "no target" where not */
   int *use = malloc(sizeof(int) * (size_t)channels * n_groups);
@@ -238,7 +242,14 @@ int rnn_amd_classify_generation(RnnAmdSet *set, const float *features, int ld_fe
   if (exact_gate) {
     rnn_amd_set_read_stats(set, &before, 0);
   }
-  rnn_amd_set_grouped_softmax_error(set, n_groups, group_offset, group_size, use, error_weight, NULL);
+  if (together) {
+    u8 *trained = malloc(channels); /* (== trains: a channel trains if one of its groups has a target left) */
+    rnn_amd_set_opinion_grouped_softmax(set, features, ld_features, n_groups, group_offset, group_size, use, error_weight,
+                                        trained);
+    free(trained);
+  } else {
+    rnn_amd_set_grouped_softmax_error(set, n_groups, group_offset, group_size, use, error_weight, NULL);
+  }
   if (trained_groups) {
     rnn_amd_set_calc_deltas(set, 1, NULL, trains); /* adds to the cleared deltas */
   }

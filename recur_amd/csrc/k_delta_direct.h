@@ -62,6 +62,12 @@ struct DdArgs {
   float *ho_delta_out; /* where the top layer's sums are to be stored as well (they came as a plane), or NULL */
   unsigned ho_n4;
   float ho_rate;
+  /* K split over workgroups, for shapes whose 64 x 64 tiles are a fraction of the chip (hidden 512: 8 x 8): the grid is
+   * ksplit times the tiles, part z takes iterations [z, z + 1) n_it / ksplit of every wave and stores (mode 0) its sums
+   * in plane z, `kplane` floats behind the last -- the planes the optimiser's launch or k_delta_finalize sum */
+  int ksplit;
+  size_t kplane;
+  int rgroups; /* row groups of the rest rows' pieces (dd_body) */
 };
 
 /* COLD: outside the loop, with five wait states in front.  An SGPR base that a vector-ALU instruction has just written
@@ -139,7 +145,10 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   /* workgroup -> tile.  Workgroups are dealt to the XCDs in turn (speed only): XCD x takes a block of the tile
    * grid, so that its L2 sees tm / 4 x tn / 2 of the operands' columns */
-  const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
+  const int ksp = a.ksplit > 1 ? a.ksplit : 1, per_part = gridDim.x / ksp;
+  const int kz = (int)blockIdx.x / per_part;
+  const int L = (int)blockIdx.x - kz * per_part, xcd = L & 7, q = L >> 3;
+  float *const dlt = a.delta + (size_t)kz * a.kplane;
   int mt, nt;
   if ((a.tm & 3) == 0 && (a.tn & 1) == 0) {
     const int bm = a.tm >> 2, bn = a.tn >> 1; /* the XCD's block: bm x bn tiles */
@@ -153,7 +162,8 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
   const int m0 = 64 * mt, n0 = 64 * nt; /* (a.e, a.w ... already point at column 1) */
   const int I = a.I;
   const int QPS = a.nrows >> 2;          /* K quads per step */
-  const int n_it = a.D * (QPS / NW);     /* this wave's iterations: every NW-th quad of K */
+  const int n_it = a.D * (QPS / NW) / ksp; /* this wave's iterations: every NW-th quad of K (of this workgroup's part of K) */
+  const int it0 = kz * n_it, g_t0 = it0 / (QPS / NW), g_w0 = NW * (it0 - g_t0 * (QPS / NW));
   const unsigned voff = (unsigned)(((size_t)(lane >> 4) * I + (lane & 15) * 4) * sizeof(float));
   /* the rest rows, for the first 16 row tiles of a column tile: NPW pieces each, piece pi = NPW mt + p = (row group
    * pi / 4, column group pi % 4) of 4 NPW row groups x 4 column groups.  A row group is rg = ceil(rest / 4 NPW)
@@ -161,8 +171,11 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
    * group's last row repeat it), a column group the columns n0 + 4 c + rj: register rj of the error quad.  The
    * load's base is the A operand's: the column distance is in the per-lane offset.  (Workgroups without a share
    * load and multiply all the same -- a branch would end the scheduling region --, their result is never stored.) */
-  const bool has_rest = a.rest > 0 && mt < 16;
-  const int rg = (a.rest + 4 * NPW - 1) / (4 * NPW);
+  /* (a.rgroups row groups: 4 NPW where a column tile has 16 row tiles to share the 16 NPW pieces out over; 4 with two
+   * pieces per workgroup where it has only 8 -- hidden 512 --, for up to 64 rest rows) */
+  const int RG = a.rgroups;
+  const bool has_rest = a.rest > 0 && NPW * mt < 4 * RG;
+  const int rg = (a.rest + RG - 1) / RG;
   int ri[NPW], rj[NPW], rrows[NPW]; /* (rrows: the group's rows that exist) */
   unsigned voff_r[NPW];
   unsigned long long sel_lo[NPW], sel_hi[NPW]; /* register rj of a quad, by two wave-uniform masks (as ?: chains hipcc makes branches of it) */
@@ -207,7 +220,7 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
    * scheduled into the shadows of the MFMAs; a division would go through the vector ALU, a branch would end the
    * scheduling region).  Past the last iteration it keeps going over valid memory (step clamped): those loads only
    * keep the counted waits exact. */
-  int g_t = 0, g_within = wv;
+  int g_t = g_t0, g_within = wv + g_w0;
   const float *g_xb, *g_eb, *g_cb;
   auto advance = [&]() {
     const int t = g_t < a.D ? g_t : a.D - 1;
@@ -319,8 +332,8 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
 #pragma unroll
     for (int j = 0; j < P; j++) rcf[j] = 0.0f;
     dd_drain<P>(ra, re, rr, rcf);
-    g_t = 0;
-    g_within = wv;
+    g_t = g_t0;
+    g_within = wv + g_w0;
     dd_static_for<P>([&](auto JC) {
       constexpr int j = decltype(JC)::value;
       advance();
@@ -369,8 +382,8 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
 #pragma unroll
     for (int w2 = 1; w2 < NW; w2++) s += *reinterpret_cast<const dd_f4 *>(p + (size_t)w2 * 64 * DD_LD);
     const size_t off = (size_t)(m0 + (ch >> 4)) * a.H + n0 + 4 * (ch & 15);
-    if (a.mode == 1) s += *reinterpret_cast<const dd_f4u *>(a.delta + off);
-    *reinterpret_cast<dd_f4u *>(a.delta + off) = s;
+    if (a.mode == 1) s += *reinterpret_cast<const dd_f4u *>(dlt + off);
+    *reinterpret_cast<dd_f4u *>(dlt + off) = s;
     if (upd) {
       dd_f4 W = *reinterpret_cast<const dd_f4u *>(a.w + off), M = *reinterpret_cast<const dd_f4u *>(a.m + off);
       update4(W, M, s, a.rate);
@@ -395,8 +408,8 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
 #pragma unroll
       for (int w2 = 1; w2 < NW; w2++) d += q[w2 * 256];
       const size_t off = (size_t)(64 * a.tm + pri * rg + c) * a.H + n0 + 4 * c2 + prj;
-      if (a.mode == 1) d += a.delta[off];
-      a.delta[off] = d;
+      if (a.mode == 1) d += dlt[off];
+      dlt[off] = d;
       if (upd) update1(off, d, a.rate, a.w, a.m);
     }
   }
@@ -412,7 +425,7 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
       const int row = rr_ < 64 ? m0 + rr_ : 64 * a.tm + rr_ - 64;
       const int col = (nt == 0 && cc == 0) ? -1 : a.hidden_size + (nt == 0 ? cc - 1 : cc);
       const ptrdiff_t off = (ptrdiff_t)row * a.H + col;
-      a.delta[off] = 0.0f;
+      dlt[off] = 0.0f;
       if (upd) {
         const float mm = a.m[off];
         a.w[off] += mm * a.mw;

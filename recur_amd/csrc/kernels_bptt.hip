@@ -1820,14 +1820,24 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     dtm--;
     drest = sh->I - 64 * dtm;
   }
-  const int npw = drest > 64 ? 2 : 1;
+  /* the rest rows' pieces: 16 per column tile (up to 64 rest rows) or 32, one or two per workgroup of the tile's first
+   * 16 row tiles -- or two per workgroup where there are only 8 row tiles (hidden 512) */
+  const int npw = dtm >= 16 ? (drest > 64 ? 2 : 1) : 2;
+  const int drg = dtm >= 16 ? 4 * npw : 4;
   const int dQPS = nrows / 4, dn_it = dQPS % DNW == 0 ? sh->D * (dQPS / DNW) : -1;
-  const bool direct = b->uniform_idx >= 0 && sh->hidden_size % 64 == 0 && dtn > 0 && rounds_ok(dtm) &&
-                      (drest == 0 || (dtm >= 16 && drest <= 128)) &&
+  /* fewer tiles than that (hidden 512: 8 x 8): K split two or four ways over workgroups, the parts' sums as planes for the
+   * optimiser's launch (or k_delta_finalize) to add -- what k_delta_dma leaves, from 64 x 64 tiles without LDS staging:
+   * 43.5 -> ... us at 512 / 128 / 30 */
+  int dks = 1;
+  if (!rounds_ok(dtm) && dn_it > 0 && env_int("RECUR_AMD_DELTA_DIRECT_SPLIT", 1))
+    for (int k = 4; k >= 2 && dks == 1; k -= 2)
+      if (dtm * dtn * k >= 192 && dtm * dtn * k <= 256 && dn_it % (k * DP) == 0 && dn_it / k >= DP) dks = k;
+  const bool direct = b->uniform_idx >= 0 && sh->hidden_size % 64 == 0 && dtn > 0 && (rounds_ok(dtm) || dks > 1) &&
+                      (drest == 0 || (dtm >= 16 && drest <= 128) || (dtm >= 8 && drest <= 64)) &&
                       nrows % (4 * DNW) == 0 && nrows <= 256 * (DD_FLAG_LOADS / 2) && row0 + nrows <= sh->Scap &&
                       sh->activation != 5 && dn_it >= DP && dn_it % DP == 0 &&
                       !(g_delta_half_hook && env_int("RECUR_AMD_DIST_OVERLAP", 0)) && env_int("RECUR_AMD_DELTA_DIRECT", 1);
-  const bool direct_fuse = direct && defer && defer->fuse_want && !accumulate && !(flags & 0xa0000000u);
+  const bool direct_fuse = direct && dks == 1 && defer && defer->fuse_want && !accumulate && !(flags & 0xa0000000u);
   /* (HoWork's preconditions: up to 256 streams, o_size <= 48, five rows of ho_delta per workgroup at most) */
   /* (not where the chain launch has workgroups without chain work -- half of it or more, ramd_chain_steps: there the
    * request costs the chain nothing, here it costs 2.4 us: the 48 loads per wave queue behind the ring's at the CU's
@@ -2041,9 +2051,10 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
     /* ---- k_delta_direct (k_delta_direct.h): 64 x 64 tiles that own ALL of K, where those fill the chip (hidden 1024:
      * 256 tiles); the sum goes straight into ih_delta -- and, when the caller's update is the momentum rule and
      * nothing else wants the sums first, weights and momentum are updated in the same epilogue (fuse_want) */
+    bool gemm_done = false;
     {
       constexpr int NW = DNW, P = DP;
-      if (direct) {
+      if (direct && (dks == 1 || (size_t)dks * n <= b->slab_floats)) {
         static bool attr_set = false;
         if (!attr_set) {
           HIP_CHECK(hipFuncSetAttribute((const void *)(k_delta_direct<NW, P, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2087,8 +2098,15 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
         a.tm = dtm;
         a.tn = dtn;
         a.rest = drest;
+        a.rgroups = drg;
         a.hidden_size = sh->hidden_size;
         a.mode = fuse ? 2 : accumulate ? 1 : 0;
+        if (dks > 1) { /* planes: stored, summed (and added to ih_delta where the call accumulates) by what follows */
+          a.delta = b->slab + 1;
+          a.ksplit = dks;
+          a.kplane = n;
+          a.mode = 0;
+        }
         if (fuse) {
           a.rate = defer->fuse_rate;
           a.momentum = defer->fuse_momentum;
@@ -2117,21 +2135,26 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
           else
             RAMD_LAUNCH((k_delta_direct_ho<NW, P, 1>), dim3(dtm * dtn), dim3(64 * NW), dd_lds_bytes(NW, 1), st, a, v, hw, ap);
         } else if (npw == 2)
-          RAMD_LAUNCH((k_delta_direct<NW, P, 2>), dim3(dtm * dtn), dim3(64 * NW), dd_lds_bytes(NW, 2), st, a);
+          RAMD_LAUNCH((k_delta_direct<NW, P, 2>), dim3(dks * dtm * dtn), dim3(64 * NW), dd_lds_bytes(NW, 2), st, a);
         else
-          RAMD_LAUNCH((k_delta_direct<NW, P, 1>), dim3(dtm * dtn), dim3(64 * NW), dd_lds_bytes(NW, 1), st, a);
+          RAMD_LAUNCH((k_delta_direct<NW, P, 1>), dim3(dks * dtm * dtn), dim3(64 * NW), dd_lds_bytes(NW, 1), st, a);
         timing_end(st, ev);
-        if (defer) {
-          defer->slab = nullptr; /* ih_delta is complete */
-          if (fuse) {
-            defer->ho_slab = nullptr;
-            defer->fuse_done = 1;
+        if (dks == 1) {
+          if (defer) {
+            defer->slab = nullptr; /* ih_delta is complete */
+            if (fuse) {
+              defer->ho_slab = nullptr;
+              defer->fuse_done = 1;
+            }
           }
+          return;
         }
-        return;
+        ks = dks; /* whole planes: every row and column of ih_delta in each */
+        gemm_done = true;
       }
     }
-    if (dma) {
+    if (gemm_done) {
+    } else if (dma) {
       /* whole 128-row tiles by LDS-DMA, one workgroup per CU; the rows above them (the
        * input rows of a text net) by the generic kernel with its own K split */
       static bool attr_set = false;

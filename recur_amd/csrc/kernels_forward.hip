@@ -1086,11 +1086,10 @@ extern "C" int ramd_launch_forward_fused(ramd_stream_t st_, const RamdShape *sh,
                                          int global_first, int n_set, int for_top, const float *dense, int ld) {
   /* for_top: the text step, which stops after the hidden layer's sums (k_text_top takes them from there); otherwise a
    * one-hot or text pass that goes on to ramd_launch_forward_finish */
+  const bool dense_ok = mode == RAMD_IN_DENSE && dense && sh->input_size <= FF_MAXIN && env_int("RECUR_AMD_FWD_FUSED_DENSE", 1);
   if (b->uniform_idx < 0 || sh->bI || sh->hidden_size % CN != 0 || row0 + nrows > sh->Scap ||
-      (for_top ? (mode != RAMD_IN_TEXT || !ramd_text_top_ok(sh))
-               : ((mode != RAMD_IN_TEXT && mode != RAMD_IN_ONE_HOT &&
-                   !(mode == RAMD_IN_DENSE && dense && sh->input_size <= FF_MAXIN && env_int("RECUR_AMD_FWD_FUSED_DENSE", 1))) ||
-                  !env_int("RECUR_AMD_FWD_FUSED_ANY", 1))) ||
+      (for_top ? ((mode != RAMD_IN_TEXT && !dense_ok) || !ramd_text_top_ok(sh))
+               : ((mode != RAMD_IN_TEXT && mode != RAMD_IN_ONE_HOT && !dense_ok) || !env_int("RECUR_AMD_FWD_FUSED_ANY", 1))) ||
       env_int("RECUR_AMD_NO_FWD_FUSED", 0)) {
     if (env_int("RECUR_AMD_TRACE_FWD", 0))
       fprintf(stderr, "librecur_amd: forward not fused: uniform_idx %d, bottom %d, hidden %d, rows %d + %d of %d, mode %d, "

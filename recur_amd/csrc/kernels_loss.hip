@@ -89,10 +89,24 @@ extern "C" void ramd_top_stamps(unsigned long long *out) {
 #else
 #define TT_STAMP(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, int fwd_ks) {
+/* KIND: which loss sits between the output layer and the backprop -- 0: the text model's softmax against the stream's
+ * next symbol; 1: rnnca's sigmoid + squared error (k_sigmoid_mse_error's arithmetic, gstrnnca.c:701-714); 2: gstclassify's
+ * class groups (k_grouped_softmax_error's, gstclassify.c:2070-2119).  1 and 2 serve rnn_amd_set_opinion_sigmoid_mse /
+ * _grouped_softmax: finalize + output layer + loss + top backprop of a dense-input generation in ONE launch instead of
+ * four (7.4 + 12.0 + 4.9 + 9.8 us at 2048 / 512, 5.0 + 4.7 + 4.8 + 5.0 us at 512 / 128). */
+struct TopLoss {
+  const float *targets; /* 1: [nrows][ld] */
+  int ld, n;
+  int ngroups;          /* 2 */
+  const int *goff, *gsize, *gt;
+  const float *weight;
+};
+template <int KIND>
+__global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, int fwd_ks, TopLoss tl) {
   extern __shared__ float tsh[];
   __shared__ float tred[16];
   __shared__ float tstat[4];
+  __shared__ int trained_sh;
   const RamdShape &s = v.sh;
   const int r = row0 + blockIdx.x;
   float *shid = tsh;                   /* [H] hidden row                    */
@@ -117,11 +131,12 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
   const int y0 = seg * per, y1 = min(s.H, y0 + per);
   constexpr int NB = 14; /* float4 in flight per lane and batch: 66 rows of a wave at 5 rows per instruction */
   int target = 0;
-  float pad_oe = 0.0f;
+  float pad_oe = 0.0f, mse_target = 0.0f;
   if (seg == 0) {
-    target = v.b.target[r];
+    if constexpr (KIND == 0) target = v.b.target[r];
     const int pi = lane < s.O ? lane : 0; /* (o_size > 64: the later columns are read where they are used) */
     pad_oe = v.b.o_error[(size_t)r * s.O + pi];
+    if constexpr (KIND == 1) mse_target = lane < tl.n ? tl.targets[(size_t)blockIdx.x * tl.ld + lane] : 0.0f;
   }
   if (fwd_ks != 0) {
     // the forward GEMM's K slabs are still in the workspace: sum them, apply the
@@ -288,15 +303,103 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
 #pragma unroll
     for (int k = 0; k < TOP_PF; k++) wrow[k] = (need && 4 * k < s.O) ? ld4(rowp + 4 * k) : zero4();
   }
-  // ---- softmax loss (charmodel-predict.c:18-27, badmaths.h:71-141): wave 0
-  if (seg == 0) text_softmax_wave(s, lane, shid, sout, sex, serr, v.b.o_error + (size_t)r * s.O, target, pad_oe, tstat);
-  __syncthreads();
-  if (threadIdx.x == 64) { /* (its loads return before the wave's backprop loads, which are issued behind them) */
-    v.b.stat_err[r] += tstat[0];
-    v.b.stat_ent[r] += tstat[1];
-    v.b.stat_correct[r] += (tstat[2] != 0.0f);
-    v.b.stat_count[r] += 1;
-    v.b.stat_zero[r] += (int)tstat[3] / (double)s.hidden_size;
+  // ---- the loss: wave 0
+  if constexpr (KIND == 0) { // softmax (charmodel-predict.c:18-27, badmaths.h:71-141)
+    if (seg == 0) text_softmax_wave(s, lane, shid, sout, sex, serr, v.b.o_error + (size_t)r * s.O, target, pad_oe, tstat);
+    __syncthreads();
+    if (threadIdx.x == 64) { /* (its loads return before the wave's backprop loads, which are issued behind them) */
+      v.b.stat_err[r] += tstat[0];
+      v.b.stat_ent[r] += tstat[1];
+      v.b.stat_correct[r] += (tstat[2] != 0.0f);
+      v.b.stat_count[r] += 1;
+      v.b.stat_zero[r] += (int)tstat[3] / (double)s.hidden_size;
+    }
+  } else if constexpr (KIND == 1) { // k_sigmoid_mse_error: sigmoid in place on the first n outputs, slope * (target - answer)
+    if (seg == 0 && lane < s.O) { /* (o_size <= 64: launcher) */
+      float oe = pad_oe; /* the rest of the error row stays what it was */
+      if (lane < tl.n) {
+        const float a = 1.0f / (1.0f + fast_expf_dev(-sout[lane] * 1.0f));
+        v.b.out[(size_t)r * s.O + lane] = a;
+        const float slope = a * (1.0f - a);
+        oe = slope * (mse_target - a);
+        v.b.o_error[(size_t)r * s.O + lane] = oe;
+      }
+      serr[lane] = oe;
+    }
+    if (threadIdx.x == 0) trained_sh = 1;
+    __syncthreads();
+  } else { // k_grouped_softmax_error, operation for operation, the outputs from LDS
+    if (seg == 0) {
+      float *err = v.b.o_error + (size_t)r * s.O;
+      if (lane < s.O) serr[lane] = pad_oe; /* (o_size <= 64: launcher) columns outside every group stay what they were */
+      int trained = 0, wins = 0;
+      float wrong = 0.0f;
+      for (int i = 0; i < tl.ngroups; i++) {
+        const int o = tl.goff[i], n = tl.gsize[i], tg = tl.gt[(size_t)blockIdx.x * tl.ngroups + i];
+        if (tg < 0 || tg >= n) {
+          for (int q = lane; q < n; q += 64) serr[o + q] = 0.0f;
+          continue;
+        }
+        const float *gs = sout + o;
+        float lo = gs[0], hi = gs[0];
+        for (int q = lane; q < n; q += 64) {
+          hi = fmaxf(hi, gs[q]);
+          lo = fminf(lo, gs[q]);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+          hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+          lo = fminf(lo, __shfl_xor(lo, off, 64));
+        }
+        float adj = 0.0f;
+        if (hi > 50.0f) adj = 50.0f - hi;
+        else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* (one wave: the last group's reads of sex are over) */
+        for (int q = lane; q < n; q += 64) sex[q] = fast_expf_dev(gs[q] + adj);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* one wave: its LDS writes are ordered */
+        float sum = 0.0f;
+        for (int q = 0; q < n; q++) sum += sex[q];
+        float best_e = -1.0f;
+        int best_i = 0x7fffffff;
+        for (int q = lane; q < n; q += 64) {
+          float e = sex[q] / sum;
+          serr[o + q] = (q == tg) ? -e + 1.0f : -e;
+          if (e > best_e) {
+            best_e = e;
+            best_i = q;
+          }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+          float oe = __shfl_xor(best_e, off, 64);
+          int oi = __shfl_xor(best_i, off, 64);
+          if (oe > best_e || (oe == best_e && oi < best_i)) {
+            best_e = oe;
+            best_i = oi;
+          }
+        }
+        wins += (best_i == tg);
+        wrong += -(sex[tg] / sum) + 1.0f;
+        trained++;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane < s.O) {
+        float oe = serr[lane];
+        if (trained && tl.weight && lane < s.output_size) oe *= tl.weight[lane];
+        serr[lane] = oe;
+        err[lane] = oe;
+      }
+      if (lane == 0) {
+        trained_sh = trained;
+        if (trained) {
+          v.b.stat_err[r] += wrong;
+          v.b.stat_correct[r] += wins;
+          v.b.stat_count[r] += trained;
+        }
+      }
+    }
+    __syncthreads();
+    /* a stream without a usable target is not trained: its rows of the error planes stay what they were, as under
+     * rnn_amd_set_calc_deltas' `active` flags (k_top_backprop) */
+    if (!trained_sh) return;
   }
   TT_STAMP(3);
   // ---- top-layer backprop + soft clip (recur-nn.c:199-228, 719-721)
@@ -662,7 +765,25 @@ extern "C" void ramd_launch_text_top(ramd_stream_t st_, const RamdShape *sh, con
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   size_t shm = (size_t)(sh->H + OUT_SEGS * 64 * 4 + (OUT_SEGS + 3) * sh->O) * sizeof(float);
-  RAMD_LAUNCH(k_text_top, dim3(nrows), dim3(1024), shm, st, v, row0, nrows, fwd_ks);
+  RAMD_LAUNCH(k_text_top<0>, dim3(nrows), dim3(1024), shm, st, v, row0, nrows, fwd_ks, TopLoss{});
+}
+
+/* the same launch with rnnca's loss (targets [nrows][ld] on the device, the first n outputs) or gstclassify's class groups
+ * (ngroups > 0: offsets, sizes, targets [nrows][ngroups], per-output weights or NULL) between the output layer and the
+ * backprop; returns 0 when the shape is not the kernel's kind (o_size > 64) and nothing was launched */
+extern "C" int ramd_launch_dense_top(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b, int row0, int nrows,
+                                     int fwd_ks, const float *targets, int ld, int n, int ngroups, const int *goff,
+                                     const int *gsize, const int *gt, const float *weight) {
+  if (!ramd_text_top_ok(sh) || sh->O > 64 || !env_int("RECUR_AMD_DENSE_TOP", 1)) return 0;
+  hipStream_t st = (hipStream_t)st_;
+  View v = make_view(sh, b);
+  size_t shm = (size_t)(sh->H + OUT_SEGS * 64 * 4 + (OUT_SEGS + 3) * sh->O) * sizeof(float);
+  TopLoss tl = {targets, ld, n, ngroups, goff, gsize, gt, weight};
+  if (ngroups > 0)
+    RAMD_LAUNCH(k_text_top<2>, dim3(nrows), dim3(1024), shm, st, v, row0, nrows, fwd_ks, tl);
+  else
+    RAMD_LAUNCH(k_text_top<1>, dim3(nrows), dim3(1024), shm, st, v, row0, nrows, fwd_ks, tl);
+  return 1;
 }
 
 extern "C" void ramd_launch_softmax_error(ramd_stream_t st_, const RamdShape *sh,

@@ -187,6 +187,11 @@ void ramd_launch_forward_finish(ramd_stream_t st, const RamdShape *sh, const Ram
                                 int fused, int part); /* part 1: the hidden layer's end, 2: the output layer, 0: both */
 void ramd_launch_text_top(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0,
                           int nrows, int fwd_ks);
+/* the same launch with rnnca's loss (targets [nrows][ld] on the device, first n outputs; ngroups == 0) or gstclassify's
+ * class groups between output layer and backprop; 0: not this kernel's shape, nothing launched */
+int ramd_launch_dense_top(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0, int nrows, int fwd_ks,
+                          const float *targets, int ld, int n, int ngroups, const int *goff, const int *gsize, const int *gt,
+                          const float *weight);
 /* o_error = onehot(target) - softmax(out) and statistics
  * (charmodel-predict.c:18-27, 299-304) */
 void ramd_launch_softmax_error(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b,

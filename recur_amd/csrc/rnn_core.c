@@ -546,6 +546,8 @@ static void stream_copy(RamdEngine *e, RecurNN *net, int to_device) {
 #undef COPY
 }
 
+static void top_done_clear(RamdEngine *e) { e->top_done = 0; }
+
 static void err_flush(RamdEngine *e) {
   if (e->err_pending) {
     ramd_launch_err_writeback(g_stream, &e->sh, &e->b, e->err_row0, e->err_nrows);
@@ -568,6 +570,7 @@ static void stream_need_dev(RamdEngine *e, RecurNN *net) {
   if (!p->dev_valid) {
     stream_copy(e, net, 1);
     dsync(); /* the host arrays may change as soon as we return */
+    top_done_clear(e);
   }
   p->dev_valid = 1;
 }
@@ -644,6 +647,7 @@ static void engine_need_dev(RamdEngine *e, int what) {
   if (!push) {
     return;
   }
+  top_done_clear(e);
   if (push & RNN_AMD_WEIGHTS) {
     h2d(e->b.ih_w, o->ih_weights, e->ih_size * sizeof(float));
     h2d(e->b.ho_w, o->ho_weights, e->ho_size * sizeof(float));
@@ -678,6 +682,9 @@ static void engine_need_dev(RamdEngine *e, int what) {
 static void engine_dev_wrote(RamdEngine *e, int what) {
   e->dev_valid |= what;
   e->host_valid &= ~what;
+  if (what & RNN_AMD_WEIGHTS) {
+    top_done_clear(e);
+  }
 }
 
 /* public: bring host copies up to date */
@@ -2011,6 +2018,7 @@ static void set_streams_to_dev(RnnAmdSet *set) {
   }
   if (any) {
     dsync();
+    top_done_clear(e);
   }
   if (!set->fwd_only) {
     push_indices(e, set->row0, set->n);
@@ -2043,6 +2051,7 @@ static void noise_speculate_from(RnnAmdSet *set, int loss_classes);
 static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, int text_i,
                        float *outputs, int advance, int hidden_only) {
   RamdEngine *e = set->eng;
+  top_done_clear(e);
   engine_need_dev(e, RNN_AMD_WEIGHTS);
   set_streams_to_dev(set);
   if (advance) {
@@ -2101,11 +2110,12 @@ static int set_forward(RnnAmdSet *set, int mode, const float *d_dense, int ld, i
     ramd_launch_assemble(g_stream, &e->sh, &e->b, r0, set->n, RAMD_IN_KEEP, NULL, 0, 0,
                          set->global_first, set->global_count, 0);
   } else {
-    if (hidden_only && advance && noise == 0.0f && !set->fwd_only) {
+    if (hidden_only && (advance || mode == RAMD_IN_DENSE) && noise == 0.0f && !set->fwd_only) {
       /* the text step: building the input rows and the hidden layer's GEMM in one launch
-       * (the ring index the kernel stores is the host's, which has just stepped) */
+       * (the ring index the kernel stores is the host's, which has just stepped); dense inputs on their way to
+       * ramd_launch_dense_top likewise */
       int fused = ramd_launch_forward_fused(g_stream, &e->sh, &e->b, r0, set->n, mode, text_i,
-                                            set->global_first, set->global_count, 1, NULL, 0);
+                                            set->global_first, set->global_count, 1, d_dense, ld);
       if (fused) {
         set_streams_dev_wrote(set);
         return fused;
@@ -2183,6 +2193,7 @@ void rnn_amd_set_one_hot_opinion(RnnAmdSet *set, const int *hot, float *outputs)
 
 void rnn_amd_set_put_o_error(RnnAmdSet *set, const float *o_error, int ld) {
   RamdEngine *e = set->eng;
+  top_done_clear(e);
   set_need_training(set, "rnn_amd_set_put_o_error");
   set_streams_to_dev(set);
   upload_rows(e->b.o_error + (size_t)set->row0 * e->sh.O, o_error, ld * sizeof(float), e->sh.O * sizeof(float),
@@ -2192,6 +2203,7 @@ void rnn_amd_set_put_o_error(RnnAmdSet *set, const float *o_error, int ld) {
 
 void rnn_amd_set_softmax_error(RnnAmdSet *set, const int *target) {
   RamdEngine *e = set->eng;
+  top_done_clear(e);
   set_need_training(set, "rnn_amd_set_softmax_error");
   set_streams_to_dev(set);
   if (target) {
@@ -2288,6 +2300,13 @@ static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ran
   } else if (e->err_pending && (d_ranges || e->err_row0 != set->row0 || e->err_nrows != set->n)) {
     err_flush(e);
   }
+  if (e->top_done && e->top_done_row0 == set->row0 && e->top_done_n == set->n && !d_ranges &&
+      (e->top_done_masked ? (active && e->active_host && e->active_host_n == set->n &&
+                             memcmp(e->active_host, active, (size_t)set->n) == 0)
+                          : !active)) {
+    extra_flags |= RAMD_TOP_DONE; /* with the loss (rnn_amd_set_opinion_sigmoid_mse / _grouped_softmax) */
+  }
+  top_done_clear(e);
   set_uniform_idx(e, set->row0, set->n);
   ramd_launch_calc_deltas(g_stream, &e->sh, &e->b, set->row0, set->n, accumulate, d_ranges,
                           dev_ranges ? range_stride : 0, d_active,
@@ -2327,6 +2346,7 @@ void rnn_amd_set_grouped_softmax_error(RnnAmdSet *set, int n_groups, const int *
                                        const float *error_weight, u8 *trained) {
   RamdEngine *e = set->eng;
   set_need_training(set, "rnn_amd_set_grouped_softmax_error");
+  top_done_clear(e);
   const RamdShape *s = &e->sh;
   int largest = 1;
   for (int i = 0; i < n_groups; i++) {
@@ -2613,6 +2633,7 @@ void rnn_amd_set_text_opinion(RnnAmdSet *set, int i, int advance) {
  * first n outputs in place, o_error = slope * (target - answer); targets: host [n_nets][ld] */
 void rnn_amd_set_sigmoid_mse_error(RnnAmdSet *set, const float *targets, int ld, int n) {
   RamdEngine *e = set->eng;
+  top_done_clear(e);
   set_need_training(set, "rnn_amd_set_sigmoid_mse_error");
   if (n < 1 || n > e->sh.output_size || ld < n) {
     fprintf(stderr, "librecur_amd: rnn_amd_set_sigmoid_mse_error over %d of %d outputs (ld %d)\n", n,
@@ -2631,6 +2652,103 @@ void rnn_amd_set_sigmoid_mse_error(RnnAmdSet *set, const float *targets, int ld,
   ramd_launch_sigmoid_mse_error(g_stream, &e->sh, &e->b, set->row0, set->n, n, (const float *)e->d_group,
                                 n);
   set_streams_dev_wrote(set);
+}
+
+/* dense inputs -> hidden layer's sums only (they stay in the workspace for ramd_launch_dense_top); 0 where that launch
+ * cannot follow */
+static int dense_top_ok(RnnAmdSet *set, const float *inputs) {
+  RamdEngine *e = set->eng;
+  return inputs && !set->fwd_only && !e->sh.bI && e->sh.O <= 64 && ramd_text_top_ok(&e->sh) &&
+         set->nets[0]->presynaptic_noise == 0.0f && set->nets[0]->bptt;
+}
+
+void rnn_amd_set_opinion_sigmoid_mse(RnnAmdSet *set, const float *inputs, int ld_inputs, const float *targets, int ld,
+                                     int n) {
+  RamdEngine *e = set->eng;
+  if (!dense_top_ok(set, inputs) || n < 1 || n > e->sh.output_size || ld < n) {
+    rnn_amd_set_opinion(set, inputs, ld_inputs, NULL);
+    rnn_amd_set_sigmoid_mse_error(set, targets, ld, n);
+    return;
+  }
+  set_need_training(set, "rnn_amd_set_opinion_sigmoid_mse");
+  size_t bytes = (size_t)set->n * n * sizeof(float);
+  if (bytes > e->d_group_bytes) {
+    dsync();
+    dev_free(e->d_group);
+    e->d_group = dev_alloc(bytes);
+    e->d_group_bytes = bytes;
+  }
+  /* inputs and targets leave together with the ring indices (set_forward's flush) */
+  upload_rows_q(e->d_dense, inputs, ld_inputs * sizeof(float), e->sh.input_size * sizeof(float), set->n, 0);
+  upload_rows_q(e->d_group, targets, ld * sizeof(float), n * sizeof(float), set->n, 0);
+  int fwd_ks = set_forward(set, RAMD_IN_DENSE, e->d_dense, e->sh.input_size, 0, NULL, 0, 1);
+  if (!ramd_launch_dense_top(g_stream, &e->sh, &e->b, set->row0, set->n, fwd_ks, (const float *)e->d_group, n, n, 0,
+                             NULL, NULL, NULL, NULL)) {
+    fprintf(stderr, "librecur_amd: rnn_amd_set_opinion_sigmoid_mse: the top launch declined a shape it had accepted\n");
+    abort();
+  }
+  set_streams_dev_wrote(set);
+  e->top_done = 1;
+  e->top_done_row0 = set->row0;
+  e->top_done_n = set->n;
+  e->top_done_masked = 0;
+}
+
+void rnn_amd_set_opinion_grouped_softmax(RnnAmdSet *set, const float *inputs, int ld_inputs, int n_groups,
+                                         const int *group_offset, const int *group_size, const int *targets,
+                                         const float *error_weight, u8 *trained) {
+  RamdEngine *e = set->eng;
+  const RamdShape *s = &e->sh;
+  if (!dense_top_ok(set, inputs) || !trained || set->n % 4 != 0) {
+    rnn_amd_set_opinion(set, inputs, ld_inputs, NULL);
+    rnn_amd_set_grouped_softmax_error(set, n_groups, group_offset, group_size, targets, error_weight, trained);
+    return;
+  }
+  set_need_training(set, "rnn_amd_set_opinion_grouped_softmax");
+  for (int i = 0; i < n_groups; i++) {
+    if (group_offset[i] < 0 || group_size[i] < 1 || group_offset[i] + group_size[i] > s->output_size) {
+      fprintf(stderr, "librecur_amd: class group %d (%d + %d) outside the %d outputs\n", i, group_offset[i],
+              group_size[i], s->output_size);
+      abort();
+    }
+  }
+  size_t ints = (size_t)2 * n_groups + (size_t)set->n * n_groups;
+  size_t bytes = ints * sizeof(int) + (error_weight ? (size_t)s->output_size * sizeof(float) : 0);
+  if (bytes > e->d_group_bytes) {
+    dsync();
+    dev_free(e->d_group);
+    e->d_group = dev_alloc(bytes);
+    e->d_group_bytes = bytes;
+  }
+  int *d = (int *)e->d_group;
+  upload_rows_q(e->d_dense, inputs, ld_inputs * sizeof(float), s->input_size * sizeof(float), set->n, 0);
+  upload_q(d, group_offset, n_groups * sizeof(int));
+  upload_q(d + n_groups, group_size, n_groups * sizeof(int));
+  upload_q(d + 2 * n_groups, targets, (size_t)set->n * n_groups * sizeof(int));
+  float *dw = NULL;
+  if (error_weight) {
+    dw = (float *)(d + ints);
+    upload_q(dw, error_weight, (size_t)s->output_size * sizeof(float));
+  }
+  for (int j = 0; j < set->n; j++) { /* a stream is trained if any of its groups has a usable target */
+    trained[j] = 0;
+    for (int i = 0; i < n_groups; i++) {
+      int t = targets[(size_t)j * n_groups + i];
+      trained[j] |= (t >= 0 && t < group_size[i]);
+    }
+  }
+  active_mask_to_dev(e, trained, set->n, 1); /* (for the delta call that follows: travels with the rest) */
+  int fwd_ks = set_forward(set, RAMD_IN_DENSE, e->d_dense, s->input_size, 0, NULL, 0, 1);
+  if (!ramd_launch_dense_top(g_stream, s, &e->b, set->row0, set->n, fwd_ks, NULL, 0, 0, n_groups, d, d + n_groups,
+                             d + 2 * n_groups, dw)) {
+    fprintf(stderr, "librecur_amd: rnn_amd_set_opinion_grouped_softmax: the top launch declined a shape it had accepted\n");
+    abort();
+  }
+  set_streams_dev_wrote(set);
+  e->top_done = 1;
+  e->top_done_row0 = set->row0;
+  e->top_done_n = set->n;
+  e->top_done_masked = 1;
 }
 
 /* fill_frame's fast_sigmoid_array(answer, answer, n) (gstrnnca.c:813-814) for every net of the

@@ -61,6 +61,10 @@ typedef struct RamdEngine {
    * first (deltas_materialize). */
   u8 *active_host; /* what b.active holds (the last active mask sent), or NULL */
   int active_host_n;
+  /* the top layer's backprop of these rows has been done with the loss (rnn_amd_set_opinion_sigmoid_mse /
+   * _grouped_softmax): the next rnn_amd_set_calc_deltas over them skips it -- unless anything touched the weights, the
+   * hidden rows or the output error in between (top_done_clear); masked: only for the active flags in active_host */
+  int top_done, top_done_row0, top_done_n, top_done_masked;
   RamdPendingDelta kept;
   int kept_live;
   float *d_kept_slab;

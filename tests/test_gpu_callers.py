@@ -285,7 +285,16 @@ def test_config4_rnnca_training_generation(amd, hidden, S, D):
     _rnnca_generation(amd, hidden, S, D)
 
 
-def _rnnca_generation(lib, hidden, S, D, n_in=35, activation=None):
+@pytest.mark.parametrize("hidden,S,D,n_in", [(2048, 512, 10, 35), (64, 20, 4, 35), (512, 64, 6, 12)])
+def test_rnnca_generation_with_opinion_and_loss_in_one_call(amd, hidden, S, D, n_in):
+    """rnn_amd_set_opinion_sigmoid_mse: the same generation with the forward pass's end, the output layer, the loss and the
+    top layer's backprop in one launch (k_text_top<1>), the delta call finding the backprop done -- from the generic
+    GEMM's K slabs (2048: the fused forward declines more than one round of tiles; 64: not a multiple of 32 columns)
+    and from the fused forward's plane (512 / 64)."""
+    _rnnca_generation(amd, hidden, S, D, n_in=n_in, combined=True)
+
+
+def _rnnca_generation(lib, hidden, S, D, n_in=35, activation=None, combined=False):
     kw = dict(input_size=n_in, hidden_size=hidden, output_size=3, S=S, D=D, learn_rate=1e-5 if hidden > 1000 else 1e-3,
               seed=81, momentum=0.95)
     if activation is not None:
@@ -298,8 +307,11 @@ def _rnnca_generation(lib, hidden, S, D, n_in=35, activation=None):
         if gpu is not None:
             lib.rnn_bptt_clear_deltas(gpu.net)
             lib.rnn_amd_set_advance(gpu.handle)
-            lib.rnn_amd_set_opinion(gpu.handle, rc.fptr(x), n_in, None)
-            lib.rnn_amd_set_sigmoid_mse_error(gpu.handle, rc.fptr(tgt), 3, 3)
+            if combined:
+                lib.rnn_amd_set_opinion_sigmoid_mse(gpu.handle, rc.fptr(x), n_in, rc.fptr(tgt), 3, 3)
+            else:
+                lib.rnn_amd_set_opinion(gpu.handle, rc.fptr(x), n_in, None)
+                lib.rnn_amd_set_sigmoid_mse_error(gpu.handle, rc.fptr(tgt), 3, 3)
             lib.rnn_amd_set_calc_deltas(gpu.handle, 1, None, None)
             lib.rnn_apply_learning(gpu.net, rc.WEIGHTED, m)
         if orc_set is not None:

@@ -1082,7 +1082,8 @@ def test_multi_head_generation_matches_oracle(amd, leakage, noise, shape):
     o.close()
 
 
-def test_class_group_loss_on_device_matches_oracle(amd):
+@pytest.mark.parametrize("combined", [False, True])
+def test_class_group_loss_on_device_matches_oracle(amd, combined):
     """gstclassify's train_channel (gstclassify.c:2070-2130) with two class groups, unknown
     targets for some groups and streams, per-output error weights, Nesterov: opinion, grouped
     softmax error on the device, calc_deltas over the streams that trained something, advance,
@@ -1103,9 +1104,14 @@ def test_class_group_loss_on_device_matches_oracle(amd):
         targets[1] = (-1, -1)                                   # nothing to train for this stream
         trained = np.zeros(S, np.uint8)
         lib.rnn_bptt_clear_deltas(g.net)
-        lib.rnn_amd_set_opinion(g.handle, rc.fptr(x), NIN, None)
-        lib.rnn_amd_set_grouped_softmax_error(g.handle, 2, rc.iptr(goff), rc.iptr(gsize), rc.iptr(targets),
-                                              rc.fptr(weight) if step % 2 else None, rc.u8ptr(trained))
+        if combined:  # (rnn_amd_set_opinion_grouped_softmax: one call, the loss and the top backprop in one launch)
+            lib.rnn_amd_set_opinion_grouped_softmax(g.handle, rc.fptr(x), NIN, 2, rc.iptr(goff), rc.iptr(gsize),
+                                                    rc.iptr(targets), rc.fptr(weight) if step % 2 else None,
+                                                    rc.u8ptr(trained))
+        else:
+            lib.rnn_amd_set_opinion(g.handle, rc.fptr(x), NIN, None)
+            lib.rnn_amd_set_grouped_softmax_error(g.handle, 2, rc.iptr(goff), rc.iptr(gsize), rc.iptr(targets),
+                                                  rc.fptr(weight) if step % 2 else None, rc.u8ptr(trained))
         lib.rnn_amd_set_calc_deltas(g.handle, 1, None, rc.u8ptr(trained))
         lib.rnn_amd_set_advance(g.handle)
         lib.rnn_apply_learning(g.net, rc.NESTEROV, 0.9)

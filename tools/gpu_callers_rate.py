@@ -41,8 +41,11 @@ if which in ("rnnca", "both"):
         m = amd.rnn_calculate_momentum_soft_start(float(i), 0.95, 2000.0)
         amd.rnn_bptt_clear_deltas(g.net)
         amd.rnn_amd_set_advance(g.handle)
-        amd.rnn_amd_set_opinion(g.handle, rc.fptr(xs[i % 4]), 35, None)
-        amd.rnn_amd_set_sigmoid_mse_error(g.handle, rc.fptr(ts[i % 4]), 3, 3)
+        if os.environ.get("RATE_SEPARATE"):
+            amd.rnn_amd_set_opinion(g.handle, rc.fptr(xs[i % 4]), 35, None)
+            amd.rnn_amd_set_sigmoid_mse_error(g.handle, rc.fptr(ts[i % 4]), 3, 3)
+        else:
+            amd.rnn_amd_set_opinion_sigmoid_mse(g.handle, rc.fptr(xs[i % 4]), 35, rc.fptr(ts[i % 4]), 3, 3)
         amd.rnn_amd_set_calc_deltas(g.handle, 1, None, None)
         amd.rnn_apply_learning(g.net, rc.WEIGHTED, m)
     for i in range(D + 5):
@@ -68,9 +71,13 @@ if which in ("classify", "both"):
     trained = np.zeros(S, np.uint8)
     def gen(i):
         amd.rnn_bptt_clear_deltas(g.net)
-        amd.rnn_amd_set_opinion(g.handle, rc.fptr(xs[i % 4]), NIN, None)
-        amd.rnn_amd_set_grouped_softmax_error(g.handle, 1, rc.iptr(goff), rc.iptr(gsize), rc.iptr(tg[i % 4]), None,
-                                              rc.u8ptr(trained))
+        if os.environ.get("RATE_SEPARATE"):
+            amd.rnn_amd_set_opinion(g.handle, rc.fptr(xs[i % 4]), NIN, None)
+            amd.rnn_amd_set_grouped_softmax_error(g.handle, 1, rc.iptr(goff), rc.iptr(gsize), rc.iptr(tg[i % 4]), None,
+                                                  rc.u8ptr(trained))
+        else:
+            amd.rnn_amd_set_opinion_grouped_softmax(g.handle, rc.fptr(xs[i % 4]), NIN, 1, rc.iptr(goff), rc.iptr(gsize),
+                                                    rc.iptr(tg[i % 4]), None, rc.u8ptr(trained))
         amd.rnn_amd_set_calc_deltas(g.handle, 1, None, rc.u8ptr(trained))
         amd.rnn_amd_set_advance(g.handle)
         amd.rnn_apply_learning(g.net, rc.NESTEROV, 0.9)
