@@ -374,6 +374,9 @@ static void engine_free_device(RamdEngine *e) {
   free(e->active_host); /* (b.active goes with the device arrays) */
   e->active_host = NULL;
   e->active_host_n = 0;
+  free(e->top_done_mask); /* (sized by Scap, which may grow) */
+  e->top_done_mask = NULL;
+  e->top_done = 0;
   dev_free(e->d_kept_slab);
   e->d_kept_slab = NULL;
   e->kept_floats = 0;
@@ -2301,8 +2304,7 @@ static void set_calc_deltas(RnnAmdSet *set, int accumulate, RecurErrorRange *ran
     err_flush(e);
   }
   if (e->top_done && e->top_done_row0 == set->row0 && e->top_done_n == set->n && !d_ranges &&
-      (e->top_done_masked ? (active && e->active_host && e->active_host_n == set->n &&
-                             memcmp(e->active_host, active, (size_t)set->n) == 0)
+      (e->top_done_masked ? (active && e->top_done_mask && memcmp(e->top_done_mask, active, (size_t)set->n) == 0)
                           : !active)) {
     extra_flags |= RAMD_TOP_DONE; /* with the loss (rnn_amd_set_opinion_sigmoid_mse / _grouped_softmax) */
   }
@@ -2749,6 +2751,10 @@ void rnn_amd_set_opinion_grouped_softmax(RnnAmdSet *set, const float *inputs, in
   e->top_done_row0 = set->row0;
   e->top_done_n = set->n;
   e->top_done_masked = 1;
+  if (!e->top_done_mask) {
+    e->top_done_mask = ramd_zalloc((size_t)e->sh.Scap + 4);
+  }
+  memcpy(e->top_done_mask, trained, (size_t)set->n); /* (a copy of its own: active_host follows whatever mask is sent next) */
 }
 
 /* fill_frame's fast_sigmoid_array(answer, answer, n) (gstrnnca.c:813-814) for every net of the

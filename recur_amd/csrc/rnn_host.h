@@ -65,6 +65,7 @@ typedef struct RamdEngine {
    * _grouped_softmax): the next rnn_amd_set_calc_deltas over them skips it -- unless anything touched the weights, the
    * hidden rows or the output error in between (top_done_clear); masked: only for the active flags in active_host */
   int top_done, top_done_row0, top_done_n, top_done_masked;
+  u8 *top_done_mask; /* masked: the streams whose backprop was done (the loss's `trained` flags) */
   RamdPendingDelta kept;
   int kept_live;
   float *d_kept_slab;

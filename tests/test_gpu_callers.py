@@ -294,6 +294,59 @@ def test_rnnca_generation_with_opinion_and_loss_in_one_call(amd, hidden, S, D, n
     _rnnca_generation(amd, hidden, S, D, n_in=n_in, combined=True)
 
 
+@pytest.mark.parametrize("between", ["nothing", "put_o_error", "host_weights", "mask_differs", "second_opinion"])
+def test_what_happens_between_the_one_call_loss_and_the_delta_call(amd, between):
+    """rnn_amd_set_opinion_sigmoid_mse / _grouped_softmax leave the top layer's backprop done for the delta call that
+    follows (RamdEngine.top_done) -- unless something touched what it was made from: another output error
+    (rnn_amd_set_put_o_error), weights edited on the host, other active flags than the loss returned, another forward
+    pass.  Two sets with the same seed, one through the one-call form, one through the separate calls, the same
+    intruder on both: a backprop that wrongly survived would show in the deltas at once (they differ by rounding
+    otherwise: the one-call launch sums the output layer in another order)."""
+    lib = amd
+    S, D, NIN = 16, 4, 12
+    goff, gsize = np.array([0, 3], np.int32), np.array([3, 4], np.int32)
+    kw = dict(input_size=NIN, hidden_size=64, output_size=7, S=S, D=D, learn_rate=3e-3, seed=52)
+    ga, gb = sc.AmdBatchedSet(lib, **kw), sc.AmdBatchedSet(lib, **kw)
+    rs = np.random.default_rng(29)
+    for step in range(6):
+        x = (rs.standard_normal((S, NIN)) * 0.6).astype(np.float32)
+        x2 = (rs.standard_normal((S, NIN)) * 0.6).astype(np.float32)
+        targets = np.stack([rs.integers(-1, 3, S), rs.integers(-1, 4, S)], axis=1).astype(np.int32)
+        targets[0] = (1, 2)
+        err = (rs.standard_normal((S, ga.O)) * 0.1).astype(np.float32)
+        err[:, 7:] = 0
+        for g, one_call in ((ga, True), (gb, False)):
+            trained = np.zeros(S, np.uint8)
+            lib.rnn_bptt_clear_deltas(g.net)
+            if one_call:
+                lib.rnn_amd_set_opinion_grouped_softmax(g.handle, rc.fptr(x), NIN, 2, rc.iptr(goff), rc.iptr(gsize),
+                                                        rc.iptr(targets), None, rc.u8ptr(trained))
+            else:
+                lib.rnn_amd_set_opinion(g.handle, rc.fptr(x), NIN, None)
+                lib.rnn_amd_set_grouped_softmax_error(g.handle, 2, rc.iptr(goff), rc.iptr(gsize), rc.iptr(targets), None,
+                                                      rc.u8ptr(trained))
+            active = trained.copy()
+            if between == "put_o_error":
+                lib.rnn_amd_set_put_o_error(g.handle, rc.fptr(err), g.O)
+            elif between == "host_weights":
+                lib.rnn_amd_sync_host(g.net, rc.RNN_AMD_WEIGHTS)
+                how = np.ctypeslib.as_array(g.net.contents.ho_weights, shape=(g.net.contents.ho_size,))
+                how[8:24] *= np.float32(1.5)
+                lib.rnn_amd_host_written(g.net, rc.RNN_AMD_WEIGHTS)
+            elif between == "mask_differs":
+                active[:] = 1  # every stream, also those the loss left without a target (their error row is zeros)
+            elif between == "second_opinion":
+                lib.rnn_amd_set_opinion(g.handle, rc.fptr(x2), NIN, None)
+            lib.rnn_amd_set_calc_deltas(g.handle, 1, None, rc.u8ptr(active))
+            lib.rnn_amd_set_advance(g.handle)
+            lib.rnn_apply_learning(g.net, rc.NESTEROV, 0.9)
+        sa, sb = ga.snapshot(), gb.snapshot()
+        replay.check(sa, sb, 2e-5, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "output", "hist",
+                                         "o_error"], exact=("index", "generation"), elementwise=False)
+    ga.close()
+    gb.close()
+
+
 def _rnnca_generation(lib, hidden, S, D, n_in=35, activation=None, combined=False):
     kw = dict(input_size=n_in, hidden_size=hidden, output_size=3, S=S, D=D, learn_rate=1e-5 if hidden > 1000 else 1e-3,
               seed=81, momentum=0.95)
