@@ -608,7 +608,10 @@ def test_two_hundred_generations_at_full_size_track_the_oracle(amd):
     # --streams-global 32`; 64 = the share over 4 GPUs is configs[1]'s shape above): two 16-stream row tiles, three
     # quarters of the chain launch's workgroups idle, the extras + control in the tails of the others
     ("small_set_1024_32_20", dict(input_size=42, hidden_size=1024, output_size=42, S=32, D=20)),
+    # (hidden 512: the direct weight-delta kernel with K split four ways over workgroups -- 8 x 8 tiles, 44 rest rows as
+    # two pieces per workgroup -- and, 12 x 8 tiles, two ways)
     ("configs2_classify_like_512_128_30", dict(input_size=42, hidden_size=512, output_size=42, S=128, D=30)),
+    ("delta_split_two_ways_512_64_10", dict(input_size=280, hidden_size=512, output_size=42, S=64, D=10)),
     ("configs4_rnnca_like_2048_512_10", dict(input_size=42, hidden_size=2048, output_size=42, S=512, D=10)),
     # hidden 2048 with fewer streams: the 64 x 64-tile chain step would leave half the chip idle (128 tiles), so
     # the step runs as 32 x 64 tiles with the K of a stage split over the wave pairs (k_chain_wide<NS, 32>);
