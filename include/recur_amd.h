@@ -450,6 +450,15 @@ void rnn_amd_set_opinion_sigmoid_mse(RnnAmdSet *set, const float *inputs, int ld
 void rnn_amd_set_opinion_grouped_softmax(RnnAmdSet *set, const float *inputs, int ld_inputs, int n_groups,
                                          const int *group_offset, const int *group_size, const int *targets,
                                          const float *error_weight, u8 *trained);
+/* rnnca's maybe_learn for every trainer at once (gstrnnca.c:693-740) as ONE call, the dense-input counterpart of
+ * rnn_amd_set_char_step: rnn_bptt_clear_deltas, the opinion of `inputs`, the sigmoid-slope loss against `targets` (first n
+ * outputs), rnn_bptt_calc_deltas for every stream, rnn_apply_learning(net, learning_style, momentum).  The same results
+ * as rnn_bptt_clear_deltas + rnn_amd_set_opinion_sigmoid_mse + rnn_amd_set_calc_deltas(set, 1, NULL, NULL) +
+ * rnn_apply_learning; knowing the update that follows, the weight-delta GEMM carries it out in its own epilogue where the
+ * rule is the momentum rule (no optimiser launch: 14 us of 879 at 2048 / 512 / 10).  The caller advances the ring first
+ * (rnn_amd_set_advance) if its trainer has a history, as the synthetic configs[4] driver does. */
+void rnn_amd_set_dense_step_sigmoid_mse(RnnAmdSet *set, const float *inputs, int ld_inputs, const float *targets, int ld,
+                                        int n, int learning_style, float momentum);
 /* fill_frame's step after the opinion (gstrnnca.c:813-814): fast_sigmoid in place on the first
  * n outputs of every net of the set (training or forward-only clones); outputs (host, n_nets x
  * o_size, may be NULL) receives the answer rows, which synchronises. */

@@ -241,6 +241,8 @@ AMD_API = {
     "rnn_amd_set_sigmoid_mse_error": (None, [C.c_void_p, c_float_p, C.c_int, C.c_int]),
     "rnn_amd_set_sigmoid_outputs": (None, [C.c_void_p, C.c_int, c_float_p]),
     "rnn_amd_set_opinion_sigmoid_mse": (None, [C.c_void_p, c_float_p, C.c_int, c_float_p, C.c_int, C.c_int]),
+    "rnn_amd_set_dense_step_sigmoid_mse": (None, [C.c_void_p, c_float_p, C.c_int, c_float_p, C.c_int, C.c_int, C.c_int,
+                                                  C.c_float]),
     "rnn_amd_set_opinion_grouped_softmax": (None, [C.c_void_p, c_float_p, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p,
                                                    c_float_p, c_u8_p]),
     "rnn_amd_run_text_heads": (None, [NetP, c_u8_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),

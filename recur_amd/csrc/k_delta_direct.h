@@ -68,6 +68,8 @@ struct DdArgs {
   int ksplit;
   size_t kplane;
   int rgroups; /* row groups of the rest rows' pieces (dd_body) */
+  int ho_ks;   /* the top layer's sums as ho_ks planes, ho_plane floats apart (a split-K GEMM left them): added here */
+  size_t ho_plane;
 };
 
 /* COLD: outside the loop, with five wait states in front.  An SGPR base that a vector-ALU instruction has just written
@@ -440,7 +442,11 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
     const unsigned idx = blockIdx.x * per + k;
     if (k < per && idx < a.ho_n4) {
       const size_t off = 4 * (size_t)idx;
-      const dd_f4 d = *reinterpret_cast<const dd_f4 *>(a.ho_delta + off);
+      dd_f4 d = *reinterpret_cast<const dd_f4 *>(a.ho_delta + off);
+      for (int z = 1; z < a.ho_ks; z++) {
+        const dd_f4 t = *reinterpret_cast<const dd_f4 *>(a.ho_delta + (size_t)z * a.ho_plane + off);
+        d[0] += t[0]; d[1] += t[1]; d[2] += t[2]; d[3] += t[3];
+      }
       if (a.ho_delta_out) *reinterpret_cast<dd_f4 *>(a.ho_delta_out + off) = d;
       dd_f4 W = *reinterpret_cast<const dd_f4 *>(a.ho_w + off), M = *reinterpret_cast<const dd_f4 *>(a.ho_m + off);
       update4(W, M, d, a.ho_rate);

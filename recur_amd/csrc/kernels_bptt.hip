@@ -2076,8 +2076,12 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
         }
         /* the top layer's sum as ONE array by now?  (the chain launch formed it, or a finalize has run) */
         const float *ho_src = nullptr;
-        if (defer && defer->ho_slab && defer->ho_ks == 1) ho_src = defer->ho_slab;
-        else if (!defer || !defer->ho_slab) ho_src = b->ho_delta;
+        int ho_src_ks = 1;
+        if (defer && defer->ho_slab) { /* (planes of a split-K GEMM: the epilogue adds them) */
+          ho_src = defer->ho_slab;
+          ho_src_ks = defer->ho_ks;
+        } else
+          ho_src = b->ho_delta;
         const bool fuse = direct_fuse && (ho_src || ho_in_delta);
         DdArgs a = {};
         a.x = b->arena + (size_t)row0 * sh->I;
@@ -2116,6 +2120,8 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
             a.ho_m = b->ho_m;
             a.ho_delta = ho_src;
             a.ho_delta_out = ho_src == b->ho_delta ? nullptr : b->ho_delta;
+            a.ho_ks = ho_src_ks;
+            a.ho_plane = defer->ho_n;
             a.ho_n4 = (unsigned)((size_t)sh->H * sh->O / 4);
             a.ho_rate = defer->fuse_ho_rate;
           }

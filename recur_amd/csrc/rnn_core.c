@@ -3021,10 +3021,29 @@ static int one_rank_exchange_forced(void) {
   return on;
 }
 
-void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float momentum) {
+/* what a one-call generation does before its update: the text step (symbol i of the resident text), or a dense-input
+ * generation with rnnca's loss (rnn_amd_set_dense_step_sigmoid_mse) */
+typedef struct {
+  int i;                /* text position, or -1: dense */
+  const float *inputs;  /* dense: host [n][ld_inputs] */
+  int ld_inputs;
+  const float *targets; /* host [n][ld], the first n_targets outputs */
+  int ld, n_targets;
+} StepSpec;
+
+static void step_deltas(RnnAmdSet *set, const StepSpec *sp, RamdPendingDelta *defer) {
+  if (sp->i >= 0) {
+    char_step_deltas(set, sp->i, defer);
+  } else {
+    rnn_amd_set_opinion_sigmoid_mse(set, sp->inputs, sp->ld_inputs, sp->targets, sp->ld, sp->n_targets);
+    set_calc_deltas(set, 0, NULL, NULL, 0, NULL, 0, defer);
+  }
+}
+
+static void set_step(RnnAmdSet *set, const StepSpec *sp, int learning_style, float momentum) {
   if (set->eng->xchg_world > 1 || (set->eng->xchg_world == 1 && one_rank_exchange_forced())) {
     /* deltas -> (barrier) -> sharded update with the sum over the ranks in it -> (barrier) */
-    char_step_deltas(set, i, NULL);
+    step_deltas(set, sp, NULL);
     rnn_amd_set_apply_exchange(set, learning_style, momentum);
     return;
   }
@@ -3052,7 +3071,7 @@ void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float mome
                    : learning_style == RNN_MOMENTUM_CLASSICAL         ? 1.0f
                                                                        : bptt->momentum_weight;
   }
-  char_step_deltas(set, i, fuse ? &pend : NULL);
+  step_deltas(set, sp, fuse ? &pend : NULL);
   if (pend.fuse_done) { /* weights and momentum are updated, the delta arrays hold the sums */
     engine_dev_wrote(set->eng, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
     return;
@@ -3069,6 +3088,23 @@ void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float mome
     }
   }
   apply_learning(set->nets[0], learning_style, momentum, (pend.slab || pend.ho_slab) ? &pend : NULL);
+}
+
+void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float momentum) {
+  StepSpec sp = {i, NULL, 0, NULL, 0, 0};
+  set_step(set, &sp, learning_style, momentum);
+}
+
+/* rnnca's maybe_learn for every trainer (gstrnnca.c:693-740) as one call: see recur_amd.h */
+void rnn_amd_set_dense_step_sigmoid_mse(RnnAmdSet *set, const float *inputs, int ld_inputs, const float *targets, int ld,
+                                        int n, int learning_style, float momentum) {
+  if (!inputs) {
+    fprintf(stderr, "librecur_amd: rnn_amd_set_dense_step_sigmoid_mse needs the inputs\n");
+    abort();
+  }
+  rnn_bptt_clear_deltas(set->nets[0]); /* (lazy: the delta call below simply does not accumulate) */
+  StepSpec sp = {-1, inputs, ld_inputs, targets, ld, n};
+  set_step(set, &sp, learning_style, momentum);
 }
 
 /* The single-net text step of rnn_char_epoch (charmodel-predict.c:312-321) without a host round trip per

@@ -294,6 +294,14 @@ def test_rnnca_generation_with_opinion_and_loss_in_one_call(amd, hidden, S, D, n
     _rnnca_generation(amd, hidden, S, D, n_in=n_in, combined=True)
 
 
+@pytest.mark.parametrize("hidden,S,D,n_in", [(2048, 512, 10, 35), (64, 20, 4, 35), (1024, 64, 5, 12)])
+def test_rnnca_generation_as_one_call(amd, hidden, S, D, n_in):
+    """rnn_amd_set_dense_step_sigmoid_mse: clear, opinion, loss, deltas and the update in one call -- the weight-delta
+    GEMM then carries out the momentum rule's update in its epilogue where it is the direct kernel (2048 / 512, 1024 /
+    64), and rnn_apply_learning's launch follows where it is not (64 / 20)."""
+    _rnnca_generation(amd, hidden, S, D, n_in=n_in, combined="step")
+
+
 @pytest.mark.parametrize("between", ["nothing", "put_o_error", "host_weights", "mask_differs", "second_opinion"])
 def test_what_happens_between_the_one_call_loss_and_the_delta_call(amd, between):
     """rnn_amd_set_opinion_sigmoid_mse / _grouped_softmax leave the top layer's backprop done for the delta call that
@@ -360,13 +368,16 @@ def _rnnca_generation(lib, hidden, S, D, n_in=35, activation=None, combined=Fals
         if gpu is not None:
             lib.rnn_bptt_clear_deltas(gpu.net)
             lib.rnn_amd_set_advance(gpu.handle)
-            if combined:
-                lib.rnn_amd_set_opinion_sigmoid_mse(gpu.handle, rc.fptr(x), n_in, rc.fptr(tgt), 3, 3)
+            if combined == "step":  # the whole generation as one call (the update in the delta GEMM's epilogue)
+                lib.rnn_amd_set_dense_step_sigmoid_mse(gpu.handle, rc.fptr(x), n_in, rc.fptr(tgt), 3, 3, rc.WEIGHTED, m)
             else:
-                lib.rnn_amd_set_opinion(gpu.handle, rc.fptr(x), n_in, None)
-                lib.rnn_amd_set_sigmoid_mse_error(gpu.handle, rc.fptr(tgt), 3, 3)
-            lib.rnn_amd_set_calc_deltas(gpu.handle, 1, None, None)
-            lib.rnn_apply_learning(gpu.net, rc.WEIGHTED, m)
+                if combined:
+                    lib.rnn_amd_set_opinion_sigmoid_mse(gpu.handle, rc.fptr(x), n_in, rc.fptr(tgt), 3, 3)
+                else:
+                    lib.rnn_amd_set_opinion(gpu.handle, rc.fptr(x), n_in, None)
+                    lib.rnn_amd_set_sigmoid_mse_error(gpu.handle, rc.fptr(tgt), 3, 3)
+                lib.rnn_amd_set_calc_deltas(gpu.handle, 1, None, None)
+                lib.rnn_apply_learning(gpu.net, rc.WEIGHTED, m)
         if orc_set is not None:
             oo = orc_set
             oo.orc.orc_clear_deltas(oo.z)

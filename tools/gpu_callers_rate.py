@@ -44,8 +44,11 @@ if which in ("rnnca", "both"):
         if os.environ.get("RATE_SEPARATE"):
             amd.rnn_amd_set_opinion(g.handle, rc.fptr(xs[i % 4]), 35, None)
             amd.rnn_amd_set_sigmoid_mse_error(g.handle, rc.fptr(ts[i % 4]), 3, 3)
-        else:
+        elif os.environ.get("RATE_TWO_CALLS"):
             amd.rnn_amd_set_opinion_sigmoid_mse(g.handle, rc.fptr(xs[i % 4]), 35, rc.fptr(ts[i % 4]), 3, 3)
+        else:  # the generation as one call: the update rides in the delta GEMM's epilogue
+            amd.rnn_amd_set_dense_step_sigmoid_mse(g.handle, rc.fptr(xs[i % 4]), 35, rc.fptr(ts[i % 4]), 3, 3, rc.WEIGHTED, m)
+            return
         amd.rnn_amd_set_calc_deltas(g.handle, 1, None, None)
         amd.rnn_apply_learning(g.net, rc.WEIGHTED, m)
     for i in range(D + 5):
