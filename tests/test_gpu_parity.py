@@ -602,6 +602,38 @@ def test_two_hundred_generations_at_full_size_track_the_oracle(amd):
     o.close()
 
 
+@pytest.mark.skipif(not rc.have_ref(), reason="oracle/_ref/librecur_ref.so was not built (needs /root/reference)")
+def test_a_hundred_generations_at_full_size_track_the_compiled_reference(amd):
+    """The same long run against the REFERENCE ITSELF (oracle/_ref: recur-nn.c + recur-nn-init.c compiled with the
+    reference's own -Ofast flags, driven through its per-net calls: rnn_bptt_advance, one-hot opinion, softmax error,
+    rnn_bptt_calc_deltas per stream, one rnn_apply_learning per generation -- charmodel-predict.c:288-327), not the
+    oracle's restatement of it: 100 generations at hidden 1024 / 256 streams / depth 20 on
+    erewhon.txt from the same cold start; the training entropy of every window of 25 generations within 1 %."""
+    kw = dict(input_size=42, hidden_size=1024, output_size=42, S=256, D=20, learn_rate=1e-6, seed=3)
+    text = rc.encode_erewhon(amd)
+    ref = rc.load_ref(fast=True)
+    g = sc.AmdBatchedSet(amd, **kw)
+    r = sc.ApiSet(ref, softmax_best_guess=ref.ref_softmax_best_guess, **kw)
+    g.load_text(text)
+    win, n_gen = 25, 100
+    ent_g, ent_r = [], []
+    for w in range(n_gen // win):
+        lg = 0.0
+        for i in range(w * win, (w + 1) * win):
+            g.char_step(text, i, rc.WEIGHTED, 0.9)
+            for e, _ in r.char_step(text, i, rc.WEIGHTED, 0.9):
+                l = 1.0 - e  # the probability given to the symbol that came (charmodel-helpers.h:11-13: capped log2)
+                lg += -100.0 if l < 1e-30 else float(np.log2(np.float32(l)))
+        st = g.stats(clear=True)
+        ent_g.append(-st.entropy / st.count)
+        ent_r.append(-lg / (win * kw["S"]))
+    print("training entropy per window  device:", np.round(ent_g, 4), " reference:", np.round(ent_r, 4))
+    assert np.allclose(ent_g, ent_r, rtol=1e-2), (ent_g, ent_r)
+    assert ent_g[-1] < ent_g[0] - 0.1, ent_g  # it learns
+    g.close()
+    r.close()
+
+
 @pytest.mark.parametrize("label,kw", [
     ("configs1_text_1024_64_20", dict(input_size=42, hidden_size=1024, output_size=42, S=64, D=20)),
     # a GPU's share of 256 streams over 8 GPUs (BASELINE.json configs[3]'s sharding; `bench.py --scaling strong
