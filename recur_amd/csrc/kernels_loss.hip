@@ -3,6 +3,12 @@
 
 // -------------------------------------------------------- loss on device --
 
+#ifdef PC_STAMPS /* development builds only (tools/mkabl.sh -DPC_STAMPS, tools/gpu_top_stamps.py) */
+__device__ unsigned long long g_tt_stamps[16];
+#define TT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tt_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TT_STAMP(i) do { } while (0)
+#endif
 #include "k_top.h"
 #pragma clang fp contract(off)
 
@@ -79,15 +85,11 @@ __global__ __launch_bounds__(64) void k_softmax_error(View v, int row0, int nrow
 // (k_softmax_error) and the top-layer backprop with its soft clip (k_top_backprop, dense
 // form), each exactly as in the separate kernels -- same operation order per value -- with
 // the hidden row, the outputs and the output error passed through LDS instead of HBM.
-#ifdef PC_STAMPS /* development builds only (tools/mkabl.sh -DPC_STAMPS, tools/gpu_top_stamps.py) */
-__device__ unsigned long long g_tt_stamps[8];
+#ifdef PC_STAMPS
 extern "C" void ramd_top_stamps(unsigned long long *out) {
   HIP_CHECK(hipDeviceSynchronize());
-  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tt_stamps), sizeof(unsigned long long) * 8));
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tt_stamps), sizeof(unsigned long long) * 16));
 }
-#define TT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tt_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define TT_STAMP(i) do { } while (0)
 #endif
 /* KIND: which loss sits between the output layer and the backprop -- 0: the text model's softmax against the stream's
  * next symbol; 1: rnnca's sigmoid + squared error (k_sigmoid_mse_error's arithmetic, gstrnnca.c:701-714); 2: gstclassify's
@@ -296,16 +298,23 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
   constexpr int TOP_PF = 12; /* float4 per row: o_size <= 48 */
   float4 wrow[TOP_PF];
   const bool top_pf = s.O <= 4 * TOP_PF;
-  if (top_pf) {
-    const int y = threadIdx.x;
-    const bool need = y != 0 && y < s.H && shid[y] != 0.0f;
-    const float *rowp = v.b.ho_w + (size_t)(need ? y : 0) * s.O;
+  auto prefetch_rows = [&]() {
+    if (top_pf) {
+      const int y = threadIdx.x;
+      const bool need = y != 0 && y < s.H && shid[y] != 0.0f;
+      const float *rowp = v.b.ho_w + (size_t)(need ? y : 0) * s.O;
 #pragma unroll
-    for (int k = 0; k < TOP_PF; k++) wrow[k] = (need && 4 * k < s.O) ? ld4(rowp + 4 * k) : zero4();
-  }
+      for (int k = 0; k < TOP_PF; k++) wrow[k] = (need && 4 * k < s.O) ? ld4(rowp + 4 * k) : zero4();
+    }
+  };
+  /* (tried, round 5: wave 0 asking for its rows from INSIDE the softmax, behind the exponentials, instead of 0.8 us in
+   * front of it -- the softmax then starts earlier and runs slower beside the other waves' loads: 9.20 against 9.16 us
+   * to its barrier) */
+  prefetch_rows();
   // ---- the loss: wave 0
   if constexpr (KIND == 0) { // softmax (charmodel-predict.c:18-27, badmaths.h:71-141)
     if (seg == 0) text_softmax_wave(s, lane, shid, sout, sex, serr, v.b.o_error + (size_t)r * s.O, target, pad_oe, tstat);
+    else if (seg == 1) text_count_zeros_wave(s, lane, shid, tstat);
     __syncthreads();
     if (threadIdx.x == 64) { /* (its loads return before the wave's backprop loads, which are issued behind them) */
       v.b.stat_err[r] += tstat[0];

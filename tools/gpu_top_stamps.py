@@ -12,9 +12,12 @@ g = sc.AmdBatchedSet(amd, input_size=42, hidden_size=1024, output_size=42, S=S, 
 g.load_text(text)
 for i in range(60):
     amd.rnn_amd_set_char_step(g.handle, i, rc.WEIGHTED, 0.95)
-buf = np.zeros(8, np.uint64)
+buf = np.zeros(16, np.uint64)
 amd.ramd_top_stamps(C.c_void_p(buf.ctypes.data))
 names = ["start", "hidden row in LDS", "output layer done", "softmax done", "backprop sums done", "end"]
 t0 = int(buf[0])
 for i, n in enumerate(names):
     print("%-22s %6.2f us" % (n, (int(buf[i]) - t0) / 100.0))
+for i, n in zip(range(8, 13), ["softmax wave: zeros counted", "max / min reduced", "exponentials in LDS", "sum formed",
+                               "error row and best guess"]):
+    print("  %-28s %6.2f us" % (n, (int(buf[i]) - t0) / 100.0))
