@@ -70,6 +70,9 @@ struct DdArgs {
   int rgroups; /* row groups of the rest rows' pieces (dd_body) */
   int ho_ks;   /* the top layer's sums as ho_ks planes, ho_plane floats apart (a split-K GEMM left them): added here */
   size_t ho_plane;
+  /* iterations of the FIRST wave of each SIMD's pair (waves w and w + 4 share SIMD w: dd_body), of the 2 n_it the pair
+   * has per K part; 0: half */
+  int fast_its;
 };
 
 /* COLD: outside the loop, with five wait states in front.  An SGPR base that a vector-ALU instruction has just written
@@ -137,6 +140,13 @@ constexpr int DD_LD = 64; /* floats per row of a wave's tile in LDS */
  * matrix pipe; with 4 hipcc keeps the accumulators in AGPRs and shuffles ring registers through them between an
  * asynchronous load and its wait); P: K quads in flight per wave (the ring); NPW: pieces of the rest rows per
  * workgroup (1: up to 64 rest rows, 2: up to 128). */
+#ifdef PC_STAMPS /* development builds only (tools/mkabl.sh -DPC_STAMPS, tools/gpu_delta_direct_stamps.py) */
+__device__ unsigned long long g_ddir_stamps[4][8];
+__device__ unsigned long long g_ddir_wave[4][8]; /* loop done, per wave */
+#define DDIR_STAMP(i) do { if ((blockIdx.x & 63) == 0 && threadIdx.x == 0) g_ddir_stamps[blockIdx.x >> 6][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DDIR_STAMP(i) do { } while (0)
+#endif
 struct DdNoPre {
   __device__ __forceinline__ void operator()() const {}
 };
@@ -147,6 +157,7 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   /* workgroup -> tile.  Workgroups are dealt to the XCDs in turn (speed only): XCD x takes a block of the tile
    * grid, so that its L2 sees tm / 4 x tn / 2 of the operands' columns */
+  DDIR_STAMP(0);
   const int ksp = a.ksplit > 1 ? a.ksplit : 1, per_part = gridDim.x / ksp;
   const int kz = (int)blockIdx.x / per_part;
   const int L = (int)blockIdx.x - kz * per_part, xcd = L & 7, q = L >> 3;
@@ -164,8 +175,19 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
   const int m0 = 64 * mt, n0 = 64 * nt; /* (a.e, a.w ... already point at column 1) */
   const int I = a.I;
   const int QPS = a.nrows >> 2;          /* K quads per step */
-  const int n_it = a.D * (QPS / NW) / ksp; /* this wave's iterations: every NW-th quad of K (of this workgroup's part of K) */
-  const int it0 = kz * n_it, g_t0 = it0 / (QPS / NW), g_w0 = NW * (it0 - g_t0 * (QPS / NW));
+  /* K over the waves: waves w and w + 4 share SIMD w (w < 4) and take every fourth quad of K from quad w on -- the pair's
+   * sequence --, the first wave items [0, nf) of it, the second [nf, 2 n_it).  NOT half each where the loop is long: the
+   * SIMD issues from its older wave first, so with equal shares wave w ran at 3.0 iterations per us and wave w + 4 at 1.6
+   * beside it, the first was done at 59 us, and the second finished ALONE, at 70 % of the pipe's rate (its five quads in
+   * flight do not cover the memory latency by themselves), at 83 us -- stamps of round 5, profiles/NOTES_r05.md section
+   * 10.  With nf = 5/8 of the pair's items both are done together. */
+  constexpr int ST = NW / 2;
+  const int n_pair = 2 * (a.D * (QPS / NW) / ksp);           /* the pair's items in this workgroup's part of K */
+  const int nf = a.fast_its > 0 ? a.fast_its : n_pair / 2;
+  const bool first_of_pair = wv < ST;
+  const int n_it = first_of_pair ? nf : n_pair - nf;         /* this wave's iterations */
+  const int q0 = (wv & (ST - 1)) + ST * (kz * n_pair + (first_of_pair ? 0 : nf));
+  const int g_t0 = q0 / QPS, g_w0 = q0 - g_t0 * QPS;
   const unsigned voff = (unsigned)(((size_t)(lane >> 4) * I + (lane & 15) * 4) * sizeof(float));
   /* the rest rows, for the first 16 row tiles of a column tile: NPW pieces each, piece pi = NPW mt + p = (row group
    * pi / 4, column group pi % 4) of 4 NPW row groups x 4 column groups.  A row group is rg = ceil(rest / 4 NPW)
@@ -217,12 +239,12 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
 
   dd_f4 ra[P], re[P];
   float rr[2][P], rcf[P]; /* (rr[1]: the second piece's loads, NPW == 2) */
-  /* The operands of this wave's iterations, in order: quad (step t, streams 4 within .. + 3), from quad wv on in
-   * steps of NW.  The generator is scalar and branch-free (counters, selects and multiplies on the scalar ALU: it is
+  /* The operands of this wave's iterations, in order: quad (step t, streams 4 within .. + 3), from quad q0 on in
+   * steps of NW / 2.  The generator is scalar and branch-free (counters, selects and multiplies on the scalar ALU: it is
    * scheduled into the shadows of the MFMAs; a division would go through the vector ALU, a branch would end the
    * scheduling region).  Past the last iteration it keeps going over valid memory (step clamped): those loads only
    * keep the counted waits exact. */
-  int g_t = g_t0, g_within = wv + g_w0;
+  int g_t = g_t0, g_within = g_w0;
   const float *g_xb, *g_eb, *g_cb;
   auto advance = [&]() {
     const int t = g_t < a.D ? g_t : a.D - 1;
@@ -232,7 +254,7 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
     g_xb = a.x + (size_t)slot * a.plane + ro + m0;
     g_eb = a.e + (size_t)t * a.plane + ro + n0;
     g_cb = a.coef + (size_t)t * a.Scap + (g_within << 2);
-    g_within += NW;
+    g_within += ST;
     const int wrap = g_within >= QPS ? 1 : 0;
     g_within -= wrap ? QPS : 0;
     g_t += wrap;
@@ -259,7 +281,9 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
   pre(); /* (its own loads are younger than the ring's: every counted wait below then waits for them too, never for less) */
   int ones;
   {
+    DDIR_STAMP(1);
     dd_flag_wait<(2 + NPW) * P>(fl_n, fl_s);
+    DDIR_STAMP(2);
     bool ok = true;
 #pragma unroll
     for (int u = 0; u < DD_FLAG_LOADS / 2; u++)
@@ -324,6 +348,10 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
   };
   if (ones) {
     for (int i0 = 0; i0 < n_it; i0 += P) round(std::true_type{});
+    DDIR_STAMP(3);
+#ifdef PC_STAMPS
+    if ((blockIdx.x & 63) == 0 && lane == 0) g_ddir_wave[blockIdx.x >> 6][wv] = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
     for (int j = 0; j < P; j++) rcf[j] = 0.0f;
     dd_drain<P>(ra, re, rr, rcf); /* the surplus loads (a wait per path: one behind the join costs copies of the ring) */
@@ -335,7 +363,7 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
     for (int j = 0; j < P; j++) rcf[j] = 0.0f;
     dd_drain<P>(ra, re, rr, rcf);
     g_t = g_t0;
-    g_within = wv + g_w0;
+    g_within = g_w0;
     dd_static_for<P>([&](auto JC) {
       constexpr int j = decltype(JC)::value;
       advance();
@@ -367,7 +395,9 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
       for (int r = 0; r < 4; r++) rb[(4 * (lane >> 4) + r) * 16 + (lane & 15)] = racc[p][r];
     }
   }
+  DDIR_STAMP(4);
   __syncthreads();
+  DDIR_STAMP(5);
   auto update4 = [&](dd_f4 &W, dd_f4 &M, const dd_f4 &d, float rate) { /* recur-nn.c:482-487 */
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -454,8 +484,10 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
       *reinterpret_cast<dd_f4 *>(a.ho_m + off) = M;
     }
   }
+  DDIR_STAMP(6);
 }
 
+/* (DDIR_STAMP(6) at the end of dd_body) */
 constexpr int dd_lds_bytes(int NW, int NPW = 1) { return (NW * 64 * DD_LD + NPW * NW * 256) * 4; }
 
 /* (one workgroup per CU: NW / 4 waves per SIMD, with the registers that leaves each -- told to hipcc, which otherwise

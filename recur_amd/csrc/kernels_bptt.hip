@@ -1000,6 +1000,13 @@ static void ramd_launch_extras_dense(hipStream_t st, const View &v, const RamdSh
 
 #include "k_delta_direct.h" /* the weight-delta GEMM without a K split over workgroups (hidden 1024 and up) */
 
+#ifdef PC_STAMPS
+extern "C" void ramd_ddir_stamps(unsigned long long *out) {
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ddir_stamps), sizeof(unsigned long long) * 32));
+  HIP_CHECK(hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_ddir_wave), sizeof(unsigned long long) * 32));
+}
+#endif
 /* k_delta_direct with the top layer's weight delta AND its update in the launch's first microseconds (the fused text step):
  * workgroup i forms rows 5 i .. of ho_delta = hidden^T . o_error over the call's streams (chain_ho_delta, k_common.h: what
  * the chain launch otherwise does in ITS first 2.5 us, on the generation's critical path), stores them and updates those
@@ -2103,6 +2110,15 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
         a.tn = dtn;
         a.rest = drest;
         a.rgroups = drg;
+        { /* the shares of a SIMD's two waves (dd_body): 5 / 8 to the first where the loop is long, rounded to whole rings */
+          const int pct = env_int("RECUR_AMD_DELTA_FAST_PCT", 66), n_pair = 2 * (dn_it / dks);
+          if (pct > 0 && dn_it / dks >= 40) {
+            int nf = (n_pair * pct / 100 + P / 2) / P * P;
+            if (nf < P) nf = P;
+            if (nf > n_pair - P) nf = n_pair - P;
+            a.fast_its = nf;
+          }
+        }
         a.hidden_size = sh->hidden_size;
         a.mode = fuse ? 2 : accumulate ? 1 : 0;
         if (dks > 1) { /* planes: stored, summed (and added to ih_delta where the call accumulates) by what follows */
