@@ -48,8 +48,10 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
             assert abs(report.training_entropy + h.value / (n - 1)) <= 2e-4 * abs(h.value / (n - 1)) + 1e-6, "training entropy"
         sg, so = g.snapshot(), o.snapshot()
         flips = int(((sg["hidden"] != 0) != (so["hidden"] != 0)).sum()) + int(((sg["hist"] != 0) != (so["hist"] != 0)).sum())
+        # (up to three texts of up to 150 symbols with batched updates in between: free-running state, so the norm metrics --
+        # the element-wise reading of the bar is for comparisons one generation deep, profiles/NOTES_r05.md section 4)
         replay.check(sg, so, 2e-4, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "hist",
-                                         "min_error_factor"], exact=("index", "generation", "rng"))
+                                         "min_error_factor"], exact=("index", "generation", "rng"), elementwise=False)
         n = int(rs.integers(1, 12))
         text = np.ascontiguousarray(rs.integers(0, A, n).astype(np.uint8))
         amd.rnn_char_multitext_spin(g.net, rc.u8ptr(text), n, None, None, None, 0)
