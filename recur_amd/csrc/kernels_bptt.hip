@@ -2112,7 +2112,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
         a.rgroups = drg;
         { /* the shares of a SIMD's two waves (dd_body): 5 / 8 to the first where the loop is long, rounded to whole rings */
           const int pct = env_int("RECUR_AMD_DELTA_FAST_PCT", 66), n_pair = 2 * (dn_it / dks);
-          if (pct > 0 && dn_it / dks >= 40) {
+          if (pct > 0 && dn_it / dks >= env_int("RECUR_AMD_DELTA_FAST_MIN", 40)) {
             int nf = (n_pair * pct / 100 + P / 2) / P * P;
             if (nf < P) nf = P;
             if (nf > n_pair - P) nf = n_pair - P;
