@@ -158,6 +158,9 @@ def test_hot_case_stepwise_on_the_direct_delta_path(amd):
 @pytest.mark.parametrize("env,node", [
     ("RECUR_AMD_DELTA_DIRECT=0", "test_full_size_generation_matches_oracle"),
     ("RECUR_AMD_DELTA_DIRECT=0", "test_hot_case_stepwise_on_the_direct_delta_path"),
+    # (k_delta_direct's other forms: equal shares of K for a SIMD's two waves; the top layer's delta left in the chain launch)
+    ("RECUR_AMD_DELTA_FAST_PCT=0", "test_full_size_generation_matches_oracle"),
+    ("RECUR_AMD_HO_IN_DELTA=0", "test_full_size_generation_matches_oracle"),
 ])
 def test_generations_with_the_direct_delta_gemm_switched_off(env, node):
     """k_delta_direct has k_delta_dma + the optimiser launch behind it (split-K planes summed by k_apply): the full-size
