@@ -102,7 +102,12 @@ int main(int argc, char **argv) {
   DdArgs a = {};
   a.x = dx; a.e = de + 1; a.coef = dc; a.n_exec = dnex; a.ih_scale = dsc; a.w = dw + 1; a.m = dm + 1; a.delta = dd + 1;
   a.plane = plane; a.I = I; a.H = H; a.Scap = S; a.hidden_size = hidden;
-  a.nrows = S; a.D = D; a.uidx = 7; a.tm = tm; a.tn = tn; a.rest = rest; a.rgroups = 4 * (two ? 2 : 1); a.mode = 0; a.rate = 1e-5f; a.momentum = 0.95f; a.mw = 0.5f;
+  a.nrows = S; a.D = D; a.uidx = 7; a.tm = tm; a.tn = tn; a.rest = rest; a.rgroups = 4 * (two ? 2 : 1); a.mode = 0;
+  { /* the library's shares for a SIMD's two waves (kernels_bptt.hip): DDM_FAST_PCT, default 66, 0 = halves */
+    const int pct = getenv("DDM_FAST_PCT") ? atoi(getenv("DDM_FAST_PCT")) : 66, n_pair = 2 * (D * (S / 4 / 8));
+    if (pct > 0 && n_pair >= 80) a.fast_its = (n_pair * pct / 100 + 2) / 5 * 5;
+  }
+  a.rate = 1e-5f; a.momentum = 0.95f; a.mw = 0.5f;
   a.ho_w = dho; a.ho_m = dhom; a.ho_delta = dhod; a.ho_delta_out = nullptr; a.ho_n4 = (unsigned)((size_t)H * O / 4); a.ho_rate = 1e-5f;
 
   // ---- correctness (mode 0, ones and general paths) on sampled elements + every rest row of a few columns
