@@ -1448,6 +1448,7 @@ float *rnn_opinion(RecurNN *net, const float *inputs, float presynaptic_noise) {
   RamdEngine *e = ramd_engine_of(net);
   RamdPriv *p = ramd_priv(net);
   engine_ensure_device(e);
+  top_done_clear(e);
   engine_need_dev(e, RNN_AMD_WEIGHTS);
   const RamdShape *s = &e->sh;
   RecurExtraLayer *bl = s->bI ? net->bottom_layer : NULL;
@@ -1525,6 +1526,7 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
     abort();
   }
   engine_ensure_device(e);
+  top_done_clear(e); /* (a per-net call between a set's one-call loss and its delta call: that set's top backprop is redone) */
   const RamdShape *s = &e->sh;
   int j = p->stream;
   if (fused) {
