@@ -605,6 +605,25 @@ def test_two_hundred_generations_at_full_size_track_the_oracle(amd):
     o.close()
 
 
+def test_the_north_star_generation_is_reproducible_bit_for_bit(amd):
+    """Every sum in the four launches of the text step has a fixed order (the weight-delta GEMM's K over eight waves in
+    wave order, with fixed shares for a SIMD's two waves; the chain's K quarters; the top layer's sums by stream groups):
+    two sets with the same seed, driven through the same 25 generations one after the other on the same device, must end
+    with identical bits in weights, momentum, deltas, history and hidden state -- what lets ranks that hold replicas stay
+    in step without ever comparing them."""
+    kw = dict(input_size=42, hidden_size=1024, output_size=42, S=256, D=20, learn_rate=1e-5, seed=4)
+    text = sc.synthetic_text(30000)
+    snaps = []
+    for _ in range(2):
+        g = sc.AmdBatchedSet(amd, **kw)
+        for i in range(25):
+            g.char_step(text, i, rc.WEIGHTED, 0.95)
+        snaps.append(g.snapshot())
+        g.close()
+    for k in ("ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hist", "hidden", "output", "o_error", "min_error_factor"):
+        assert np.array_equal(snaps[0][k], snaps[1][k]), k
+
+
 @pytest.mark.skipif(not rc.have_ref(), reason="oracle/_ref/librecur_ref.so was not built (needs /root/reference)")
 def test_a_hundred_generations_at_full_size_track_the_compiled_reference(amd):
     """The same long run against the REFERENCE ITSELF (oracle/_ref: recur-nn.c + recur-nn-init.c compiled with the
