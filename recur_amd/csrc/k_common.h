@@ -507,6 +507,7 @@ struct XcWork {
   const unsigned char *active;
   unsigned flags;
   int done;
+  int dense; /* the inputs are dense (every input column counts): extras_dense_tail instead of the gather form */
 };
 RAMD_LOCAL int ramd_chain_steps(hipStream_t st, const View &v, const RamdShape *sh, const RamdBuffers *b,
                                 int row0, int nrows, HoWork *ho, XcWork *xc);

@@ -548,3 +548,169 @@ __device__ __forceinline__ void extras_control_tail(const View &v, int r, int j,
     XC_STAMP(8);
   }
 }
+
+// The tail of the one-launch chain for nets with DENSE inputs (gstclassify's features, up to 47 of them): ONE stream's
+// extras -- k_extras_dense's work for the rows (step t, stream r), t = 0 .. D - 1: the error rows times W_ih's bias and input
+// rows on the matrix cores (v_mfma_f32_16x16x4_f32, operands straight from memory, the rows past the L1: other CUs of this
+// XCD wrote them during the launch), the row rule, the sums of squares -- and the stream's control logic, by the workgroup
+// whose column tile the stream belongs to.  Instead of a k_extras_dense launch and a k_bptt_control launch behind the
+// chain (10.1 + 4.9 us at 512 / 128 / 30).  32 rows (steps) per pass, the eight waves every eighth 16-deep chunk of K.
+// lds: THREADS / 64 * 32 * 49 + THREADS / 64 * 32 + 192 + D floats (52 KB: the chain's operand area at hidden >= 512).
+template <int THREADS, class WaitLast>
+__device__ __forceinline__ void extras_dense_tail(const View &v, int r, int j, int nx, int nxp, const unsigned char *active,
+                                                  unsigned flags, float *lds, WaitLast &&wait_last) {
+  constexpr int NW = THREADS / 64, NT3 = 3, PF = 4, LD = 16 * NT3 + 1;
+  const RamdShape &s = v.sh;
+  const int D = s.D;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = tid & 63;
+  const int lm = lane & 15, kq = lane >> 4;
+  float *red = lds;                  /* [NW][32][LD] */
+  float *rsq = red + NW * 32 * LD;   /* [NW][32]: the waves' shares of the rows' sums of squares */
+  float *rowsq = rsq + NW * 32;      /* [64]: sum of squares of plane t's row */
+  float *sqx = rowsq + 64;           /* [64]: sum of squares of step t's extras */
+  float *es_sh = sqx + 64;           /* [D] */
+  ControlIn ci = {0.0f, 0.0f, 1.0f, 0.0, true};
+  if (wave == 0) ci = bptt_control_load(v, r, j, active);
+  XC_STAMP(3);
+  if (wave == NW - 1) wait_last(); /* the last plane's row: its column tiles' flags (earlier planes were seen complete in the loop) */
+  __syncthreads();
+  XC_STAMP(5);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)v.b.ehi, 0, 0x7fffffff, 0x00020000);
+  const float *brow[NT3];
+#pragma unroll
+  for (int jn = 0; jn < NT3; jn++) {
+    const int c = 16 * jn + lm;
+    brow[jn] = v.b.ih_w + (size_t)((c == 0 || c >= nx) ? 0 : s.hidden_size + c) * s.H; /* (columns >= nx: discarded below) */
+  }
+  const int nchunks = (s.H + 15) / 16;
+  const int mine = (nchunks - wave + NW - 1) / NW; /* chunks wave, wave + NW, .. */
+  const float *xin0 = input_row<true>(v, r, 0); /* (the one-launch chain: one ring position) */
+  (void)xin0;
+  for (int t0 = 0; t0 <= D; t0 += 32) {
+    unsigned row_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int t = min(t0 + 16 * i + lm, D);
+      row_off[i] = (unsigned)((t * s.Scap + r) * s.I) * 4u;
+    }
+    f32x4 acc[2][NT3];
+    float sq2[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int jn = 0; jn < NT3; jn++) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 fa[PF][2], fb[PF][NT3];
+    float fm[PF];
+    auto request = [&](int slot, int n) {
+      const int k = 16 * (wave + NW * n) + 4 * kq;
+      const bool in = n < mine && k < s.H;
+      const int kc = in ? k : 0;
+      fm[slot] = in ? 1.0f : 0.0f; /* (a factor on the values: a select on the loaded registers would wait for them here) */
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(row_off[i] + 4u * (unsigned)kc), 0, 16 /* sc1 */);
+        fa[slot][i] = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+      }
+#pragma unroll
+      for (int jn = 0; jn < NT3; jn++) fb[slot][jn] = ld4(brow[jn] + kc);
+    };
+#pragma unroll
+    for (int p = 0; p < PF; p++) request(p, p);
+    /* the row rule's input values, requested with the first operands: thread (row, sub) of the epilogue */
+    const int erow = (tid >> 3) & 31, sub = tid & 7;
+    const int et = min(t0 + erow, D - 1);
+    constexpr int CPT = (16 * NT3 + 7) / 8;
+    float xv[CPT];
+    if (tid < 8 * 32) {
+      const float *x = input_row<true>(v, r, et);
+#pragma unroll
+      for (int q = 0; q < CPT; q++) {
+        const int c = sub + 8 * q;
+        xv[q] = x[(c == 0 || c >= nx) ? 0 : s.hidden_size + c];
+      }
+    }
+    for (int n0 = 0; n0 < mine; n0 += PF) {
+#pragma unroll
+      for (int p = 0; p < PF; p++) {
+        if (n0 + p < mine) { /* (wave-uniform) */
+          float4 a[2], bb[NT3];
+          const float m = fm[p];
+#pragma unroll
+          for (int i = 0; i < 2; i++) a[i] = make_float4(fa[p][i].x * m, fa[p][i].y * m, fa[p][i].z * m, fa[p][i].w * m);
+#pragma unroll
+          for (int jn = 0; jn < NT3; jn++) bb[jn] = fb[p][jn];
+          request(p, n0 + p + PF);
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            sq2[i] += (a[i].x * a[i].x + a[i].y * a[i].y) + (a[i].z * a[i].z + a[i].w * a[i].w);
+#pragma unroll
+            for (int jn = 0; jn < NT3; jn++) {
+              acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, bb[jn].x, acc[i][jn], 0, 0, 0);
+              acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, bb[jn].y, acc[i][jn], 0, 0, 0);
+              acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, bb[jn].z, acc[i][jn], 0, 0, 0);
+              acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bb[jn].w, acc[i][jn], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    XC_STAMP(4);
+    // accumulator register rr of tile (i, jn): row 16 i + 4 kq + rr, column 16 jn + lm
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int jn = 0; jn < NT3; jn++)
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) red[(wave * 32 + 16 * i + 4 * kq + rr) * LD + 16 * jn + lm] = acc[i][jn][rr];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      sq2[i] += __shfl_xor(sq2[i], 16, 64);
+      sq2[i] += __shfl_xor(sq2[i], 32, 64);
+      if (kq == 0) rsq[wave * 32 + 16 * i + lm] = sq2[i];
+    }
+    __syncthreads();
+    if (tid < 8 * 32) {
+      const int t = t0 + erow;
+      const bool live = t < D;
+      float sq = 0.0f;
+      float *dst = v.b.ex + ((size_t)(et + 1) * s.Scap + r) * nxp;
+#pragma unroll
+      for (int q = 0; q < CPT; q++) {
+        const int c = sub + 8 * q;
+        if (c < nx) {
+          float e = 0.0f;
+#pragma unroll
+          for (int w = 0; w < NW; w++) e += red[(w * 32 + erow) * LD + c];
+          const float xi = xv[q];
+          const bool on = xi != 0.0f && (s.activation != 5 || xi < 20.0f);
+          e = on ? e : 0.0f;
+          if (on && s.activation == 2) e /= 2 * (xi + 1.0f);
+          if (live) dst[c] = e;
+          sq += e * e;
+        }
+      }
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1) sq += __shfl_xor(sq, off, 64);
+      if (sub == 0 && live) sqx[t] = sq;
+    } else if (tid < 8 * 32 + 32) {
+      const int row = tid - 8 * 32, t = t0 + row;
+      float tot = 0.0f;
+#pragma unroll
+      for (int w = 0; w < NW; w++) tot += rsq[w * 32 + row];
+      if (t <= D) rowsq[t] = tot;
+    }
+    __syncthreads();
+    XC_STAMP(6);
+  }
+  XC_STAMP(7);
+  if (wave == 0) {
+    for (int k = lane; k < D; k += 64) {
+      const float es = rowsq[k + 1] + sqx[k];
+      es_sh[k] = es;
+      as_global(v.b.esum)[(size_t)k * s.Scap + r] = es;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the wave's own LDS writes before it reads them back */
+    bptt_control_wave(v, r, j, lane, ci, flags, es_sh, 1);
+    XC_STAMP(8);
+  }
+}

@@ -1970,6 +1970,18 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       xc_req.nxp = nxp;
       xc_req.active = active;
       xc_req.flags = flags;
+    } else if (b->dense_inputs && nx > 8 && nx <= 16 * XD_NT && (sh->hidden_size == 512 || sh->hidden_size == 1024) &&
+               sh->D <= 63 && !env_int("RECUR_AMD_EXTRAS_GEMM", 0) && env_int("RECUR_AMD_XC_IN_CHAIN", 1) &&
+               env_int("RECUR_AMD_XC_DENSE_IN_CHAIN", 1) &&
+               (size_t)(sh->D + 1) * sh->Scap * sh->I * sizeof(float) < ((size_t)1 << 31)) {
+      /* dense inputs (gstclassify's features): the extras as a small GEMM in the one-launch chain's tail (extras_dense_tail) */
+      xc_req.on = 1;
+      xc_req.dense = 1;
+      xc_req.row0 = row0;
+      xc_req.nx = nx;
+      xc_req.nxp = nxp;
+      xc_req.active = active;
+      xc_req.flags = flags;
     }
     tn_parts = ramd_chain_steps(st, v, sh, b, row0, nrows, ho_asked ? &ho_req : nullptr, xc_req.on ? &xc_req : nullptr);
     if (ho_asked && ho_req.done) {

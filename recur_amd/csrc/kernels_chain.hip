@@ -556,7 +556,7 @@ __device__ unsigned long long g_pc_stamps[2][64][8];
 /* PAD (with ONE): the set is not whole row tiles -- only rows [vlo, nvalid) of the launch are its
  * own; the others belong to other streams or to nobody: they are multiplied like the rest (rows
  * do not mix) and never stored. */
-template <int ACT, int K, bool ONE = false, bool PAD = false> /* rnn_activation; hidden size: 1024, 512 or 256 */
+template <int ACT, int K, bool ONE = false, bool PAD = false, bool XD = false> /* rnn_activation; hidden size: 1024, 512 or 256; XD: the tail for DENSE inputs (an instantiation of its own: the text step's kernel stays what it is) */
 __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ vp, int uniform_idx,
                                                        int row0, int nrows, int depth, unsigned seq,
                                                        ChainSync *sy, unsigned *host_abort, int nvalid, int vlo,
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   const int tn = NT;
   const size_t plane_stride = (size_t)s.Scap * s.I;
   /* the tail's first stream (row tile's stream j): what it can ask for now (extras_tail_prefetch) */
-  const bool xc_first = xc.on && j < TR && !(PAD && (m0 + j < vlo || m0 + j >= nvalid));
+  const bool xc_first = !XD && xc.on && j < TR && !(PAD && (m0 + j < vlo || m0 + j >= nvalid));
   TailPre tpre;
   if (xc_first) tpre = extras_tail_prefetch<512>(v, row0 + m0 + j, row0 + m0 + j - xc.row0, xc.nx, xc.active);
 
@@ -1036,7 +1036,10 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     };
     constexpr int XQ = (K / 4 + 1 + 63) / 64; /* float4 per lane of an error row (h_size = K + 4) */
     const int r = row0 + sr;
-    extras_control_tail<XQ, 512>(v, r, r - xc.row0, xc.nx, xc.nxp, xc.active, xc.flags, abuf, (i == j && xc_first) ? &tpre : nullptr, wait_last);
+    if constexpr (XD) /* (the operand area holds its 52 KB from hidden 512 on: launcher) */
+      extras_dense_tail<512>(v, r, r - xc.row0, xc.nx, xc.nxp, xc.active, xc.flags, abuf, wait_last);
+    else
+      extras_control_tail<XQ, 512>(v, r, r - xc.row0, xc.nx, xc.nxp, xc.active, xc.flags, abuf, (i == j && xc_first) ? &tpre : nullptr, wait_last);
     XC_STAMP(9);
     __syncthreads();
   }
@@ -1237,6 +1240,30 @@ static void launch_chain_persist_k(hipStream_t st, const View *d_view, const Ram
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_persist<ACT, K, true, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, pc_lds_bytes(K)));
     attr_set = true;
+  }
+  if constexpr (K >= 512) {
+    if (xc.on && xc.dense) { /* the tail for dense inputs */
+      static bool attr_xd = false;
+      if (!attr_xd) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)(k_chain_persist<ACT, K, false, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, pc_lds_bytes(K)));
+        HIP_CHECK(hipFuncSetAttribute((const void *)(k_chain_persist<ACT, K, true, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, pc_lds_bytes(K)));
+        HIP_CHECK(hipFuncSetAttribute((const void *)(k_chain_persist<ACT, K, true, true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, pc_lds_bytes(K)));
+        attr_xd = true;
+      }
+      if (one && (nvalid < nrows || vlo > 0))
+        RAMD_LAUNCH((k_chain_persist<ACT, K, true, true, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
+                    b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nvalid, vlo, hw, xc, (int)use_static, tseq, g_seats);
+      else if (one)
+        RAMD_LAUNCH((k_chain_persist<ACT, K, true, false, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
+                    b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw, xc, (int)use_static, tseq, g_seats);
+      else
+        RAMD_LAUNCH((k_chain_persist<ACT, K, false, false, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
+                    b->uniform_idx, row0, nrows, sh->D, seq, g_chain_sync, g_chain_abort_dev, nrows, 0, hw, xc, (int)use_static, tseq, g_seats);
+      return;
+    }
   }
   if (one && (nvalid < nrows || vlo > 0))
     RAMD_LAUNCH((k_chain_persist<ACT, K, true, true>), dim3(256), dim3(512), pc_lds_bytes(K), st, d_view,
