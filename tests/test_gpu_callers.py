@@ -267,7 +267,11 @@ def _rnnca_inputs(rs, S, n_in=35):
 
 @pytest.mark.parametrize("hidden,S,D,n_in,activation", [(36, 5, 3, 1, rc.RELU), (100, 33, 7, 46, rc.RESQRT),
                                                          (516, 17, 5, 15, rc.RECLIP20), (256, 48, 4, 47, rc.RELU),
-                                                         (128, 9, 6, 16, rc.RESQRT)])
+                                                         (128, 9, 6, 16, rc.RESQRT),
+                                                         # (hidden 512 / 1024: the extras in the one-launch chain's tail --
+                                                         # extras_dense_tail -- with whole and with padded 16-stream tiles)
+                                                         (512, 48, 7, 33, rc.RESQRT), (512, 33, 5, 46, rc.RELU),
+                                                         (1024, 32, 4, 20, rc.RECLIP20)])
 def test_dense_input_generation_with_other_shapes(amd, hidden, S, D, n_in, activation):
     """k_extras_dense at its edges: 1 to 47 dense inputs (2 to 48 extra columns: the three 16-column tiles full), h_size
     not a multiple of the 16-deep K chunks, fewer (step, stream) rows than a workgroup takes, every activation's row
