@@ -19,7 +19,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
     sg, so = g.snapshot(), o.snapshot()
     flips = int(((sg["hidden"] != 0) != (so["hidden"] != 0)).sum()) + int(((sg["hist"] != 0) != (so["hist"] != 0)).sum())
     try:
-        replay.check(sg, so, 2e-4, keys=["ih_w", "ho_w", "ih_delta", "ho_delta", "hidden", "hist", "min_error_factor", "ih_scale", "output", "o_error"], exact=("index", "generation"))
+        replay.check(sg, so, 2e-4, keys=["ih_w", "ho_w", "ih_delta", "ho_delta", "hidden", "hist", "min_error_factor", "ih_scale", "output", "o_error"], exact=("index", "generation"), elementwise=False)
         res = "ok"
     except AssertionError as e:
         res = "MISMATCH " + str(e)[:150]

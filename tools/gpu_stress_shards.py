@@ -71,10 +71,10 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
         both = {k: np.concatenate([s_[k] for s_ in snaps], axis=1 if k == "hist" else 0)
                 for k in ("hist", "hidden", "output", "o_error", "min_error_factor", "ih_scale", "index", "generation", "rng")}
         flips = int(((both["hidden"] != 0) != (so["hidden"] != 0)).sum()) + int(((both["hist"] != 0) != (so["hist"] != 0)).sum())
-        replay.check(snaps[0], so, 2e-4, keys=["ih_w", "ho_w", "ih_m", "ho_m"], exact=())
-        replay.check(snaps[R - 1], so, 2e-4, keys=["ih_delta", "ho_delta"], exact=())
+        replay.check(snaps[0], so, 2e-4, keys=["ih_w", "ho_w", "ih_m", "ho_m"], exact=(), elementwise=False)
+        replay.check(snaps[R - 1], so, 2e-4, keys=["ih_delta", "ho_delta"], exact=(), elementwise=False)
         replay.check(both, so, 2e-4, keys=["hist", "hidden", "output", "o_error", "min_error_factor", "ih_scale"],
-                     exact=("index", "generation", "rng"))
+                     exact=("index", "generation", "rng"), elementwise=False)
     except AssertionError as e:
         res = "MISMATCH " + str(e)[:300]
         if flips == 0 or "replicas" in str(e):

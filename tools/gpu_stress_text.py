@@ -40,7 +40,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     flips = int(((sg["hidden"] != 0) != (so["hidden"] != 0)).sum()) + int(((sg["hist"] != 0) != (so["hist"] != 0)).sum())
     try:
         replay.check(sg, so, 2e-4, keys=["ih_w", "ho_w", "ih_m", "ho_m", "ih_delta", "ho_delta", "hidden", "output", "hist",
-                                         "o_error", "min_error_factor", "ih_scale"], exact=("index", "generation", "rng"))
+                                         "o_error", "min_error_factor", "ih_scale"], exact=("index", "generation", "rng"), elementwise=False)
         res = "ok"
     except AssertionError as e:
         res = "MISMATCH " + str(e)[:200]
