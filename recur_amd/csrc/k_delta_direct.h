@@ -467,10 +467,12 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
   }
   /* the top layer's update, shared out over the workgroups */
   if (upd && a.ho_n4) {
+    /* (a loop: a wide top layer -- H * O / 4 above 64 NW float4s per workgroup -- gives a workgroup more than one
+     * float4 per thread; without it the tail of every share kept its old weights and fuse_done hid the omission) */
     const unsigned per = (a.ho_n4 + gridDim.x - 1) / gridDim.x;
-    const unsigned k = threadIdx.x;
-    const unsigned idx = blockIdx.x * per + k;
-    if (k < per && idx < a.ho_n4) {
+    for (unsigned k = threadIdx.x; k < per; k += 64 * NW) {
+      const unsigned idx = blockIdx.x * per + k;
+      if (idx >= a.ho_n4) break;
       const size_t off = 4 * (size_t)idx;
       dd_f4 d = *reinterpret_cast<const dd_f4 *>(a.ho_delta + off);
       for (int z = 1; z < a.ho_ks; z++) {

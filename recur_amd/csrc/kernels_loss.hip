@@ -780,10 +780,16 @@ extern "C" void ramd_launch_text_top(ramd_stream_t st_, const RamdShape *sh, con
 /* the same launch with rnnca's loss (targets [nrows][ld] on the device, the first n outputs) or gstclassify's class groups
  * (ngroups > 0: offsets, sizes, targets [nrows][ngroups], per-output weights or NULL) between the output layer and the
  * backprop; returns 0 when the shape is not the kernel's kind (o_size > 64) and nothing was launched */
+/* the launch below takes the shape (and its switch is on): callers decide on the two-call form UP FRONT with this -- by the
+ * time the launch could decline, the forward pass has run for it (hidden sums only) and cannot be redone */
+extern "C" int ramd_dense_top_ok(const RamdShape *sh) {
+  return ramd_text_top_ok(sh) && sh->O <= 64 && env_int("RECUR_AMD_DENSE_TOP", 1);
+}
+
 extern "C" int ramd_launch_dense_top(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b, int row0, int nrows,
                                      int fwd_ks, const float *targets, int ld, int n, int ngroups, const int *goff,
                                      const int *gsize, const int *gt, const float *weight) {
-  if (!ramd_text_top_ok(sh) || sh->O > 64 || !env_int("RECUR_AMD_DENSE_TOP", 1)) return 0;
+  if (!ramd_dense_top_ok(sh)) return 0;
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
   size_t shm = (size_t)(sh->H + OUT_SEGS * 64 * 4 + (OUT_SEGS + 3) * sh->O) * sizeof(float);

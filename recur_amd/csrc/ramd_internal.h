@@ -178,6 +178,7 @@ int ramd_launch_forward_hidden(ramd_stream_t st, const RamdShape *sh, const Ramd
 #define RAMD_HEADBITS_AT 130
 #define RAMD_MULTI_RANGE_STRIDE 132
 int ramd_text_top_ok(const RamdShape *sh);
+int ramd_dense_top_ok(const RamdShape *sh); /* ramd_launch_dense_top will take the shape (O <= 64, RECUR_AMD_DENSE_TOP) */
 int ramd_launch_forward_fused(ramd_stream_t st, const RamdShape *sh, const RamdBuffers *b, int row0,
                               int nrows, int mode, int text_i, int global_first, int n_set, int for_top,
                               const float *dense, int ld); /* (dense, ld: the inputs of mode RAMD_IN_DENSE, [nrows][ld]) */

@@ -1983,6 +1983,8 @@ void rnn_amd_set_shard(RnnAmdSet *set, int global_first, int global_count) {
   set->global_count = global_count;
   if (global_count != set->n) {
     set->eng->sharded_sticky = 1;
+  } else if (global_first == 0) {
+    set->eng->sharded_sticky = 0; /* the whole set again: host draws come from the nets' own generators as before */
   }
   set->eng->sharded = set->eng->sharded_sticky || set->eng->sharded_sets > 0;
 }
@@ -2662,7 +2664,7 @@ void rnn_amd_set_sigmoid_mse_error(RnnAmdSet *set, const float *targets, int ld,
  * cannot follow */
 static int dense_top_ok(RnnAmdSet *set, const float *inputs) {
   RamdEngine *e = set->eng;
-  return inputs && !set->fwd_only && !e->sh.bI && e->sh.O <= 64 && ramd_text_top_ok(&e->sh) &&
+  return inputs && !set->fwd_only && !e->sh.bI && ramd_dense_top_ok(&e->sh) &&
          set->nets[0]->presynaptic_noise == 0.0f && set->nets[0]->bptt;
 }
 

@@ -149,6 +149,10 @@ def _multi_head_generation(lib, A, NC, H, S, D, leakage, deep=False, stray_every
     ("RECUR_AMD_NOISE_AHEAD=0", "test_multi_head_generation_with_streams_that_have_no_head_of_their_own[2]"),
     ("RECUR_AMD_STALE_FROM_PLANES=0", "test_config3_multi_head_generation_at_size[32]"),
     ("RECUR_AMD_EXTRAS_DENSE=0 RECUR_AMD_KEEP_DELTAS=0", "test_config2_classify_generations_with_balanced_training"),
+    # (opinion + loss as one call fall back to the two calls UP FRONT when the one-launch top layer is switched off:
+    # round 5 aborted here -- the switch was read only by the launch, after the forward pass had run for it)
+    ("RECUR_AMD_DENSE_TOP=0", "test_config2_classify_generations_with_balanced_training"),
+    ("RECUR_AMD_DENSE_TOP=0", "test_rnnca_generation_with_opinion_and_loss_in_one_call[512-64-6-12]"),
 ])
 def test_callers_generations_with_the_newer_kernels_switched_off(env, node):
     """Every specialised form has the form it replaced behind it: the multi-head top layer per trained head
@@ -306,6 +310,16 @@ def test_rnnca_generation_as_one_call(amd, hidden, S, D, n_in):
     _rnnca_generation(amd, hidden, S, D, n_in=n_in, combined="step")
 
 
+@pytest.mark.parametrize("hidden,S,D,n_in,n_out", [(1024, 64, 5, 12, 640), (1024, 32, 5, 20, 1100), (1024, 96, 5, 33, 516)])
+def test_one_call_generation_with_a_wide_top_layer(amd, hidden, S, D, n_in, n_out):
+    """The fused update's share of the TOP layer (k_delta_direct.h, mode 2: H * O / 4 float4s shared out over the
+    launch's workgroups) where a workgroup's share is more than one float4 per thread: hidden 1024 with 640 / 1100
+    outputs is 643 / 1105 float4s per workgroup of 512 threads (round 5's epilogue had no loop there: the tail of
+    every share kept its old weights and momentum, and fuse_done suppressed the optimiser launch that would have
+    updated them).  Every output carries error (the sigmoid loss over all of them), so every weight moves."""
+    _rnnca_generation(amd, hidden, S, D, n_in=n_in, combined="step", n_out=n_out)
+
+
 @pytest.mark.parametrize("between", ["nothing", "put_o_error", "host_weights", "mask_differs", "second_opinion"])
 def test_what_happens_between_the_one_call_loss_and_the_delta_call(amd, between):
     """rnn_amd_set_opinion_sigmoid_mse / _grouped_softmax leave the top layer's backprop done for the delta call that
@@ -359,8 +373,8 @@ def test_what_happens_between_the_one_call_loss_and_the_delta_call(amd, between)
     gb.close()
 
 
-def _rnnca_generation(lib, hidden, S, D, n_in=35, activation=None, combined=False):
-    kw = dict(input_size=n_in, hidden_size=hidden, output_size=3, S=S, D=D, learn_rate=1e-5 if hidden > 1000 else 1e-3,
+def _rnnca_generation(lib, hidden, S, D, n_in=35, activation=None, combined=False, n_out=3):
+    kw = dict(input_size=n_in, hidden_size=hidden, output_size=n_out, S=S, D=D, learn_rate=1e-5 if hidden > 1000 else 1e-3,
               seed=81, momentum=0.95)
     if activation is not None:
         kw["activation"] = activation
@@ -373,13 +387,13 @@ def _rnnca_generation(lib, hidden, S, D, n_in=35, activation=None, combined=Fals
             lib.rnn_bptt_clear_deltas(gpu.net)
             lib.rnn_amd_set_advance(gpu.handle)
             if combined == "step":  # the whole generation as one call (the update in the delta GEMM's epilogue)
-                lib.rnn_amd_set_dense_step_sigmoid_mse(gpu.handle, rc.fptr(x), n_in, rc.fptr(tgt), 3, 3, rc.WEIGHTED, m)
+                lib.rnn_amd_set_dense_step_sigmoid_mse(gpu.handle, rc.fptr(x), n_in, rc.fptr(tgt), n_out, n_out, rc.WEIGHTED, m)
             else:
                 if combined:
-                    lib.rnn_amd_set_opinion_sigmoid_mse(gpu.handle, rc.fptr(x), n_in, rc.fptr(tgt), 3, 3)
+                    lib.rnn_amd_set_opinion_sigmoid_mse(gpu.handle, rc.fptr(x), n_in, rc.fptr(tgt), n_out, n_out)
                 else:
                     lib.rnn_amd_set_opinion(gpu.handle, rc.fptr(x), n_in, None)
-                    lib.rnn_amd_set_sigmoid_mse_error(gpu.handle, rc.fptr(tgt), 3, 3)
+                    lib.rnn_amd_set_sigmoid_mse_error(gpu.handle, rc.fptr(tgt), n_out, n_out)
                 lib.rnn_amd_set_calc_deltas(gpu.handle, 1, None, None)
                 lib.rnn_apply_learning(gpu.net, rc.WEIGHTED, m)
         if orc_set is not None:
@@ -388,14 +402,14 @@ def _rnnca_generation(lib, hidden, S, D, n_in=35, activation=None, combined=Fals
             for j in range(S):
                 oo.orc.orc_advance(oo.z, j)
                 oo.orc.orc_opinion(oo.z, j, rc.fptr(np.ascontiguousarray(x[j])), 0.0)
-                oo.orc.orc_sigmoid_mse_error(oo.z, j, rc.fptr(np.ascontiguousarray(tgt[j])), 3)
+                oo.orc.orc_sigmoid_mse_error(oo.z, j, rc.fptr(np.ascontiguousarray(tgt[j])), n_out)
                 oo.orc.orc_calc_deltas(oo.z, j, 1, None)
             oo.orc.orc_apply_learning(oo.z, rc.WEIGHTED, m)
 
     n_warm = D + 2
     t0 = time.perf_counter()
     for gen in range(n_warm):
-        generation(g, None, _rnnca_inputs(rs, S, n_in), (rs.integers(0, 256, (S, 3)) / np.float32(255)).astype(np.float32),
+        generation(g, None, _rnnca_inputs(rs, S, n_in), (rs.integers(0, 256, (S, n_out)) / np.float32(255)).astype(np.float32),
                    gen)
     lib.rnn_amd_synchronize()
     print("configs[4] rnnca training generation, hidden %d, %d cells: %.0f cell-timesteps/s"
@@ -409,7 +423,7 @@ def _rnnca_generation(lib, hidden, S, D, n_in=35, activation=None, combined=Fals
         # from where the device is and take the next one.
         _sync_oracle_to(o, g.snapshot())
         x = _rnnca_inputs(rs, S, n_in)
-        tgt = np.ascontiguousarray((rs.integers(0, 256, (S, 3)) / np.float32(255)).astype(np.float32))
+        tgt = np.ascontiguousarray((rs.integers(0, 256, (S, n_out)) / np.float32(255)).astype(np.float32))
         generation(g, o, x, tgt, n_warm + attempt)
         sg, so = g.snapshot(), o.snapshot()
         if np.array_equal(sg["hidden"] != 0, so["hidden"] != 0):
@@ -417,8 +431,8 @@ def _rnnca_generation(lib, hidden, S, D, n_in=35, activation=None, combined=Fals
         _same_mask(sg["hidden"], so["hidden"])
     else:
         raise AssertionError("no generation without a rounding-level mask flip in 4 attempts")
-    assert np.abs(so["o_error"][:, :3]).max() > 0 and (so["o_error"][:, 3:] == 0).all()
-    assert (so["output"][:, :3] > 0).all() and (so["output"][:, :3] < 1).all()  # the sigmoid landed in place
+    assert np.abs(so["o_error"][:, :n_out]).max() > 0 and (so["o_error"][:, n_out:] == 0).all()
+    assert (so["output"][:, :n_out] > 0).all() and (so["output"][:, :n_out] < 1).all()  # the sigmoid landed in place
     replay.check(sg, so, RTOL, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "ih_m", "ho_m", "hidden", "output",
                                      "o_error", "hist", "min_error_factor", "ih_scale"],
                  exact=("index", "generation"))

@@ -71,7 +71,7 @@ def _stepwise(amd, kw, text, steps, method, depth):
     g = sc.AmdBatchedSet(amd, **kw)
     o = sc.OracleSet(**kw)
     seen_clamp = seen_exit = False
-    compared = compared_clamped = 0
+    compared = compared_clamped = skipped = 0
     for i in range(steps):
         g.char_step(text, i, method, 0.9)
         o.char_step(text, i, method, 0.9)
@@ -86,6 +86,17 @@ def _stepwise(amd, kw, text, steps, method, depth):
                                              "min_error_factor"], elem_floor=1e-1)  # (the hot regime's floor: replay.check)
             compared += 1
             compared_clamped += clamped
+        else:
+            # a stream's error sum sat on a threshold: the streams whose decision DOES agree are still held to the bar on
+            # everything that is theirs alone (the deltas and weights are sums over all streams and cannot be), and the
+            # disagreeing ones must be a few -- a systematic flip could not hide in the skipped half
+            agree = (sg["ih_scale"] == 1.0) == (so["ih_scale"] == 1.0)
+            assert agree.sum() >= len(agree) - max(1, len(agree) // 8), "break decisions differ on %d of %d streams" % (
+                (~agree).sum(), len(agree))
+            replay.check({k: sg[k][agree] for k in ("hidden", "ih_scale", "min_error_factor")},
+                         {k: so[k][agree] for k in ("hidden", "ih_scale", "min_error_factor")}, 1e-4,
+                         keys=["hidden", "ih_scale", "min_error_factor"], exact=(), elem_floor=1e-1)
+            skipped += 1
         seen_clamp |= clamped
         seen_exit |= bool((so["bptt_depth"] < depth).any()) and i >= depth  # not the ring filling up
         # resynchronise the device to the oracle's state
@@ -96,6 +107,7 @@ def _stepwise(amd, kw, text, steps, method, depth):
     # clamped ones among them -- were actually compared
     assert seen_clamp and seen_exit
     assert compared >= steps // 2 and compared_clamped >= 1, (compared, compared_clamped)
+    print("stepwise: %d generations compared in full, %d on the agreeing streams only" % (compared, skipped))
 
 
 @pytest.mark.parametrize("batched", [True, False])
@@ -705,17 +717,29 @@ def test_baseline_config_shapes_one_generation_matches_oracle(amd, label, kw):
     n = kw["D"] + 3
     for i in range(n):
         g.char_step(text, i, rc.WEIGHTED, 0.95)
-    snap = g.snapshot()
     o = sc.OracleSet(**kw)
     a = o.arrays()
-    for k in ("ih_w", "ho_w", "ih_m", "ho_m", "hist", "hidden", "index", "min_error_factor"):
-        a[k][:] = snap[k]
-    a["generation"][:] = snap["generation"]
-    g.stats(clear=True)
-    g.char_step(text, n, rc.WEIGHTED, 0.95)
-    o.char_step(text, n, rc.WEIGHTED, 0.95)
-    sg, so = g.snapshot(), o.snapshot()
-    assert np.array_equal(sg["hidden"] != 0, so["hidden"] != 0)
+    for attempt in range(4):
+        # One generation on both sides from the device's state.  A pre-activation within rounding of zero may take its
+        # mask from the summation order (test_mask_flips_stay_at_the_rounding_level_rate bounds how often: 10 per
+        # million, each within 1e-5 of zero); a generation in which that happens is held to exactly that bound and is
+        # not an element-wise parity case (the flipped unit's error exists on one side only): take the next one.
+        snap = g.snapshot()
+        for k in ("ih_w", "ho_w", "ih_m", "ho_m", "hist", "hidden", "index", "min_error_factor"):
+            a[k][:] = snap[k]
+        a["generation"][:] = snap["generation"]
+        g.stats(clear=True)
+        g.char_step(text, n + attempt, rc.WEIGHTED, 0.95)
+        o.char_step(text, n + attempt, rc.WEIGHTED, 0.95)
+        sg, so = g.snapshot(), o.snapshot()
+        flipped = (sg["hidden"] != 0) != (so["hidden"] != 0)
+        if not flipped.any():
+            break
+        assert 1e6 * flipped.sum() / flipped.size <= 10.0, "%d of %d hidden values differ in being zero" % (
+            flipped.sum(), flipped.size)
+        assert np.abs(np.where(sg["hidden"][flipped] != 0, sg["hidden"][flipped], so["hidden"][flipped])).max() < 1e-5
+    else:
+        raise AssertionError("no generation without a rounding-level mask flip in 4 attempts")
     assert g.stats().bptt_depth_sum == float(so["bptt_depth"].sum())
     replay.check(sg, so, RTOL, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "ih_m", "ho_m", "hidden",
                                      "output", "o_error", "hist", "min_error_factor", "ih_scale"])
