@@ -17,8 +17,18 @@ Multi-GPU: one process per GPU, streams sharded over ranks (weak scaling: 256
 streams per GPU), ONE RCCL all-reduce of ih_delta||ho_delta per generation INSIDE
 the library (rnn_amd_dist_*; recur_amd/csrc/dist.c), replicated optimiser step.
 `--gpus N` without a launcher's WORLD_SIZE starts the N ranks itself (children are
-spawned before anything touches a GPU); under `python -m torch.distributed.run`
+spawned before anything touches a GPU; a wall-clock watchdog ends them all and
+exits 124 when a run hangs); under `python -m torch.distributed.run`
 the ranks are the launcher's.  No PyTorch in the data path (nor imported).
+
+A run with more than one rank validates itself (round 6): the JSON line carries
+`rccl_ranks`, every rank's 64-bit replica checksum -- read by a kernel through the
+caches AND over a copy -- with `replicas_identical`, and `exchange_us` (HIP events
+around the exchange step, per generation); replicas that differ end the run with
+exit status 3.  `--exchange auto` (the default with N > 1) makes one update through
+RCCL and one through the kernel-issued exchange from the SAME deltas, times both,
+and takes the kernel-issued form only if its replicas are identical, its result
+is RCCL's to rounding, and it is faster; `config.parallelism` says which and why.
 
 Prints ONE JSON line on rank 0.
 """
@@ -63,19 +73,28 @@ def parse():
     ap.add_argument("--prefill", type=int, default=300, help="untimed generations before the warm-up")
     ap.add_argument("--dist", action="store_true",
                     help="join an RCCL group even with one rank (exercises the exchange step)")
-    ap.add_argument("--exchange", choices=("rccl", "kernel"), default=os.environ.get("RECUR_AMD_DIST_EXCHANGE", "rccl"),
-                    help="the exchange step of a sharded run: one RCCL all-reduce per generation (default), or the "
-                         "library's kernel-issued reduce-scatter -> sharded update -> all-gather through peer pointers "
-                         "(rnn_amd_set_exchange_*; also with one rank)")
+    ap.add_argument("--exchange", choices=("auto", "rccl", "kernel"), default=os.environ.get("RECUR_AMD_DIST_EXCHANGE", "auto"),
+                    help="the exchange step of a sharded run: one RCCL all-reduce per generation, the library's "
+                         "kernel-issued reduce-scatter -> sharded update -> all-gather through peer pointers "
+                         "(rnn_amd_set_exchange_*; also with one rank), or auto (default): with more than one rank both "
+                         "are cross-checked and timed at the start and the kernel-issued form is taken only if its "
+                         "replicas are identical, its result equals RCCL's to rounding and it is faster; one rank: rccl")
+    ap.add_argument("--rank-timeout", type=float, default=float(os.environ.get("RECUR_BENCH_RANK_TIMEOUT", "1500")),
+                    help="--gpus N without a launcher: seconds of wall clock after which the parent ends every rank "
+                         "(the exact children it started) and exits 124")
     ap.add_argument("--all-cores-leg", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
 # ------------------------------------------------------------------ launcher --
 
-def spawn_ranks(n):
+def spawn_ranks(n, limit_s):
     """--gpus N with no launcher: start N ranks of this script (one per GPU) as child
-    processes, BEFORE this process touches a GPU, and relay rank 0's JSON line."""
+    processes, BEFORE this process touches a GPU, and relay rank 0's JSON line.  The parent
+    never touches a GPU: it only watches -- a rank that dies takes the others with it, and a
+    run that is still going after limit_s seconds of wall clock (a rank stuck in a collective,
+    a barrier nobody else reaches) is ended child by child, exit status 124."""
+    t_start = time.time()
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -95,12 +114,19 @@ def spawn_ranks(n):
         for r, p in enumerate(procs):
             if rcs[r] is None:
                 rcs[r] = p.poll()
-        if any(rc not in (None, 0) for rc in rcs):
-            time.sleep(2.0)
+        timed_out = time.time() - t_start > limit_s
+        if timed_out or any(rc not in (None, 0) for rc in rcs):
+            if timed_out:
+                sys.stderr.write("bench.py: %d ranks still running after %.0f s (--rank-timeout): ending them\n"
+                                 % (sum(rc is None for rc in rcs), limit_s))
+            else:
+                time.sleep(2.0)
             for r, p in enumerate(procs):
                 if p.poll() is None:
                     p.kill()  # this exact child
                 rcs[r] = p.wait()
+            if timed_out:
+                sys.exit(124)
             break
         time.sleep(0.05)
     out0.seek(0)
@@ -144,37 +170,172 @@ def exchange_id(amd, rank, world):
         os.unlink(path)
 
 
-def join_kernel_exchange(amd, handle, rank, world):
-    """--exchange kernel: every rank's 256-byte blob (IPC handles of its delta and weight arrays) and the 64 bytes of
-    arrival counters live in one file in /dev/shm that all ranks of the node map."""
+class HostGroup:
+    """The ranks of ONE node meeting in a 4 KB file in /dev/shm that all of them map: the kernel-issued exchange's arrival
+    counters and blobs, and -- host side only, nothing of the data path -- a barrier and an all-gather of 8-byte values
+    (checksums, times, decisions), so that what the JSON line says about the ranks does not itself depend on the
+    collective library it is checking.  Layout: [0, 64) the exchange's counters; [64, 128) one barrier word per rank;
+    [128, 192) "blob r is there"; [256, 256 + 8 x 256) blobs; [3072, 3072 + 8 x 8) the gather's slots."""
     B = 256
-    key = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("RECUR_BENCH_RUN_ID") or
-                     (os.getppid() if world > 1 else os.getpid()))
-    path = "/dev/shm/recur_amd_exchange_" + key
-    if rank == 0:
-        with open(path + ".tmp", "wb") as f:
-            f.write(b"\0" * 4096)
-        os.replace(path + ".tmp", path)
-    t0 = time.time()
-    while not (os.path.exists(path) and os.path.getmtime(path) > t0 - 300):
-        if time.time() - t0 > 300:
-            raise SystemExit("bench.py: rank %d never saw the exchange file" % rank)
-        time.sleep(0.02)
-    fd = os.open(path, os.O_RDWR)
-    mm = mmap.mmap(fd, 4096)  # [0, 64) counters; [256, 256 + 8 B) blobs; [3072 + r] "blob r is there"
-    blob = C.create_string_buffer(B)
-    amd.rnn_amd_set_exchange_export(handle, blob)
-    mm[256 + rank * B:256 + (rank + 1) * B] = blob.raw
-    mm[3072 + rank] = 1
-    while not all(mm[3072 + r] for r in range(world)):
-        if time.time() - t0 > 300:
-            raise SystemExit("bench.py: rank %d: not every rank exported its arrays" % rank)
-        time.sleep(0.01)
-    blobs = C.create_string_buffer(bytes(mm[256:256 + world * B]), world * B)
-    counters = (C.c_char * 64).from_buffer(mm, 0)
-    if amd.rnn_amd_set_exchange_join(handle, rank, world, blobs, counters, 0) != 0:
-        raise SystemExit("bench.py: rnn_amd_set_exchange_join failed on rank %d" % rank)
-    return path, mm, counters  # (kept alive by the caller; rank 0 unlinks the file at the end)
+
+    def __init__(self, rank, world, timeout_s=300.0):
+        import struct
+        self.struct = struct
+        self.rank, self.world, self.timeout_s = rank, world, timeout_s
+        key = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("RECUR_BENCH_RUN_ID") or
+                         (os.getppid() if world > 1 else os.getpid()))
+        self.path = "/dev/shm/recur_amd_bench_" + key
+        t0 = time.time()
+        if rank == 0:
+            with open(self.path + ".tmp", "wb") as f:
+                f.write(b"\0" * 4096)
+            os.replace(self.path + ".tmp", self.path)
+        while not (os.path.exists(self.path) and os.path.getmtime(self.path) > t0 - 300):
+            if time.time() - t0 > timeout_s:
+                raise SystemExit("bench.py: rank %d never saw the ranks' file %s" % (rank, self.path))
+            time.sleep(0.02)
+        self.fd = os.open(self.path, os.O_RDWR)
+        self.mm = mmap.mmap(self.fd, 4096)
+        self.seq = 0
+        self.counters = None
+
+    def barrier(self):
+        self.seq += 1
+        self.struct.pack_into("<I", self.mm, 64 + 4 * self.rank, self.seq)
+        t0 = time.time()
+        while True:
+            if all(self.struct.unpack_from("<I", self.mm, 64 + 4 * r)[0] >= self.seq for r in range(self.world)):
+                return
+            if time.time() - t0 > self.timeout_s:
+                raise SystemExit("bench.py: rank %d waited %.0f s at a host barrier: a rank is missing" % (self.rank, self.timeout_s))
+            time.sleep(0.0002)
+
+    def gather(self, value, fmt="<Q"):
+        """every rank's 8-byte value, in rank order, on every rank"""
+        self.struct.pack_into(fmt, self.mm, 3072 + 8 * self.rank, value)
+        self.barrier()
+        got = [self.struct.unpack_from(fmt, self.mm, 3072 + 8 * r)[0] for r in range(self.world)]
+        self.barrier()
+        return got
+
+    def join_kernel_exchange(self, amd, handle):
+        """every rank's 256-byte blob (IPC handles of its delta and weight arrays) to every rank, then the join on the
+        shared counters (which need no zeroing: the library counts on from where they stand)"""
+        B = self.B
+        blob = C.create_string_buffer(B)
+        amd.rnn_amd_set_exchange_export(handle, blob)
+        self.mm[256 + self.rank * B:256 + (self.rank + 1) * B] = blob.raw
+        self.barrier()
+        blobs = C.create_string_buffer(bytes(self.mm[256:256 + self.world * B]), self.world * B)
+        if self.counters is None:
+            self.counters = (C.c_char * 64).from_buffer(self.mm, 0)
+        rc_ = amd.rnn_amd_set_exchange_join(handle, self.rank, self.world, blobs, self.counters, 0)
+        ok = min(self.gather(1 if rc_ == 0 else 0))  # (also the rendezvous: nobody steps before everybody has joined)
+        return ok == 1
+
+    def close(self):
+        self.barrier()  # nobody maps the counters any more
+        self.counters = None
+        try:
+            self.mm.close()
+        except BufferError:
+            pass
+        os.close(self.fd)
+        if self.rank == 0 and os.path.exists(self.path):
+            os.unlink(self.path)
+
+
+def replica_checksums(amd, gpu, group, with_momentum):
+    """every rank's checksum of its replica, formed by a kernel (through the caches) and over a copy: lists in rank order"""
+    dev = amd.rnn_amd_set_replica_checksum(gpu.handle, int(with_momentum), 1)
+    host = amd.rnn_amd_set_replica_checksum(gpu.handle, int(with_momentum), 0)
+    if group is None:
+        return [dev], [host]
+    return group.gather(dev), group.gather(host)
+
+
+def select_exchange(amd, rc, gpu, group, rank, world, i, have_rccl, n_time=20):
+    """--exchange auto with more than one rank: ONE update through each exchange from the same local deltas and the same
+    weights, then n_time generations of each, timed.  The kernel-issued form is taken only if (1) after its update every
+    rank's replica is the same, read through the caches and over a copy -- that is the visibility of peers' stores that
+    include/recur_amd.h says is not established between devices --, (2) its weights are RCCL's to rounding (the two add
+    the ranks' sums in different orders), (3) it is faster.  Every rank decides from the same gathered numbers.
+    Returns (use_kernel, report, next i)."""
+    import numpy as np
+    W = rc.RNN_AMD_WEIGHTS | rc.RNN_AMD_MOMENTUMS | rc.RNN_AMD_DELTAS
+    rep = {"generations_timed": n_time}
+    net = gpu.net
+    n0, b0 = net.contents, net.contents.bptt.contents
+    views = lambda: {"ih_w": rc.view(n0.ih_weights, gpu.I, gpu.H), "ho_w": rc.view(n0.ho_weights, gpu.H, gpu.O),
+                     "ih_m": rc.view(b0.ih_momentum, gpu.I, gpu.H), "ho_m": rc.view(b0.ho_momentum, gpu.H, gpu.O),
+                     "ih_delta": rc.view(b0.ih_delta, gpu.I, gpu.H), "ho_delta": rc.view(b0.ho_delta, gpu.H, gpu.O)}
+
+    def restore(saved):
+        amd.rnn_amd_sync_host(net, W)
+        for k, v in views().items():
+            v[:] = saved[k]
+        amd.rnn_amd_host_written(net, W)
+
+    def timed(n, i):
+        amd.rnn_amd_synchronize()
+        group.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            amd.rnn_amd_set_char_step(gpu.handle, i, rc.WEIGHTED, MOMENTUM)
+            i += 1
+        amd.rnn_amd_synchronize()
+        group.barrier()
+        return max(group.gather(time.perf_counter() - t0, "<d")) / n * 1e6, i
+
+    # the local deltas of one generation, and the state they are applied to
+    amd.rnn_amd_set_char_step_deltas(gpu.handle, i)
+    i += 1
+    amd.rnn_amd_sync_host(net, W)
+    saved = {k: v.copy() for k, v in views().items()}
+    # -- the kernel-issued exchange
+    kernel_ok = group.join_kernel_exchange(amd, gpu.handle)
+    rep["kernel_join"] = bool(kernel_ok)
+    wk = None
+    if kernel_ok:
+        amd.rnn_amd_set_apply_exchange(gpu.handle, rc.WEIGHTED, MOMENTUM)
+        dev, host = replica_checksums(amd, gpu, group, False)
+        rep["kernel_replicas_identical"] = len(set(dev)) == 1 and dev == host
+        amd.rnn_amd_sync_host(net, rc.RNN_AMD_WEIGHTS)
+        wk = {k: views()[k].copy() for k in ("ih_w", "ho_w")}
+        rep["kernel_us_per_generation"], i = timed(n_time, i)
+        amd.rnn_amd_set_exchange_leave(gpu.handle)
+        group.barrier()
+    restore(saved)  # replicated weights, whole momentum arrays, the SAME local deltas
+    use_kernel = False
+    if have_rccl:
+        amd.rnn_amd_set_dist_all_reduce_deltas(gpu.handle)
+        amd.rnn_apply_learning(net, rc.WEIGHTED, MOMENTUM)
+        dev, host = replica_checksums(amd, gpu, group, True)
+        rep["rccl_replicas_identical"] = len(set(dev)) == 1 and dev == host
+        if wk is not None:
+            amd.rnn_amd_sync_host(net, rc.RNN_AMD_WEIGHTS)
+            err = max(float(np.abs(views()[k] - wk[k]).max() / max(np.abs(wk[k]).max(), 1e-30)) for k in wk)
+            rep["kernel_vs_rccl_max_err"] = max(group.gather(err, "<d"))
+        rep["rccl_us_per_generation"], i = timed(n_time, i)
+        use_kernel = bool(kernel_ok and rep["kernel_replicas_identical"] and rep["kernel_vs_rccl_max_err"] <= 1e-6 and
+                          rep["kernel_us_per_generation"] < rep["rccl_us_per_generation"])
+        rep["why"] = ("kernel-issued: replicas identical, RCCL's result to %.1e, %.1f against %.1f us per generation"
+                      % (rep["kernel_vs_rccl_max_err"], rep["kernel_us_per_generation"], rep["rccl_us_per_generation"])
+                      ) if use_kernel else (
+            "rccl: " + ("the peers' arrays could not be opened" if not kernel_ok else
+                        "the kernel-issued exchange left replicas that differ" if not rep["kernel_replicas_identical"] else
+                        "the kernel-issued update is %.1e from RCCL's" % rep["kernel_vs_rccl_max_err"]
+                        if rep["kernel_vs_rccl_max_err"] > 1e-6 else
+                        "%.1f us per generation against the kernel-issued %.1f" % (rep["rccl_us_per_generation"],
+                                                                                  rep["kernel_us_per_generation"])))
+    else:  # ranks that share a GPU (the one-GPU emulation): RCCL refuses duplicate devices
+        use_kernel = bool(kernel_ok and rep["kernel_replicas_identical"])
+        rep["why"] = "kernel-issued: the ranks share a GPU (no RCCL group); replicas identical: %s" % rep.get("kernel_replicas_identical")
+        if not use_kernel:
+            raise SystemExit("bench.py: ranks that share a GPU have only the kernel-issued exchange, and it failed: %r" % rep)
+    if min(group.gather(1 if use_kernel else 0)) != max(group.gather(1 if use_kernel else 0)):
+        raise SystemExit("bench.py: the ranks disagree about the exchange to use")
+    return use_kernel, rep, i
 
 
 # --------------------------------------------------------------- CPU baseline --
@@ -361,9 +522,12 @@ def cpu_all_cores(args, text):
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        spawn_ranks(args.gpus)
+        spawn_ranks(args.gpus, args.rank_timeout)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    hang = os.environ.get("RECUR_BENCH_TEST_HANG")
+    if "WORLD_SIZE" in os.environ and (hang == "all" or (hang == "1" and rank == world - 1)):
+        time.sleep(3600)  # (tests/test_dist_host.py: a rank that never arrives -- the parent's watchdog has to end the run)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import numpy as np
     from recur_amd import api as rc, drivers as sc  # the measured path's driver lives with the package
@@ -378,7 +542,7 @@ def main():
     # device has ramped to the clocks it holds under this load (measured: a 20-step timed region
     # right after 30 generations runs 2.4 % slower than after 300; sustained rate is the metric)
     prefill = max(D + 5, args.prefill)
-    total_steps = prefill + args.warmup + args.steps + 260
+    total_steps = prefill + args.warmup + args.steps + 400
     text = sc.synthetic_text_np(max(20000, S * world * 40 + total_steps + 16), ALPHABET, 7)
 
     if args.all_cores_leg:
@@ -389,36 +553,63 @@ def main():
 
     if args.dist and world == 1:  # (with one rank the library skips the exchange step unless told to keep it in)
         os.environ.setdefault("RECUR_AMD_DIST_ONE_RANK_EXCHANGE", "1")
+    if world > 1 and os.environ.get("RECUR_BENCH_SHARE_GPU", "0") == "1":
+        # ranks that share a GPU: two one-launch chains (256 workgroups each, one per CU, waiting for one another) cannot
+        # both be resident -- the emulation takes the launch-per-step chain (the library reads its switches once, at load)
+        os.environ.setdefault("RECUR_AMD_CHAIN_PERSIST", "0")
     amd = rc.load_amd()
     ndev = amd.rnn_amd_device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU (librecur_amd has no CPU fallback)")
+    # RECUR_BENCH_SHARE_GPU=1: every rank on device 0 -- the one-GPU emulation of a sharded run (tests/test_gpu_dist.py):
+    # no RCCL group (it refuses duplicate devices), the kernel-issued exchange between the processes, host-side bracket
+    share_gpu = world > 1 and os.environ.get("RECUR_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     if local_rank >= ndev:
         raise SystemExit("bench.py: rank %d of %d but only %d GPU(s) are visible" % (rank, world, ndev))
     amd.rnn_amd_use_device(local_rank, None)
-    dist = world > 1 or args.dist or os.environ.get("RECUR_BENCH_FORCE_DIST", "0") == "1"
+    dist = (world > 1 or args.dist or os.environ.get("RECUR_BENCH_FORCE_DIST", "0") == "1") and not share_gpu
     if dist:
         exchange_id(amd, rank, world)
         assert amd.rnn_amd_dist_world() == world and amd.rnn_amd_dist_rank() == rank
+    group = HostGroup(rank, world) if (world > 1 or args.exchange == "kernel") else None
 
     gpu = sc.AmdBatchedSet(amd, input_size=ALPHABET, hidden_size=Hd, output_size=ALPHABET, S=S,
                            D=D, learn_rate=LEARN_RATE, seed=1, momentum=MOMENTUM,
                            shard=(rank * S, world * S))
     gpu.load_text(text)
     amd.rnn_amd_set_shard(gpu.handle, rank * S, world * S)
-    xchg = None
-    if args.exchange == "kernel" and (dist or any(a.startswith("--exchange") for a in sys.argv)):
-        xchg = join_kernel_exchange(amd, gpu.handle, rank, world)
 
-    def step(i):  # deltas -> (all-reduce over ranks, inside the library) -> update
+    def step(i):  # deltas -> (the exchange between the ranks, inside the library) -> update
         amd.rnn_amd_set_char_step(gpu.handle, i, rc.WEIGHTED, MOMENTUM)
 
     def fence():
         amd.rnn_amd_synchronize()
-        amd.rnn_amd_dist_barrier()
+        if dist:
+            amd.rnn_amd_dist_barrier()
+        elif group is not None:
+            group.barrier()
         amd.rnn_amd_synchronize()
 
     i = 0
+    # which exchange (more than one rank): asked for, or cross-checked and timed here (select_exchange)
+    xchg, selection = False, None
+    if args.exchange == "kernel" and group is not None:
+        if not group.join_kernel_exchange(amd, gpu.handle):
+            raise SystemExit("bench.py: rnn_amd_set_exchange_join failed (rank %d)" % rank)
+        xchg = True
+    elif world > 1 and (args.exchange == "auto" or share_gpu):
+        for _ in range(D + 5):  # a full history ring first: the deltas that are cross-checked are a real generation's
+            step(i)
+            i += 1
+        fence()
+        use_kernel, selection, i = select_exchange(amd, rc, gpu, group, rank, world, i, have_rccl=dist)
+        if use_kernel:
+            if not group.join_kernel_exchange(amd, gpu.handle):
+                raise SystemExit("bench.py: the second rnn_amd_set_exchange_join failed (rank %d)" % rank)
+            xchg = True
+
     for _ in range(prefill + args.warmup):
         step(i)
         i += 1
@@ -432,7 +623,8 @@ def main():
         i += 1
     fence()
     elapsed = time.perf_counter() - t0
-    elapsed = amd.rnn_amd_dist_max(elapsed)  # max over ranks (identity for one rank)
+    # max over ranks (identity for one rank)
+    elapsed = amd.rnn_amd_dist_max(elapsed) if dist else max(group.gather(elapsed, "<d")) if group is not None else elapsed
     amd.rnn_amd_set_read_stats(gpu.handle, C.byref(st), 1)
     mean_depth = st.bptt_depth_sum / max(st.count, 1)
     zero_frac = st.hidden_zeros / max(st.count, 1)
@@ -441,6 +633,7 @@ def main():
     # roofline leg: HIP events around the GEMM launches, on the launch stream, over a further
     # short run of the same loop (kept out of the timed region: the event records cost time)
     roofline = None
+    exchange_us = 0.0 if world == 1 and not (dist or xchg) else None
     if not args.no_roofline:
         I, H = gpu.I, gpu.H
         amd.rnn_amd_kernel_time_enable(1)
@@ -457,6 +650,8 @@ def main():
             n = C.c_long(0)
             ms = amd.rnn_amd_kernel_time_ms(which, C.byref(n), 0)
             cls[name] = (ms, n.value)
+        n_x = C.c_long(0)
+        exchange_us = 1e3 * amd.rnn_amd_kernel_time_ms(5, C.byref(n_x), 0) / n_roof  # (class 5: include/recur_amd.h)
         amd.rnn_amd_kernel_time_ms(0, None, 1)
         amd.rnn_amd_set_read_stats(gpu.handle, C.byref(st), 1)
         d_exec = st.bptt_depth_sum / max(st.count, 1)
@@ -531,6 +726,19 @@ def main():
         gen["achieved"] = gen["flop"] / (elapsed / args.steps) / 1e12
         gen["frac"] = gen["achieved"] / PEAK_FP32_MFMA_TFLOPS
 
+    # the replicas after the timed region and the roofline leg (behind both: the copies and the host's sum would let the
+    # device's clocks drop in front of the leg's 50 generations): every rank's checksum of its weights (and momentum, where every rank holds
+    # all of it: the kernel-issued exchange keeps a range's momentum on its owner), read by a kernel and over a copy
+    if os.environ.get("RECUR_BENCH_INJECT_FAULT") == "replica" and rank == world - 1:
+        # (tests: one weight of the last rank's replica moves by one ulp -- the run must say so and fail)
+        import numpy as np
+        amd.rnn_amd_sync_host(gpu.net, rc.RNN_AMD_WEIGHTS)
+        w = rc.view(gpu.net.contents.ih_weights, gpu.I, gpu.H)
+        w[5, 5] = np.nextafter(w[5, 5], np.float32(2.0))
+        amd.rnn_amd_host_written(gpu.net, rc.RNN_AMD_WEIGHTS)
+    cks_dev, cks_host = replica_checksums(amd, gpu, group if world > 1 else None, with_momentum=not xchg)
+    replicas_identical = len(set(cks_dev)) == 1 and cks_dev == cks_host
+
     out = {
         "metric": "BPTT timesteps*streams/sec at 1024-hidden/256-stream",
         "value": args.steps * S * world / elapsed,
@@ -553,6 +761,9 @@ def main():
                            ("streams sharded x%d, one RCCL all-reduce of the weight deltas per generation "
                             "(in librecur_amd)" % world) if dist else "single GPU",
             "rccl_ranks": amd.rnn_amd_dist_world() if dist else 0,
+            "exchange": "kernel-issued" if xchg else "rccl" if dist else "none",
+            "exchange_selection": selection,
+            "ranks_share_one_gpu": share_gpu,
             "untimed_prefill_generations": prefill,
             "mean_bptt_depth": mean_depth, "hidden_zero_fraction": zero_frac,
             "training_entropy_bits": t_entropy,
@@ -562,6 +773,17 @@ def main():
             "parity_bar": {"rtol": 1e-4, "elementwise_floor_of_max": 1e-2, "elementwise_floor_hot_regime": 1e-1},
         },
     }
+    if selection:
+        out["config"]["parallelism"] += " -- chosen at start-up (--exchange auto): " + selection["why"]
+    # a sharded run says of itself whether it was one: the group RCCL reports, the replicas after the timed region
+    # (bit-identical by construction on both exchange paths), what the exchange step cost a rank per generation
+    out["replicas_identical"] = replicas_identical
+    out["replica_checksums"] = ["%016x" % c for c in cks_dev]
+    out["replica_checksums_over_a_copy"] = ["%016x" % c for c in cks_host]
+    out["replica_checksum_of"] = "ih_weights||ho_weights" + ("" if xchg else "||ih_momentum||ho_momentum")
+    out["exchange_us"] = exchange_us
+    if world > 1 and not share_gpu and out["config"]["rccl_ranks"] != world:
+        raise SystemExit("bench.py: %d ranks but the RCCL group has %d" % (world, out["config"]["rccl_ranks"]))
     if roofline is not None:
         out["roofline"] = roofline
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -589,12 +811,8 @@ def main():
         out["cpu_baseline"] = base
     if xchg:
         amd.rnn_amd_set_exchange_leave(gpu.handle)
-        if dist:
-            amd.rnn_amd_dist_barrier()  # (every rank has left: nobody maps the file any more)
-        path, mm, counters = xchg
-        del counters
-        if rank == 0 and os.path.exists(path):
-            os.unlink(path)
+    if group is not None:
+        group.close()  # (a barrier first: every rank has left, nobody maps the counters any more)
     if dist:
         amd.rnn_amd_dist_barrier()
         amd.rnn_amd_dist_finalize()
@@ -604,6 +822,11 @@ def main():
         sys.stdout.flush()
         C.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
+    if not replicas_identical:
+        sys.stderr.write("bench.py: the ranks' replicas DIFFER after the timed region (checksums through a kernel %s, over "
+                         "a copy %s): the number above is not a valid measurement\n" % (out["replica_checksums"],
+                                                                                      out["replica_checksums_over_a_copy"]))
+        sys.exit(3)
 
 
 if __name__ == "__main__":

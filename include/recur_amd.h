@@ -534,10 +534,11 @@ int rnn_amd_dist_world(void); /* 1 when no group is joined */
  *      handles; same-process peers are recognised and take the plain pointers);
  *   2. the launcher hands every blob to every rank (a file, shared memory, a pipe) and provides `counters`: 64 bytes
  *      of zeroed host memory that ALL ranks have mapped (MAP_SHARED memory made before fork, or a file in /dev/shm);
- *      ZEROED AGAIN before every join -- the barriers count from 0, and on counters left from an earlier session the
- *      first ones would pass at once -- and no rank steps before every rank has joined (the launcher's rendezvous);
- *   3. each rank: rnn_amd_set_exchange_join(set, rank, world, blobs, counters, 0); from then on
- *      rnn_amd_set_char_step runs deltas -> barrier -> sharded update -> barrier.
+ *      they need no zeroing between sessions (round 6): the barriers count on from where words 0 .. 7 stand at the
+ *      join, words 8 .. 15 carry the join's own rendezvous, named by a token made of the session's blobs;
+ *   3. each rank: rnn_amd_set_exchange_join(set, rank, world, blobs, counters, 0) -- COLLECTIVE: it returns when every
+ *      rank of the session has called it (RECUR_AMD_XCHG_JOIN_TIMEOUT seconds at most, default 120: -1 then); from then
+ *      on rnn_amd_set_char_step runs deltas -> barrier -> sharded update -> barrier.
  * lockstep != 0: the ranks are sets of ONE process driven by one thread (counters may be NULL): no barriers are
  * launched, the caller gives the order -- rnn_amd_set_char_step_deltas on every rank, then
  * rnn_amd_set_apply_exchange on every rank.  After a step ih_delta || ho_delta hold the sum over the ranks in the
@@ -547,6 +548,14 @@ int rnn_amd_dist_world(void); /* 1 when no group is joined */
  * different devices that has not run yet.
  * Returns 0, or -1 with a message (a peer's arrays cannot be opened, bad arguments). */
 #define RNN_AMD_EXCHANGE_BLOB_BYTES 256
+/* A 64-bit checksum of this rank's replica: sum over the 32-bit words of ih_weights || ho_weights (with_momentum: ||
+ * ih_momentum || ho_momentum) of word_i * (2 i + 1) mod 2^64.  through_kernel != 0: formed by a kernel on the library's
+ * stream, i.e. through the caches the path's own kernels read the arrays through; 0: over a device-to-host copy.  The
+ * replicas of a sharded run are bit-identical (RCCL: every rank adds the same sum; kernel-issued: every range has one
+ * owner), so a launcher compares the ranks' values after a run -- and the two readings of ONE rank, which differ only
+ * if a peer's stores did not reach what this rank's kernels see (bench.py does both and exits non-zero).  In the
+ * kernel-issued exchange momentum lives in the owner's range only: compare weights there.  Synchronises. */
+uint64_t rnn_amd_set_replica_checksum(RnnAmdSet *set, int with_momentum, int through_kernel);
 void rnn_amd_set_exchange_export(RnnAmdSet *set, void *blob);
 int rnn_amd_set_exchange_join(RnnAmdSet *set, int rank, int world, const void *blobs, void *counters, int lockstep);
 void rnn_amd_set_exchange_leave(RnnAmdSet *set);
@@ -603,7 +612,9 @@ void rnn_amd_synchronize(void);
 
 /* Timing hook for bench.py: HIP-event time (ms) accumulated over the dominant
  * kernel class since the last reset, and the number of launches.
- * which: 0 = BPTT chain GEMM, 1 = delta GEMM, 2 = forward GEMM, 3 = optimiser. */
+ * which: 0 = BPTT chain GEMM, 1 = delta GEMM, 2 = forward GEMM, 3 = optimiser, 4 = other launches,
+ * 5 = the exchange step between ranks (the RCCL all-reduce of a generation, or the kernel-issued exchange's two
+ * arrivals and sharded update: what a rank waits and works for between its deltas and its next forward pass). */
 void rnn_amd_kernel_time_enable(int enable);
 double rnn_amd_kernel_time_ms(int which, long *launches, int reset);
 

@@ -226,6 +226,7 @@ AMD_API = {
     "rnn_amd_set_exchange_leave": (None, [C.c_void_p]),
     "rnn_amd_set_apply_exchange": (None, [C.c_void_p, C.c_int, C.c_float]),
     "rnn_amd_set_exchange_range": (None, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "rnn_amd_set_replica_checksum": (C.c_uint64, [C.c_void_p, C.c_int, C.c_int]),
     "rnn_amd_set_char_step_fused": (None, [C.c_void_p, C.c_int, C.c_uint]),
     "rnn_amd_set_read_stats": (None, [C.c_void_p, C.POINTER(AmdStats), C.c_int]),
     "rnn_amd_set_external_delta": (None, [C.c_void_p, C.c_void_p]),

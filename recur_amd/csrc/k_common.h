@@ -365,7 +365,7 @@ constexpr int W_STAGE_FLOATS = (WM + WN) * WK; /* 32 KB */
 
 // ---- launch-side support (kernels_support.hip) ----
 // HIP-event timing of the kernel classes (bench.py's roofline leg)
-enum { T_CHAIN = 0, T_DELTA = 1, T_FWD = 2, T_APPLY = 3, T_OTHER = 4, T_CLASSES = 5 };
+enum { T_CHAIN = 0, T_DELTA = 1, T_FWD = 2, T_APPLY = 3, T_OTHER = 4, T_XCHG = 5, T_CLASSES = 6 }; /* (T_XCHG = RAMD_T_XCHG: the exchange between ranks, bracketed by rnn_core.c) */
 #define RAMD_LOCAL __attribute__((visibility("hidden"))) /* shared by the kernel files, not exported */
 RAMD_LOCAL int timing_begin(hipStream_t st, int cls, int count = 1);
 RAMD_LOCAL void timing_end(hipStream_t st, int i);

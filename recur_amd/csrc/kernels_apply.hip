@@ -429,6 +429,43 @@ extern "C" void ramd_launch_apply_xchg(ramd_stream_t st_, int method, int rank, 
   timing_end(st, ev);
 }
 
+// A replica's checksum, formed ON THE DEVICE through the loads every kernel of the path uses (L2, the per-XCD
+// caches): sum over the 32-bit words of `n_arrays` arrays in a row of word_i * (2 i + 1) mod 2^64, i counted through
+// the row -- independent of the order of summation (atomics), sensitive to position.  Beside the same sum over a
+// device-to-host COPY of the arrays (rnn_core.c: rnn_amd_set_replica_checksum) it is what tells a launcher that what
+// peers stored into this rank's arrays is what this rank's kernels read.
+struct CksumArgs {
+  const unsigned *a[4];
+  unsigned long long n[4], first[4]; /* words, index of the array's first word in the row */
+  int n_arrays;
+};
+__global__ __launch_bounds__(256) void k_replica_checksum(CksumArgs c, unsigned long long *out) {
+  unsigned long long acc = 0;
+  for (int k = 0; k < c.n_arrays; k++) {
+    const unsigned *a = c.a[k];
+    const unsigned long long n = c.n[k], f = c.first[k];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256)
+      acc += (unsigned long long)a[i] * (2 * (f + i) + 1);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+extern "C" void ramd_launch_replica_checksum(ramd_stream_t st, int n_arrays, const float *const *arrays, const size_t *n_floats,
+                                             unsigned long long *out_dev) {
+  CksumArgs c = {};
+  unsigned long long first = 0;
+  c.n_arrays = n_arrays < 4 ? n_arrays : 4;
+  for (int k = 0; k < c.n_arrays; k++) {
+    c.a[k] = reinterpret_cast<const unsigned *>(arrays[k]);
+    c.n[k] = n_floats[k];
+    c.first[k] = first;
+    first += n_floats[k];
+  }
+  HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(unsigned long long), (hipStream_t)st));
+  RAMD_LAUNCH(k_replica_checksum, dim3(512), dim3(256), 0, (hipStream_t)st, c, out_dev);
+}
+
 extern "C" void ramd_launch_apply(ramd_stream_t st_, int method, float *w, const float *delta,
                                   float *m, float *aux, size_t n, float rate, float momentum,
                                   float mw, const float *rs) {

@@ -38,8 +38,12 @@ static void timing_collect() {
   g_nev = 0;
 }
 extern "C" void ramd_timing_enable(int enable) { g_timing = enable; }
+/* the same bracket for the host code (rnn_core.c: the exchange step between ranks, class RAMD_T_XCHG) */
+extern "C" int ramd_timing_begin(ramd_stream_t st, int cls) { return timing_begin((hipStream_t)st, cls, 1); }
+extern "C" void ramd_timing_end(ramd_stream_t st, int i) { timing_end((hipStream_t)st, i); }
 extern "C" double ramd_timing_ms(int which, long *launches, int reset) {
   timing_collect();
+  if (which < 0 || which >= T_CLASSES) return 0.0;
   double ms = g_ms[which];
   if (launches) *launches = g_launches[which];
   if (reset) {

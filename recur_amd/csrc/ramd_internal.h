@@ -269,6 +269,9 @@ void ramd_launch_apply_multi(ramd_stream_t st, int method, int nseg, float *cons
                              float momentum_weight, const float *rate_scale_dev,
                              const RamdPendingDelta *pend);
 /* the exchange step as kernel-issued peer traffic (kernels_apply.hip: k_apply_xchg, k_xchg_barrier) */
+/* sum of word_i * (2 i + 1) mod 2^64 over the arrays in a row, on the device (kernels_apply.hip: k_replica_checksum) */
+void ramd_launch_replica_checksum(ramd_stream_t st, int n_arrays, const float *const *arrays, const size_t *n_floats,
+                                  unsigned long long *out_dev);
 void ramd_launch_xchg_barrier(ramd_stream_t st, unsigned *flags_dev, int rank, int world, unsigned seq,
                               unsigned *abort_word_dev);
 void ramd_launch_apply_xchg(ramd_stream_t st, int method, int rank, int world, float *const *w,
@@ -295,6 +298,9 @@ void ramd_note_side_stream(void);
 /* ---- timing hooks ---- */
 void ramd_timing_enable(int enable);
 double ramd_timing_ms(int which, long *launches, int reset);
+#define RAMD_T_XCHG 5 /* rnn_amd_kernel_time_ms(5, ..): the exchange step between ranks, per generation */
+int ramd_timing_begin(ramd_stream_t st, int cls); /* HIP events on st around what follows, when timing is on (else -1) */
+void ramd_timing_end(ramd_stream_t st, int i);
 
 #ifdef __cplusplus
 }

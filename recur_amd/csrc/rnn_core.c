@@ -13,6 +13,7 @@
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <unistd.h>
+#include <time.h>
 
 #define HIP_OK(x)                                                                  \
   do {                                                                             \
@@ -1996,7 +1997,9 @@ void rnn_amd_set_dist_all_reduce_deltas(RnnAmdSet *set) {
   }
   engine_need_dev(e, RNN_AMD_DELTAS);
   /* ih_delta||ho_delta are one allocation (library-owned or the caller's external buffer) */
+  const int tev = ramd_timing_begin(g_stream, RAMD_T_XCHG);
   rnn_amd_dist_all_reduce(e->b.ih_delta, e->ih_size + e->ho_size);
+  ramd_timing_end(g_stream, tev);
   engine_dev_wrote(e, RNN_AMD_DELTAS);
 }
 
@@ -2845,6 +2848,7 @@ static void delta_half_ready(void *ctx, int half, size_t first_float, size_t n_f
 /* ---- the exchange step as kernel-issued peer traffic (include/recur_amd.h; kernels_apply.hip: k_apply_xchg) ---- */
 typedef struct XchgBlob {
   uint64_t pid;
+  uint64_t nonce;     /* of this export: the ranks' blobs together name the session (xchg_session_token) */
   uint64_t raw[3];    /* delta, ih_w, ho_w as this process sees them                        */
   uint64_t offset[3]; /* of each inside its allocation (IPC handles name whole allocations) */
   hipIpcMemHandle_t handle[3];
@@ -2858,6 +2862,12 @@ void rnn_amd_set_exchange_export(RnnAmdSet *set, void *blob) {
   XchgBlob b;
   memset(&b, 0, sizeof(b));
   b.pid = (uint64_t)getpid();
+  {
+    static uint64_t exports = 0;
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    b.nonce = ((uint64_t)ts.tv_sec << 30) ^ (uint64_t)ts.tv_nsec ^ (++exports << 48);
+  }
   void *arrays[3] = {e->b.ih_delta, e->b.ih_w, e->b.ho_w};
   for (int k = 0; k < 3; k++) {
     hipDeviceptr_t base = NULL;
@@ -2894,6 +2904,59 @@ void rnn_amd_set_exchange_leave(RnnAmdSet *set) {
   e->xchg_flags_host = NULL;
   e->xchg_flags_dev = NULL;
   e->xchg_world = 0;
+}
+
+/* The session's name: every rank holds the same `world` blobs in the same order, every export has its own nonce -- a
+ * 32-bit hash of them all is the same on every rank and new for every session.  Even and not 0: T = arrived, T | 1 = has
+ * read the counters. */
+static unsigned xchg_session_token(const void *blobs, int world) {
+  unsigned h = 2166136261u; /* FNV-1a */
+  const unsigned char *p = blobs;
+  for (size_t i = 0; i < (size_t)world * RNN_AMD_EXCHANGE_BLOB_BYTES; i++) {
+    h = (h ^ p[i]) * 16777619u;
+  }
+  h &= ~1u;
+  return h ? h : 2u;
+}
+
+/* The join is COLLECTIVE between processes: a rendezvous on the host in words 8 .. 15 of the shared counters (the
+ * barrier kernels count in words 0 .. 7).  Phase 1: everybody has arrived in THIS session (stale words of an earlier
+ * one do not match its token); then every rank reads where the barrier counters stand; phase 2: everybody has read them
+ * -- only then may anyone step and move them.  Bounded: RECUR_AMD_XCHG_JOIN_TIMEOUT seconds (default 120). */
+static int xchg_rendezvous(unsigned *c, int rank, int world, unsigned token, unsigned *top_out) {
+  const char *te = getenv("RECUR_AMD_XCHG_JOIN_TIMEOUT");
+  double limit = te && atof(te) > 0 ? atof(te) : 120.0;
+  struct timespec t0, t;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int phase = 0; phase < 2; phase++) {
+    if (phase == 1) {
+      unsigned top = __atomic_load_n(&c[0], __ATOMIC_ACQUIRE);
+      for (int p = 1; p < world; p++) {
+        const unsigned v = __atomic_load_n(&c[p], __ATOMIC_ACQUIRE);
+        if ((int)(v - top) > 0) {
+          top = v;
+        }
+      }
+      *top_out = top;
+    }
+    __atomic_store_n(&c[8 + rank], token | (unsigned)phase, __ATOMIC_RELEASE);
+    for (int p = 0; p < world; p++) {
+      for (;;) {
+        const unsigned v = __atomic_load_n(&c[8 + p], __ATOMIC_ACQUIRE);
+        if (v == (token | 1u) || (phase == 0 && v == token)) {
+          break;
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        if ((t.tv_sec - t0.tv_sec) + 1e-9 * (t.tv_nsec - t0.tv_nsec) > limit) {
+          fprintf(stderr, "librecur_amd: rnn_amd_set_exchange_join: rank %d has waited %.0f s for rank %d to join (every "
+                          "rank calls the join, with the same blobs and counters that all of them map)\n", rank, limit, p);
+          return -1;
+        }
+        usleep(50);
+      }
+    }
+  }
+  return 0;
 }
 
 int rnn_amd_set_exchange_join(RnnAmdSet *set, int rank, int world, const void *blobs, void *counters, int lockstep) {
@@ -2949,10 +3012,57 @@ int rnn_amd_set_exchange_join(RnnAmdSet *set, int rank, int world, const void *b
   e->xchg_world = world;
   e->xchg_rank = rank;
   e->xchg_lockstep = lockstep;
-  /* (the barriers count from 0: the launcher zeroes the shared counters before EVERY join -- a group that re-joins on
-   * counters left from an earlier session would see its first barriers pass at once; include/recur_amd.h says so) */
+  /* The barriers count on from where the shared counters stand (round 6; they counted from 0 and trusted the launcher to
+   * have zeroed them: on counters left from an earlier session the first barriers would have passed at once).  Every
+   * rank reads the same `world` words -- between the two phases of the rendezvous, when nobody can be stepping -- and
+   * takes the same start: the furthest of them, compared as the barrier compares (wrap-safe). */
   e->xchg_seq = 0;
+  if (!lockstep) {
+    unsigned top = 0;
+    if (xchg_rendezvous(counters, rank, world, xchg_session_token(blobs, world), &top) != 0) {
+      rnn_amd_set_exchange_leave(set);
+      return -1;
+    }
+    e->xchg_seq = top;
+  }
   return 0;
+}
+
+/* A 64-bit checksum of this replica -- ih_weights || ho_weights (|| ih_momentum || ho_momentum) -- for launchers that
+ * want to KNOW that the ranks' replicas stayed identical (include/recur_amd.h).  through_kernel: summed by a kernel on
+ * the library's stream, through the caches the path's kernels read through; otherwise over a device-to-host copy (the
+ * copy engine reads memory).  The two agree unless something stored into the arrays behind the caches' back. */
+uint64_t rnn_amd_set_replica_checksum(RnnAmdSet *set, int with_momentum, int through_kernel) {
+  RamdEngine *e = set->eng;
+  engine_need_dev(e, RNN_AMD_WEIGHTS | (with_momentum ? RNN_AMD_MOMENTUMS : 0));
+  const float *arrays[4] = {e->b.ih_w, e->b.ho_w, e->b.ih_m, e->b.ho_m};
+  const size_t n[4] = {e->ih_size, e->ho_size, e->ih_size, e->ho_size};
+  const int n_arrays = with_momentum ? 4 : 2;
+  uint64_t sum = 0;
+  if (through_kernel) {
+    unsigned long long *d = dev_alloc(sizeof(*d));
+    ramd_launch_replica_checksum(g_stream, n_arrays, arrays, n, d);
+    d2h(&sum, d, sizeof(sum));
+    dsync();
+    dev_free(d);
+    return sum;
+  }
+  uint64_t first = 0;
+  for (int k = 0; k < n_arrays; k++) {
+    uint32_t *h = malloc(n[k] * sizeof(uint32_t));
+    if (!h) {
+      fprintf(stderr, "librecur_amd: rnn_amd_set_replica_checksum: out of memory\n");
+      abort();
+    }
+    d2h(h, arrays[k], n[k] * sizeof(uint32_t));
+    dsync();
+    for (size_t i = 0; i < n[k]; i++) {
+      sum += (uint64_t)h[i] * (2 * (first + i) + 1);
+    }
+    first += n[k];
+    free(h);
+  }
+  return sum;
 }
 
 void rnn_amd_set_exchange_range(const RnnAmdSet *set, int which, size_t *first, size_t *count) {
@@ -3006,9 +3116,11 @@ void rnn_amd_set_apply_exchange(RnnAmdSet *set, int learning_style, float moment
   float *m[2] = {e->b.ho_m, e->b.ih_m}, *aux[2] = {e->b.ho_aux, e->b.ih_aux}, *dout[2] = {e->b.ho_delta, e->b.ih_delta};
   size_t n[2] = {e->ho_size, e->ih_size};
   float rate[2] = {bptt->learn_rate * bptt->ho_scale, bptt->learn_rate};
+  const int tev = ramd_timing_begin(g_stream, RAMD_T_XCHG); /* (the two arrivals and the sharded update: what a rank waits and works for) */
   xchg_barrier(e); /* every rank's local sums are complete (and nobody still multiplies with the old weights) */
   ramd_launch_apply_xchg(g_stream, method, e->xchg_rank, W, w, d, m, aux, dout, n, rate, momentum, mw);
   xchg_barrier(e); /* every range of the weights has arrived here */
+  ramd_timing_end(g_stream, tev);
   engine_dev_wrote(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
 }
 
@@ -3088,7 +3200,9 @@ static void set_step(RnnAmdSet *set, const StepSpec *sp, int learning_style, flo
       HIP_OK(hipStreamWaitEvent(g_stream, g_half_summed[0], 0));
       HIP_OK(hipStreamWaitEvent(g_stream, g_half_summed[1], 0));
     } else { /* a shape the two-halves form does not take: one all-reduce behind the deltas */
+      const int tev = ramd_timing_begin(g_stream, RAMD_T_XCHG);
       rnn_amd_dist_all_reduce(set->eng->b.ih_delta, set->eng->ih_size + set->eng->ho_size);
+      ramd_timing_end(g_stream, tev);
     }
   }
   apply_learning(set->nets[0], learning_style, momentum, (pend.slab || pend.ho_slab) ? &pend : NULL);

@@ -82,3 +82,59 @@ def test_bench_gpus_n_spawns_n_ranks_and_propagates_failure():
     assert r.returncode != 0
     assert r.stderr.count("needs a GPU") == 2 and "ranks failed" in r.stderr
     assert "stream-timesteps" not in r.stdout
+
+
+# ---- bench.py's launcher side (round 6): the parent's watchdog, the ranks' host-side meeting place
+
+def test_bench_parent_ends_a_run_that_hangs():
+    """bench.py --gpus N without a launcher starts the ranks itself; ranks that never finish (stuck in a collective, a
+    barrier nobody else reaches) are ended by the parent -- the exact children it started -- after --rank-timeout
+    seconds, exit status 124.  RECUR_BENCH_TEST_HANG=all makes every rank sleep before it touches anything."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rank-timeout", "2"],
+                       env=dict(os.environ, RECUR_BENCH_TEST_HANG="all"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 124, (r.returncode, r.stderr[-1000:])
+    assert "ending them" in r.stderr and time.time() - t0 < 60
+    assert r.stdout.strip() == ""  # no JSON line from a run that did not finish
+
+
+GROUP_SCRIPT = r"""
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import bench
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+g = bench.HostGroup(rank, world, timeout_s=60.0)
+got = []
+for k in range(50):
+    got.append(g.gather(1000 * k + rank))
+d = g.gather(0.5 + rank, "<d")
+g.barrier()
+g.close()
+print("RESULT " + json.dumps({"got": got, "d": d}))
+"""
+
+
+def test_bench_host_group_gathers_in_rank_order():
+    """bench.HostGroup: the ranks of one node meet in a file in /dev/shm -- a barrier and an all-gather of 8-byte values on
+    the HOST, so that what the JSON line says about the ranks (checksums, times, which exchange) does not depend on the
+    collective library it checks.  Three processes, fifty gathers: everybody sees everybody's value of that round."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT="0", RECUR_BENCH_RUN_ID="hostgroup_test_%d" % os.getpid())
+    procs = [subprocess.Popen([sys.executable, "-c", GROUP_SCRIPT % {"root": root}, str(r), "3"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "RESULT " in so, so[-500:] + se[-1500:]
+        res = json.loads(so.split("RESULT ", 1)[1])
+        assert res["got"] == [[1000 * k + r for r in range(3)] for k in range(50)]
+        assert res["d"] == [0.5, 1.5, 2.5]
+    assert not os.path.exists("/dev/shm/recur_amd_bench_0_hostgroup_test_%d" % os.getpid())

@@ -13,6 +13,7 @@
 The sum being distributed is recur-nn.c:724-739 over the sharing of recur-nn-init.c:232-241.
 """
 import ctypes as C
+import json
 import os
 import subprocess
 import sys
@@ -398,3 +399,118 @@ def test_c_driver_with_G_1_goes_through_the_library_exchange_step():
         assert [int(x[0]) for x in rows[tag]] == [50, 100, 150]
     for a, b in zip(rows["plain"], rows["G1"]):
         assert abs(float(a[1]) - float(b[1])) < 2e-4 and abs(float(a[2]) - float(b[2])) < 2e-3, (a, b)
+
+
+# ---- bench.py with more than one rank validates itself (round 6; the sum replaced is recur-nn.c:724-739)
+
+def _bench(args, env_extra, timeout=900):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_with_two_ranks_says_of_itself_whether_it_was_a_sharded_run():
+    """`bench.py --gpus 2` as the driver would start it, the two ranks sharing this box's one GPU (RECUR_BENCH_SHARE_GPU=1:
+    no RCCL group -- it refuses duplicate devices --, the kernel-issued exchange between the two processes): the start-up
+    cross-check runs (one update through the exchange, replicas compared through a kernel's loads and over a copy), the
+    JSON line carries every rank's checksum, replicas_identical, exchange_us and which exchange ran and why."""
+    r, out = _bench(["--gpus", "2", "--steps", "10", "--warmup", "2", "--prefill", "30", "--streams", "64",
+                     "--no-cpu-baseline"], {"RECUR_BENCH_SHARE_GPU": "1"})
+    assert r.returncode == 0 and out, r.stdout[-2000:] + r.stderr[-3000:]
+    assert out["n_gpus"] == 2 and out["config"]["global_streams"] == 128
+    assert out["replicas_identical"] is True
+    assert len(out["replica_checksums"]) == 2 and len(set(out["replica_checksums"])) == 1
+    assert out["replica_checksums"] == out["replica_checksums_over_a_copy"]
+    assert out["exchange_us"] > 0 and out["config"]["exchange"] == "kernel-issued"
+    sel = out["config"]["exchange_selection"]
+    assert sel["kernel_join"] and sel["kernel_replicas_identical"] and sel["kernel_us_per_generation"] > 0
+    assert out["config"]["ranks_share_one_gpu"] is True and out["config"]["rccl_ranks"] == 0
+    assert "chosen at start-up" in out["config"]["parallelism"]
+    assert out["value"] > 0 and abs(out["value"] - 10 * 128 / (out["ms_per_step"] * 1e-3 * 10)) < 1e-6 * out["value"]
+
+
+def test_bench_fails_when_the_replicas_differ():
+    """The same run with ONE weight of the last rank's replica moved by one ulp after the timed region
+    (RECUR_BENCH_INJECT_FAULT=replica): replicas_identical is false, the ranks' checksums differ, exit status 3."""
+    r, out = _bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--prefill", "25", "--streams", "32",
+                     "--no-cpu-baseline", "--no-roofline"], {"RECUR_BENCH_SHARE_GPU": "1", "RECUR_BENCH_INJECT_FAULT": "replica"})
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert out and out["replicas_identical"] is False and len(set(out["replica_checksums"])) == 2
+    assert "DIFFER" in r.stderr
+
+
+def test_replica_checksum_through_a_kernel_and_over_a_copy(amd):
+    """rnn_amd_set_replica_checksum: sum of word_i (2 i + 1) mod 2^64 over ih_weights || ho_weights (|| the momentum
+    arrays), by a kernel and over a copy -- equal to each other and to numpy's over a snapshot, and it moves when one
+    weight moves by one ulp."""
+    g = sc.AmdBatchedSet(amd, input_size=42, hidden_size=128, output_size=42, S=16, D=5, learn_rate=1e-3, seed=4)
+    text = sc.synthetic_text(3000)
+    for i in range(7):
+        g.char_step(text, i, rc.WEIGHTED, 0.9)
+    s = g.snapshot()
+
+    def want(keys):
+        words = np.concatenate([s[k].reshape(-1).view(np.uint32) for k in keys]).astype(np.uint64)
+        idx = np.arange(words.size, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            return int((words * (np.uint64(2) * idx + np.uint64(1))).sum(dtype=np.uint64))
+
+    for with_m, keys in ((0, ("ih_w", "ho_w")), (1, ("ih_w", "ho_w", "ih_m", "ho_m"))):
+        dev = amd.rnn_amd_set_replica_checksum(g.handle, with_m, 1)
+        host = amd.rnn_amd_set_replica_checksum(g.handle, with_m, 0)
+        assert dev == host == want(keys), (with_m, hex(dev), hex(host), hex(want(keys)))
+    before = amd.rnn_amd_set_replica_checksum(g.handle, 0, 1)
+    amd.rnn_amd_sync_host(g.net, rc.RNN_AMD_WEIGHTS)
+    w = rc.view(g.net.contents.ho_weights, g.H, g.O)
+    w[3, 2] = np.nextafter(w[3, 2], np.float32(9.0))
+    amd.rnn_amd_host_written(g.net, rc.RNN_AMD_WEIGHTS)
+    assert amd.rnn_amd_set_replica_checksum(g.handle, 0, 1) != before
+    g.close()
+
+
+REJOIN_SCRIPT = r"""
+import ctypes as C, sys
+sys.path.insert(0, %(tests)r)
+import numpy as np, recur_ctypes as rc, scenarios as sc
+amd = rc.load_amd()
+amd.rnn_amd_use_device(0, None)
+kw = dict(input_size=42, hidden_size=64, output_size=42, S=16, D=5, learn_rate=1e-3, seed=8)
+text = sc.synthetic_text(3000)
+g = sc.AmdBatchedSet(amd, **kw)
+g.load_text(text)
+counters = (C.c_uint32 * 16)()
+blob = C.create_string_buffer(rc.RNN_AMD_EXCHANGE_BLOB_BYTES)
+i = 0
+for session in range(2):
+    amd.rnn_amd_set_exchange_export(g.handle, blob)
+    assert amd.rnn_amd_set_exchange_join(g.handle, 0, 1, blob, counters, 0) == 0
+    for _ in range(8):
+        amd.rnn_amd_set_char_step(g.handle, i, rc.WEIGHTED, 0.9)
+        i += 1
+    amd.rnn_amd_synchronize()
+    amd.rnn_amd_set_exchange_leave(g.handle)
+    assert counters[0] == 16 * (session + 1), (session, counters[0])  # two barriers per generation, counted ON
+plain = sc.AmdBatchedSet(amd, **kw)
+for k in range(16):
+    plain.char_step(text, k, rc.WEIGHTED, 0.9)
+a, b = g.snapshot(), plain.snapshot()
+for k in ("ih_w", "ho_w"):
+    assert rc.rel_err(a[k], b[k]) < 1e-6, k
+print("RESULT ok")
+"""
+
+
+def test_exchange_rejoins_on_counters_an_earlier_session_left():
+    """rnn_amd_set_exchange_join counts its barriers on from where the shared counters stand (round 5 counted from 0 and
+    trusted the launcher to have zeroed them: on counters an earlier session left, the first barriers would have passed
+    at once).  One rank with real barriers (counters in host memory; RECUR_AMD_DIST_ONE_RANK_EXCHANGE=1 keeps the step
+    in, read once per process: a subprocess), eight generations, leave, join AGAIN on the same counters, eight more: the
+    counter stands at 16, then 32, and the weights equal a plain set's."""
+    env = dict(os.environ, RECUR_AMD_DIST_ONE_RANK_EXCHANGE="1")
+    r = subprocess.run([sys.executable, "-c", REJOIN_SCRIPT % {"tests": os.path.dirname(os.path.abspath(__file__))}],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "RESULT ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
