@@ -363,6 +363,23 @@ constexpr int OUT_SEGS = 16;
 constexpr int WM = 64, WN = 64, WK = 64, W_STAGES = 4;
 constexpr int W_STAGE_FLOATS = (WM + WN) * WK; /* 32 KB */
 
+// ---- development builds (tools/mkabl.sh bnd -DBND_STAMPS -- NOT with -DPC_STAMPS: the half-step stamps of one workgroup slow its
+// whole row tile down, 6.5 us per chain launch): when every workgroup of a launch starts and ends, by the 100 MHz
+// clock all CUs share -- tools/gpu_boundary_stamps.py turns the four launches' marks into what the launch boundaries of a
+// generation cost WITHOUT a profiler's per-dispatch instrumentation between them
+#ifdef BND_STAMPS
+#define BND_DECL(sym, reader)                                                                  \
+  __device__ unsigned long long sym[2][1024];                                                  \
+  extern "C" void reader(unsigned long long *out) {                                            \
+    HIP_CHECK(hipDeviceSynchronize());                                                         \
+    HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(sym), sizeof(unsigned long long) * 2048));   \
+  }
+#define BND_MARK(sym, which) do { if (threadIdx.x == 0 && blockIdx.x < 1024) sym[which][blockIdx.x] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BND_DECL(sym, reader)
+#define BND_MARK(sym, which) do { } while (0)
+#endif
+
 // ---- launch-side support (kernels_support.hip) ----
 // HIP-event timing of the kernel classes (bench.py's roofline leg)
 enum { T_CHAIN = 0, T_DELTA = 1, T_FWD = 2, T_APPLY = 3, T_OTHER = 4, T_XCHG = 5, T_CLASSES = 6 }; /* (T_XCHG = RAMD_T_XCHG: the exchange between ranks, bracketed by rnn_core.c) */

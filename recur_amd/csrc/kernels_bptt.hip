@@ -1000,6 +1000,7 @@ static void ramd_launch_extras_dense(hipStream_t st, const View &v, const RamdSh
 
 #include "k_delta_direct.h" /* the weight-delta GEMM without a K split over workgroups (hidden 1024 and up) */
 
+BND_DECL(g_bnd_delta, ramd_bnd_delta_stamps)
 #ifdef PC_STAMPS
 extern "C" void ramd_ddir_stamps(unsigned long long *out) {
   HIP_CHECK(hipDeviceSynchronize());
@@ -1017,7 +1018,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                                                                                                                 HoWork hw, HoApply ap) {
   extern __shared__ __attribute__((aligned(16))) float ddh_lds[];
   __builtin_amdgcn_s_setprio(2);
+  BND_MARK(g_bnd_delta, 0);
   dd_body<NW, P, NPW>(a, ddh_lds, [&]() { chain_ho_delta<5, 8>(v, hw, ddh_lds, (int)blockIdx.x, ap); });
+  BND_MARK(g_bnd_delta, 1);
 }
 
 // ------------------------------------------------ weight-delta GEMM by LDS-DMA --

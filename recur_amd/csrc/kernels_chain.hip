@@ -6,6 +6,7 @@ __device__ unsigned long long g_xc_stamps[16];
 #define XC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == ((i) == 10 ? 256 : 0)) g_xc_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #endif
 #include "k_extras.h"
+BND_DECL(g_bnd_chain, ramd_bnd_chain_stamps)
 
 // ------------------------------------------------------ BPTT chain step --
 //
@@ -577,6 +578,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   float *red = psm + 2 * BUF;                 /* [2][4 waves][16 rows][32 cols]        */
   unsigned *wg_info = reinterpret_cast<unsigned *>(red + 2 * PC_RED_FLOATS);
   XC_STAMP(0);
+  BND_MARK(g_bnd_chain, 0);
   View v = *vp;
   v.b.uniform_idx = uniform_idx;
   const RamdShape &s = v.sh;
@@ -1043,6 +1045,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     XC_STAMP(9);
     __syncthreads();
   }
+  BND_MARK(g_bnd_chain, 1);
 }
 
 /* the device copy of the View for the kernels that take it by pointer, rewritten only when

@@ -551,6 +551,7 @@ extern "C" void ramd_fwd_stamps(unsigned long long *out) {
 #else
 #define FF_STAMP(i) do { } while (0)
 #endif
+BND_DECL(g_bnd_fwd, ramd_bnd_fwd_stamps)
 constexpr int FF_MAXIN = 64;
 template <int NS = 0>
 __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, int new_idx, int row0,
@@ -558,6 +559,7 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
                                                    int mode, int text_i, int global_first,
                                                    int n_set, const float *__restrict__ dense, int ld) {
   FF_STAMP(0);
+  BND_MARK(g_bnd_fwd, 0);
   View v = *vp;
   const int nstages = NS > 0 ? NS : nstages_arg;
   __shared__ __attribute__((aligned(16))) float smem[C_STAGES * C_STAGE_FLOATS];
@@ -895,6 +897,7 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
       for (int k = sub; k < s.input_size; k += 8) slot[s.hidden_size + 1 + k] = (k == hot) ? scale : 0.0f;
   }
   FF_STAMP(5);
+  BND_MARK(g_bnd_fwd, 1);
 }
 
 // ------------------------------------ one stream, small net: forward in one launch --

@@ -10,6 +10,7 @@ __device__ unsigned long long g_tt_stamps[16];
 #define TT_STAMP(i) do { } while (0)
 #endif
 #include "k_top.h"
+BND_DECL(g_bnd_top, ramd_bnd_top_stamps)
 #pragma clang fp contract(off)
 
 // net_error_bptt's loss (charmodel-predict.c:18-27): softmax (badmaths.h:71-111),
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
   float *hid = v.b.hidden + (size_t)r * s.H;
   const int seg = threadIdx.x >> 6, lane = threadIdx.x & 63;
   TT_STAMP(0);
+  BND_MARK(g_bnd_top, 0);
   /* What does not depend on anything computed here is requested FIRST (round 3, from stamps of the 12.2 us
    * between the first and the last instruction: the target, the pad of o_error and the statistics'
    * read-modify-writes were three memory round trips inside the one-wave softmax): wave 0 asks for the
@@ -463,6 +465,7 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
     v.b.top_scaled[r] = scaled;
   }
   TT_STAMP(5);
+  BND_MARK(g_bnd_top, 1);
 }
 
 // multi_softmax_error (charmodel-multi-predict.c:17-58) after the opinion: the output row is

@@ -12,6 +12,7 @@ rm -rf "$out" && mkdir -p "$out"
 CMD="python3 bench.py --no-cpu-baseline --steps 60 --warmup 10"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o s -- $CMD > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
 cp $(find "$out/trace" -name 's_kernel_stats.csv' | head -1) "$out/kernel_stats.csv"
+python3 tools/launch_boundaries.py $(find "$out/trace" -name 's_kernel_trace.csv' | head -1) k_fwd_fused 40 > "$out/launch_boundaries.txt"
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   set -- $pass; name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/$name" -o p -- $CMD > "$out/bench_$name.json" 2> "$out/$name.err"
@@ -21,4 +22,4 @@ python3 tools/pmc_summary.py "$out/fetch" "$out/write" > "$out/pmc_fetch_write_p
 python3 tools/pmc_mfma_lds.py "$out/mfma" "$out/lds" > "$out/pmc_mfma_lds_per_kernel.txt"
 python3 tools/pmc_traffic_json.py "$out/fetch" "$out/write" > "$out/pmc_traffic.json"
 rm -rf "$out/trace" "$out/fetch" "$out/write" "$out/mfma" "$out/lds"
-head -12 "$out/kernel_stats.csv"; cat "$out/pmc_fetch_write_per_kernel.txt"; cat "$out/pmc_mfma_lds_per_kernel.txt"; cat "$out/pmc_traffic.json"
+head -12 "$out/kernel_stats.csv"; cat "$out/launch_boundaries.txt"; cat "$out/pmc_fetch_write_per_kernel.txt"; cat "$out/pmc_mfma_lds_per_kernel.txt"; cat "$out/pmc_traffic.json"
