@@ -135,6 +135,17 @@ template <int N, class F> __device__ __forceinline__ void dd_static_for(F &&f) {
 }
 
 constexpr int DD_LD = 64; /* floats per row of a wave's tile in LDS */
+/* the epilogue's stores of the tile: 0 plain; 1: the delta and the momentum (nobody reads them before the next
+ * generation's weight-delta launch) as non-temporal stores, 2: the weights too -- an experiment about what the launch leaves
+ * for the end-of-kernel write-back (profiles/NOTES_r06.md) */
+#ifndef DD_NT_STORES
+#define DD_NT_STORES 1
+#endif
+template <int LEVEL> __device__ __forceinline__ void dd_store4(float *p, const float __attribute__((ext_vector_type(4))) & v) {
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  if constexpr (DD_NT_STORES >= LEVEL) __builtin_nontemporal_store(v, reinterpret_cast<f4u *>(p));
+  else *reinterpret_cast<f4u *>(p) = v;
+}
 
 /* NW: waves per workgroup (8: two per SIMD -- while one waits for operands or sits in its epilogue the other has the
  * matrix pipe; with 4 hipcc keeps the accumulators in AGPRs and shuffles ring registers through them between an
@@ -415,12 +426,12 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
     for (int w2 = 1; w2 < NW; w2++) s += *reinterpret_cast<const dd_f4 *>(p + (size_t)w2 * 64 * DD_LD);
     const size_t off = (size_t)(m0 + (ch >> 4)) * a.H + n0 + 4 * (ch & 15);
     if (a.mode == 1) s += *reinterpret_cast<const dd_f4u *>(dlt + off);
-    *reinterpret_cast<dd_f4u *>(dlt + off) = s;
+    dd_store4<1>(dlt + off, s);
     if (upd) {
       dd_f4 W = *reinterpret_cast<const dd_f4u *>(a.w + off), M = *reinterpret_cast<const dd_f4u *>(a.m + off);
       update4(W, M, s, a.rate);
-      *reinterpret_cast<dd_f4u *>(a.w + off) = W;
-      *reinterpret_cast<dd_f4u *>(a.m + off) = M;
+      dd_store4<2>(a.w + off, W);
+      dd_store4<1>(a.m + off, M);
     }
   }
   auto update1 = [&](size_t off, float d, float rate, float *w, float *m) {

@@ -468,6 +468,274 @@ __global__ __launch_bounds__(1024) void k_text_top(View v, int row0, int nrows, 
   BND_MARK(g_bnd_top, 1);
 }
 
+// ---- the text step's top launch, round 6 form (k_text_top2): W_ho once per workgroup, from registers both times --
+//
+// k_text_top<0> by stamps (round 5): hidden row in LDS at 2.0 us, output layer 3.8, one-wave softmax 3.4, backprop 2.3, and
+// with sixteen waves on a CU every phase is the vector ALU's instruction count times sixteen cycles.  Here
+//   * the workgroup's rows of W_ho are requested FIRST, before the hidden row (nothing they need is computed here), 17
+//     float4 per lane: wave w has rows y0 .. y0 + per - 1 of the matrix, lane (rsub, c4) of it rows y0 + rsub + 4 i and
+//     columns 4 c4 .. + 3 -- sixteen lanes a row;
+//   * they STAY in registers for the backprop (e[y] = sum over x of W_ho[y][x] o_error[x], recur-nn.c:199-228: the same
+//     numbers, the other contraction): no second pass over W_ho, no prefetch to park across the softmax.  The sixteen
+//     lanes' partial sums of sixteen rows are added by a transposing butterfly (15 exchanges instead of 64 row
+//     reductions): lane c4 ends up with row y0 + rsub + 4 c4 -- a wave's 64 lanes hold 64 consecutive rows, one store;
+//   * the softmax of up to 64 outputs stays in one wave's registers (text_softmax_regs: the sum of the exponentials by a
+//     tree instead of in index order -- VERDICT round 5 item 3; the bar is 1e-4 element-wise, and the tests hold it);
+//   * the error row is stored as it is formed; the soft clip (recur-nn.c:719-721: rare, a hot net) stores it again, scaled.
+// Measured and dropped on the way (profiles/NOTES_r06.md): several streams per workgroup sharing the one copy of W_ho in its
+// registers (the launch is not bound by what the L2s hand out but by vector-ALU instructions: 2 streams 16.1 us, 4 streams
+// 25.7 against 11.0 with one).
+// Text loss only (KIND 0), o_size <= 64, a wave's rows in one batch (h_size <= 1088): else k_text_top.
+constexpr int T2_NB = 17;
+#define T2_DPP(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
+#define T2_SWZ(x, xorm) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), ((xorm) << 10) | 0x1f))
+__device__ __forceinline__ float dpp_row_sum16(float x) {
+  x += T2_DPP(x, 0xB1);  /* quad_perm [1, 0, 3, 2] */
+  x += T2_DPP(x, 0x4E);  /* quad_perm [2, 3, 0, 1] */
+  x += T2_DPP(x, 0x141); /* row_half_mirror */
+  x += T2_DPP(x, 0x140); /* row_mirror */
+  return x;
+}
+/* p[k]: this lane's partial sum of row k (k = 0 .. 15) of its sixteen-lane group; returns the group's sum of row c4 (the
+ * lane's number in the group): a butterfly that halves the rows a lane still carries at every exchange */
+__device__ __forceinline__ float transpose_sum16(const float (&p)[16], int c4) {
+  float u[8], w[4], x[2];
+  const bool b3 = c4 & 8, b2 = c4 & 4, b1 = c4 & 2, b0 = c4 & 1;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const float keep = b3 ? p[k + 8] : p[k], send = b3 ? p[k] : p[k + 8];
+    u[k] = keep + T2_SWZ(send, 8);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float keep = b2 ? u[k + 4] : u[k], send = b2 ? u[k] : u[k + 4];
+    w[k] = keep + T2_SWZ(send, 4);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const float keep = b1 ? w[k + 2] : w[k], send = b1 ? w[k] : w[k + 2];
+    x[k] = keep + T2_DPP(send, 0x4E);
+  }
+  const float keep = b0 ? x[1] : x[0], send = b0 ? x[0] : x[1];
+  return keep + T2_DPP(send, 0xB1);
+}
+/* text_softmax_wave (k_top.h) for o_size <= 64 without LDS round trips: lane i holds output i.  The same arithmetic value
+ * by value (adjustment, fast_expf_dev, the division, +1 on the target, best guess with the lowest index on a tie); the sum
+ * of the exponentials is a tree over the lanes, not the reference's index order.  Leaves the error row in serr (LDS) and
+ * err (global), the statistics in tstat[0..2]. */
+__device__ __forceinline__ void text_softmax_regs(const RamdShape &s, int lane, const float *sout, float *serr, float *err,
+                                                  int target, float pad_oe, float *tstat) {
+#pragma clang fp contract(off)
+  const int len = s.output_size;
+  const bool in = lane < len;
+  const float o = sout[in ? lane : 0];
+  float hi = o, lo = o;
+  for (int off = 32; off > 0; off >>= 1) {
+    hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    lo = fminf(lo, __shfl_xor(lo, off, 64));
+  }
+  float adj = 0.0f;
+  if (hi > 50.0f) adj = 50.0f - hi;
+  else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
+  const float ex = in ? fast_expf_dev(o + adj) : 0.0f;
+  float sum = ex;
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  const float e = ex / sum;
+  float best_e = in ? e : -1.0f;
+  int best_i = in ? lane : 0x7fffffff;
+  if (lane < s.O) {
+    const float oe = in ? ((lane == target) ? -e + 1.0f : -e) : pad_oe; /* the pad of o_error stays what it was (zero) */
+    if (in) err[lane] = oe;
+    serr[lane] = oe;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const float oe = __shfl_xor(best_e, off, 64);
+    const int oi = __shfl_xor(best_i, off, 64);
+    if (oe > best_e || (oe == best_e && oi < best_i)) {
+      best_e = oe;
+      best_i = oi;
+    }
+  }
+  const float et = __shfl(e, target, 64);
+  if (lane == 0) {
+    const float e1 = -et + 1.0f;
+    const float l = 1.0f - e1;
+    tstat[0] = e1;
+    tstat[1] = (l < 1e-30f) ? -100.0f : log2f(l);
+    tstat[2] = (best_i == target) ? 1.0f : 0.0f;
+  }
+}
+__global__ __launch_bounds__(1024) void k_text_top2(View v, int row0, int nrows, int fwd_ks) {
+  extern __shared__ float tsh[];
+  __shared__ float tred[16];
+  __shared__ float tstat[4];
+  const RamdShape &s = v.sh;
+  const int seg = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rsub = lane >> 4, c4 = lane & 15, OQ = s.O >> 2;
+  const bool colq = c4 < OQ;
+  float *shid = tsh;             /* [H] hidden row                        */
+  float *wsum = shid + s.H;      /* [16 waves][O] the waves' column sums   */
+  float *sout = wsum + 16 * s.O; /* [O] outputs, [O] output error          */
+  float *serr = sout + s.O;
+  const int j = blockIdx.x, r = row0 + j; /* the stream: within the call, state row */
+  BND_MARK(g_bnd_top, 0);
+  // ---- 1. this wave's rows of W_ho: requested before anything else
+  const int per = (s.H + 15) / 16, y0 = seg * per, y1 = min(s.H, y0 + per);
+  float4 wv[T2_NB];
+  {
+    const float *wb = v.b.ho_w + 4 * (colq ? c4 : 0);
+#pragma unroll
+    for (int i = 0; i < T2_NB; i++) {
+      const int y = y0 + rsub + 4 * i;
+      wv[i] = ld4(wb + (size_t)(y < y1 ? y : y0) * s.O);
+    }
+  }
+  int target = 0;
+  float pad_oe = 0.0f;
+  if (seg == 0) { /* wave 0 runs the softmax: the target and the pad of the error row */
+    target = v.b.target[r];
+    pad_oe = v.b.o_error[(size_t)r * s.O + (lane < s.O ? lane : 0)];
+  }
+  // ---- 2. the hidden row (k_text_top's first phase)
+  float *hid = v.b.hidden + (size_t)r * s.H;
+  if (fwd_ks != 0) {
+    const float *p = v.b.slab + (size_t)j * s.H;
+    const int npart = fwd_ks < 0 ? -fwd_ks : 0;
+    if (fwd_ks < 0) fwd_ks = 1;
+    const size_t plane = (size_t)nrows * s.H;
+    for (int i = threadIdx.x; i < s.H; i += 1024) {
+      float xs[8];
+#pragma unroll
+      for (int z = 0; z < 8; z++) xs[z] = (z < fwd_ks) ? p[z * plane + i] : 0.0f;
+      float x = xs[0];
+#pragma unroll
+      for (int z = 1; z < 8; z++)
+        if (z < fwd_ks) x += xs[z];
+      for (int z = 8; z < fwd_ks; z++) x += p[z * plane + i];
+      if (npart && i >= s.H - 4) continue; /* the tail columns: below */
+      if (s.activation == 2) {
+        x = (x > 0.0f) ? sqrtf(x + 1.0f) - 1.0f : 0.0f;
+      } else if (s.activation == 5) {
+        x = x < 20.0f ? x : 20.0f;
+        x = (x > 0.0f) ? x : 0.0f;
+      } else {
+        x = (x > 0.0f) ? x : 0.0f;
+      }
+      if (i == 0) x = 1.0f; /* the bias node, recur-nn.c:148 */
+      hid[i] = x;
+      shid[i] = x;
+    }
+    if (npart && seg < 4) { /* k_fwd_fused's four tail columns: wave p4 adds column p4's per-tile partial sums */
+      const int p4 = seg;
+      const float *pd = v.b.slab + (size_t)nrows * s.H + (size_t)j * 4 + p4;
+      float x = 0.0f;
+      for (int t = lane; t < npart; t += 64) x += pd[(size_t)t * nrows * 4];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      if (s.activation == 2) {
+        x = (x > 0.0f) ? sqrtf(x + 1.0f) - 1.0f : 0.0f;
+      } else if (s.activation == 5) {
+        x = x < 20.0f ? x : 20.0f;
+        x = (x > 0.0f) ? x : 0.0f;
+      } else {
+        x = (x > 0.0f) ? x : 0.0f;
+      }
+      if (lane == 0) {
+        hid[s.H - 4 + p4] = x;
+        shid[s.H - 4 + p4] = x;
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < s.H; i += 1024) shid[i] = hid[i];
+  }
+  __syncthreads();
+  // ---- 3. output layer (recur-nn.c:150-151): the lane's rows, then the four row groups of the wave, then the waves
+  {
+    float4 acc = zero4();
+#pragma unroll
+    for (int i = 0; i < T2_NB; i++) {
+      const int y = y0 + rsub + 4 * i;
+      const float hv = (colq && y < y1) ? shid[y < y1 ? y : y0] : 0.0f;
+      acc.x += hv * wv[i].x;
+      acc.y += hv * wv[i].y;
+      acc.z += hv * wv[i].z;
+      acc.w += hv * wv[i].w;
+    }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      acc.x += __shfl_xor(acc.x, off, 64);
+      acc.y += __shfl_xor(acc.y, off, 64);
+      acc.z += __shfl_xor(acc.z, off, 64);
+      acc.w += __shfl_xor(acc.w, off, 64);
+    }
+    if (rsub == 0 && colq) *reinterpret_cast<float4 *>(wsum + seg * s.O + 4 * c4) = acc;
+  }
+  __syncthreads();
+  if (seg == 0) { /* the sixteen waves' sums in wave order, then -- the same wave -- the loss */
+    if (lane < s.O) {
+      float t[16];
+#pragma unroll
+      for (int g = 0; g < 16; g++) t[g] = wsum[g * s.O + lane];
+      float sum = t[0];
+#pragma unroll
+      for (int g = 1; g < 16; g++) sum += t[g];
+      v.b.out[(size_t)r * s.O + lane] = sum;
+      sout[lane] = sum;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* one wave: its own LDS writes are ordered */
+    // ---- 4. the loss (charmodel-predict.c:18-27, badmaths.h:71-141)
+    text_softmax_regs(s, lane, sout, serr, v.b.o_error + (size_t)r * s.O, target, pad_oe, tstat);
+  } else if (seg == 1) {
+    text_count_zeros_wave(s, lane, shid, tstat); /* the hidden row's zeros, for the statistics */
+  }
+  __syncthreads();
+  if (threadIdx.x == 128) {
+    v.b.stat_err[r] += tstat[0];
+    v.b.stat_ent[r] += tstat[1];
+    v.b.stat_correct[r] += (tstat[2] != 0.0f);
+    v.b.stat_count[r] += 1;
+    v.b.stat_zero[r] += (int)tstat[3] / (double)s.hidden_size;
+  }
+  // ---- 5. top-layer backprop + soft clip (recur-nn.c:199-228, 719-721) from the rows in registers
+  const float4 se = colq ? *reinterpret_cast<const float4 *>(serr + 4 * c4) : zero4();
+  float pr[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) pr[i] = (wv[i].x * se.x + wv[i].y * se.y) + (wv[i].z * se.z + wv[i].w * se.w);
+  /* (a lane outside the columns holds zeros in se; rows past y1 are dropped below) */
+  const float last = dpp_row_sum16((wv[16].x * se.x + wv[16].y * se.y) + (wv[16].z * se.z + wv[16].w * se.w));
+  const float mine = transpose_sum16(pr, c4);
+  /* this lane's row: y0 + rsub + 4 c4 -- the wave's 64 lanes hold rows y0 .. y0 + 63; the seventeenth row of a group
+   * (y0 + rsub + 64) is lane c4 == 0's second */
+  const int ya = y0 + rsub + 4 * c4, yb = y0 + rsub + 64;
+  const bool rowa = ya < y1, rowb = c4 == 0 && yb < y1;
+  const float ea = (rowa && ya != 0 && shid[rowa ? ya : 0] != 0.0f) ? mine : 0.0f;
+  const float eb = (rowb && yb != 0 && shid[rowb ? yb : 0] != 0.0f) ? last : 0.0f;
+  float *dst = v.b.ehi + (size_t)r * s.I; /* step 0 plane */
+  if (rowa) dst[ya] = (ya == 0 || ya > s.hidden_size) ? 0.0f : ea;
+  if (rowb) dst[yb] = (yb == 0 || yb > s.hidden_size) ? 0.0f : eb;
+  float sum = fabsf(ea) + fabsf(eb);
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if (lane == 0) tred[seg] = sum;
+  __syncthreads();
+  {
+    const float g0 = (tred[0] + tred[1]) + (tred[2] + tred[3]), g1 = (tred[4] + tred[5]) + (tred[6] + tred[7]);
+    const float g2 = (tred[8] + tred[9]) + (tred[10] + tred[11]), g3 = (tred[12] + tred[13]) + (tred[14] + tred[15]);
+    sum = (g0 + g1) + (g2 + g3);
+  }
+  const float halfmax = s.H * MAX_TOP_ERROR_FACTOR_F;
+  float scaled = sum;
+  if (sum > halfmax) { /* rare (a hot net): the row once more, scaled */
+    const float scale = soft_clip_dev(sum, halfmax);
+    scaled = scale * sum;
+    if (rowa) dst[ya] = (ya == 0 || ya > s.hidden_size) ? 0.0f : ea * scale;
+    if (rowb) dst[yb] = (yb == 0 || yb > s.hidden_size) ? 0.0f : eb * scale;
+  }
+  if (threadIdx.x == 0) {
+    v.b.top_raw[r] = sum;
+    v.b.top_scaled[r] = scaled;
+  }
+  BND_MARK(g_bnd_top, 1);
+}
+
 // multi_softmax_error (charmodel-multi-predict.c:17-58) after the opinion: the output row is
 // n_classes heads of alphabet_len symbols.  The head of the stream's own class is always
 // trained; every other head with probability `leakage`, decided by a draw from the
@@ -776,6 +1044,13 @@ extern "C" void ramd_launch_text_top(ramd_stream_t st_, const RamdShape *sh, con
                                      int row0, int nrows, int fwd_ks) {
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
+  /* round 6's form where its preconditions hold (k_text_top2): o_size a multiple of 4 up to 64 (sixteen lanes a row of
+   * W_ho), a wave's rows of W_ho in one batch of T2_NB x 4 */
+  if (sh->O % 4 == 0 && sh->O <= 64 && (sh->H + 15) / 16 <= 4 * T2_NB && env_int("RECUR_AMD_TEXT_TOP2", 1)) {
+    const size_t shm2 = (size_t)(sh->H + 16 * sh->O + 2 * sh->O) * sizeof(float);
+    RAMD_LAUNCH(k_text_top2, dim3(nrows), dim3(1024), shm2, st, v, row0, nrows, fwd_ks);
+    return;
+  }
   size_t shm = (size_t)(sh->H + OUT_SEGS * 64 * 4 + (OUT_SEGS + 3) * sh->O) * sizeof(float);
   RAMD_LAUNCH(k_text_top<0>, dim3(nrows), dim3(1024), shm, st, v, row0, nrows, fwd_ks, TopLoss{});
 }

@@ -36,8 +36,10 @@ def marks():
         buf = np.zeros((2, 1024), np.uint64)
         f(C.c_void_p(buf.ctypes.data))
         b = buf[:, :nwg[k]].astype(np.int64)
-        per_xcd.setdefault(k, []).append([(b[1][x::8].max() - b[0].min()) / 100.0 for x in range(8)] +
-                                         [(b[1][x::8].min() - b[0].min()) / 100.0 for x in range(8)])
+        b = b[:, (b[0] > 0) & (b[1] > 0)]  # (a launch with fewer workgroups than that: the marks that were written)
+        if b.shape[1] >= 8:
+            per_xcd.setdefault(k, []).append([(b[1][x::8].max() - b[0].min()) / 100.0 for x in range(8)] +
+                                             [(b[1][x::8].min() - b[0].min()) / 100.0 for x in range(8)])
         out[k] = dict(first_start=int(b[0].min()), last_start=int(b[0].max()), first_end=int(b[1].min()), last_end=int(b[1].max()))
     return out
 

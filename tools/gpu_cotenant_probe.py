@@ -45,17 +45,32 @@ for i in range(24, 24 + N):
 amd.rnn_amd_synchronize()
 dt = time.perf_counter() - t0
 alive = other.poll() is None
-snap = g.snapshot()
 o = sc.OracleSet(**kw)
 a = o.arrays()
-for k in ("ih_w", "ho_w", "ih_m", "ho_m", "hist", "hidden", "index", "min_error_factor"):
-    a[k][:] = snap[k]
-a["generation"][:] = snap["generation"]
-g.char_step(text, 24 + N, rc.WEIGHTED, 0.95)
-o.char_step(text, 24 + N, rc.WEIGHTED, 0.95)
-sg, so = g.snapshot(), o.snapshot()
+for attempt in range(4):
+    # one generation on both sides from the device's state; a generation in which a pre-activation within rounding of zero
+    # takes its mask from the summation order is held to the flip bound (tests/test_gpu_parity.py:
+    # test_mask_flips_stay_at_the_rounding_level_rate) and is not a parity case: take the next one
+    snap = g.snapshot()
+    for k in ("ih_w", "ho_w", "ih_m", "ho_m", "hist", "hidden", "index", "min_error_factor"):
+        a[k][:] = snap[k]
+    a["generation"][:] = snap["generation"]
+    g.char_step(text, 24 + N + attempt, rc.WEIGHTED, 0.95)
+    o.char_step(text, 24 + N + attempt, rc.WEIGHTED, 0.95)
+    sg, so = g.snapshot(), o.snapshot()
+    flipped = (sg["hidden"] != 0) != (so["hidden"] != 0)
+    if not flipped.any():
+        break
+    print("generation %d: %d hidden values differ in being zero (largest %.1e): the next one" % (
+        24 + N + attempt, flipped.sum(), np.abs(np.where(sg["hidden"][flipped] != 0, sg["hidden"][flipped], so["hidden"][flipped])).max()))
+    assert 1e6 * flipped.sum() / flipped.size <= 10.0
+    assert np.abs(np.where(sg["hidden"][flipped] != 0, sg["hidden"][flipped], so["hidden"][flipped])).max() < 1e-5
+else:
+    raise AssertionError("no generation without a rounding-level mask flip in 4 attempts")
 still = other.poll() is None
-worst = max(max(rc.rel_err(sg[k], so[k]), rc.max_err(sg[k], so[k])) for k in ("ih_delta", "ho_delta", "ih_w", "ho_w", "hidden"))
+errs = {k: max(rc.rel_err(sg[k], so[k]), rc.max_err(sg[k], so[k])) for k in ("ih_delta", "ho_delta", "ih_w", "ho_w", "hidden")}
+print("errors by array: %s" % errs)
+worst = max(errs.values())
 print("%d generations beside the other process (%s at the end of the loop, %s at the compared generation): %.1f us per "
       "generation; one generation from synchronised state against the oracle: worst error %.2e" % (
           N, "running" if alive else "GONE", "running" if still else "gone", 1e6 * dt / N, worst))
