@@ -320,6 +320,25 @@ def test_one_call_generation_with_a_wide_top_layer(amd, hidden, S, D, n_in, n_ou
     _rnnca_generation(amd, hidden, S, D, n_in=n_in, combined="step", n_out=n_out)
 
 
+def _dense_step_sweep():
+    rs = np.random.default_rng(707)
+    cases = []
+    for hidden in (512, 768, 1024, 1536, 2048):
+        for _ in range(2):
+            cases.append((hidden, 32 * int(rs.integers(1, 4)), int(rs.choice([5, 10])), int(rs.choice([3, 12, 35, 47, 90])),
+                          int(rs.choice([3, 8, 64, 200, 900])), int(rs.choice([rc.RELU, rc.RESQRT, rc.RECLIP20]))))
+    return cases
+
+
+@pytest.mark.parametrize("hidden,S,D,n_in,n_out,activation", _dense_step_sweep())
+def test_dense_step_shape_sweep(amd, hidden, S, D, n_in, n_out, activation):
+    """rnn_amd_set_dense_step_sigmoid_mse over a seeded sweep of shapes either side of the launcher
+    predicates of its fused forms (the dense forward's one round of tiles, the one-launch top layer's o_size <= 64, the
+    direct weight-delta kernel's rounds / rest rows / K split, the top layer's share of the fused update), one generation
+    from the device's state against the oracle."""
+    _rnnca_generation(amd, hidden, S, D, n_in=n_in, activation=activation, combined="step", n_out=n_out)
+
+
 @pytest.mark.parametrize("between", ["nothing", "put_o_error", "host_weights", "mask_differs", "second_opinion"])
 def test_what_happens_between_the_one_call_loss_and_the_delta_call(amd, between):
     """rnn_amd_set_opinion_sigmoid_mse / _grouped_softmax leave the top layer's backprop done for the delta call that

@@ -711,6 +711,43 @@ def test_baseline_config_shapes_one_generation_matches_oracle(amd, label, kw):
     warm the ring up on the device, then one generation on both sides from the same state
     (the generic-stage chain kernel, the delta DMA kernel at other tilings, and at hidden
     2048 the dense extras GEMM and the unfused top layer)"""
+    _one_generation_from_device_state(amd, kw)
+
+
+def _text_step_sweep():
+    """seeded: hidden sizes either side of every launcher predicate of the fused step (whole rounds of 64 x 64 tiles, the K
+    split over workgroups, rest rows 0 .. 128, the top layer's share of the fused update from 11 to ~1500 float4 per
+    workgroup, k_text_top2's o_size <= 64 and h_size <= 1088), streams in multiples of 32, depths that do and do not make
+    whole rings of five iterations"""
+    rs = np.random.default_rng(606)
+    cases = []
+    for hidden in (512, 768, 1024, 1536, 2048):
+        for _ in range(2):
+            S = 32 * int(rs.integers(1, 4))
+            D = int(rs.choice([5, 8, 10, 15]))
+            n_in = int(rs.choice([42, 60, 107, 150, 280]))
+            n_out = int(rs.choice([42, 64, 300, 700, 1100]))
+            act = int(rs.choice([rc.RELU, rc.RELU, rc.RESQRT]))
+            cases.append(("h%d_s%d_d%d_i%d_o%d_a%d" % (hidden, S, D, n_in, n_out, act),
+                          dict(input_size=n_in, hidden_size=hidden, output_size=n_out, S=S, D=D, activation=act)))
+    # and by hand: the direct kernel's fused update (hidden 1024, whole rings of five) under wide top layers -- 643 and
+    # 1105 float4 of W_ho per workgroup of 512 threads -- and its K-split form (hidden 512) under one
+    for hidden, S, D, n_in, n_out in ((1024, 64, 10, 42, 640), (1024, 32, 15, 150, 1100), (512, 64, 10, 42, 1100)):
+        cases.append(("h%d_s%d_d%d_i%d_o%d_wide_top" % (hidden, S, D, n_in, n_out),
+                      dict(input_size=n_in, hidden_size=hidden, output_size=n_out, S=S, D=D)))
+    return cases
+
+
+@pytest.mark.parametrize("label,kw", _text_step_sweep())
+def test_text_step_shape_sweep(amd, label, kw):
+    """the fused paths update weights IN PLACE behind hand-derived launcher predicates, so a predicate that
+    drifts from its kernel's assumptions trains silently wrong (round 5's missed bound on the top layer's share).  A seeded
+    sweep of rnn_amd_set_char_step over shapes either side of those predicates, one generation from the device's state
+    against the oracle, weights and momentum included."""
+    _one_generation_from_device_state(amd, kw)
+
+
+def _one_generation_from_device_state(amd, kw):
     kw = dict(kw, learn_rate=1e-5, seed=3)
     g = sc.AmdBatchedSet(amd, **kw)
     text = sc.synthetic_text(30000)
