@@ -166,6 +166,11 @@ __global__ void k_noise_speculate(View v, int row0, int nrows, float deviation, 
   }
   state[j] = g;
 }
+/* (Round 6, measured and removed: a WAVE per stream with the recurrence on the scalar unit -- four 64-bit scalar
+ * registers, s_lshl_b64 / s_or_b64 / s_add_u32 + s_addc_u32, the twelve 16-bit fields of a value added two at a time in
+ * the halves of a 64-bit word, lane k keeping value k of 64: bit-exact, and SLOWER -- 283 against 218 us per generation
+ * of 32 streams, 384 against 338 of 256: a dependent scalar instruction takes ~7 cycles here, and the form has 85 of them
+ * per value against the vector form's 60.  profiles/NOTES_r06.md.) */
 /* ... and their use by the forward pass: slab plane 0 += values, generators = the states after them */
 __global__ __launch_bounds__(256) void k_noise_apply(View v, int row0, int nrows) {
   const RamdShape &s = v.sh;

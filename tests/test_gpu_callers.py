@@ -453,8 +453,13 @@ def _rnnca_generation(lib, hidden, S, D, n_in=35, activation=None, combined=Fals
     assert np.abs(so["o_error"][:, :n_out]).max() > 0 and (so["o_error"][:, n_out:] == 0).all()
     assert (so["output"][:, :n_out] > 0).all() and (so["output"][:, :n_out] < 1).all()  # the sigmoid landed in place
     replay.check(sg, so, RTOL, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "ih_m", "ho_m", "hidden", "output",
-                                     "o_error", "hist", "min_error_factor", "ih_scale"],
+                                     "hist", "min_error_factor", "ih_scale"],
                  exact=("index", "generation"))
+    # o_error = slope * (target - answer) CANCELS against the target (gstrnnca.c:701-714): where the answer is within a
+    # hundredth of its target an element carries the answer's 1e-6 a hundredfold -- with hundreds of outputs per cell a few
+    # of 50,000 elements read 1.2e-4 of themselves under one summation order and 0.9e-4 under another (round 6: the case
+    # with 516 outputs through the generic output layer).  Held to the norm bars; the answers element by element above.
+    replay.check(sg, so, RTOL, keys=["o_error"], exact=(), elementwise=n_out <= 3)
     g.close()
     o.close()
 

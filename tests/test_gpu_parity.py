@@ -188,6 +188,31 @@ def test_generations_with_the_direct_delta_gemm_switched_off(env, node):
     assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_the_general_kernels_alone():
+    """~35 RECUR_AMD_* switches select specialised kernels, each with the general kernel it replaced
+    still behind it -- and only a handful were exercised "off".  tools/all_fast_paths_off.env switches EVERY one of them off
+    at once: the whole GPU suite passes on what is left (profiles/r06_all_fast_paths_off.txt: 230 of 232; the two others
+    look for the one-launch chain's own give-up message).  This node runs a selection of it on every box, in a process
+    of its own (the library reads its switches once): the golden replays, the fused single-net path, the sparse ranges,
+    conditioning, the hot regime stepwise, a full-size generation, one shape of every sweep."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    for line in open(os.path.join(here, "..", "tools", "all_fast_paths_off.env")):
+        if line.strip() and not line.startswith("#"):
+            k, v = line.strip().split("=")
+            env[k] = v
+    sel = ("golden or fused_single_net or sparse_error or conditioning or hot_case_stepwise or "
+           "full_size_generation_matches_oracle or h1024_s64_d10_i42_o640 or h2048_s64 or small_set_1024_32_20 or "
+           "one_sub_chain_resqrt_512 or text_step_emergency")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-m", "gpu",
+                        "-k", sel], capture_output=True, text=True, env=env, timeout=1500, cwd=here)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    import re
+    assert int(re.search(r"(\d+) passed", r.stdout).group(1)) >= 20, r.stdout[-500:]
+
+
 @pytest.mark.parametrize("act,S,lr", [(rc.RELU, 1, 0.08), (rc.RESQRT, 3, 0.05), (rc.RECLIP20, 2, 0.08),
                                       (rc.RELU, 2, 1e-3)])
 def test_per_net_calls_on_a_small_net_stepwise(amd, orc, act, S, lr):
