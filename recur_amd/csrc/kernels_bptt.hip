@@ -1019,7 +1019,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
   extern __shared__ __attribute__((aligned(16))) float ddh_lds[];
   __builtin_amdgcn_s_setprio(2);
   BND_MARK(g_bnd_delta, 0);
+#ifndef DD_HO_AT_END
+#define DD_HO_AT_END 1
+#endif
+#if DD_HO_AT_END /* round 6 (profiles/NOTES_r06.md): the hook behind the GEMM's epilogue instead of in front of its first wait */
+  dd_body<NW, P, NPW>(a, ddh_lds);
+  __syncthreads();
+  chain_ho_delta<5, 8>(v, hw, ddh_lds, (int)blockIdx.x, ap);
+#else
   dd_body<NW, P, NPW>(a, ddh_lds, [&]() { chain_ho_delta<5, 8>(v, hw, ddh_lds, (int)blockIdx.x, ap); });
+#endif
   BND_MARK(g_bnd_delta, 1);
 }
 
