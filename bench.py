@@ -52,7 +52,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
 # HBM-side bytes per launch come from the PMC passes of THIS round's kernels, summarised by
 # tools/pmc_summary.py into this file (rocprofv3 cannot run inside the timed process)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
 
 
 def parse():

@@ -579,6 +579,7 @@ __global__ __launch_bounds__(1024) void k_text_top2(View v, int row0, int nrows,
   float *serr = sout + s.O;
   const int j = blockIdx.x, r = row0 + j; /* the stream: within the call, state row */
   BND_MARK(g_bnd_top, 0);
+  TT_STAMP(0);
   // ---- 1. this wave's rows of W_ho: requested before anything else
   const int per = (s.H + 15) / 16, y0 = seg * per, y1 = min(s.H, y0 + per);
   float4 wv[T2_NB];
@@ -648,6 +649,7 @@ __global__ __launch_bounds__(1024) void k_text_top2(View v, int row0, int nrows,
     for (int i = threadIdx.x; i < s.H; i += 1024) shid[i] = hid[i];
   }
   __syncthreads();
+  TT_STAMP(1);
   // ---- 3. output layer (recur-nn.c:150-151): the lane's rows, then the four row groups of the wave, then the waves
   {
     float4 acc = zero4();
@@ -670,6 +672,7 @@ __global__ __launch_bounds__(1024) void k_text_top2(View v, int row0, int nrows,
     if (rsub == 0 && colq) *reinterpret_cast<float4 *>(wsum + seg * s.O + 4 * c4) = acc;
   }
   __syncthreads();
+  TT_STAMP(2);
   if (seg == 0) { /* the sixteen waves' sums in wave order, then -- the same wave -- the loss */
     if (lane < s.O) {
       float t[16];
@@ -688,6 +691,7 @@ __global__ __launch_bounds__(1024) void k_text_top2(View v, int row0, int nrows,
     text_count_zeros_wave(s, lane, shid, tstat); /* the hidden row's zeros, for the statistics */
   }
   __syncthreads();
+  TT_STAMP(3);
   if (threadIdx.x == 128) {
     v.b.stat_err[r] += tstat[0];
     v.b.stat_ent[r] += tstat[1];
@@ -715,7 +719,9 @@ __global__ __launch_bounds__(1024) void k_text_top2(View v, int row0, int nrows,
   float sum = fabsf(ea) + fabsf(eb);
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
   if (lane == 0) tred[seg] = sum;
+  TT_STAMP(6);
   __syncthreads();
+  TT_STAMP(4);
   {
     const float g0 = (tred[0] + tred[1]) + (tred[2] + tred[3]), g1 = (tred[4] + tred[5]) + (tred[6] + tred[7]);
     const float g2 = (tred[8] + tred[9]) + (tred[10] + tred[11]), g3 = (tred[12] + tred[13]) + (tred[14] + tred[15]);
@@ -733,6 +739,7 @@ __global__ __launch_bounds__(1024) void k_text_top2(View v, int row0, int nrows,
     v.b.top_raw[r] = sum;
     v.b.top_scaled[r] = scaled;
   }
+  TT_STAMP(5);
   BND_MARK(g_bnd_top, 1);
 }
 

@@ -94,6 +94,25 @@ static void *dev_alloc(size_t bytes) {
   HIP_OK(hipMemsetAsync(p, 0, bytes, g_stream));
   return p;
 }
+/* The arrays that PEERS read and write in the kernel-issued exchange (weights, delta sums): RECUR_AMD_XCHG_FINEGRAINED=1
+ * makes them fine-grained device allocations (hipExtMallocWithFlags: coherent between devices inside a kernel, not only
+ * at kernel boundaries) -- for a node on which bench.py's start-up cross-check finds the coarse-grained default's
+ * replicas differing (nothing of the kind has been seen: no multi-GPU node has run this yet).
+ * Costs the owner's own kernels their L2 for these arrays (measured on one GPU: profiles/NOTES_r06.md). */
+static void *dev_alloc_exchanged(size_t bytes) {
+  static int fine = -1;
+  if (fine < 0) {
+    const char *v = getenv("RECUR_AMD_XCHG_FINEGRAINED");
+    fine = v && *v == '1';
+  }
+  if (!fine) {
+    return dev_alloc(bytes);
+  }
+  void *p = NULL;
+  HIP_OK(hipExtMallocWithFlags(&p, bytes ? bytes : 16, hipDeviceMallocFinegrained));
+  HIP_OK(hipMemsetAsync(p, 0, bytes ? bytes : 16, g_stream));
+  return p;
+}
 static void dev_free(void *p) {
   if (p) {
     HIP_OK(hipFree(p));
@@ -827,15 +846,15 @@ static void engine_ensure_device(RamdEngine *e) {
   e->has_momentum = o->bptt && o->bptt->ih_momentum;
   e->has_aux = o->bptt && o->bptt->ih_aux;
   e->has_delta = o->bptt && o->bptt->ih_delta;
-  b->ih_w = dev_alloc(e->ih_size * fl);
-  b->ho_w = dev_alloc(e->ho_size * fl);
+  b->ih_w = dev_alloc_exchanged(e->ih_size * fl);
+  b->ho_w = dev_alloc_exchanged(e->ho_size * fl);
   b->ih_m = dev_alloc(e->ih_size * fl);
   b->ho_m = dev_alloc(e->ho_size * fl);
   if (e->has_aux) {
     b->ih_aux = dev_alloc(e->ih_size * fl);
     b->ho_aux = dev_alloc(e->ho_size * fl);
   }
-  e->delta_own = dev_alloc((e->ih_size + e->ho_size) * fl);
+  e->delta_own = dev_alloc_exchanged((e->ih_size + e->ho_size) * fl);
   b->ih_delta = e->delta_own;
   b->ho_delta = e->delta_own + e->ih_size;
   b->arena = dev_alloc(((D * S + F) * I + 128) * fl); /* + slack: k_delta_dma's rest tile reads up to 128 floats from column rows_core of the last row */

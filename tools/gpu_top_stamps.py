@@ -14,7 +14,7 @@ for i in range(60):
     amd.rnn_amd_set_char_step(g.handle, i, rc.WEIGHTED, 0.95)
 buf = np.zeros(16, np.uint64)
 amd.ramd_top_stamps(C.c_void_p(buf.ctypes.data))
-names = ["start", "hidden row in LDS", "output layer done", "softmax done", "backprop sums done", "end"]
+names = ["start", "hidden row in LDS", "output layer: waves' sums in LDS", "softmax done", "backprop: barrier passed", "end", "backprop: row stored, wave's sum in LDS"]
 t0 = int(buf[0])
 for i, n in enumerate(names):
     print("%-22s %6.2f us" % (n, (int(buf[i]) - t0) / 100.0))
