@@ -156,11 +156,15 @@ struct XchgArgs {
   int world, rank;
   unsigned first1; /* first block of segment 1 */
 };
+/* "a barrier of this process's exchange has given up": the DEVICE's copy of what k_xchg_barrier tells the host through
+ * the host-mapped abort word.  Round 6: k_apply_xchg read that host word itself, every thread of it, over PCIe -- 50 us
+ * of a launch that takes 6 (profiles/NOTES_r06.md section 9; the emulated exchange read +34 .. +86 us per rank). */
+__device__ unsigned g_xchg_gave_up;
 template <int METHOD>
 __global__ __launch_bounds__(256) void k_apply_xchg(XchgArgs xa, float momentum, float mw, const unsigned *abort_word) {
   /* a barrier in front of this launch gave up (a rank missing): the ranks' sums are not all there -- touch nothing;
    * the host aborts at its next synchronisation (rnn_core.c: dsync), until then no weights are made from half a sum */
-  if (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+  if (abort_word && __hip_atomic_load(&g_xchg_gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   const int g = blockIdx.x >= xa.first1 ? 1 : 0;
   const XchgSeg &sg = xa.seg[g];
   const size_t q = sg.lo4 + (size_t)(blockIdx.x - (g ? xa.first1 : 0u)) * 256 + threadIdx.x;
@@ -191,19 +195,26 @@ __global__ __launch_bounds__(256) void k_apply_xchg(XchgArgs xa, float momentum,
 // rank has mapped: visible across processes and GPUs inside a kernel) takes `seq`, then the launch waits until every
 // slot has reached it.  What the previous kernels of this stream wrote is visible to the peers' later kernels through
 // the kernel boundaries (release at the end of a launch, acquire at the start of the next, both at system scope).
-// Bounded: ~20 s of polling raise *abort_word (see dsync in rnn_core.c).
-__global__ void k_xchg_barrier(unsigned *flags, int rank, int world, unsigned seq, unsigned *abort_word) {
+// Bounded: 20 s of polling by the device's own clock (RECUR_AMD_XCHG_BARRIER_TIMEOUT_S) raise *abort_word (see dsync in
+// rnn_core.c) and the device's copy of it.
+__global__ void k_xchg_barrier(unsigned *flags, int rank, int world, unsigned seq, unsigned *abort_word,
+                               unsigned long long timeout_ticks) {
   const int p = threadIdx.x;
   if (p == 0) {
     __threadfence_system();
     __hip_atomic_store(&flags[rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  /* (a barrier of this process has given up already: the ranks are out of step for good -- later barriers do not wait
+   * their time out again, the host aborts at its next synchronisation) */
+  if (__hip_atomic_load(&g_xchg_gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   if (p < world) {
-    for (unsigned spins = 0;; spins++) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); /* 100 MHz */
+    for (;;) {
       /* (seq - got) as a signed number: counters that have wrapped still compare */
       if ((int)(__hip_atomic_load(&flags[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) >= 0) break;
-      if (spins > (1u << 24)) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
         if (abort_word) __hip_atomic_store(abort_word, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&g_xchg_gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
       __builtin_amdgcn_s_sleep(32);
@@ -382,7 +393,8 @@ extern "C" void ramd_launch_apply_multi(ramd_stream_t st_, int method, int nseg,
 
 extern "C" void ramd_launch_xchg_barrier(ramd_stream_t st, unsigned *flags_dev, int rank, int world, unsigned seq,
                                          unsigned *abort_word_dev) {
-  RAMD_LAUNCH(k_xchg_barrier, dim3(1), dim3(64), 0, (hipStream_t)st, flags_dev, rank, world, seq, abort_word_dev);
+  const unsigned long long ticks = 100000000ull * (unsigned long long)env_int("RECUR_AMD_XCHG_BARRIER_TIMEOUT_S", 20);
+  RAMD_LAUNCH(k_xchg_barrier, dim3(1), dim3(64), 0, (hipStream_t)st, flags_dev, rank, world, seq, abort_word_dev, ticks);
 }
 
 /* the sharded update (k_apply_xchg): w / delta: [2][world] device pointers of every rank's top-layer (0) and recurrent

@@ -135,7 +135,7 @@ static void dsync(void) {
   if (ramd_chain_abort_word()) {
     const unsigned code = ramd_chain_abort_word();
     if (code == 6) {
-      fprintf(stderr, "librecur_amd: a rank waited ~20 s at a barrier of the kernel-issued exchange: not every rank "
+      fprintf(stderr, "librecur_amd: a rank waited its time out (20 s; RECUR_AMD_XCHG_BARRIER_TIMEOUT_S) at a barrier of the kernel-issued exchange: not every rank "
                       "reached it (did one die, or drive fewer generations?); the replicas are out of step.\n");
     } else if (code == 2) {
       fprintf(stderr, "librecur_amd: a workgroup of the one-launch BPTT chain was not on the XCD its number implies (code 2): "

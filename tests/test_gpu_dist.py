@@ -217,6 +217,8 @@ while not all(mm[3072 + r] for r in range(world)):
 blobs = C.create_string_buffer(bytes(mm[256:256 + world * B]), world * B)
 counters = (C.c_char * 64).from_buffer(mm, 0)
 assert amd.rnn_amd_set_exchange_join(g.handle, rank, world, blobs, counters, 0) == 0
+if os.environ.get("XCHG_TEST_RANK1_STALLS") and rank == 1:
+    time.sleep(300)  # (joined, never steps: the other rank's first barrier has to give up; the test ends this process)
 for i in range(8):
     amd.rnn_amd_set_char_step(g.handle, i, rc.WEIGHTED, 0.9)
 s = g.snapshot()
@@ -399,6 +401,34 @@ def test_c_driver_with_G_1_goes_through_the_library_exchange_step():
         assert [int(x[0]) for x in rows[tag]] == [50, 100, 150]
     for a, b in zip(rows["plain"], rows["G1"]):
         assert abs(float(a[1]) - float(b[1])) < 2e-4 and abs(float(a[2]) - float(b[2])) < 2e-3, (a, b)
+
+
+def test_a_rank_that_never_steps_ends_the_other_with_a_message_not_with_half_a_sum():
+    """Two processes join the kernel-issued exchange; rank 1 never steps.  Rank 0's first arrival barrier polls its time out
+    (20 s by the device's clock; 3 s here), gives
+    up, raises the abort word (code 6) -- and the device's own copy of it, which is what k_apply_xchg reads (round 6: it
+    read the host's word, every thread, over PCIe: 50 us per launch) so that no weights are made from half a sum --, and
+    rank 0's next synchronisation ends the process with the message that says what happened."""
+    shm = "/dev/shm/recur_amd_xchg_stall_%d" % os.getpid()
+    with open(shm, "wb") as f:
+        f.write(b"\0" * 4096)
+    env = dict(os.environ, XCHG_TEST_RANK1_STALLS="1", RECUR_AMD_XCHG_BARRIER_TIMEOUT_S="3")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    script = XCHG_IPC_SCRIPT % {"tests": os.path.dirname(os.path.abspath(__file__))}
+    procs = [subprocess.Popen([sys.executable, "-c", script, str(r), "2", shm], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    try:
+        so_, se_ = procs[0].communicate(timeout=240)
+        assert procs[0].returncode != 0 and "RESULT ok" not in so_
+        assert "at a barrier of the kernel-issued exchange" in se_, se_[-2000:]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()  # these exact children
+            p.wait()
+        for f in (shm, shm + ".rank0.npz", shm + ".rank1.npz"):
+            if os.path.exists(f):
+                os.unlink(f)
 
 
 # ---- bench.py with more than one rank validates itself (round 6; the sum replaced is recur-nn.c:724-739)
