@@ -588,7 +588,10 @@ __global__ __launch_bounds__(1024) void k_text_top2(View v, int row0, int nrows,
 #pragma unroll
     for (int i = 0; i < T2_NB; i++) {
       const int y = y0 + rsub + 4 * i;
-      wv[i] = ld4(wb + (size_t)(y < y1 ? y : y0) * s.O);
+      /* (a row past the wave's share is multiplied by a zero hidden value below: it has to be FINITE -- row 0 of the
+       * matrix, not whatever lies behind it: a net with h_size < 16 leaves whole waves without rows, and tools/gpu_fuzz_api.py
+       * seed 13616 found their out-of-range rows holding NaN) */
+      wv[i] = ld4(wb + (size_t)(y < y1 ? y : 0) * s.O);
     }
   }
   int target = 0;
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(1024) void k_text_top2(View v, int row0, int nrows,
 #pragma unroll
     for (int i = 0; i < T2_NB; i++) {
       const int y = y0 + rsub + 4 * i;
-      const float hv = (colq && y < y1) ? shid[y < y1 ? y : y0] : 0.0f;
+      const float hv = (colq && y < y1) ? shid[y < y1 ? y : 0] : 0.0f;
       acc.x += hv * wv[i].x;
       acc.y += hv * wv[i].y;
       acc.z += hv * wv[i].z;

@@ -760,6 +760,10 @@ def _text_step_sweep():
     for hidden, S, D, n_in, n_out in ((1024, 64, 10, 42, 640), (1024, 32, 15, 150, 1100), (512, 64, 10, 42, 1100)):
         cases.append(("h%d_s%d_d%d_i%d_o%d_wide_top" % (hidden, S, D, n_in, n_out),
                       dict(input_size=n_in, hidden_size=hidden, output_size=n_out, S=S, D=D)))
+    # and tiny nets: k_text_top2's sixteen waves share h_size rows -- below 16 of them whole waves have none (the fuzzer's
+    # seed 13616, round 6: their out-of-range rows of W_ho were multiplied by zero and were NaN)
+    for hidden, S, D in ((7, 3, 4), (12, 1, 3), (20, 32, 5), (61, 5, 6)):
+        cases.append(("h%d_s%d_d%d_tiny" % (hidden, S, D), dict(input_size=42, hidden_size=hidden, output_size=42, S=S, D=D)))
     return cases
 
 
