@@ -7,7 +7,7 @@ surplus loads were still in flight).  This walks the kernel's assembly in text o
 queue (loads retire in order; `s_waitcnt vmcnt(N)` leaves the N youngest outstanding; the state at a branch is carried
 to its target) and reports every instruction that touches a register with a load outstanding on it.
 
-usage: isa_lint_async_loads.py file.s kernel_symbol_substring   (exit status 1 when something is found)"""
+usage: isa_lint_async_loads.py file.s kernel_symbol_substring [--hazards-only]   (exit status 1 when something is found)"""
 import re
 import sys
 
@@ -163,7 +163,12 @@ def main():
         body.append((i + 1, text[i]))
         if "s_endpgm" in text[i]:
             break
-    problems = lint(body) + lint_valu_to_mfma(body) + lint_valu_sgpr_to_vmem(body)
+    # --hazards-only (round 6, k_chain_persist): the two wait-state rules without the load-queue walk -- that kernel mixes
+    # hipcc's own loads (which hipcc tracks) with inline-asm ones behind `s_waitcnt vmcnt(0)`, and its A fragments are LDS
+    # reads with counted lgkmcnt waits across a loop's back edge, which the queue model (one in-order vmcnt queue, state
+    # carried to a label from the first branch that targets it) does not describe
+    hazards_only = len(sys.argv) > 3 and sys.argv[3] == "--hazards-only"
+    problems = ([] if hazards_only else lint(body)) + lint_valu_to_mfma(body) + lint_valu_sgpr_to_vmem(body)
     loads = sum(1 for _, l in body if l.strip().startswith("global_load"))
     print("%s: %d instructions, %d global loads, %d problems" % (sym, len(body), loads, len(problems)))
     for no, line, hit in problems[:40]:
