@@ -231,6 +231,8 @@ class HostGroup:
             self.counters = (C.c_char * 64).from_buffer(self.mm, 0)
         rc_ = amd.rnn_amd_set_exchange_join(handle, self.rank, self.world, blobs, self.counters, 0)
         ok = min(self.gather(1 if rc_ == 0 else 0))  # (also the rendezvous: nobody steps before everybody has joined)
+        if ok != 1 and rc_ == 0:
+            amd.rnn_amd_set_exchange_leave(handle)  # (another rank could not join: nobody uses this exchange)
         return ok == 1
 
     def close(self):

@@ -2950,6 +2950,9 @@ void rnn_amd_set_exchange_export(RnnAmdSet *set, void *blob) {
     struct timespec ts;
     clock_gettime(CLOCK_REALTIME, &ts);
     b.nonce = ((uint64_t)ts.tv_sec << 30) ^ (uint64_t)ts.tv_nsec ^ (++exports << 48);
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    b.nonce = (b.nonce & ~(uint64_t)0xff) | (uint64_t)(dev & 0xff); /* (low byte: the exporting rank's device, for the join's peer-access check) */
   }
   void *arrays[3] = {e->b.ih_delta, e->b.ih_w, e->b.ho_w};
   for (int k = 0; k < 3; k++) {
@@ -3054,6 +3057,27 @@ int rnn_amd_set_exchange_join(RnnAmdSet *set, int rank, int world, const void *b
   }
   engine_need_dev(e, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS | RNN_AMD_DELTAS);
   deltas_materialize(e);
+  { /* can this rank's kernels reach every peer's device at all?  Asked BEFORE anything is opened: a kernel that stores
+     * through a pointer it may not use faults, and a launcher that tries this exchange beside RCCL (bench.py --exchange
+     * auto) must get a -1 to fall back on, not a dead rank */
+    int mydev = 0;
+    HIP_OK(hipGetDevice(&mydev));
+    for (int p = 0; p < world; p++) {
+      XchgBlob b;
+      memcpy(&b, (const char *)blobs + (size_t)p * RNN_AMD_EXCHANGE_BLOB_BYTES, sizeof(b));
+      const int peerdev = (int)(b.nonce & 0xff);
+      int can = 1;
+      if (p != rank && peerdev != mydev && hipDeviceCanAccessPeer(&can, mydev, peerdev) != hipSuccess) {
+        (void)hipGetLastError();
+        can = 0;
+      }
+      if (!can) {
+        fprintf(stderr, "librecur_amd: rank %d (device %d) has no peer access to rank %d's device %d: the kernel-issued "
+                        "exchange needs it (use the RCCL all-reduce)\n", rank, mydev, p, peerdev);
+        return -1;
+      }
+    }
+  }
   float **dst[3] = {e->xchg_delta, e->xchg_ihw, e->xchg_how};
   void *own[3] = {e->b.ih_delta, e->b.ih_w, e->b.ho_w};
   memset(e->xchg_opened, 0, sizeof(e->xchg_opened));
