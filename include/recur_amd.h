@@ -420,6 +420,12 @@ void rnn_amd_set_grouped_softmax_error(RnnAmdSet *set, int n_groups, const int *
 void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *next,
                                    const int *target_class, int alphabet_len, float leakage,
                                    int accumulate);
+/* The same generation with its update, as ONE call: rnn_amd_set_multi_step_deltas(..., accumulate 0) + rnn_apply_learning(
+ * nets[0], learning_style, momentum) (charmodel-multi-predict.c:244-262: text_train's step and its rnn_apply_learning).
+ * The same results; knowing the update that follows, the weight-delta GEMM carries it out in its own epilogue where the
+ * rule is ADAGRAD (the trainer's default) or the momentum rule -- no optimiser launch (round 6). */
+void rnn_amd_set_multi_step(RnnAmdSet *set, const int *hot, const int *next, const int *target_class,
+                            int alphabet_len, float leakage, int learning_style, float momentum);
 
 /* The two halves of rnn_amd_set_multi_step_deltas with the text on the device (stream j reads
  * text[o], is scored against text[o + 1], o as in rnn_amd_set_char_step): the loss leaves

@@ -236,6 +236,7 @@ AMD_API = {
     "rnn_amd_set_grouped_softmax_error": (None, [C.c_void_p, C.c_int, c_int_p, c_int_p, c_int_p, c_float_p,
                                                  c_u8_p]),
     "rnn_amd_set_multi_step_deltas": (None, [C.c_void_p, c_int_p, c_int_p, c_int_p, C.c_int, C.c_float, C.c_int]),
+    "rnn_amd_set_multi_step": (None, [C.c_void_p, c_int_p, c_int_p, c_int_p, C.c_int, C.c_float, C.c_int, C.c_float]),
     "rnn_amd_set_multi_text_loss": (None, [C.c_void_p, C.c_int, c_int_p, C.c_int, C.c_float]),
     "rnn_amd_set_multi_calc_deltas": (None, [C.c_void_p, C.c_int]),
     "rnn_amd_set_text_opinion": (None, [C.c_void_p, C.c_int, C.c_int]),

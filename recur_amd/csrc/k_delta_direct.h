@@ -54,7 +54,8 @@ struct DdArgs {
   int tm, tn;          /* 64-row and 64-column tiles (columns start at column 1)                       */
   int rest;            /* I - 64 tm (a multiple of 4, <= 64 NPW; tm >= 16), 0: none                     */
   int hidden_size;     /* 64 tn                                                                         */
-  int mode;            /* 0: delta = sum, 1: delta += sum, 2: delta = sum and the update (method 0)     */
+  int mode;            /* 0: delta = sum, 1: delta += sum, 2: delta = sum and the update (`method`)    */
+  int method;          /* mode 2: 0 the momentum rule (recur-nn.c:482-487), 4 ADAGRAD (518-524: the momentum array is its accumulator) */
   float rate, momentum, mw;
   /* mode 2: the top layer's update rides along (recur-nn.c:653-676): ho_n4 float4s shared out over the workgroups */
   float *ho_w, *ho_m;
@@ -409,12 +410,19 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
   DDIR_STAMP(4);
   __syncthreads();
   DDIR_STAMP(5);
-  auto update4 = [&](dd_f4 &W, dd_f4 &M, const dd_f4 &d, float rate) { /* recur-nn.c:482-487 */
+  const bool adagrad = a.method == 4; /* (a kernel argument: uniform) */
+  auto update4 = [&](dd_f4 &W, dd_f4 &M, const dd_f4 &d, float rate) { /* recur-nn.c:482-487, or 518-524 (k_apply<4>'s arithmetic) */
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const float t = d[k] * rate, mm = M[k];
-      W[k] += t + mm * a.mw;
-      M[k] = (mm + t) * a.momentum;
+      if (adagrad) {
+        const float acc2 = M[k] + d[k] * d[k];
+        W[k] += d[k] * rate / sqrtf(acc2);
+        M[k] = acc2;
+      } else {
+        const float t = d[k] * rate, mm = M[k];
+        W[k] += t + mm * a.mw;
+        M[k] = (mm + t) * a.momentum;
+      }
     }
   };
 #pragma unroll
@@ -435,6 +443,12 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
     }
   }
   auto update1 = [&](size_t off, float d, float rate, float *w, float *m) {
+    if (adagrad) {
+      const float acc2 = m[off] + d * d;
+      w[off] += d * rate / sqrtf(acc2);
+      m[off] = acc2;
+      return;
+    }
     const float t = d * rate, mm = m[off];
     w[off] += t + mm * a.mw;
     m[off] = (mm + t) * a.momentum;
@@ -469,7 +483,9 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
       const int col = (nt == 0 && cc == 0) ? -1 : a.hidden_size + (nt == 0 ? cc - 1 : cc);
       const ptrdiff_t off = (ptrdiff_t)row * a.H + col;
       dlt[off] = 0.0f;
-      if (upd) {
+      if (upd && adagrad) { /* the rule with a delta of 0, as the optimiser's launch computes it (0 / sqrt(0) where nothing was ever added) */
+        a.w[off] += 0.0f * a.rate / sqrtf(a.m[off]);
+      } else if (upd) {
         const float mm = a.m[off];
         a.w[off] += mm * a.mw;
         a.m[off] = mm * a.momentum;

@@ -1867,7 +1867,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   /* (not where the chain launch has workgroups without chain work -- half of it or more, ramd_chain_steps: there the
    * request costs the chain nothing, here it costs 2.4 us: the 48 loads per wave queue behind the ring's at the CU's
    * 64 bytes per clock.  256 streams at hidden 1024: chain 107.6 -> 104.1 us, this launch 91.9 -> 94.3, generation 221.0 -> 219.9) */
-  const bool ho_in_delta = direct_fuse && !ranges && !active && nrows >= 16 && nrows <= 256 && sh->O <= 48 && sh->O % 4 == 0 &&
+  const bool ho_in_delta = direct_fuse && defer->fuse_method == 0 && !ranges && !active && nrows >= 16 && nrows <= 256 && sh->O <= 48 && sh->O % 4 == 0 &&
                            sh->H <= 5 * dtm * dtn && (nrows / 32) * (sh->hidden_size / 32) > 128 &&
                            env_int("RECUR_AMD_HO_IN_DELTA", 1);
   bool ho_paired = false, ho_finalize_after = false, ho_in_final = false;
@@ -2161,6 +2161,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
           a.rate = defer->fuse_rate;
           a.momentum = defer->fuse_momentum;
           a.mw = defer->fuse_mw;
+          a.method = defer->fuse_method;
           if (!ho_in_delta) { /* the top layer's sums are there (the chain launch formed them): its update, shared out */
             a.ho_w = b->ho_w;
             a.ho_m = b->ho_m;

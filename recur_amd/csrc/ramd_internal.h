@@ -122,6 +122,7 @@ typedef struct RamdPendingDelta {
    * delta arrays hold the sums: nothing is left pending */
   int fuse_want, fuse_done;
   float fuse_rate, fuse_ho_rate, fuse_momentum, fuse_mw;
+  int fuse_method; /* 0: the momentum rule (recur-nn.c:482-487); 4: ADAGRAD (recur-nn.c:518-524; round 6) */
 } RamdPendingDelta;
 
 enum { RAMD_IN_KEEP = 0, RAMD_IN_ONE_HOT = 1, RAMD_IN_DENSE = 2, RAMD_IN_TEXT = 3 };

@@ -2649,7 +2649,7 @@ static void multi_loss(RnnAmdSet *set, const int *target_class, int alphabet_len
   }
 }
 
-void rnn_amd_set_multi_calc_deltas(RnnAmdSet *set, int accumulate) {
+static void multi_calc_deltas(RnnAmdSet *set, int accumulate, RamdPendingDelta *defer) {
   RamdEngine *e = set->eng;
   set_need_training(set, "rnn_amd_set_multi_calc_deltas");
   if (!e->d_mranges) {
@@ -2658,12 +2658,19 @@ void rnn_amd_set_multi_calc_deltas(RnnAmdSet *set, int accumulate) {
   }
   /* (heads of at least 24 columns: a stream's ranges then lie at least 16 columns apart, see k_top_backprop_heads) */
   set_calc_deltas(set, accumulate, NULL, NULL, e->mheads_alen >= 24 ? RAMD_RANGES_ARE_HEADS : 0,
-                  e->d_mranges + (size_t)set->row0 * MULTI_RANGE_STRIDE, MULTI_RANGE_STRIDE, NULL);
+                  e->d_mranges + (size_t)set->row0 * MULTI_RANGE_STRIDE, MULTI_RANGE_STRIDE, defer);
 }
+void rnn_amd_set_multi_calc_deltas(RnnAmdSet *set, int accumulate) { multi_calc_deltas(set, accumulate, NULL); }
 
+static void multi_step_deltas(RnnAmdSet *set, const int *hot, const int *next, const int *target_class, int alphabet_len,
+                              float leakage, int accumulate, RamdPendingDelta *defer);
 void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *next,
                                    const int *target_class, int alphabet_len, float leakage,
                                    int accumulate) {
+  multi_step_deltas(set, hot, next, target_class, alphabet_len, leakage, accumulate, NULL);
+}
+static void multi_step_deltas(RnnAmdSet *set, const int *hot, const int *next, const int *target_class, int alphabet_len,
+                              float leakage, int accumulate, RamdPendingDelta *defer) {
   RamdEngine *e = set->eng;
   set_need_training(set, "rnn_amd_set_multi_step_deltas");
   int n_classes = multi_heads(e, alphabet_len);
@@ -2683,7 +2690,7 @@ void rnn_amd_set_multi_step_deltas(RnnAmdSet *set, const int *hot, const int *ne
     early = 1;
   }
   multi_loss(set, NULL, alphabet_len, n_classes, leakage, early);
-  rnn_amd_set_multi_calc_deltas(set, accumulate);
+  multi_calc_deltas(set, accumulate, defer);
 }
 
 static void check_text_pos(RamdEngine *e, int i, int last_ok, const char *what) {
@@ -3247,16 +3254,24 @@ static int one_rank_exchange_forced(void) {
 /* what a one-call generation does before its update: the text step (symbol i of the resident text), or a dense-input
  * generation with rnnca's loss (rnn_amd_set_dense_step_sigmoid_mse) */
 typedef struct {
-  int i;                /* text position, or -1: dense */
+  int i;                /* text position, or -1: dense, or -2: the multi-head step */
   const float *inputs;  /* dense: host [n][ld_inputs] */
   int ld_inputs;
   const float *targets; /* host [n][ld], the first n_targets outputs */
   int ld, n_targets;
+  /* the multi-head step (rnn_amd_set_multi_step_deltas's arguments) */
+  const int *hot, *next, *target_class;
+  int alphabet_len;
+  float leakage;
 } StepSpec;
 
+static void multi_step_deltas(RnnAmdSet *set, const int *hot, const int *next, const int *target_class, int alphabet_len,
+                              float leakage, int accumulate, RamdPendingDelta *defer);
 static void step_deltas(RnnAmdSet *set, const StepSpec *sp, RamdPendingDelta *defer) {
   if (sp->i >= 0) {
     char_step_deltas(set, sp->i, defer);
+  } else if (sp->i == -2) {
+    multi_step_deltas(set, sp->hot, sp->next, sp->target_class, sp->alphabet_len, sp->leakage, 0, defer);
   } else {
     rnn_amd_set_opinion_sigmoid_mse(set, sp->inputs, sp->ld_inputs, sp->targets, sp->ld, sp->n_targets);
     set_calc_deltas(set, 0, NULL, NULL, 0, NULL, 0, defer);
@@ -3279,7 +3294,15 @@ static void set_step(RnnAmdSet *set, const StepSpec *sp, int learning_style, flo
     g_halves_seen = 0;
     ramd_set_delta_half_hook(delta_half_ready, set->eng);
   }
-  if (fuse && !set->eng->sh.bI &&
+  if (fuse && !set->eng->sh.bI && learning_style == RNN_ADAGRAD) {
+    /* ADAGRAD (recur-nn.c:518-524, the multi-head trainer's rule): the same epilogue with the other arithmetic (round 6) */
+    const RecurNNBPTT *bptt = set->nets[0]->bptt;
+    engine_need_dev(set->eng, RNN_AMD_WEIGHTS | RNN_AMD_MOMENTUMS);
+    pend.fuse_want = 1;
+    pend.fuse_method = 4;
+    pend.fuse_rate = bptt->learn_rate;
+    pend.fuse_ho_rate = bptt->learn_rate * bptt->ho_scale;
+  } else if (fuse && !set->eng->sh.bI &&
       (learning_style == RNN_MOMENTUM_WEIGHTED || learning_style == RNN_MOMENTUM_SIMPLIFIED_NESTEROV ||
        learning_style == RNN_MOMENTUM_CLASSICAL || learning_style >= RNN_LAST_LEARNING_METHOD || learning_style < 0)) {
     /* the momentum rule (recur-nn.c:482-487, 653-676): the weight-delta GEMM may carry the update out in its own
@@ -3315,8 +3338,17 @@ static void set_step(RnnAmdSet *set, const StepSpec *sp, int learning_style, flo
   apply_learning(set->nets[0], learning_style, momentum, (pend.slab || pend.ho_slab) ? &pend : NULL);
 }
 
+/* the multi-head generation as ONE call: rnn_amd_set_multi_step_deltas (accumulate 0) + rnn_apply_learning -- knowing the
+ * update that follows, the weight-delta GEMM carries it out in its own epilogue where the rule is ADAGRAD (the trainer's)
+ * or the momentum rule: no optimiser launch (17 us of configs[3]'s 340) */
+void rnn_amd_set_multi_step(RnnAmdSet *set, const int *hot, const int *next, const int *target_class, int alphabet_len,
+                            float leakage, int learning_style, float momentum) {
+  StepSpec sp = {-2, NULL, 0, NULL, 0, 0, hot, next, target_class, alphabet_len, leakage};
+  set_step(set, &sp, learning_style, momentum);
+}
+
 void rnn_amd_set_char_step(RnnAmdSet *set, int i, int learning_style, float momentum) {
-  StepSpec sp = {i, NULL, 0, NULL, 0, 0};
+  StepSpec sp = {i, NULL, 0, NULL, 0, 0, NULL, NULL, NULL, 0, 0.0f};
   set_step(set, &sp, learning_style, momentum);
 }
 
@@ -3328,7 +3360,7 @@ void rnn_amd_set_dense_step_sigmoid_mse(RnnAmdSet *set, const float *inputs, int
     abort();
   }
   rnn_bptt_clear_deltas(set->nets[0]); /* (lazy: the delta call below simply does not accumulate) */
-  StepSpec sp = {-1, inputs, ld_inputs, targets, ld, n};
+  StepSpec sp = {-1, inputs, ld_inputs, targets, ld, n, NULL, NULL, NULL, 0, 0.0f};
   set_step(set, &sp, learning_style, momentum);
 }
 

@@ -71,6 +71,41 @@ def test_config3_multi_head_generation_at_size(amd, S):
     _multi_head_generation(amd, 73, 50, 1024, S, 20, 0.1, deep=True)
 
 
+@pytest.mark.parametrize("S", [256, 32])
+def test_config3_multi_head_generation_as_one_call(amd, S):
+    """rnn_amd_set_multi_step: the multi-head generation with its ADAGRAD update as ONE call -- the weight-delta GEMM carries
+    the update out in its epilogue (DdArgs.method 4: recur-nn.c:518-524, `m += d d; w += d rate / sqrt(m)`, both layers, the
+    76 rest rows, the zero-delta columns), no optimiser launch: the same generation against the oracle, weights and
+    accumulators included."""
+    _multi_head_generation(amd, 73, 50, 1024, S, 20, 0.1, deep=True, one_call=True)
+
+
+def test_text_step_with_adagrad_in_the_delta_gemms_epilogue(amd):
+    """rnn_amd_set_char_step with RNN_ADAGRAD at hidden 1024: the same epilogue through the text step (the top layer's delta
+    from the chain launch or the split-K planes, not from the hook, which is the momentum rule's)."""
+    kw = dict(input_size=42, hidden_size=1024, output_size=42, S=64, D=10, learn_rate=1e-4, seed=5)
+    g = sc.AmdBatchedSet(amd, **kw)
+    amd.rnn_set_momentum_values(g.net, 50.0)
+    text = sc.synthetic_text(8000)
+    for i in range(13):
+        g.char_step(text, i, rc.ADAGRAD, 0.9)
+    o = sc.OracleSet(**kw)
+    for attempt in range(4):
+        _sync_oracle_to(o, g.snapshot())
+        g.char_step(text, 13 + attempt, rc.ADAGRAD, 0.9)
+        o.char_step(text, 13 + attempt, rc.ADAGRAD, 0.9)
+        sg, so = g.snapshot(), o.snapshot()
+        if np.array_equal(sg["hidden"] != 0, so["hidden"] != 0):
+            break
+        _same_mask(sg["hidden"], so["hidden"])
+    else:
+        raise AssertionError("no generation without a rounding-level mask flip in 4 attempts")
+    replay.check(sg, so, RTOL, keys=["ih_delta", "ho_delta", "ih_w", "ho_w", "ih_m", "ho_m", "hidden", "hist"],
+                 exact=("index", "generation"))
+    g.close()
+    o.close()
+
+
 @pytest.mark.parametrize("A,NC,H,S,D,leakage", [(128, 11, 256, 40, 6, 0.3), (24, 64, 512, 300, 5, 0.05),
                                                  (100, 3, 128, 7, 4, 0.9), (31, 20, 256, 64, 6, 0.2)])
 def test_multi_head_generation_with_other_head_shapes(amd, A, NC, H, S, D, leakage):
@@ -89,7 +124,7 @@ def test_multi_head_generation_with_streams_that_have_no_head_of_their_own(amd, 
     _multi_head_generation(amd, 31, 6, 128, 40, 5, 0.3, stray_every=stray_every)
 
 
-def _multi_head_generation(lib, A, NC, H, S, D, leakage, deep=False, stray_every=0):
+def _multi_head_generation(lib, A, NC, H, S, D, leakage, deep=False, stray_every=0, one_call=False):
     kw = dict(input_size=A, hidden_size=H, output_size=A * NC, S=S, D=D, learn_rate=1e-4, seed=61,
               activation=rc.RESQRT, noise=0.01, flags=rc.FLAG_STANDARD | rc.FLAG_ADAPTIVE_MIN_ERROR)
     g = sc.AmdBatchedSet(lib, **kw)
@@ -110,8 +145,11 @@ def _multi_head_generation(lib, A, NC, H, S, D, leakage, deep=False, stray_every
     n_warm = D + 3
     for _ in range(n_warm):
         hot, nxt, cls = draw()
-        lib.rnn_amd_set_multi_step_deltas(g.handle, rc.iptr(hot), rc.iptr(nxt), rc.iptr(cls), A, leakage, 0)
-        lib.rnn_apply_learning(g.net, rc.ADAGRAD, 0.9)
+        if one_call:  # the update in the weight-delta GEMM's epilogue (ADAGRAD: round 6)
+            lib.rnn_amd_set_multi_step(g.handle, rc.iptr(hot), rc.iptr(nxt), rc.iptr(cls), A, leakage, rc.ADAGRAD, 0.9)
+        else:
+            lib.rnn_amd_set_multi_step_deltas(g.handle, rc.iptr(hot), rc.iptr(nxt), rc.iptr(cls), A, leakage, 0)
+            lib.rnn_apply_learning(g.net, rc.ADAGRAD, 0.9)
     lib.rnn_amd_synchronize()
     rate = n_warm * S / (time.perf_counter() - t0)
     print("configs[3] multi-head step, %d streams: %.0f stream-timesteps/s (host uploads per step included)"
@@ -121,8 +159,11 @@ def _multi_head_generation(lib, A, NC, H, S, D, leakage, deep=False, stray_every
     _sync_oracle_to(o, snap, g)
     hot, nxt, cls = draw()
     g.stats(clear=True)
-    lib.rnn_amd_set_multi_step_deltas(g.handle, rc.iptr(hot), rc.iptr(nxt), rc.iptr(cls), A, leakage, 0)
-    lib.rnn_apply_learning(g.net, rc.ADAGRAD, 0.9)
+    if one_call:
+        lib.rnn_amd_set_multi_step(g.handle, rc.iptr(hot), rc.iptr(nxt), rc.iptr(cls), A, leakage, rc.ADAGRAD, 0.9)
+    else:
+        lib.rnn_amd_set_multi_step_deltas(g.handle, rc.iptr(hot), rc.iptr(nxt), rc.iptr(cls), A, leakage, 0)
+        lib.rnn_apply_learning(g.net, rc.ADAGRAD, 0.9)
     ranges = (C.c_int * (2 * (NC + 1)))()
     for j in range(S):
         o.orc.orc_advance(o.z, j)

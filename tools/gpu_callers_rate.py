@@ -18,8 +18,11 @@ if which in ("multi", "both"):
               rs.integers(0, NC, S).astype(np.int32)) for _ in range(8)]
     def gen(i):
         hot, nxt, cls = draws[i % 8]
-        amd.rnn_amd_set_multi_step_deltas(g.handle, rc.iptr(hot), rc.iptr(nxt), rc.iptr(cls), A, 0.1, 0)
-        amd.rnn_apply_learning(g.net, rc.ADAGRAD, 0.9)
+        if os.environ.get("RATE_TWO_CALLS"):  # the deltas, then rnn_apply_learning's launch (until round 5 the only form)
+            amd.rnn_amd_set_multi_step_deltas(g.handle, rc.iptr(hot), rc.iptr(nxt), rc.iptr(cls), A, 0.1, 0)
+            amd.rnn_apply_learning(g.net, rc.ADAGRAD, 0.9)
+        else:  # one call: the ADAGRAD update in the weight-delta GEMM's epilogue
+            amd.rnn_amd_set_multi_step(g.handle, rc.iptr(hot), rc.iptr(nxt), rc.iptr(cls), A, 0.1, rc.ADAGRAD, 0.9)
     for i in range(D + 5):
         gen(i)
     amd.rnn_amd_synchronize()
