@@ -380,31 +380,6 @@ constexpr int W_STAGE_FLOATS = (WM + WN) * WK; /* 32 KB */
 #define BND_MARK(sym, which) do { } while (0)
 #endif
 
-// ---- the per-net calls' small copies (rnn_core.c's mailbox): up to 12 word-wise copies between a pinned, device-mapped host
-// mailbox and the device arrays -- as a launch of their own (k_segcopy, kernels_apply.hip) or, round 6, in the FIRST / LAST
-// instructions of the single-workgroup kernel that consumes / produces them (k_fwd_small, k_top_backprop, k_bptt_small): a
-// per-net call of a small net was four k_segcopy launches around three kernels, each launch 3.8 us plus its boundary.
-struct SegCopy {
-  unsigned *dst[12];
-  const unsigned *src[12];
-  unsigned n[12];
-  int nseg;
-};
-/* every thread of the (one) workgroup calls it; `after`: behind a barrier (what this workgroup has written is copied out) */
-__device__ __forceinline__ void segs_run(const SegCopy &sc, bool after) {
-  if (sc.nseg == 0) return; /* (a kernel argument: uniform) */
-  if (after) __syncthreads();
-  for (int g = 0; g < sc.nseg; g++)
-    for (unsigned i = threadIdx.x; i < sc.n[g]; i += blockDim.x) sc.dst[g][i] = sc.src[g][i];
-  if (!after) {
-    __threadfence();
-    __syncthreads();
-  }
-}
-#define RAMD_LOCAL_ __attribute__((visibility("hidden")))
-RAMD_LOCAL_ SegCopy ramd_take_staged(int out); /* what rnn_core.c staged for the next consumer (ramd_stage_segs), emptied */
-RAMD_LOCAL_ void ramd_flush_staged_in(hipStream_t st); /* ... or as a k_segcopy launch after all (the launcher cannot consume it) */
-
 // ---- launch-side support (kernels_support.hip) ----
 // HIP-event timing of the kernel classes (bench.py's roofline leg)
 enum { T_CHAIN = 0, T_DELTA = 1, T_FWD = 2, T_APPLY = 3, T_OTHER = 4, T_XCHG = 5, T_CLASSES = 6 }; /* (T_XCHG = RAMD_T_XCHG: the exchange between ranks, bracketed by rnn_core.c) */

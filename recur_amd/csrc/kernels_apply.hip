@@ -326,6 +326,12 @@ __global__ void k_tall_poppy(float *a, const BestAbs *part, int nparts, float th
 
 // Up to 12 small word-wise copies in one launch: the per-net calls' traffic between a pinned
 // host mailbox and the device arrays (either side may be the host: the mailbox is mapped).
+struct SegCopy {
+  unsigned *dst[12];
+  const unsigned *src[12];
+  unsigned n[12];
+  int nseg;
+};
 __global__ __launch_bounds__(256) void k_segcopy(SegCopy sc) {
   const int g = blockIdx.y;
   if (g >= sc.nseg) return;
@@ -347,43 +353,6 @@ extern "C" void ramd_launch_segcopy(ramd_stream_t st_, int nseg, void *const *ds
   unsigned bx = (most + 255) / 256;
   if (bx > 16) bx = 16;
   RAMD_LAUNCH(k_segcopy, dim3(bx, nseg), dim3(256), 0, st, sc);
-}
-
-/* staged instead of launched: the next single-workgroup consumer (in) / producer (out) carries the copies itself */
-static SegCopy g_staged[2];
-extern "C" void ramd_stage_segs(int out, int nseg, void *const *dst, const void *const *src, const unsigned *nwords) {
-  SegCopy &sc = g_staged[out ? 1 : 0];
-  if (sc.nseg + nseg > 12) { /* (callers stage one batch per call: cannot happen) */
-    fprintf(stderr, "librecur_amd: more than 12 staged copies\n");
-    abort();
-  }
-  for (int g = 0; g < nseg; g++) {
-    sc.dst[sc.nseg] = (unsigned *)dst[g];
-    sc.src[sc.nseg] = (const unsigned *)src[g];
-    sc.n[sc.nseg] = nwords[g];
-    sc.nseg++;
-  }
-}
-SegCopy ramd_take_staged(int out) {
-  SegCopy sc = g_staged[out ? 1 : 0];
-  g_staged[out ? 1 : 0].nseg = 0;
-  return sc;
-}
-static void launch_staged(hipStream_t st, int out) {
-  SegCopy sc = ramd_take_staged(out);
-  if (!sc.nseg) return;
-  unsigned most = 1;
-  for (int g = 0; g < sc.nseg; g++)
-    if (sc.n[g] > most) most = sc.n[g];
-  unsigned bx = (most + 255) / 256;
-  if (bx > 16) bx = 16;
-  RAMD_LAUNCH(k_segcopy, dim3(bx, sc.nseg), dim3(256), 0, st, sc);
-}
-void ramd_flush_staged_in(hipStream_t st) { launch_staged(st, 0); }
-/* whatever is still staged, as launches: inbound first (rnn_core.c: before it synchronises and delivers) */
-extern "C" void ramd_flush_staged(ramd_stream_t st) {
-  launch_staged((hipStream_t)st, 0);
-  launch_staged((hipStream_t)st, 1);
 }
 
 extern "C" void ramd_launch_apply_multi(ramd_stream_t st_, int method, int nseg, float *const *w,

@@ -54,10 +54,9 @@ __global__ __launch_bounds__(256) void k_bottom_delta(View v, int row0, int nrow
 // ehi[0] (what the BPTT chain reads) and leaves err_a for the lazy write-back.
 __global__ __launch_bounds__(256) void k_top_backprop(View v, int row0, const int *ranges,
                                                       int range_stride,
-                                                      const unsigned char *active, SegCopy pre) {
+                                                      const unsigned char *active) {
   extern __shared__ float sh[];
   __shared__ float red[4];
-  segs_run(pre, false); /* (a per-net call's inbound mailbox copies -- the output error -- with one workgroup: see SegCopy) */
   const RamdShape &s = v.sh;
   int j = blockIdx.x, r = row0 + j;
   if (active && !active[j]) return;
@@ -1441,7 +1440,7 @@ __global__ __launch_bounds__(THREADS) void k_extras_control(View v, int row0, in
 // ih_delta (+)= ih_scale * the accumulated matrix at the end.
 // Preconditions (launcher): h_size <= 128, i_size <= 256, D * i_size floats fit in LDS.
 __global__ __launch_bounds__(1024) void k_bptt_small(View v, int r, int accumulate, unsigned flags,
-                                                     int nx, int nxp, SegCopy post) {
+                                                     int nx, int nxp) {
   extern __shared__ __attribute__((aligned(16))) float bsm[];
   const RamdShape &s = v.sh;
   const int I = s.I, H = s.H, hs = s.hidden_size, D = s.D;
@@ -1619,7 +1618,6 @@ __global__ __launch_bounds__(1024) void k_bptt_small(View v, int r, int accumula
       }
     }
   }
-  segs_run(post, true); /* the per-net call's outbound copies: the error images and the two scalars this workgroup left */
 }
 
 // ------------------------------------------------------- finalize: delta --
@@ -1766,9 +1764,6 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
   g_calc_wrote_images = 0;
   hipStream_t st = (hipStream_t)st_;
   View v = make_view(sh, b);
-  /* a per-net call's inbound mailbox copies ride in the plain k_top_backprop of ONE stream (its first launch: below); any
-   * other first launch needs them done: as a launch of their own */
-  if (!(nrows == 1 && !ranges && !(flags & (0x40000000u | RAMD_IMAGES_PENDING)))) ramd_flush_staged_in(st);
   // top layer
   size_t shm = (size_t)(sh->O + sh->H) * sizeof(float);
   bool images_done = !(flags & RAMD_IMAGES_PENDING);
@@ -1820,8 +1815,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       if (nb > 1)
         RAMD_LAUNCH(k_top_backprop_scale, dim3(nrows), dim3(256), 0, st, v, row0, active, b->slab, nb);
     } else
-      RAMD_LAUNCH(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges, range_stride, active,
-                  nrows == 1 ? ramd_take_staged(0) : SegCopy{});
+      RAMD_LAUNCH(k_top_backprop, dim3(nrows), dim3(256), shm, st, v, row0, ranges, range_stride, active);
   }
   /* the weight-delta GEMM's path is decided here already: when it ends with the small GEMM
    * over the rows above the last whole 128-row tile, the top layer's equally small delta
@@ -1969,7 +1963,7 @@ extern "C" void ramd_launch_calc_deltas(ramd_stream_t st_, const RamdShape *sh,
       }
       if (defer) defer->slab = nullptr; /* ih_delta is written here: nothing left for the optimiser to sum */
       int ev = timing_begin(st, T_CHAIN, 1);
-      RAMD_LAUNCH(k_bptt_small, dim3(1), dim3(1024), shm, st, v, row0, accumulate, flags, nx, nxp, ramd_take_staged(1));
+      RAMD_LAUNCH(k_bptt_small, dim3(1), dim3(1024), shm, st, v, row0, accumulate, flags, nx, nxp);
       timing_end(st, ev);
       g_calc_wrote_images = 1; /* the error images are done: no k_err_writeback for this call */
       return;

@@ -914,9 +914,8 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
 // Thread (g = tid / HC, n = tid % HC) walks the input rows y = g, g + G, .. of column n (a wave
 // reads whole contiguous rows of W_ih), the G partial sums per column are added in order.
 // Preconditions (launcher): h_size <= 256, i_size <= 512, o_size <= 64.
-__global__ __launch_bounds__(1024) void k_fwd_small(View v, int r, SegCopy pre, SegCopy post) {
+__global__ __launch_bounds__(1024) void k_fwd_small(View v, int r) {
   __shared__ float xs[512], hsh[256], part[1024], red[16];
-  segs_run(pre, false); /* the call's inbound mailbox copies (the inputs): before anything is read */
   const RamdShape &s = v.sh;
   const int I = s.I, H = s.H, O = s.O, hs = s.hidden_size;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -987,7 +986,6 @@ __global__ __launch_bounds__(1024) void k_fwd_small(View v, int r, SegCopy pre, 
       v.b.out[(size_t)r * O + tid] = x;
     }
   }
-  segs_run(post, true); /* the call's outbound copies: the layers this workgroup has just written, into the host's mailbox */
 }
 
 #pragma clang fp contract(off)
@@ -1146,14 +1144,11 @@ extern "C" int ramd_launch_forward_hidden(ramd_stream_t st_, const RamdShape *sh
 /* rnn_opinion's device work for one stream of a small net in one launch (k_fwd_small); returns 0
  * when the shape is not its kind and nothing was launched */
 extern "C" int ramd_launch_forward_small(ramd_stream_t st_, const RamdShape *sh, const RamdBuffers *b, int r) {
+  if (sh->H > 256 || sh->I > 512 || sh->O > 64 || sh->bI || !env_int("RECUR_AMD_FWD_SMALL", 1)) return 0;
   hipStream_t st = (hipStream_t)st_;
-  if (sh->H > 256 || sh->I > 512 || sh->O > 64 || sh->bI || !env_int("RECUR_AMD_FWD_SMALL", 1)) {
-    ramd_flush_staged_in(st); /* (whoever runs instead reads what the mailbox brought: as a launch, then) */
-    return 0;
-  }
   View v = make_view(sh, b);
   int ev = timing_begin(st, T_FWD);
-  RAMD_LAUNCH(k_fwd_small, dim3(1), dim3(1024), 0, st, v, r, ramd_take_staged(0), ramd_take_staged(1));
+  RAMD_LAUNCH(k_fwd_small, dim3(1), dim3(1024), 0, st, v, r);
   timing_end(st, ev);
   return 1;
 }

@@ -296,10 +296,6 @@ unsigned *ramd_abort_word_dev(void);
  * deriving its workgroups' XCDs from their numbers (kernels_chain.hip) */
 void ramd_note_side_stream(void);
 
-/* the per-net calls' mailbox copies STAGED instead of launched (k_common.h: SegCopy): the next single-workgroup kernel of
- * the call carries them in its first (out == 0) / last (out != 0) instructions; ramd_flush_staged launches what nobody took */
-void ramd_stage_segs(int out, int nseg, void *const *dst, const void *const *src, const unsigned *nwords);
-void ramd_flush_staged(ramd_stream_t st);
 /* ---- timing hooks ---- */
 void ramd_timing_enable(int enable);
 double ramd_timing_ms(int which, long *launches, int reset);

@@ -188,29 +188,6 @@ static void mail_in_flush(void) {
     g_mail.in_sync = g_syncs;
   }
 }
-/* Round 6: STAGED instead of launched -- the next single-workgroup kernel of the call (k_fwd_small, k_top_backprop) makes the
- * copies in its first instructions (ramd_stage_segs; a launcher that cannot take them launches them after all).  A per-net
- * call of a small net was four mailbox launches around three kernels. */
-static int mail_fold(void) {
-  static int on = -1;
-  if (on < 0) {
-    const char *v = getenv("RECUR_AMD_MAIL_FOLD");
-    on = !(v && *v == '0');
-  }
-  return on;
-}
-static void mail_in_stage(void) {
-  if (!mail_fold()) {
-    mail_in_flush();
-    return;
-  }
-  if (g_mail.nseg) {
-    ramd_stage_segs(0, g_mail.nseg, g_mail.dst, g_mail.src, g_mail.n);
-    g_mail.nseg = 0;
-    g_mail.in_busy = 1;
-    g_mail.in_sync = g_syncs;
-  }
-}
 static void mail_in(void *dev, const void *host, size_t bytes) {
   unsigned words = (unsigned)(bytes / 4);
   if (!bytes) {
@@ -256,29 +233,17 @@ static struct {
   int nseg;
   unsigned cur;
 } g_mail_out;
-static int g_mail_out_staged = 0; /* how many of the queued outbound copies a kernel has been handed (mail_out_stage) */
 static void mail_out_flush(void) {
   mail_in_flush();
-  ramd_flush_staged(g_stream); /* (what was staged and not taken by a kernel: as launches, inbound first) */
-  if (g_mail_out.nseg > g_mail_out_staged) { /* queued behind the staging: a launch for those */
-    ramd_launch_segcopy(g_stream, g_mail_out.nseg - g_mail_out_staged, g_mail_out.dst + g_mail_out_staged,
-                        g_mail_out.src + g_mail_out_staged, g_mail_out.n + g_mail_out_staged);
+  if (g_mail_out.nseg) {
+    ramd_launch_segcopy(g_stream, g_mail_out.nseg, g_mail_out.dst, g_mail_out.src, g_mail_out.n);
   }
-  g_mail_out_staged = 0;
   dsync();
   for (int g = 0; g < g_mail_out.nseg; g++) {
     memcpy(g_mail_out.host[g], g_mail_out.dst[g], (size_t)g_mail_out.n[g] * 4);
   }
   g_mail_out.nseg = 0;
   g_mail_out.cur = 0;
-}
-/* the queued outbound copies handed to the call's LAST single-workgroup kernel (k_fwd_small, k_bptt_small), which makes them
- * in its last instructions; mail_out_flush then finds nothing to launch (or launches what nobody took), synchronises, delivers */
-static void mail_out_stage(void) {
-  if (mail_fold() && g_mail_out.nseg && !g_mail_out_staged) {
-    ramd_stage_segs(1, g_mail_out.nseg, g_mail_out.dst, g_mail_out.src, g_mail_out.n);
-    g_mail_out_staged = g_mail_out.nseg;
-  }
 }
 static void mail_out(void *host, const void *dev, size_t bytes) {
   unsigned words = (unsigned)(bytes / 4);
@@ -1537,21 +1502,6 @@ float *rnn_opinion(RecurNN *net, const float *inputs, float presynaptic_noise) {
     mail_in(d_slot + s->hidden_size + 1, net->real_inputs, sizeof(float) * s->input_size);
   }
   set_uniform_idx(e, p->stream >= 0 ? p->stream : e->n_streams, p->stream >= 0 ? 1 : 0);
-  if (!bl && presynaptic_noise == 0.0f) {
-    /* the plain call: the inputs ride into the forward launch, the layers ride out of it (k_fwd_small; a net that is not
-     * its kind gets the copies as launches after all: ramd_launch_forward_small, mail_out_flush) */
-    mail_in_stage();
-    mail_out(net->input_layer, d_slot, sizeof(float) * s->I);
-    mail_out(net->hidden_layer, e->b.hidden + (size_t)r * s->H, sizeof(float) * s->H);
-    mail_out(net->output_layer, e->b.out + (size_t)r * s->O, sizeof(float) * s->O);
-    mail_out_stage();
-    if (!ramd_launch_forward_small(g_stream, s, &e->b, r)) {
-      ramd_launch_assemble(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1, 0);
-      ramd_launch_forward(g_stream, s, &e->b, r, 1, presynaptic_noise);
-    }
-    mail_out_flush();
-    return net->output_layer;
-  }
   mail_in_flush();
   if (bl) {
     ramd_launch_bottom_forward(g_stream, s, &e->b, r, 1, RAMD_IN_KEEP, NULL, 0, 0, 0, 1,
@@ -1636,19 +1586,7 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
     err_flush(e);
   }
   set_uniform_idx(e, j, 1);
-  const int fold = !ranges && !s->bI;
-  if (fold) {
-    /* the output error rides into the top backprop's launch, the error images and the two scalars ride out of the
-     * one-workgroup BPTT's (k_top_backprop, k_bptt_small; other shapes: as launches after all) */
-    mail_in_stage();
-    mail_out(bp->h_error, e->b.err_a + (size_t)j * s->I, sizeof(float) * s->I);
-    mail_out(bp->i_error, e->b.err_b + (size_t)j * s->I, sizeof(float) * s->I);
-    mail_out(&bp->min_error_factor, e->b.mef + j, sizeof(float));
-    mail_out(&bp->ih_scale, e->b.ih_scale + j, sizeof(float));
-    mail_out_stage();
-  } else {
-    mail_in_flush();
-  }
+  mail_in_flush();
   ramd_launch_calc_deltas(g_stream, s, &e->b, j, 1, accumulate, d_ranges, 0, NULL,
                           net->flags | (fused ? 0x80000000u : 0) | (fused == 2 ? 0x20000000u : 0), NULL);
   if (s->bI && !fused) { /* the fused path passes no bottom error (recur-nn.c:972, 986) */
@@ -1668,12 +1606,10 @@ static void calc_deltas_one(RecurNN *net, int accumulate, RecurErrorRange *range
     e->err_nrows = 1;
     err_flush(e);
   }
-  if (!fold) {
-    mail_out(bp->h_error, e->b.err_a + (size_t)j * s->I, sizeof(float) * s->I);
-    mail_out(bp->i_error, e->b.err_b + (size_t)j * s->I, sizeof(float) * s->I);
-    mail_out(&bp->min_error_factor, e->b.mef + j, sizeof(float));
-    mail_out(&bp->ih_scale, e->b.ih_scale + j, sizeof(float));
-  }
+  mail_out(bp->h_error, e->b.err_a + (size_t)j * s->I, sizeof(float) * s->I);
+  mail_out(bp->i_error, e->b.err_b + (size_t)j * s->I, sizeof(float) * s->I);
+  mail_out(&bp->min_error_factor, e->b.mef + j, sizeof(float));
+  mail_out(&bp->ih_scale, e->b.ih_scale + j, sizeof(float));
   mail_out_flush();
   net->generation++;
   log_bptt(e, net, mef_before);
