@@ -544,3 +544,31 @@ def test_exchange_rejoins_on_counters_an_earlier_session_left():
     r = subprocess.run([sys.executable, "-c", REJOIN_SCRIPT % {"tests": os.path.dirname(os.path.abspath(__file__))}],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "RESULT ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+FINEGRAINED_SCRIPT = r"""
+import sys, json, hashlib
+sys.path.insert(0, %(tests)r)
+import numpy as np, recur_ctypes as rc, scenarios as sc
+amd = rc.load_amd()
+amd.rnn_amd_use_device(0, None)
+g = sc.AmdBatchedSet(amd, input_size=42, hidden_size=1024, output_size=42, S=32, D=10, learn_rate=1e-4, seed=3)
+text = sc.synthetic_text(5000)
+for i in range(14):
+    g.char_step(text, i, rc.WEIGHTED, 0.9)
+s = g.snapshot()
+print("RESULT " + json.dumps({k: hashlib.sha256(s[k].tobytes()).hexdigest() for k in ("ih_w", "ho_w", "ih_m", "ih_delta")}))
+"""
+
+
+def test_exchanged_arrays_as_fine_grained_allocations_train_the_same_bits():
+    """RECUR_AMD_XCHG_FINEGRAINED=1 (for a node on which bench.py's start-up cross-check finds the
+    kernel-issued exchange's replicas differing): weights and delta sums as hipExtMallocWithFlags(fine-grained) allocations
+    -- the same fourteen generations at hidden 1024, the same bits in weights, momentum and deltas."""
+    out = []
+    for fine in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", FINEGRAINED_SCRIPT % {"tests": os.path.dirname(os.path.abspath(__file__))}],
+                           capture_output=True, text=True, env=dict(os.environ, RECUR_AMD_XCHG_FINEGRAINED=fine), timeout=600)
+        assert r.returncode == 0 and "RESULT " in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+        out.append(json.loads(r.stdout.split("RESULT ", 1)[1]))
+    assert out[0] == out[1]
