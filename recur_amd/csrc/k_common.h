@@ -97,6 +97,22 @@ __device__ __forceinline__ float soft_clip_dev(float sum, float halfmax) {
   return 2.0f * x / (1 + x * x * fudge);
 }
 
+// A wave-wide sum that every lane gets, without the LDS crossbar (round 6): a butterfly over the sixteen lanes of a row in
+// four DPP steps, then the four rows' values through scalar registers (v_readlane) -- a dozen instructions of a few cycles
+// each where six __shfl_xor steps are six dependent ds_bpermute round trips.  (Every lane of the wave must be active.)
+__device__ __forceinline__ float wave_sum_all(float x) {
+#define RAMD_DPP_ADD_(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
+  RAMD_DPP_ADD_(x, 0xB1);  /* quad_perm [1, 0, 3, 2] */
+  RAMD_DPP_ADD_(x, 0x4E);  /* quad_perm [2, 3, 0, 1] */
+  RAMD_DPP_ADD_(x, 0x141); /* row_half_mirror */
+  RAMD_DPP_ADD_(x, 0x140); /* row_mirror */
+#undef RAMD_DPP_ADD_
+  const int xi = __builtin_bit_cast(int, x);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
 // deterministic block-wide sum (fixed tree), blockDim.x == 256
 __device__ __forceinline__ float block_sum_256(float v, float *red) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

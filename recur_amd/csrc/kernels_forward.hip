@@ -846,13 +846,13 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
   pp.y = ((a4.x * wt[0].y + a4.y * wt[1].y) + (a4.z * wt[2].y + a4.w * wt[3].y));
   pp.z = ((a4.x * wt[0].z + a4.y * wt[1].z) + (a4.z * wt[2].z + a4.w * wt[3].z));
   pp.w = ((a4.x * wt[0].w + a4.y * wt[1].w) + (a4.z * wt[2].w + a4.w * wt[3].w));
-#pragma unroll
-  for (int off = 1; off < 8; off <<= 1) {
-    pp.x += __shfl_xor(pp.x, off, 64);
-    pp.y += __shfl_xor(pp.y, off, 64);
-    pp.z += __shfl_xor(pp.z, off, 64);
-    pp.w += __shfl_xor(pp.w, off, 64);
-  }
+  /* the eight lanes of a row: two quad permutes and a half-row mirror (DPP: a few cycles each; as __shfl_xor twelve
+   * dependent ds_bpermute round trips in the launch's last microsecond) */
+#define FF_DPP_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
+  FF_DPP_ADD(pp.x, 0xB1); FF_DPP_ADD(pp.y, 0xB1); FF_DPP_ADD(pp.z, 0xB1); FF_DPP_ADD(pp.w, 0xB1);
+  FF_DPP_ADD(pp.x, 0x4E); FF_DPP_ADD(pp.y, 0x4E); FF_DPP_ADD(pp.z, 0x4E); FF_DPP_ADD(pp.w, 0x4E);
+  FF_DPP_ADD(pp.x, 0x141); FF_DPP_ADD(pp.y, 0x141); FF_DPP_ADD(pp.z, 0x141); FF_DPP_ADD(pp.w, 0x141);
+#undef FF_DPP_ADD
   if (!live) return;
   float *out = v.b.slab + (size_t)er * s.H;
   float *slot = v.b.arena + ((size_t)new_idx * s.Scap + grow) * s.I;

@@ -519,6 +519,19 @@ __device__ __forceinline__ float transpose_sum16(const float (&p)[16], int c4) {
   const float keep = b0 ? x[1] : x[0], send = b0 ? x[0] : x[1];
   return keep + T2_DPP(send, 0xB1);
 }
+/* a wave-wide max / min / sum that every lane gets, without the LDS crossbar: a butterfly over the sixteen lanes of a row in
+ * four DPP steps, then the four rows' values through scalar registers (v_readlane) -- ~12 instructions of a few cycles each
+ * where six __shfl_xor steps are six dependent ds_bpermute round trips (the one-wave softmax was 1.6 us of the launch) */
+template <class OP> __device__ __forceinline__ float wave_all(float x, OP op) {
+  x = op(x, T2_DPP(x, 0xB1));
+  x = op(x, T2_DPP(x, 0x4E));
+  x = op(x, T2_DPP(x, 0x141));
+  x = op(x, T2_DPP(x, 0x140));
+  const int xi = __builtin_bit_cast(int, x);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+  return op(op(r0, r1), op(r2, r3));
+}
 /* text_softmax_wave (k_top.h) for o_size <= 64 without LDS round trips: lane i holds output i.  The same arithmetic value
  * by value (adjustment, fast_expf_dev, the division, +1 on the target, best guess with the lowest index on a tie); the sum
  * of the exponentials is a tree over the lanes, not the reference's index order.  Leaves the error row in serr (LDS) and
@@ -529,32 +542,22 @@ __device__ __forceinline__ void text_softmax_regs(const RamdShape &s, int lane, 
   const int len = s.output_size;
   const bool in = lane < len;
   const float o = sout[in ? lane : 0];
-  float hi = o, lo = o;
-  for (int off = 32; off > 0; off >>= 1) {
-    hi = fmaxf(hi, __shfl_xor(hi, off, 64));
-    lo = fminf(lo, __shfl_xor(lo, off, 64));
-  }
+  const float hi = wave_all(o, [](float a, float b) { return fmaxf(a, b); }); /* (a lane past the outputs holds output 0) */
+  const float lo = wave_all(o, [](float a, float b) { return fminf(a, b); });
   float adj = 0.0f;
   if (hi > 50.0f) adj = 50.0f - hi;
   else if (lo < -60.0f) adj = fminf(-60.0f - lo, 50.0f - hi);
   const float ex = in ? fast_expf_dev(o + adj) : 0.0f;
-  float sum = ex;
-  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  const float sum = wave_all(ex, [](float a, float b) { return a + b; });
   const float e = ex / sum;
-  float best_e = in ? e : -1.0f;
-  int best_i = in ? lane : 0x7fffffff;
+  /* the best guess: the largest e, the lowest index on a tie (badmaths.h:113-141) -- the first lane that holds the maximum */
+  const float emax = wave_all(in ? e : -1.0f, [](float a, float b) { return fmaxf(a, b); });
+  const unsigned long long at = __ballot(in && e == emax);
+  const int best_i = at ? __ffsll((long long)at) - 1 : 0x7fffffff;
   if (lane < s.O) {
     const float oe = in ? ((lane == target) ? -e + 1.0f : -e) : pad_oe; /* the pad of o_error stays what it was (zero) */
     if (in) err[lane] = oe;
     serr[lane] = oe;
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    const float oe = __shfl_xor(best_e, off, 64);
-    const int oi = __shfl_xor(best_i, off, 64);
-    if (oe > best_e || (oe == best_e && oi < best_i)) {
-      best_e = oe;
-      best_i = oi;
-    }
   }
   const float et = __shfl(e, target, 64);
   if (lane == 0) {
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(1024) void k_text_top2(View v, int row0, int nrows,
       const float *pd = v.b.slab + (size_t)nrows * s.H + (size_t)j * 4 + p4;
       float x = 0.0f;
       for (int t = lane; t < npart; t += 64) x += pd[(size_t)t * nrows * 4];
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      x = wave_sum_all(x);
       if (s.activation == 2) {
         x = (x > 0.0f) ? sqrtf(x + 1.0f) - 1.0f : 0.0f;
       } else if (s.activation == 5) {
@@ -719,8 +722,7 @@ __global__ __launch_bounds__(1024) void k_text_top2(View v, int row0, int nrows,
   float *dst = v.b.ehi + (size_t)r * s.I; /* step 0 plane */
   if (rowa) dst[ya] = (ya == 0 || ya > s.hidden_size) ? 0.0f : ea;
   if (rowb) dst[yb] = (yb == 0 || yb > s.hidden_size) ? 0.0f : eb;
-  float sum = fabsf(ea) + fabsf(eb);
-  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  float sum = wave_all(fabsf(ea) + fabsf(eb), [](float a, float b) { return a + b; });
   if (lane == 0) tred[seg] = sum;
   TT_STAMP(6);
   __syncthreads();
