@@ -890,7 +890,9 @@ __global__ __launch_bounds__(512) void k_fwd_fused(const View *__restrict__ vp, 
     float *pd = v.b.slab + (size_t)nrows * s.H + ((size_t)nt * nrows + er) * 4;
     *reinterpret_cast<float4 *>(pd) = make_float4(pp.x * scale, pp.y * scale, pp.z * scale, pp.w * scale);
   }
-  if (nt == 0) { /* the rest of k_assemble's row: input columns, ring index, target */
+  /* (by column tile 1's workgroups where there is one: column tile 0's have the tail columns' extra loads and sums above,
+   * and were the launch's last to end by 0.9 us -- round 6, the workgroups' own marks) */
+  if (nt == (tn > 1 ? 1 : 0)) { /* the rest of k_assemble's row: input columns, ring index, target */
     const int sub = etid & 7;
     if (sub == 0) {
       v.b.idx[grow] = new_idx;
