@@ -27,6 +27,7 @@ readers = {k: getattr(amd, "ramd_bnd_%s_stamps" % k) for k in ("fwd", "top", "ch
 nwg = {"fwd": (S // 32) * 32, "top": S, "chain": 256, "delta": 256}
 
 
+late = {}  # kernel -> list of [12]: the workgroup numbers that ended last
 per_xcd = {}  # kernel -> list of [8] (workgroups blockIdx % 8 == x: the dispatcher deals them to the XCDs in turn): latest end, relative to the launch's first start
 
 
@@ -37,6 +38,7 @@ def marks():
         f(C.c_void_p(buf.ctypes.data))
         b = buf[:, :nwg[k]].astype(np.int64)
         b = b[:, (b[0] > 0) & (b[1] > 0)]  # (a launch with fewer workgroups than that: the marks that were written)
+        late.setdefault(k, []).append(np.argsort(-(buf[1, :nwg[k]].astype(np.int64)))[:12])
         if b.shape[1] >= 8:
             per_xcd.setdefault(k, []).append([(b[1][x::8].max() - b[0].min()) / 100.0 for x in range(8)] +
                                              [(b[1][x::8].min() - b[0].min()) / 100.0 for x in range(8)])
@@ -89,3 +91,10 @@ for k, v in per_xcd.items():
     a = np.array(v).mean(axis=0)
     print("%-6s last end  " % k + " ".join("%7.2f" % x for x in a[:8]))
     print("%-6s first end " % k + " ".join("%7.2f" % x for x in a[8:]))
+print("the twelve workgroups that ended last, by how often over the samples (workgroup number: times)")
+for k, v in late.items():
+    cnt = {}
+    for a in v:
+        for w in a:
+            cnt[int(w)] = cnt.get(int(w), 0) + 1
+    print("%-6s " % k + " ".join("%d:%d" % (w, c) for w, c in sorted(cnt.items(), key=lambda t: -t[1])[:16]))
