@@ -317,7 +317,6 @@ __device__ __forceinline__ TailPre extras_tail_prefetch(const View &v, int r, in
   p.ci = ControlIn{0.0f, 0.0f, 1.0f, 0.0, true};
   if (wave == 0) p.ci = bptt_control_load(v, r, j, active);
   const int xcol[2] = {(lane == 0 || lane >= nx) ? 0 : s.hidden_size + lane, lane + 64 < nx ? s.hidden_size + lane + 64 : 0};
-  const unsigned xmask[2] = {lane < nx ? 0xffffffffu : 0u, lane + 64 < nx ? 0xffffffffu : 0u};
   int t0, stride, t_end;
   tail_items(wave, NW, D, t0, stride, t_end);
 #pragma unroll
@@ -325,7 +324,7 @@ __device__ __forceinline__ TailPre extras_tail_prefetch(const View &v, int r, in
     const int t = t0 + stride * b;
     const auto *x = as_global(input_row<true>(v, r, t < D ? t : D - 1));
 #pragma unroll
-    for (int h = 0; h < 2; h++) p.xi[b][h] = __uint_as_float(__float_as_uint(x[xcol[h]]) & xmask[h]);
+    for (int h = 0; h < 2; h++) p.xi[b][h] = x[xcol[h]]; /* as loaded: a mask applied HERE is a wait for the load, a memory round trip in front of the chain's weight panel (0.9 us by stamps); the tail masks it */
   }
   return p;
 }
@@ -393,8 +392,8 @@ __device__ __forceinline__ void extras_control_tail(const View &v, int r, int j,
 #pragma unroll
     for (int b = 0; b < BB; b++) {
       if (xpre) { /* (uniform) */
-        xi[b][0] = xpre[b][0];
-        xi[b][1] = xpre[b][1];
+        xi[b][0] = __uint_as_float(__float_as_uint(xpre[b][0]) & xmask[0]);
+        xi[b][1] = __uint_as_float(__float_as_uint(xpre[b][1]) & xmask[1]);
       } else {
         const int t = tb + t_stride * b;
         const auto *x = as_global(input_row<true>(v, r, t < D ? t : D - 1)); /* (the one-launch chain: one ring position) */

@@ -2,8 +2,16 @@
 // (k_chain_main, k_chain_wide) or all steps in one launch (k_chain_persist), and their launch logic.
 #include "k_common.h"
 #ifdef PC_STAMPS /* development builds only: stamps of the chain's tail (tools/gpu_chain_stamps.py) */
-__device__ unsigned long long g_xc_stamps[16];
+__device__ unsigned long long g_xc_stamps[24];
 #define XC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == ((i) == 10 ? 256 : 0)) g_xc_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PRO_STAMP(i, tid) do { if (blockIdx.x == PRO_WG && threadIdx.x == (tid)) g_xc_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PRO_STAMP_DEP(i, tid, dep) do { if (blockIdx.x == PRO_WG && threadIdx.x == (tid) && (dep) != 0x7ffffff1) g_xc_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#ifndef PRO_WG
+#define PRO_WG 0
+#endif
+#else
+#define PRO_STAMP(i, tid) do { } while (0)
+#define PRO_STAMP_DEP(i, tid, dep) do { } while (0)
 #endif
 #include "k_extras.h"
 BND_DECL(g_bnd_chain, ramd_bnd_chain_stamps)
@@ -579,7 +587,10 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   unsigned *wg_info = reinterpret_cast<unsigned *>(red + 2 * PC_RED_FLOATS);
   XC_STAMP(0);
   BND_MARK(g_bnd_chain, 0);
+  PRO_STAMP_DEP(16, 256, nrows);        /* the launch's arguments are here */
+  PRO_STAMP_DEP(17, 256, (int)hw_seat); /* the seat */
   View v = *vp;
+  PRO_STAMP_DEP(18, 256, v.sh.H);       /* the view */
   v.b.uniform_idx = uniform_idx;
   const RamdShape &s = v.sh;
   const int wave8 = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -649,7 +660,9 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   /* the tail's first stream (row tile's stream j): what it can ask for now (extras_tail_prefetch) */
   const bool xc_first = !XD && xc.on && j < TR && !(PAD && (m0 + j < vlo || m0 + j >= nvalid));
   TailPre tpre;
+  PRO_STAMP(19, 256);
   if (xc_first) tpre = extras_tail_prefetch<512>(v, row0 + m0 + j, row0 + m0 + j - xc.row0, xc.nx, xc.active);
+  PRO_STAMP(20, 256);
 
   if (wave8 >= 4) {
     // ============================================ multiply, finish, publish
@@ -681,6 +694,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     const int wv = __builtin_amdgcn_readfirstlane(wave8) - 4, m = lane & 15, kq = lane >> 4;
     const int col = lane & 31, rh = lane >> 5;
     if (ho_here) chain_ho_delta<5, HO_BATCH>(v, hw, red, (int)blockIdx.x); /* before the panel's loads: its own loads need the registers, and return first */
+    PRO_STAMP(11, 256);
     float wreg[KB][4][2];
     {
       const float *wb = v.b.ih_w + (size_t)(n0 + m) * s.H + 1 + (K / 4) * wv + 4 * kq;
@@ -690,6 +704,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
         for (int i = 0; i < 4; i++)
 #pragma unroll
           for (int h = 0; h < 2; h++) wreg[u][i][h] = wb[(size_t)16 * h * s.H + 16 * u + i];
+      PRO_STAMP(12, 256);
       /* The panel has to have LANDED before the loop, as far as hipcc can tell: otherwise it puts the
        * `s_waitcnt vmcnt(0)` for these loads in front of the loop's first MFMA, where it waits in EVERY
        * half-step for the gate loads issued just before (inline asm, not on its scoreboard).  An empty
@@ -698,6 +713,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
       for (int u = 0; u < KB; u++)
         asm volatile("" : : "v"(wreg[u][0][0]), "v"(wreg[u][0][1]), "v"(wreg[u][1][0]), "v"(wreg[u][1][1]),
                      "v"(wreg[u][2][0]), "v"(wreg[u][2][1]), "v"(wreg[u][3][0]), "v"(wreg[u][3][1]));
+      PRO_STAMP(13, 256);
     }
     // this thread's two outputs per half-step: rows 4 wv + rh and + 2 of the sub-chain, column
     // n0 + col.  Byte offset of (row, column) within a plane of [Scap][I] floats, relative to
@@ -740,6 +756,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     f32x4 af[4];
     bool mdead = false; /* somebody gave up: no more polling, only the barriers */
     __syncthreads(); /* barrier 0: both operands of the first two half-steps have landed */
+    PRO_STAMP(14, 256);
 
     // one half-step; XC: which sub-chain it MULTIPLIES (it finishes the other one's previous half-step)
     auto half = [&](auto XC, const int k) -> bool {
@@ -974,6 +991,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   if (halfsteps > 1 && !ONE) fetch(1, 0);
   if (ho_here) chain_ho_delta<5, HO_BATCH>(v, hw, red, (int)blockIdx.x); /* while the first operand rows are on their way */
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PRO_STAMP(15, 0);
   __syncthreads(); /* barrier 0 */
   for (int k = 0; k < halfsteps; k++) {
     PC_STAMP(1, k, 0);
@@ -1113,7 +1131,7 @@ extern "C" void ramd_chain_stamps(unsigned long long *out) {
 }
 extern "C" void ramd_chain_tail_stamps(unsigned long long *out) {
   HIP_CHECK(hipDeviceSynchronize());
-  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xc_stamps), sizeof(unsigned long long) * 16));
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xc_stamps), sizeof(unsigned long long) * 24));
 }
 #endif
 

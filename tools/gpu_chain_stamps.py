@@ -24,11 +24,14 @@ for k in range(41):
         k, us(c[0]), us(c[2]), us(c[3]), us(c[1]), us(l[0]), us(l[2]), us(l[3]), us(l[4])))
 
 if hasattr(amd, "ramd_chain_tail_stamps"):
-    tb = np.zeros(16, np.uint64)
+    tb = np.zeros(24, np.uint64)
     amd.ramd_chain_tail_stamps(C.c_void_p(tb.ctypes.data))
     b0 = int(tb[0])
     names = ["kernel start", "tail start (wave 0)", "last flags seen (last wave)", "tail set up", "weight rows requested",
-             "error rows requested", "items done (wave 0)", "barrier", "control done", "stream done", "tail start (wave 4)"]
+             "error rows requested", "items done (wave 0)", "barrier", "control done", "stream done", "tail start (wave 4)",
+             "prologue: wave 4 set up", "prologue: panel requested", "prologue: panel landed", "prologue: barrier 0 passed (wave 4)",
+             "prologue: first operands landed (wave 0)", "prologue: launch arguments read (wave 4)", "prologue: seat read (wave 4)",
+             "prologue: view read (wave 4)", "prologue: before the tail's early requests (wave 4)", "prologue: after them (wave 4)"]
     print("tail of workgroup 0 (us from its first instruction):")
     for i, n in enumerate(names):
         print("  %-24s %8.2f" % (n, (int(tb[i]) - b0) / 100.0 if int(tb[i]) else float("nan")))
