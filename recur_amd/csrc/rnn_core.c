@@ -129,34 +129,8 @@ static void d2h(void *h, const void *d, size_t bytes) {
   }
 }
 static unsigned long g_syncs = 0; /* completed stream synchronisations */
-/* The wait for the stream: polled for a while before it blocks.  hipStreamSynchronize goes to sleep on the queue's signal
- * after ~0.1 ms and is woken by an interrupt -- tens of microseconds after the last kernel has ended, which a caller that
- * synchronises every few milliseconds (a report interval of a few generations; bench.py's 20-step window) pays every time.
- * RECUR_AMD_SYNC_SPIN_US: how long to poll first (default 20000; 0: block at once). */
-static void stream_wait(void) {
-  static long spin_us = -1;
-  if (spin_us < 0) {
-    const char *v = getenv("RECUR_AMD_SYNC_SPIN_US");
-    spin_us = v ? atol(v) : 20000;
-    if (spin_us < 0) spin_us = 0;
-  }
-  if (spin_us > 0) {
-    struct timespec t0, t;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (;;) {
-      const hipError_t q = hipStreamQuery(g_stream);
-      if (q == hipSuccess) break;
-      if (q != hipErrorNotReady) HIP_OK(q);
-      clock_gettime(CLOCK_MONOTONIC, &t);
-      if ((t.tv_sec - t0.tv_sec) * 1000000L + (t.tv_nsec - t0.tv_nsec) / 1000L > spin_us) break;
-    }
-    (void)hipGetLastError(); /* ("not ready" is remembered as the thread's last error: the next launch's check would find it) */
-  }
-  HIP_OK(hipStreamSynchronize(g_stream));
-}
-
 static void dsync(void) {
-  stream_wait();
+  HIP_OK(hipStreamSynchronize(g_stream));
   g_syncs++;
   if (ramd_chain_abort_word()) {
     const unsigned code = ramd_chain_abort_word();
