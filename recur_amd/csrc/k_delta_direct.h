@@ -521,9 +521,14 @@ constexpr int dd_lds_bytes(int NW, int NPW = 1) { return (NW * 64 * DD_LD + NPW 
 
 /* (one workgroup per CU: NW / 4 waves per SIMD, with the registers that leaves each -- told to hipcc, which otherwise
  * aims at a higher occupancy and parks ring registers in AGPRs between an asynchronous load and its wait) */
+#ifndef DD_BND_MARK /* (development builds, -DBND_STAMPS: kernels_bptt.hip marks this launch's workgroups too) */
+#define DD_BND_MARK(which) do { } while (0)
+#endif
 template <int NW, int P, int NPW = 1>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void k_delta_direct(DdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dd_lds[];
   __builtin_amdgcn_s_setprio(2);
+  DD_BND_MARK(0);
   dd_body<NW, P, NPW>(a, dd_lds);
+  DD_BND_MARK(1);
 }

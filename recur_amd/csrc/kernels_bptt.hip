@@ -998,9 +998,12 @@ static void ramd_launch_extras_dense(hipStream_t st, const View &v, const RamdSh
     RAMD_LAUNCH(k_extras_dense<1>, dim3((M + 15) / 16), dim3(64 * XD_WAVES), 0, st, v, row0, nrows, nx, nxp, tn_parts, t0, nt);
 }
 
+BND_DECL(g_bnd_delta, ramd_bnd_delta_stamps)
+#ifdef BND_STAMPS
+#define DD_BND_MARK(which) BND_MARK(g_bnd_delta, which)
+#endif
 #include "k_delta_direct.h" /* the weight-delta GEMM without a K split over workgroups (hidden 1024 and up) */
 
-BND_DECL(g_bnd_delta, ramd_bnd_delta_stamps)
 #ifdef PC_STAMPS
 extern "C" void ramd_ddir_stamps(unsigned long long *out) {
   HIP_CHECK(hipDeviceSynchronize());
