@@ -155,9 +155,12 @@ template <int LEVEL> __device__ __forceinline__ void dd_store4(float *p, const f
 #ifdef PC_STAMPS /* development builds only (tools/mkabl.sh -DPC_STAMPS, tools/gpu_delta_direct_stamps.py) */
 __device__ unsigned long long g_ddir_stamps[4][8];
 __device__ unsigned long long g_ddir_wave[4][8]; /* loop done, per wave */
+__device__ unsigned long long g_ddir_clk[4][4];  /* the loop by both clocks: s_memrealtime, s_memtime at its start and end */
+#define DDIR_CLOCKS(i) do { if ((blockIdx.x & 63) == 0 && threadIdx.x == 0) { g_ddir_clk[blockIdx.x >> 6][i] = __builtin_amdgcn_s_memrealtime(); g_ddir_clk[blockIdx.x >> 6][(i) + 1] = __builtin_amdgcn_s_memtime(); } } while (0)
 #define DDIR_STAMP(i) do { if ((blockIdx.x & 63) == 0 && threadIdx.x == 0) g_ddir_stamps[blockIdx.x >> 6][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define DDIR_STAMP(i) do { } while (0)
+#define DDIR_CLOCKS(i) do { } while (0)
 #endif
 struct DdNoPre {
   __device__ __forceinline__ void operator()() const {}
@@ -296,6 +299,7 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
     DDIR_STAMP(1);
     dd_flag_wait<(2 + NPW) * P>(fl_n, fl_s);
     DDIR_STAMP(2);
+    DDIR_CLOCKS(0);
     bool ok = true;
 #pragma unroll
     for (int u = 0; u < DD_FLAG_LOADS / 2; u++)
@@ -361,6 +365,7 @@ __device__ __forceinline__ void dd_body(const DdArgs &a, float *lds, PRE pre = P
   if (ones) {
     for (int i0 = 0; i0 < n_it; i0 += P) round(std::true_type{});
     DDIR_STAMP(3);
+    DDIR_CLOCKS(2);
 #ifdef PC_STAMPS
     if ((blockIdx.x & 63) == 0 && lane == 0) g_ddir_wave[blockIdx.x >> 6][wv] = __builtin_amdgcn_s_memrealtime();
 #endif

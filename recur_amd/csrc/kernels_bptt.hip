@@ -1010,6 +1010,10 @@ extern "C" void ramd_ddir_stamps(unsigned long long *out) {
   HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ddir_stamps), sizeof(unsigned long long) * 32));
   HIP_CHECK(hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_ddir_wave), sizeof(unsigned long long) * 32));
 }
+extern "C" void ramd_ddir_clocks(unsigned long long *out) {
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ddir_clk), sizeof(unsigned long long) * 16));
+}
 #endif
 /* k_delta_direct with the top layer's weight delta AND its update in the launch's first microseconds (the fused text step):
  * workgroup i forms rows 5 i .. of ho_delta = hidden^T . o_error over the call's streams (chain_ho_delta, k_common.h: what

@@ -2,16 +2,19 @@
 // (k_chain_main, k_chain_wide) or all steps in one launch (k_chain_persist), and their launch logic.
 #include "k_common.h"
 #ifdef PC_STAMPS /* development builds only: stamps of the chain's tail (tools/gpu_chain_stamps.py) */
-__device__ unsigned long long g_xc_stamps[24];
+__device__ unsigned long long g_xc_stamps[32];
 #define XC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == ((i) == 10 ? 256 : 0)) g_xc_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define PRO_STAMP(i, tid) do { if (blockIdx.x == PRO_WG && threadIdx.x == (tid)) g_xc_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define PRO_STAMP_DEP(i, tid, dep) do { if (blockIdx.x == PRO_WG && threadIdx.x == (tid) && (dep) != 0x7ffffff1) g_xc_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+/* both clocks: slot i the 100 MHz one, slot i + 1 the shader clock (s_memtime): the clock the chip ran at between two of these */
+#define PRO_CLOCKS(i, tid) do { if (blockIdx.x == PRO_WG && threadIdx.x == (tid)) { g_xc_stamps[i] = __builtin_amdgcn_s_memrealtime(); g_xc_stamps[(i) + 1] = __builtin_amdgcn_s_memtime(); } } while (0)
 #ifndef PRO_WG
 #define PRO_WG 0
 #endif
 #else
 #define PRO_STAMP(i, tid) do { } while (0)
 #define PRO_STAMP_DEP(i, tid, dep) do { } while (0)
+#define PRO_CLOCKS(i, tid) do { } while (0)
 #endif
 #include "k_extras.h"
 BND_DECL(g_bnd_chain, ramd_bnd_chain_stamps)
@@ -757,6 +760,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
     bool mdead = false; /* somebody gave up: no more polling, only the barriers */
     __syncthreads(); /* barrier 0: both operands of the first two half-steps have landed */
     PRO_STAMP(14, 256);
+    PRO_CLOCKS(24, 256);
 
     // one half-step; XC: which sub-chain it MULTIPLIES (it finishes the other one's previous half-step)
     auto half = [&](auto XC, const int k) -> bool {
@@ -1026,6 +1030,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const View *__restrict__ 
   if (!xc.on) return;
   XC_STAMP(1);
   XC_STAMP(10);
+  PRO_CLOCKS(26, 256);
   /* (the sums' scratch is the operand area: nobody reads it behind the loop's last barrier, while the
    * multiplying waves' last finish still reads `red` -- no barrier in front of the tail) */
   for (int i = j; i < TR; i += NT) {
@@ -1131,7 +1136,7 @@ extern "C" void ramd_chain_stamps(unsigned long long *out) {
 }
 extern "C" void ramd_chain_tail_stamps(unsigned long long *out) {
   HIP_CHECK(hipDeviceSynchronize());
-  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xc_stamps), sizeof(unsigned long long) * 24));
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xc_stamps), sizeof(unsigned long long) * 32));
 }
 #endif
 

@@ -24,7 +24,7 @@ for k in range(41):
         k, us(c[0]), us(c[2]), us(c[3]), us(c[1]), us(l[0]), us(l[2]), us(l[3]), us(l[4])))
 
 if hasattr(amd, "ramd_chain_tail_stamps"):
-    tb = np.zeros(24, np.uint64)
+    tb = np.zeros(32, np.uint64)
     amd.ramd_chain_tail_stamps(C.c_void_p(tb.ctypes.data))
     b0 = int(tb[0])
     names = ["kernel start", "tail start (wave 0)", "last flags seen (last wave)", "tail set up", "weight rows requested",
@@ -33,5 +33,8 @@ if hasattr(amd, "ramd_chain_tail_stamps"):
              "prologue: first operands landed (wave 0)", "prologue: launch arguments read (wave 4)", "prologue: seat read (wave 4)",
              "prologue: view read (wave 4)", "prologue: before the tail's early requests (wave 4)", "prologue: after them (wave 4)"]
     print("tail of workgroup 0 (us from its first instruction):")
+    if int(tb[24]) and int(tb[26]):
+        rt, ct = int(tb[26]) - int(tb[24]), int(tb[27]) - int(tb[25])
+        print("  the loop (barrier 0 -> tail, wave 4): %.2f us, %d shader clocks: %.3f GHz" % (rt / 100.0, ct, ct / (rt * 10.0)))
     for i, n in enumerate(names):
         print("  %-24s %8.2f" % (n, (int(tb[i]) - b0) / 100.0 if int(tb[i]) else float("nan")))

@@ -20,3 +20,11 @@ for w in range(4):
     print("workgroup %3d: " % (64 * w) + "  ".join("%s %.2f" % (n, (int(buf[w, i]) - t0) / 100.0) for i, n in enumerate(names)))
 for w in range(4):
     print("workgroup %3d, loop done per wave: " % (64 * w) + " ".join("%.1f" % ((int(x) - t0) / 100.0) for x in buf[4 + w]))
+
+if hasattr(amd, "ramd_ddir_clocks"):
+    ck = np.zeros((4, 4), np.uint64)
+    amd.ramd_ddir_clocks(C.c_void_p(ck.ctypes.data))
+    for w in range(4):
+        rt, ct = int(ck[w, 2]) - int(ck[w, 0]), int(ck[w, 3]) - int(ck[w, 1])
+        if rt > 0:
+            print("workgroup %3d, the loop (wave 0) by both clocks: %.2f us, %d shader clocks: %.3f GHz" % (64 * w, rt / 100.0, ct, ct / (rt * 10.0)))
